@@ -1,0 +1,131 @@
+"""TEST INFRASTRUCTURE ONLY -- golden-vector generator (runs in the BUILD CONTAINER only).
+
+Runs the UNMODIFIED reference ``lib/decompose.py::dictionary`` / ``fc_kernel``
+(/root/reference, loaded by oracle/ref_loader.py) on seeded synthetic operands
+(oracle/cp_oracle.py::synth_layer = the generator of SURVEY.md section 8d) and stores the
+outputs under tests/golden/.  Inputs are NOT stored: every case is regenerated from its
+parameters (``synth_layer`` + ``np.random.seed``), which is bit-reproducible for a
+fixed numpy version (recorded in each file).
+
+Per case the file holds: params (json), samples, the per-fit log
+[(alpha, nnz, n_iter)] captured by wrapping ``Lasso.fit``, idxs, newW2, newB2,
+``cfgs.alpha`` after the call, and the next draw of numpy's global RNG after the call
+(pins the RNG-stream consumption: 1 + #fits draws, SURVEY.md section 8b "Ownership").
+
+Usage:  python oracle/gen_golden.py [--only NAME ...] [--skip-large]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cp_oracle  # noqa: E402
+import ref_loader  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+# name -> parameters.  layer_id seeds both the operands (1000+id) and the global RNG (1234+id).
+CASES = {
+    # small: full float64 outputs, run by the CPU suite and the GPU parity suite
+    "s01_c32_k3": dict(layer_id=1, N=400, c=32, n=24, k=3, rank=16),
+    "s02_c64_k3": dict(layer_id=2, N=600, c=64, n=48, k=3, rank=32),
+    "s03_c64_k1": dict(layer_id=3, N=600, c=64, n=64, k=1, rank=16),
+    "s04_c48_dc": dict(layer_id=4, N=400, c=48, n=32, k=3, rank=41),       # int(c/1.15)
+    "s05_rank_eq_c": dict(layer_id=5, N=300, c=16, n=16, k=3, rank=16),    # decompose.py:487
+    "s06_dead": dict(layer_id=6, N=600, c=32, n=32, k=3, rank=16, dead=4),
+    "s07_N_lt_p": dict(layer_id=7, N=200, c=32, n=16, k=3, rank=24),       # min-norm refit
+    "s08_resid_k1": dict(layer_id=8, N=500, c=64, n=32, k=1, rank=32, residual=True),
+    "s09_ridge": dict(layer_id=9, N=400, c=32, n=24, k=3, rank=16, fc_ridge=0.5),
+    "s10_alpha_carry": dict(layer_id=10, N=400, c=32, n=24, k=3, rank=8, alpha_in=0.008),
+    "s11_rank_eq_c_dead": dict(layer_id=11, N=300, c=16, n=16, k=3, rank=16, dead=2),
+    "s12_c96_n40": dict(layer_id=12, N=800, c=96, n=40, k=3, rank=24),     # ragged sizes
+    "s13_rank_tol_1": dict(layer_id=13, N=400, c=32, n=24, k=3, rank=16, rank_tol=2),
+    # BASELINE.json configs[0]
+    "m01_config1": dict(layer_id=20, N=500, c=256, n=256, k=3, rank=128),
+    # BASELINE.json configs[1] (the bench workload): VGG-16 conv3_x block, 5000 samples
+    "L01_conv2_2_conv3_1": dict(layer_id=31, N=5000, c=128, n=256, k=3, rank=64, large=True),
+    "L02_conv3_1_conv3_2": dict(layer_id=32, N=5000, c=256, n=256, k=3, rank=128, large=True),
+    "L03_conv3_2_conv3_3": dict(layer_id=33, N=5000, c=256, n=256, k=3, rank=128, large=True),
+    "L04_conv3_1_dc222": dict(layer_id=34, N=5000, c=256, n=256, k=3, rank=222, large=True),
+}
+
+
+def versions():
+    import scipy
+    import sklearn
+    return dict(numpy=np.__version__, scipy=scipy.__version__, sklearn=sklearn.__version__)
+
+
+def run_reference(p):
+    """One call of the real reference dictionary() under the case's seeds."""
+    D, cfgs = ref_loader.load()
+    from sklearn.linear_model import Lasso
+    X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"],
+                                         dead=p.get("dead", 0), residual=p.get("residual", False))
+    fits = []
+    orig_fit = Lasso.fit
+
+    def logging_fit(self, Xa, ya, *a, **kw):
+        r = orig_fit(self, Xa, ya, *a, **kw)
+        fits.append((float(self.alpha), int(np.sum(self.coef_ != 0.)), int(self.n_iter_)))
+        return r
+
+    samples_box = []
+    orig_randint = np.random.randint
+    cfgs.alpha = p.get("alpha_in", 1e-3)
+    D.dcfgs.dic.rank_tol = p.get("rank_tol", .1)
+    D.dcfgs.fc_ridge = p.get("fc_ridge", 0)
+    np.random.seed(1234 + p["layer_id"])
+    state0 = np.random.get_state()
+    Lasso.fit = logging_fit
+    try:
+        t0 = time.perf_counter()
+        idxs, newW2, newB2 = D.dictionary(X.astype(np.float64), W2, Y, rank=p["rank"], B2=B2)
+        dt = time.perf_counter() - t0
+    finally:
+        Lasso.fit = orig_fit
+        D.dcfgs.fc_ridge = 0
+        D.dcfgs.dic.rank_tol = .1
+    alpha_out = float(cfgs.alpha)
+    rng_next = int(np.random.randint(0, 2147483647))
+    # recover `samples` (first draw) by replaying the stream
+    np.random.set_state(state0)
+    samples = np.random.randint(0, p["N"], min(400, p["N"] // 20))
+    del samples_box, orig_randint
+    return dict(idxs=np.asarray(idxs, dtype=bool), newW2=newW2, newB2=newB2,
+                fits=np.array(fits, dtype=np.float64).reshape(-1, 3), samples=samples,
+                alpha_out=alpha_out, rng_next=rng_next, seconds=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--skip-large", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, p in CASES.items():
+        if args.only and name not in args.only:
+            continue
+        if args.skip_large and p.get("large"):
+            continue
+        r = run_reference(p)
+        w = r["newW2"]
+        # large cases: weights kept as float32 (rounding 6e-8 << the 1e-5 parity budget)
+        wstore = w.astype(np.float32) if p.get("large") else w
+        np.savez_compressed(
+            os.path.join(GOLDEN_DIR, name + ".npz"),
+            params=json.dumps(p), versions=json.dumps(versions()),
+            idxs=r["idxs"], newW2=wstore, newB2=r["newB2"], fits=r["fits"],
+            samples=r["samples"], alpha_out=r["alpha_out"], rng_next=r["rng_next"],
+            ref_seconds=r["seconds"], newW2_fro=float(np.linalg.norm(w)))
+        print("%-24s kept %4d/%4d  fits %2d  %.2fs  alpha_out %.6g" % (
+            name, int(r["idxs"].sum()), p["c"], len(r["fits"]), r["seconds"], r["alpha_out"]))
+
+
+if __name__ == "__main__":
+    main()
