@@ -1,0 +1,281 @@
+"""ctypes binding of libcpmi355.so (C ABI declared in include/cpmi355.h).
+
+This is the only place the shared library is loaded.  There is NO CPU fallback: if the
+library is missing or no gfx950 device is visible, loading / context creation raises, and
+every product entry point (lib/decompose.py, lib/net.py) propagates that error.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpmi355.so")
+
+CP_F32, CP_F64 = 0, 1
+CP_CD_RECIPROCAL = 1
+CP_MAX_STAGES = 32
+
+_c_int, _c_i64, _c_dbl, _c_u32 = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32
+_vp = ctypes.c_void_p
+
+
+class CdResult(ctypes.Structure):
+    _fields_ = [("gap", _c_dbl), ("tol_scaled", _c_dbl), ("n_iter", ctypes.c_int32), ("nnz", ctypes.c_int32)]
+
+
+class RefitInfo(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_int32), ("rank", ctypes.c_int32), ("fallback", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class CpError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        super().__init__("libcpmi355: %s failed: %s (%d)%s" % (what, _strerror(code), code,
+                                                              (" -- " + detail) if detail else ""))
+
+
+# name -> (restype, argtypes); must list every symbol include/cpmi355.h declares
+SIGNATURES = {
+    "cp_version": (_c_int, []),
+    "cp_strerror": (ctypes.c_char_p, [_c_int]),
+    "cp_last_error": (ctypes.c_char_p, [_vp]),
+    "cp_device_count": (_c_int, [ctypes.POINTER(_c_int)]),
+    "cp_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_vp)]),
+    "cp_ctx_destroy": (_c_int, [_vp]),
+    "cp_ctx_set_stream": (_c_int, [_vp, _vp]),
+    "cp_sync": (_c_int, [_vp]),
+    "cp_malloc": (_c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "cp_free": (_c_int, [_vp, _vp]),
+    "cp_memcpy_h2d": (_c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "cp_memcpy_d2h": (_c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "cp_memset": (_c_int, [_vp, _vp, _c_int, ctypes.c_size_t]),
+    "cp_patch_gather": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int,
+                                 _c_int, _c_int, _vp, _c_i64]),
+    "cp_assemble_y": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _vp]),
+    "cp_lasso_gram": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
+                               _vp, _vp, _vp]),
+    "cp_enet_cd_gram": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _c_int, _c_dbl, _c_dbl, _c_u32, _c_int, _c_dbl,
+                                 _c_int, _vp, ctypes.POINTER(CdResult)]),
+    "cp_lasso_alpha_search": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _c_int, _c_dbl, _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                       _vp, _c_int, _c_int, _c_dbl, _c_int, _vp, ctypes.POINTER(_c_int),
+                                       ctypes.POINTER(_c_dbl), _vp, _vp]),
+    "cp_lstsq_refit": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _c_dbl, _vp, _vp,
+                                ctypes.POINTER(RefitInfo)]),
+    "cp_probe_mfma_f64": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
+    "cp_probe_hbm_copy": (_c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_c_dbl)]),
+    "cp_last_stage_times": (_c_int, [_vp, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_float)]),
+    "cp_stage_name": (ctypes.c_char_p, [_vp, _c_int]),
+    "cp_enable_stage_timing": (_c_int, [_vp, _c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libcpmi355.so (never falls back to anything else)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError("libcpmi355.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C channel-pruning_amd/csrc` (expected at %s)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _strerror(code):
+    try:
+        return load().cp_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return "error"
+
+
+def _ptr(x):
+    """device pointer of a DevBuf / torch tensor / int; host pointer of a numpy array."""
+    if x is None:
+        return None
+    if isinstance(x, DevBuf):
+        return x.ptr
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+class DevBuf:
+    """A device allocation owned by a Context (cp_malloc / cp_free)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = _vp()
+        ctx._check(ctx.lib.cp_malloc(ctx.h, self.nbytes, ctypes.byref(p)), "cp_malloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            self.ctx.lib.cp_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + one stream (cp_ctx).  Create it inside the process that uses it."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.cp_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise CpError(rc, "cp_ctx_create(device=%d)" % device,
+                          "a gfx950 (MI355X) device is required; there is no CPU fallback")
+        self.h = h.value
+        self.device = int(device)
+        self.pid = os.getpid()
+
+    def close(self):
+        if getattr(self, "h", None) and self.pid == os.getpid():
+            self.lib.cp_ctx_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CpError(rc, what, self.lib.cp_last_error(self.h).decode() if self.h else "")
+
+    # -- memory ---------------------------------------------------------------------
+    def empty(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def to_device(self, arr, buf=None):
+        arr = np.ascontiguousarray(arr)
+        if buf is None:
+            buf = DevBuf(self, max(arr.nbytes, 8))
+        assert buf.nbytes >= arr.nbytes
+        self._check(self.lib.cp_memcpy_h2d(self.h, buf.ptr, arr.ctypes.data, arr.nbytes), "cp_memcpy_h2d")
+        return buf
+
+    def to_host(self, buf, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._check(self.lib.cp_memcpy_d2h(self.h, out.ctypes.data, _ptr(buf), out.nbytes), "cp_memcpy_d2h")
+        return out
+
+    def zeros(self, nbytes):
+        b = DevBuf(self, nbytes)
+        self._check(self.lib.cp_memset(self.h, b.ptr, 0, nbytes), "cp_memset")
+        return b
+
+    def sync(self):
+        self._check(self.lib.cp_sync(self.h), "cp_sync")
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.cp_ctx_set_stream(self.h, stream_ptr), "cp_ctx_set_stream")
+
+    # -- hot path -------------------------------------------------------------------
+    def patch_gather(self, fmap, B, C, H, W, xs, ys, k, pad, stride, relu, X_out, row0):
+        xs = np.ascontiguousarray(xs, dtype=np.int32)
+        ys = np.ascontiguousarray(ys, dtype=np.int32)
+        self._check(self.lib.cp_patch_gather(self.h, _ptr(fmap), B, C, H, W, xs.ctypes.data, ys.ctypes.data,
+                                             xs.shape[0], k, pad, stride, int(bool(relu)), _ptr(X_out),
+                                             int(row0)), "cp_patch_gather")
+
+    def assemble_y(self, feats, bias, resY, N, n, Y):
+        self._check(self.lib.cp_assemble_y(self.h, _ptr(feats), _ptr(bias), _ptr(resY), int(N), int(n), _ptr(Y)),
+                    "cp_assemble_y")
+
+    def lasso_gram(self, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, Q, q, stats):
+        samples = np.ascontiguousarray(samples, dtype=np.int64)
+        self._check(self.lib.cp_lasso_gram(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), _ptr(W2), w_dtype,
+                                           int(n), _ptr(Y), samples.ctypes.data, samples.shape[0], _ptr(Q),
+                                           _ptr(q), _ptr(stats)), "cp_lasso_gram")
+
+    def enet_cd_gram(self, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, w, max_iter=1000, tol=1e-4, flags=0):
+        res = CdResult()
+        self._check(self.lib.cp_enet_cd_gram(self.h, _ptr(Q), int(ldq), _ptr(q), _ptr(stats), int(c),
+                                             float(l1_reg), float(l2_reg), int(seed), int(max_iter), float(tol),
+                                             int(flags), _ptr(w), ctypes.byref(res)), "cp_enet_cd_gram")
+        return res
+
+    def lasso_alpha_search(self, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound, seeds, w,
+                           max_iter=1000, tol=1e-4, flags=0):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        mf = seeds.shape[0]
+        fits_used = _c_int()
+        alpha_out = _c_dbl()
+        log = (CdResult * mf)()
+        alphas = np.zeros(mf, dtype=np.float64)
+        self._check(self.lib.cp_lasso_alpha_search(self.h, _ptr(Q), int(ldq), _ptr(q), _ptr(stats), int(c),
+                                                   float(M), float(alpha_right0), float(rank), float(lbound),
+                                                   float(rbound), seeds.ctypes.data, mf, int(max_iter), float(tol),
+                                                   int(flags), _ptr(w), ctypes.byref(fits_used),
+                                                   ctypes.byref(alpha_out), ctypes.cast(log, _vp),
+                                                   alphas.ctypes.data), "cp_lasso_alpha_search")
+        nf = fits_used.value
+        fits = [(float(alphas[i]), int(log[i].nnz), int(log[i].n_iter)) for i in range(nf)]
+        return nf, alpha_out.value, fits
+
+    def lstsq_refit(self, X, x_dtype, N, c, kk, mask, Y, n, ridge, W_out, b_out):
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        info = RefitInfo()
+        self._check(self.lib.cp_lstsq_refit(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), mask.ctypes.data,
+                                            _ptr(Y), int(n), float(ridge), _ptr(W_out), _ptr(b_out),
+                                            ctypes.byref(info)), "cp_lstsq_refit")
+        return info
+
+    # -- measurement ------------------------------------------------------------------
+    def probe_mfma_f64(self):
+        v = _c_dbl()
+        self._check(self.lib.cp_probe_mfma_f64(self.h, ctypes.byref(v)), "cp_probe_mfma_f64")
+        return v.value
+
+    def probe_hbm_copy(self, nbytes=1 << 30):
+        v = _c_dbl()
+        self._check(self.lib.cp_probe_hbm_copy(self.h, int(nbytes), ctypes.byref(v)), "cp_probe_hbm_copy")
+        return v.value
+
+    def enable_stage_timing(self, on=True):
+        self._check(self.lib.cp_enable_stage_timing(self.h, int(bool(on))), "cp_enable_stage_timing")
+
+    def last_stage_times(self):
+        cnt = _c_int()
+        ms = (ctypes.c_float * CP_MAX_STAGES)()
+        self._check(self.lib.cp_last_stage_times(self.h, ctypes.byref(cnt), ms), "cp_last_stage_times")
+        return [(self.lib.cp_stage_name(self.h, i).decode(), float(ms[i])) for i in range(cnt.value)]
+
+
+def device_count():
+    n = _c_int()
+    load().cp_device_count(ctypes.byref(n))
+    return n.value
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Per-process (fork-safe) default context on `device` (default: CP_DEVICE or 0)."""
+    if device is None:
+        device = int(os.environ.get("CP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    key = (os.getpid(), device)
+    ctx = _default_ctx.get(key)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[key] = ctx
+    return ctx

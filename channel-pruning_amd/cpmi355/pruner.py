@@ -1,0 +1,173 @@
+"""Device-resident driver of one channel-pruning problem (one producer/consumer conv pair).
+
+Mirrors the control flow of the reference's ``dictionary()`` (lib/decompose.py:386-634)
+with the arithmetic on the GPU.  Everything that touches NumPy's RNG stays on the host and
+consumes the stream exactly as the reference does:
+  draw 1        samples = rng.randint(0, N, min(400, N // 20))          decompose.py:425
+  draw 2..F+1   one seed per Lasso.fit: rng.randint(0, 2147483647)      _cd_fast.pyx:164
+The alpha search itself (bracket doubling + bisection, decompose.py:490-525) runs either
+  mode="device": one kernel launch for the whole search; the host pre-draws MAX_FITS seeds,
+                 then rewinds the RNG and re-draws exactly the number of seeds the search
+                 consumed, so the RNG state after the call equals the reference's;
+  mode="host":   one launch per fit, the host deciding the next alpha (debug / logging).
+"""
+import numpy as np
+
+from . import capi
+
+RAND_R_MAX = 2147483647  # sklearn/linear_model/_cd_fast.pyx:26
+MAX_FITS = 64
+
+
+def _np_dtype_code(arr):
+    if arr.dtype == np.float32:
+        return capi.CP_F32
+    if arr.dtype == np.float64:
+        return capi.CP_F64
+    raise TypeError("X/W2 must be float32 or float64, got %s" % arr.dtype)
+
+
+class LayerProblem:
+    """X[N,c,k,k], W2[n,c,k,k], Y[N,n] resident in HBM plus the small per-layer outputs."""
+
+    def __init__(self, ctx, X, W2, Y, flags=0):
+        self.ctx = ctx
+        X = np.ascontiguousarray(X)
+        W2 = np.ascontiguousarray(W2)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        if W2.dtype not in (np.float32, np.float64):
+            W2 = W2.astype(np.float64)
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        self.N, self.c = int(X.shape[0]), int(X.shape[1])
+        self.kk = int(np.prod(X.shape[2:])) if X.ndim > 2 else 1
+        self.k = int(X.shape[2]) if X.ndim > 2 else 1
+        self.n = int(W2.shape[0])
+        if W2.shape[1] != self.c or int(np.prod(W2.shape[2:])) != self.kk or Y.shape != (self.N, self.n):
+            raise ValueError("inconsistent shapes X%s W2%s Y%s" % (X.shape, W2.shape, Y.shape))
+        self.x_dtype, self.w_dtype = _np_dtype_code(X), _np_dtype_code(W2)
+        self.h2d_bytes = X.nbytes + W2.nbytes + Y.nbytes
+        self.Xd = ctx.to_device(X)
+        self.W2d = ctx.to_device(W2)
+        self.Yd = ctx.to_device(Y)
+        c, n = self.c, self.n
+        self.Qd = ctx.empty(c * c * 8)
+        self.qd = ctx.empty(c * 8)
+        self.statsd = ctx.empty(4 * 8)
+        self.wd = ctx.zeros(c * 8)
+        self.Wout = ctx.empty(n * c * self.kk * 8)
+        self.bout = ctx.empty(n * 8)
+        self.flags = flags
+        self.S = 0
+        self.fits = []          # [(alpha, nnz, n_iter)] of the last search
+        self.refit_info = None
+
+    # -- decompose.py:425-437 + Lasso.fit preprocessing ------------------------------
+    def lasso_gram(self, samples):
+        self.S = int(len(samples))
+        self.ctx.lasso_gram(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype, self.n,
+                            self.Yd, samples, self.Qd, self.qd, self.statsd)
+
+    @property
+    def M(self):
+        return float(self.S * self.n)
+
+    def reset_w(self):
+        self.ctx._check(self.ctx.lib.cp_memset(self.ctx.h, self.wd.ptr, 0, self.c * 8), "cp_memset")
+
+    # -- decompose.py:453-466: one solve(alpha) -----------------------------------------
+    def solve(self, alpha, seed):
+        r = self.ctx.enet_cd_gram(self.Qd, self.c, self.qd, self.statsd, self.c, alpha * self.M, 0.0, seed,
+                                  self.wd, flags=self.flags)
+        self.fits.append((float(alpha), int(r.nnz), int(r.n_iter)))
+        return int(r.nnz)
+
+    def mask(self):
+        w = self.ctx.to_host(self.wd, (self.c,), np.float64)
+        return w != 0.
+
+    # -- decompose.py:490-525 -----------------------------------------------------------
+    def alpha_search(self, rank, alpha_right0, rank_tol, rng, mode="device"):
+        lbound = rank
+        if rank_tol >= 1:
+            rbound = rank + rank_tol
+        else:
+            rbound = rank + rank_tol * rank
+            if rank_tol == .2:            # decompose.py:498-501
+                lbound = rank + 0.1 * rank
+                rbound = rank + 0.2 * rank
+        self.fits = []
+        self.reset_w()
+        if mode == "device":
+            state = rng.get_state()
+            seeds = np.array([rng.randint(0, RAND_R_MAX) for _ in range(MAX_FITS)], dtype=np.uint32)
+            try:
+                nf, alpha, fits = self.ctx.lasso_alpha_search(self.Qd, self.c, self.qd, self.statsd, self.c, self.M,
+                                                              alpha_right0, rank, lbound, rbound, seeds, self.wd,
+                                                              flags=self.flags)
+            except capi.CpError as e:
+                if e.code != -5:
+                    raise
+                nf = -1
+            rng.set_state(state)
+            if nf > 0:
+                for _ in range(nf):        # consume exactly what the reference would have
+                    rng.randint(0, RAND_R_MAX)
+                self.fits = fits
+                return alpha
+            self.reset_w()                 # did not settle within MAX_FITS: replay fit by fit
+        left, right = 0, alpha_right0
+        while True:
+            tmp = self.solve(right, rng.randint(0, RAND_R_MAX))
+            if tmp < rank:
+                break
+            right *= 2
+        while True:
+            alpha = (left + right) / 2
+            tmp = self.solve(alpha, rng.randint(0, RAND_R_MAX))
+            if tmp > rbound:
+                left = alpha
+            elif tmp < lbound:
+                right = alpha
+            else:
+                break
+        return alpha
+
+    # -- decompose.py:622-623 -> fc_kernel ------------------------------------------------
+    def refit(self, idxs, ridge=0.0):
+        idxs = np.asarray(idxs, dtype=bool)
+        info = self.ctx.lstsq_refit(self.Xd, self.x_dtype, self.N, self.c, self.kk, idxs.astype(np.uint8), self.Yd,
+                                    self.n, ridge, self.Wout, self.bout)
+        self.refit_info = info
+        p = int(info.p)
+        W = self.ctx.to_host(self.Wout, (self.n, p), np.float64)
+        b = self.ctx.to_host(self.bout, (self.n,), np.float64)
+        return W, b
+
+    def free(self):
+        for name in ("Xd", "W2d", "Yd", "Qd", "qd", "statsd", "wd", "Wout", "bout"):
+            buf = getattr(self, name, None)
+            if buf is not None:
+                buf.free()
+
+
+GLOBAL_RNG = np.random  # module-level legacy RandomState: randint / get_state / set_state
+
+
+def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="device", alpha_arg=1e-4):
+    """dictionary() on a resident LayerProblem -> (idxs, newW2[n,nnz,k,k], newB2, alpha_out)."""
+    rng = GLOBAL_RNG if rng is None else rng
+    N, c, n, k = prob.N, prob.c, prob.n, prob.k
+    samples = rng.randint(0, N, min(400, N // 20))               # decompose.py:425
+    prob.samples = samples
+    if rank == c:                                                 # decompose.py:487-488
+        idxs = np.array([True] * rank)
+        alpha = alpha_arg
+        prob.fits = []
+    else:
+        prob.lasso_gram(samples)
+        alpha = prob.alpha_search(rank, alpha_in, rank_tol, rng, mode=mode)
+        idxs = prob.mask()
+    W, b = prob.refit(idxs, ridge=ridge)
+    nnz = int(idxs.sum())
+    return idxs, W.reshape((n, nnz, k, k)), b, alpha

@@ -1,0 +1,484 @@
+// Coordinate-descent LASSO on the Gram matrix: the device form of
+// sklearn.linear_model._cd_fast.enet_coordinate_descent_gram (_cd_fast.pyx:564-737), which is
+// what Lasso.fit(Z, reY) inside solve() (lib/decompose.py:453-466) reduces to once
+// Q = Zc^T Zc, q = Zc^T yc are available (cp_lasso_gram).  The coordinate order is sklearn's
+// our_rand_r xorshift32 (sklearn/utils/_random.pxd:20-35) so the visit sequence, the epoch
+// count and therefore the zero pattern of w are those of the reference.
+//
+// Execution model.  The sweep is a strictly sequential dependency chain (every coordinate
+// update needs H = Q w as left by the previous one), so it is latency- not bandwidth- or
+// MFMA-bound.  ONE wavefront runs the whole fit (or the whole alpha search): no barriers, no
+// inter-workgroup traffic.
+//   * H lives in registers: lane l holds H[l + 64 r], r < R (R = ceil(c/64), template).
+//   * The visit order does not depend on the data, so the RNG runs D steps ahead on the
+//     scalar unit and row Q[ii,:] of every future step is already in flight (register ring of
+//     D slots, L2-resident Q) when the chain reaches it.
+//   * w, q and diag(Q) sit in LDS; the scalar operands of a step (w_ii, q_ii, Q_ii) are
+//     uniform ds_reads issued one step early, H_ii comes out of the register file with one
+//     v_readlane pair.
+//   * Every multiply-add that sklearn's daxpy performs is an explicit fma, in the same order,
+//     so w is bit-identical to oracle/cd_oracle.c::cpo_enet_cd_gram (the epoch-end dual-gap
+//     reductions are tree-ordered and only feed the stopping test).
+#include "cp_common.h"
+#include "xorshift_jump.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double u = __shfl_xor(v, o, WAVE);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+
+// uniform-lane read of a double held in `v` (lane index is wave-uniform)
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+
+// 8-byte row-element load: SGPR descriptor + SGPR row offset + per-lane column offset.  No
+// address arithmetic on the vector unit, and the load stays on the vector-memory path (an
+// s_load would share lgkmcnt with the LDS reads and force full drains).
+__device__ __forceinline__ double load_q(__amdgpu_buffer_rsrc_t rsrc, uint32_t col_bytes, uint32_t row_bytes) {
+    const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col_bytes, row_bytes, 0);
+    return __hiloint2double(int(v[1]), int(v[0]));
+}
+
+// Coordinate stream rand_int(c) of _cd_fast.pyx:30-32, produced 64 values at a time
+// (xorshift_jump.h): lane l of `idx`/`off` holds the coordinate / row byte offset of value
+// 64*batch + l; `pos` (wave-uniform) is the next lane to hand out.
+struct IdxStream {
+    uint32_t st, idx, off;
+    uint32_t n, row_stride_bytes;
+    uint64_t magic;
+    __device__ __forceinline__ void derive() {
+        idx = cpx::fastmod(st & 0x7fffffffu, magic, n);
+        off = idx * row_stride_bytes;
+    }
+    __device__ __forceinline__ void init(uint32_t seed, uint32_t n_, uint32_t row_stride_bytes_, int lane) {
+        n = n_;
+        row_stride_bytes = row_stride_bytes_;
+        magic = cpx::fastmod_magic(n_);
+        uint32_t s = seed == 0 ? 1u : seed;  // _random.pxd:24-25
+        for (int i = 0; i <= lane; ++i) s = cpx::xs_step(s);
+        st = s;
+        derive();
+    }
+    // value number `pos` (wave-uniform, < 64) of the current batch
+    __device__ __forceinline__ void take(int pos, int &ii, uint32_t &row_off) const {
+        ii = __builtin_amdgcn_readlane(int(idx), pos);
+        row_off = uint32_t(__builtin_amdgcn_readlane(int(off), pos));
+    }
+    __device__ __forceinline__ void next_batch() {
+        st = cpx::xs_jump64(st);
+        derive();
+    }
+    // drop the first k (< 64) values of the batch: lane l takes over value l + k
+    __device__ __forceinline__ void realign(int k, int lane) {
+        const uint32_t rot = uint32_t(__shfl(int(st), (lane + k) & 63, WAVE));
+        const uint32_t adv = cpx::xs_jump64(rot);
+        st = lane + k >= 64 ? adv : rot;
+        derive();
+    }
+};
+
+struct FitOut {
+    double gap;
+    int n_iter;
+    int nnz;
+};
+
+template <int R>
+struct Ring {
+    // steps per register set; two sets ping-pong, so a row is requested D..2D steps before use
+    static constexpr int D = R <= 2 ? 8 : (R <= 8 ? 4 : (R <= 16 ? 2 : 1));
+};
+
+// Everything step t needs except w_ii and H_ii, fetched >= D steps early.
+template <int R>
+struct Slot {
+    int ii;
+    double row[R];  // Q[ii, lane + 64 r]
+    double qi, Qii, den;
+};
+
+// One fit.  w_lds holds the warm start on entry and the solution on exit.
+// feat[4 j + {0,1,2}] = { q[j], Q[j,j], Q[j,j] + beta (or its reciprocal, CP_CD_RECIPROCAL) }.
+template <int R>
+__device__ __forceinline__ FitOut cd_fit(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
+                                         uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
+                                         double y_norm2, int recip, double *w_lds, const double *feat) {
+    constexpr int D = Ring<R>::D;
+    const int lane = threadIdx.x;
+    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    // lanes past the last column re-read column c-1: their H entries are never consumed
+    uint32_t colb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int col = r * WAVE + lane;
+        colb[r] = uint32_t(col < c ? col : c - 1) * 8u;
+    }
+    double H[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) H[r] = 0.0;
+
+    // H = Q w, accumulated row by row in index order (cpo_enet_cd_gram does the same).
+    constexpr int U = R <= 4 ? 8 : (R <= 8 ? 4 : (R <= 16 ? 2 : 1));
+    for (int j0 = 0; j0 < c; j0 += U) {
+        double row[U][R];
+        double wj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u;
+            wj[u] = j < c ? w_lds[j] : 0.0;
+            const uint32_t roff = uint32_t(j < c ? j : c - 1) * row_stride_bytes;
+#pragma unroll
+            for (int r = 0; r < R; ++r) row[u][r] = load_q(rsrc, colb[r], roff);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (wj[u] != 0.0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(wj[u], row[u][r], H[r]);
+            }
+    }
+
+    IdxStream rng;
+    rng.init(seed, uint32_t(c), row_stride_bytes, lane);
+    int pos = 0;  // first unconsumed value of the current 64-value index batch (multiple of D)
+
+    Slot<R> A[D], B[D];
+    auto fill = [&](Slot<R>(&S)[D]) {  // request the next D steps' operands
+        if (pos == 64) {
+            rng.next_batch();
+            pos = 0;
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            int ii;
+            uint32_t roff;
+            rng.take(pos + d, ii, roff);
+            S[d].ii = ii;
+#pragma unroll
+            for (int r = 0; r < R; ++r) S[d].row[r] = load_q(rsrc, colb[r], roff);
+            const double2 qQ = *reinterpret_cast<const double2 *>(feat + 4 * ii);
+            S[d].qi = qQ.x;
+            S[d].Qii = qQ.y;
+            S[d].den = feat[4 * ii + 2];
+        }
+        pos += D;
+    };
+    // Make the compiler drain a set's loads here (they were issued >= D steps ago), so that no
+    // load is in flight across the loop back-edge: a loop-carried pending load would be waited
+    // for with vmcnt(0) at its first use, which would also wait for the set requested just
+    // before it.
+    auto settle = [&](Slot<R>(&S)[D]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(S[d].row[r]));
+        }
+    };
+
+    FitOut out;
+    out.gap = tol_scaled + 1.0;
+    out.n_iter = 0;
+    int n_iter = 0, f = 0;
+    double w_max = 0.0, d_w_max = 0.0;
+
+    // end of epoch, _cd_fast.pyx:684-731; returns true when the fit is finished
+    auto epoch_end = [&]() -> bool {
+        bool done = false;
+        if (w_max == 0.0 || d_w_max / w_max < d_w_tol || n_iter == max_iter - 1) {
+            double s_qw = 0, s_wh = 0, s_ww = 0, s_l1 = 0, m_xta = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int col = r * WAVE + lane;
+                if (col < c) {
+                    const double wv = w_lds[col], qv = feat[4 * col];
+                    const double xta = qv - H[r] - beta * wv;
+                    s_qw += wv * qv;
+                    s_wh += wv * H[r];
+                    s_ww += wv * wv;
+                    s_l1 += fabs(wv);
+                    m_xta = fmax(m_xta, fabs(xta));
+                }
+            }
+            const double q_dot_w = wave_sum(s_qw), wh = wave_sum(s_wh), w_norm2 = wave_sum(s_ww),
+                         l1 = wave_sum(s_l1), dual_norm = wave_max(m_xta);
+            const double R_norm2 = y_norm2 + wh - 2.0 * q_dot_w;
+            double const_, gap;
+            if (dual_norm > alpha) {
+                const_ = alpha / dual_norm;
+                const double A_norm2 = R_norm2 * (const_ * const_);
+                gap = 0.5 * (R_norm2 + A_norm2);
+            } else {
+                const_ = 1.0;
+                gap = R_norm2;
+            }
+            gap += alpha * l1 - const_ * y_norm2 + const_ * q_dot_w + 0.5 * beta * (1.0 + const_ * const_) * w_norm2;
+            out.gap = gap;
+            if (gap < tol_scaled) done = true;
+        }
+        ++n_iter;
+        w_max = 0.0;
+        d_w_max = 0.0;
+        f = 0;
+        return done || n_iter == max_iter;
+    };
+
+    fill(A);
+    double w_cur = w_lds[A[0].ii];  // w_ii of the step about to run
+
+    // one coordinate update (_cd_fast.pyx:644-682); `nx` is the slot of the following step
+    auto step = [&](const Slot<R> &S, const Slot<R> &nx) -> bool {
+        const int ii = S.ii;
+        const int ii_next = nx.ii;
+        const double w_pre = w_lds[ii_next];  // issued early; patched below if ii_next == ii
+        const double Qii = S.Qii;
+        double w_next = w_pre;
+        if (Qii != 0.0) {  // _cd_fast.pyx:651
+            const double w_ii = w_cur;
+            const int r_ii = ii >> 6, l_ii = ii & 63;
+            double hsel = H[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) hsel = (r == r_ii) ? H[r] : hsel;
+            double H_ii = read_lane(hsel, l_ii);
+            if (w_ii != 0.0) {  // H -= w_ii * Q[ii]
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(-w_ii, S.row[r], H[r]);
+                H_ii = fma(-w_ii, Qii, H_ii);
+            }
+            const double tmp = S.qi - H_ii;
+            // fsign(tmp) * fmax(|tmp| - alpha, 0)
+            const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+            const double w_new = recip ? thr * S.den : thr / S.den;
+            if (w_new != 0.0) {  // H += w[ii] * Q[ii]
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(w_new, S.row[r], H[r]);
+            }
+            if (lane == 0) w_lds[ii] = w_new;
+            d_w_max = fmax(d_w_max, fabs(w_new - w_ii));
+            w_max = fmax(w_max, fabs(w_new));
+            w_next = (ii_next == ii) ? w_new : w_pre;
+        }
+        w_cur = w_next;
+        if (++f == c) return epoch_end();
+        return false;
+    };
+
+    for (;;) {
+        fill(B);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (step(A[d], d + 1 < D ? A[d + 1] : B[0])) goto fit_done;
+        fill(A);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (step(B[d], d + 1 < D ? B[d + 1] : A[0])) goto fit_done;
+        settle(A);
+    }
+fit_done:
+    out.n_iter = n_iter;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int col = r * WAVE + lane;
+        cnt += (col < c && w_lds[col] != 0.0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+    out.nnz = cnt;
+    return out;
+}
+
+// LDS image shared by both kernels: w[c] | feat[4 c]
+__device__ __forceinline__ void load_features(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
+                                              const double *__restrict__ w_in, int c, double l2, int flags,
+                                              double *w_lds, double *feat) {
+    for (int j = threadIdx.x; j < c; j += WAVE) {
+        const double dj = Q[size_t(j) * ldq + j];
+        w_lds[j] = w_in ? w_in[j] : 0.0;
+        feat[4 * j + 0] = q[j];
+        feat[4 * j + 1] = dj;
+        feat[4 * j + 2] = (flags & CP_CD_RECIPROCAL) ? 1.0 / (dj + l2) : dj + l2;
+        feat[4 * j + 3] = 0.0;
+    }
+    __syncthreads();
+}
+
+struct DevResult {  // mirrors cp_cd_result
+    double gap;
+    double tol_scaled;
+    int32_t n_iter;
+    int32_t nnz;
+};
+
+template <int R>
+__global__ void __launch_bounds__(WAVE) k_cd_fit(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
+                                                 const double *__restrict__ stats, int c, double l1, double l2,
+                                                 uint32_t seed, int max_iter, double tol, int flags,
+                                                 double *__restrict__ w, DevResult *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *feat = smem, *w_lds = smem + 4 * c;
+    load_features(Q, ldq, q, w, c, l2, flags, w_lds, feat);
+    const double y_norm2 = stats[0];
+    const double tol_scaled = tol * y_norm2;
+    FitOut o = cd_fit<R>(Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, flags & CP_CD_RECIPROCAL,
+                         w_lds, feat);
+    __syncthreads();
+    for (int j = threadIdx.x; j < c; j += WAVE) w[j] = w_lds[j];
+    if (threadIdx.x == 0) {
+        res->gap = o.gap;
+        res->tol_scaled = tol_scaled;
+        res->n_iter = o.n_iter;
+        res->nnz = o.nnz;
+    }
+}
+
+// Whole alpha search of lib/decompose.py:490-525 on the device.
+template <int R>
+__global__ void __launch_bounds__(WAVE)
+k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
+            int c, double M, double right0, double rank, double lbound, double rbound,
+            const uint32_t *__restrict__ seeds, int max_fits, int max_iter, double tol, int flags,
+            double *__restrict__ w, DevResult *__restrict__ log, double *__restrict__ log_alpha,
+            int *__restrict__ fits_used, double *__restrict__ alpha_out) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *feat = smem, *w_lds = smem + 4 * c;
+    load_features(Q, ldq, q, nullptr, c, 0.0, flags, w_lds, feat);
+    const double y_norm2 = stats[0];
+    const double tol_scaled = tol * y_norm2;
+    int fit = 0;
+    double left = 0.0, right = right0, alpha = right0;
+    bool bracketing = true, ok = false;
+    while (fit < max_fits) {
+        alpha = bracketing ? right : (left + right) / 2;
+        FitOut o = cd_fit<R>(Q, ldq, c, alpha * M, 0.0, seeds[fit], max_iter, tol_scaled, tol, y_norm2,
+                             flags & CP_CD_RECIPROCAL, w_lds, feat);
+        if (threadIdx.x == 0) {
+            log[fit].gap = o.gap;
+            log[fit].tol_scaled = tol_scaled;
+            log[fit].n_iter = o.n_iter;
+            log[fit].nnz = o.nnz;
+            log_alpha[fit] = alpha;
+        }
+        ++fit;
+        const double tmp = double(o.nnz);
+        if (bracketing) {  // decompose.py:502-515
+            if (tmp < rank)
+                bracketing = false;
+            else
+                right *= 2;
+        } else {  // decompose.py:516-525
+            if (tmp > rbound)
+                left = alpha;
+            else if (tmp < lbound)
+                right = alpha;
+            else {
+                ok = true;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < c; j += WAVE) w[j] = w_lds[j];
+    if (threadIdx.x == 0) {
+        *fits_used = ok ? fit : -fit;  // negative: ran out of pre-drawn seeds
+        *alpha_out = alpha;
+    }
+}
+
+}  // namespace
+
+#define CP_CD_DISPATCH(KERNEL, R_, ...)                                      \
+    switch (R_) {                                                            \
+        case 1: KERNEL<1><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;   \
+        case 2: KERNEL<2><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;   \
+        case 4: KERNEL<4><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;   \
+        case 8: KERNEL<8><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;   \
+        case 16: KERNEL<16><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break; \
+        default: KERNEL<32><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break; \
+    }
+
+static int pick_R(int c) {
+    int R = 1;
+    while (R * WAVE < c) R *= 2;
+    return R;
+}
+
+extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c,
+                               double l1_reg, double l2_reg, uint32_t seed, int max_iter, double tol, int flags,
+                               double *w, cp_cd_result *result) {
+    if (!ctx || !Q || !q || !stats || !w || !result || c <= 0 || ldq < c || max_iter <= 0) return CP_ERR_ARG;
+    if (c > 32 * WAVE) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d > %d channels", c, 32 * WAVE);
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    CP_TRY(cp_arena_reserve(ctx, 4096));
+    DevResult *dres = reinterpret_cast<DevResult *>(cp_arena_take(ctx, sizeof(DevResult)));
+    const size_t lds = size_t(5) * c * sizeof(double);
+    const int R = pick_R(c);
+    CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
+    CP_LAUNCH_CHECK(ctx);
+    static_assert(sizeof(DevResult) == sizeof(cp_cd_result), "layout");
+    CP_TRY(cp_pinned_reserve(ctx, 4096));
+    CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dres, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(result, ctx->pinned, sizeof(cp_cd_result));
+    return CP_OK;
+}
+
+extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats,
+                                     int c, double M, double alpha_right0, double rank, double lbound, double rbound,
+                                     const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
+                                     double *w, int *fits_used, double *alpha_out, cp_cd_result *fit_log,
+                                     double *fit_alpha) {
+    if (!ctx || !Q || !q || !stats || !w || !seeds || !fits_used || !alpha_out || c <= 0 || ldq < c ||
+        max_fits <= 0 || max_fits > 4096 || max_iter <= 0)
+        return CP_ERR_ARG;
+    if (c > 32 * WAVE) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d > %d channels", c, 32 * WAVE);
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t log_bytes = size_t(max_fits) * sizeof(DevResult), al_bytes = size_t(max_fits) * sizeof(double),
+                 seed_bytes = size_t(max_fits) * sizeof(uint32_t);
+    CP_TRY(cp_arena_reserve(ctx, log_bytes + al_bytes + seed_bytes + 4096));
+    DevResult *dlog = reinterpret_cast<DevResult *>(cp_arena_take(ctx, log_bytes));
+    double *dal = reinterpret_cast<double *>(cp_arena_take(ctx, al_bytes));
+    uint32_t *dseeds = reinterpret_cast<uint32_t *>(cp_arena_take(ctx, seed_bytes));
+    int *dfits = reinterpret_cast<int *>(cp_arena_take(ctx, 64));
+    double *dalpha = reinterpret_cast<double *>(cp_arena_take(ctx, 64));
+    CP_HIP(ctx, hipMemcpyAsync(dseeds, seeds, seed_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const size_t lds = size_t(5) * c * sizeof(double);
+    const int R = pick_R(c);
+    CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound, dseeds, max_fits,
+                   max_iter, tol, flags, w, dlog, dal, dfits, dalpha);
+    CP_LAUNCH_CHECK(ctx);
+    const size_t total = log_bytes + al_bytes + 128;
+    CP_TRY(cp_pinned_reserve(ctx, total));
+    char *h = ctx->pinned;
+    CP_HIP(ctx, hipMemcpyAsync(h, dfits, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(h + 64, dalpha, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(h + 128, dlog, log_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(h + 128 + log_bytes, dal, al_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(fits_used, h, sizeof(int));
+    memcpy(alpha_out, h + 64, sizeof(double));
+    if (fit_log) memcpy(fit_log, h + 128, log_bytes);
+    if (fit_alpha) memcpy(fit_alpha, h + 128 + log_bytes, al_bytes);
+    if (*fits_used < 0)
+        return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search did not terminate within %d fits", max_fits);
+    return CP_OK;
+}

@@ -1,0 +1,78 @@
+// Internal declarations shared by the HIP translation units of libcpmi355.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cpmi355.h"
+
+struct cp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // Grow-only scratch arena: one hipMalloc, re-grown (after a stream sync) when a call
+    // needs more.  All intermediates of one call are carved from it.
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    size_t arena_used = 0;
+    // pinned host staging for small D2H results
+    char *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    char err[512] = {0};
+    // stage timing
+    bool timing = false;
+    int n_stages = 0;
+    hipEvent_t ev[CP_MAX_STAGES + 1] = {};
+    const char *stage_names[CP_MAX_STAGES] = {};
+    float stage_ms[CP_MAX_STAGES] = {};
+    int cu_count = 256;
+};
+
+int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
+
+#define CP_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return cp_set_error((ctx), CP_ERR_HIP, "%s failed: %s (%s:%d)", #call,             \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                    \
+    } while (0)
+
+#define CP_TRY(expr)               \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != CP_OK) return rc_; \
+    } while (0)
+
+#define CP_LAUNCH_CHECK(ctx) CP_HIP(ctx, hipGetLastError())
+
+// arena ------------------------------------------------------------------------------
+int cp_arena_reserve(cp_ctx *ctx, size_t bytes);  // ensure capacity (may sync + realloc); resets used=0
+void *cp_arena_take(cp_ctx *ctx, size_t bytes);   // 256-B aligned carve; nullptr if exhausted
+template <typename T>
+static inline T *cp_arena_take_t(cp_ctx *ctx, size_t count) {
+    return reinterpret_cast<T *>(cp_arena_take(ctx, count * sizeof(T)));
+}
+static inline size_t cp_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int cp_pinned_reserve(cp_ctx *ctx, size_t bytes);
+
+// stage timing -----------------------------------------------------------------------
+void cp_stage_begin(cp_ctx *ctx);                   // resets the stage list, records ev[0]
+void cp_stage_mark(cp_ctx *ctx, const char *name);  // closes the stage that just ran
+void cp_stage_finish(cp_ctx *ctx);                  // after a stream sync: compute ms
+
+// f64 GEMM (gemm_f64.hip) --------------------------------------------------------------
+// C[M,N] = alpha * sum_k A[k,m] * B[k,n] + beta * C   (both operands k-major, "TN").
+// Requirements: M % 128 == 0, N % 128 == 0, K % 16 == 0, lda/ldb/ldc even, 16-B aligned
+// bases.  tri: 0 general, 1 lower tiles only (tile_n <= tile_m) + mirror to the upper
+// part (A and B must then describe the same matrix), 2 upper tiles only (no mirror).
+// Deterministic: split-K partials are reduced in a fixed order.
+enum { CP_TRI_NONE = 0, CP_TRI_LOWER_MIRROR = 1, CP_TRI_UPPER = 2 };
+int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda,
+                   const double *B, int ldb, double beta, double *C, int ldc, int tri);
+size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri);

@@ -1,0 +1,290 @@
+// Context, error reporting, device-memory helpers, stage timing and the two roofline
+// micro-probes of libcpmi355.so.
+#include "cp_common.h"
+
+int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+extern "C" int cp_version(void) { return CP_VERSION; }
+
+extern "C" const char *cp_strerror(int code) {
+    switch (code) {
+        case CP_OK: return "ok";
+        case CP_ERR_ARG: return "invalid argument";
+        case CP_ERR_HIP: return "HIP runtime error";
+        case CP_ERR_NOMEM: return "out of device memory";
+        case CP_ERR_UNSUPPORTED: return "unsupported shape";
+        case CP_ERR_NUMERIC: return "numerical breakdown";
+        case CP_ERR_NODEVICE: return "no gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+extern "C" const char *cp_last_error(const cp_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+
+extern "C" int cp_device_count(int *count) {
+    if (!count) return CP_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        *count = 0;
+        return CP_ERR_NODEVICE;
+    }
+    *count = n;
+    return CP_OK;
+}
+
+extern "C" int cp_ctx_create(int device, cp_ctx **out) {
+    if (!out) return CP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CP_ERR_NODEVICE;
+    if (device < 0 || device >= n) return CP_ERR_ARG;
+    cp_ctx *ctx = new cp_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete ctx;
+        return CP_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->cu_count = prop.multiProcessorCount;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            // The code object only carries gfx950 ISA; any other device cannot run it.
+            delete ctx;
+            return CP_ERR_NODEVICE;
+        }
+    }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return CP_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    for (int i = 0; i <= CP_MAX_STAGES; ++i) hipEventCreate(&ctx->ev[i]);
+    *out = ctx;
+    return CP_OK;
+}
+
+extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
+    if (!ctx) return CP_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    for (int i = 0; i <= CP_MAX_STAGES; ++i)
+        if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return CP_OK;
+}
+
+extern "C" int cp_ctx_set_stream(cp_ctx *ctx, void *hip_stream) {
+    if (!ctx) return CP_ERR_ARG;
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return CP_OK;
+}
+
+extern "C" int cp_sync(cp_ctx *ctx) {
+    if (!ctx) return CP_ERR_ARG;
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CP_OK;
+}
+
+extern "C" int cp_malloc(cp_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return cp_set_error(ctx, CP_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return CP_OK;
+}
+
+extern "C" int cp_free(cp_ctx *ctx, void *dptr) {
+    if (!ctx) return CP_ERR_ARG;
+    if (dptr) CP_HIP(ctx, hipFree(dptr));
+    return CP_OK;
+}
+
+extern "C" int cp_memcpy_h2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return CP_ERR_ARG;
+    // pageable source: hipMemcpyAsync stages it before returning, so the caller may reuse src.
+    CP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return CP_OK;
+}
+
+extern "C" int cp_memcpy_d2h(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return CP_ERR_ARG;
+    CP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CP_OK;
+}
+
+extern "C" int cp_memset(cp_ctx *ctx, void *dst, int value, size_t bytes) {
+    if (!ctx || (bytes && !dst)) return CP_ERR_ARG;
+    CP_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return CP_OK;
+}
+
+// ---- arena ---------------------------------------------------------------------------
+int cp_arena_reserve(cp_ctx *ctx, size_t bytes) {
+    bytes = cp_align_up(bytes + 4096, 1 << 20);
+    if (bytes > ctx->arena_bytes) {
+        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->arena) CP_HIP(ctx, hipFree(ctx->arena));
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->arena), want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(reinterpret_cast<void **>(&ctx->arena), want);
+        }
+        if (e != hipSuccess)
+            return cp_set_error(ctx, CP_ERR_NOMEM, "arena hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        ctx->arena_bytes = want;
+    }
+    ctx->arena_used = 0;
+    return CP_OK;
+}
+
+void *cp_arena_take(cp_ctx *ctx, size_t bytes) {
+    size_t off = cp_align_up(ctx->arena_used, 256);
+    if (off + bytes > ctx->arena_bytes) return nullptr;
+    ctx->arena_used = off + bytes;
+    return ctx->arena + off;
+}
+
+int cp_pinned_reserve(cp_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_bytes) return CP_OK;
+    if (ctx->pinned) {
+        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CP_HIP(ctx, hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    bytes = cp_align_up(bytes, 4096);
+    CP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), bytes, hipHostMallocDefault));
+    ctx->pinned_bytes = bytes;
+    return CP_OK;
+}
+
+// ---- stage timing ----------------------------------------------------------------------
+void cp_stage_begin(cp_ctx *ctx) {
+    ctx->n_stages = 0;
+    if (ctx->timing) hipEventRecord(ctx->ev[0], ctx->stream);
+}
+
+void cp_stage_mark(cp_ctx *ctx, const char *name) {
+    if (!ctx->timing || ctx->n_stages >= CP_MAX_STAGES) return;
+    ctx->stage_names[ctx->n_stages] = name;
+    ++ctx->n_stages;
+    hipEventRecord(ctx->ev[ctx->n_stages], ctx->stream);
+}
+
+void cp_stage_finish(cp_ctx *ctx) {
+    if (!ctx->timing) return;
+    for (int i = 0; i < ctx->n_stages; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]) != hipSuccess) ms = -1.f;
+        ctx->stage_ms[i] = ms;
+    }
+}
+
+extern "C" int cp_enable_stage_timing(cp_ctx *ctx, int on) {
+    if (!ctx) return CP_ERR_ARG;
+    ctx->timing = on != 0;
+    return CP_OK;
+}
+
+extern "C" int cp_last_stage_times(cp_ctx *ctx, int *count, float *ms) {
+    if (!ctx || !count || !ms) return CP_ERR_ARG;
+    *count = ctx->n_stages;
+    for (int i = 0; i < ctx->n_stages; ++i) ms[i] = ctx->stage_ms[i];
+    return CP_OK;
+}
+
+extern "C" const char *cp_stage_name(cp_ctx *ctx, int index) {
+    if (!ctx || index < 0 || index >= ctx->n_stages) return "";
+    return ctx->stage_names[index];
+}
+
+// ---- roofline micro-probes -----------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// 8 independent accumulators per wave, 4 waves per SIMD: measures the sustained issue
+// rate of v_mfma_f64_16x16x4_f64 (2*16*16*4 = 2048 FLOP per wave-instruction).
+__global__ void __launch_bounds__(256) k_probe_mfma_f64(double *out, int iters) {
+    v4f64 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = v4f64{0., 0., 0., 0.};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;  // keep the chain live
+}
+
+extern "C" int cp_probe_mfma_f64(cp_ctx *ctx, double *tflops) {
+    if (!ctx || !tflops) return CP_ERR_ARG;
+    CP_TRY(cp_arena_reserve(ctx, 4096));
+    double *out = cp_arena_take_t<double>(ctx, 8);
+    const int iters = 4000, blocks = ctx->cu_count * 4;
+    hipEvent_t e0, e1;
+    CP_HIP(ctx, hipEventCreate(&e0));
+    CP_HIP(ctx, hipEventCreate(&e1));
+    k_probe_mfma_f64<<<blocks, 256, 0, ctx->stream>>>(out, 100);  // warm-up
+    CP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    k_probe_mfma_f64<<<blocks, 256, 0, ctx->stream>>>(out, iters);
+    CP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    CP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    double flops = double(blocks) * 4 /*waves*/ * iters * 8.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return CP_OK;
+}
+
+__global__ void __launch_bounds__(256) k_probe_copy(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                    size_t n) {
+    size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int cp_probe_hbm_copy(cp_ctx *ctx, size_t bytes, double *gbps) {
+    if (!ctx || !gbps || bytes < (1 << 20)) return CP_ERR_ARG;
+    bytes = bytes / 16 * 16;
+    CP_TRY(cp_arena_reserve(ctx, 2 * bytes + 8192));
+    float4 *src = reinterpret_cast<float4 *>(cp_arena_take(ctx, bytes));
+    float4 *dst = reinterpret_cast<float4 *>(cp_arena_take(ctx, bytes));
+    if (!src || !dst) return cp_set_error(ctx, CP_ERR_NOMEM, "probe arena");
+    CP_HIP(ctx, hipMemsetAsync(src, 1, bytes, ctx->stream));
+    size_t n = bytes / 16;
+    int blocks = ctx->cu_count * 8;
+    hipEvent_t e0, e1;
+    CP_HIP(ctx, hipEventCreate(&e0));
+    CP_HIP(ctx, hipEventCreate(&e1));
+    k_probe_copy<<<blocks, 256, 0, ctx->stream>>>(src, dst, n);
+    CP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) k_probe_copy<<<blocks, 256, 0, ctx->stream>>>(src, dst, n);
+    CP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    CP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *gbps = 2.0 * double(bytes) * reps / (ms * 1e-3) / 1e9;
+    return CP_OK;
+}

@@ -1,0 +1,279 @@
+// f64 "TN" GEMM on v_mfma_f64_16x16x4_f64 for gfx950:
+//     C[M,N] = alpha * sum_k A[k,m] * B[k,n] + beta * C
+// Both operands are k-major (row = k), which is the natural layout of every Gram-type
+// contraction on the pruning path: rows are samples, columns are channels/features
+//   LASSO Gram   Q = Zc^T Zc            (K = S*n,  M = N = c)         lib/decompose.py:434 + Lasso.fit
+//   refit Gram   G = Xc^T Xc, R = Xc^T Yc  (K = N samples)            lib/decompose.py:622 -> LinearRegression
+//   Cholesky trailing updates / block solves (K = 128).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves, 64x64 per wave = 4x4 MFMA
+// tiles, 128 accumulator VGPRs), BK = 16 per LDS stage, next stage prefetched into
+// registers while the current one is multiplied.  LDS rows are padded by 16 doubles so the
+// two k-rows a 32-lane half reads land on disjoint bank halves (ds_read_b64, 64 banks).
+// Small outputs are split along K (multiples of 8 splits; split z of every tile is placed
+// on XCD z % 8 so the tiles that share a k-chunk share an L2) and reduced by a second
+// kernel in a fixed order -> bitwise run-to-run reproducible, no atomics.
+#include "cp_common.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LPAD = 16, LLD = BM + LPAD;  // LLD = 144
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int &ti, int &tj) {
+    if (tri == CP_TRI_NONE) {
+        ti = tile / tiles_n;
+        tj = tile - ti * tiles_n;
+        return;
+    }
+    // row-wise enumeration of the lower triangle: tile = a(a+1)/2 + b, b <= a
+    int a = int((sqrtf(8.f * float(tile) + 1.f) - 1.f) * 0.5f);
+    while ((a + 1) * (a + 2) / 2 <= tile) ++a;
+    while (a * (a + 1) / 2 > tile) --a;
+    int b = tile - a * (a + 1) / 2;
+    if (tri == CP_TRI_LOWER_MIRROR) {
+        ti = a;
+        tj = b;
+    } else {
+        ti = b;
+        tj = a;
+    }
+}
+
+template <int TRI>
+__global__ void __launch_bounds__(NTHREADS, 2)
+k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
+              const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
+              double *__restrict__ P, int splits, int kchunk, int n_tiles, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) double As[BK * LLD];
+    __shared__ __attribute__((aligned(16))) double Bs[BK * LLD];
+
+    const int tid = threadIdx.x;
+    int tile, z;
+    if (splits > 1) {  // XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        z = xcd + 8 * (slot / n_tiles);
+        tile = slot % n_tiles;
+    } else {
+        tile = blockIdx.x;
+        z = 0;
+    }
+    int ti, tj;
+    decode_tile(TRI, tile, tiles_n, ti, tj);
+    const int m0 = ti * BM, n0 = tj * BN;
+    const int k0 = z * kchunk;
+    int k1 = k0 + kchunk;
+    if (k1 > K) k1 = K;
+    const int nk = k1 > k0 ? (k1 - k0) / BK : 0;
+
+    // global -> register staging: thread loads rows (lrow + 4 i), 2 doubles at column lcol
+    const int lrow = tid >> 6, lcol = (tid & 63) * 2;
+    const double *Ag = A + size_t(k0 + lrow) * lda + m0 + lcol;
+    const double *Bg = B + size_t(k0 + lrow) * ldb + n0 + lcol;
+    double2 ar[4], br[4];
+    auto load_tile = [&](int kt) {
+        const double *a = Ag + size_t(kt) * BK * lda;
+        const double *b = Bg + size_t(kt) * BK * ldb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ar[i] = *reinterpret_cast<const double2 *>(a + size_t(4 * i) * lda);
+            br[i] = *reinterpret_cast<const double2 *>(b + size_t(4 * i) * ldb);
+        }
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int fk = lane >> 4, fi = lane & 15;
+
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0., 0., 0., 0.};
+
+    if (nk > 0) load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<double2 *>(&As[(lrow + 4 * i) * LLD + lcol]) = ar[i];
+            *reinterpret_cast<double2 *>(&Bs[(lrow + 4 * i) * LLD + lcol]) = br[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = As[(kk * 4 + fk) * LLD + wm + i * 16 + fi];
+                b[i] = Bs[(kk * 4 + fk) * LLD + wn + i * 16 + fi];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  D layout of v_mfma_f64_16x16x4_f64: lane l, reg r -> row (l>>4) + 4r, col l&15.
+    if (splits > 1) {
+        double *dst = P + size_t(z) * M * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
+                    dst[size_t(row) * N + col] = acc[i][j][r];
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
+                    double v = alpha * acc[i][j][r];
+                    double *c = C + size_t(row) * ldc + col;
+                    if (beta != 0.0) v += beta * *c;
+                    *c = v;
+                }
+    }
+}
+
+// Fixed-order reduction of the split-K partials: C = alpha * sum_z P[z] + beta * C, one
+// 128x128 tile per workgroup; TRI == lower-mirror also writes the transposed element.
+template <int TRI>
+__global__ void __launch_bounds__(NTHREADS)
+k_gemm_reduce(int M, int N, double alpha, const double *__restrict__ P, int splits, double beta,
+              double *__restrict__ C, int ldc, int tiles_n) {
+    int ti, tj;
+    decode_tile(TRI, blockIdx.x, tiles_n, ti, tj);
+    const int m0 = ti * BM, n0 = tj * BN;
+    const size_t plane = size_t(M) * N;
+    for (int e = threadIdx.x; e < BM * BN / 2; e += NTHREADS) {
+        const int r = e / (BN / 2), cc = (e % (BN / 2)) * 2;
+        const size_t off = size_t(m0 + r) * N + n0 + cc;
+        double2 s = {0., 0.};
+        for (int z = 0; z < splits; ++z) {
+            const double2 v = *reinterpret_cast<const double2 *>(P + size_t(z) * plane + off);
+            s.x += v.x;
+            s.y += v.y;
+        }
+        s.x *= alpha;
+        s.y *= alpha;
+        double *c = C + size_t(m0 + r) * ldc + n0 + cc;
+        if (beta != 0.0) {
+            s.x += beta * c[0];
+            s.y += beta * c[1];
+        }
+        c[0] = s.x;
+        c[1] = s.y;
+        if (TRI == CP_TRI_LOWER_MIRROR && ti != tj) {
+            C[size_t(n0 + cc) * ldc + m0 + r] = s.x;
+            C[size_t(n0 + cc + 1) * ldc + m0 + r] = s.y;
+        }
+    }
+}
+
+// splits == 1 lower-triangle product: copy tile (ti,tj), tj < ti, to (tj,ti) transposed.
+__global__ void __launch_bounds__(NTHREADS) k_mirror_lower(double *__restrict__ C, int ldc, int tiles_n) {
+    __shared__ double t[32][33];
+    int ti, tj;
+    decode_tile(CP_TRI_LOWER_MIRROR, blockIdx.x, tiles_n, ti, tj);
+    if (ti == tj) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int br = 0; br < BM; br += 32)
+        for (int bc = 0; bc < BN; bc += 32) {
+            for (int y = ty; y < 32; y += 8) t[y][tx] = C[size_t(ti * BM + br + y) * ldc + tj * BN + bc + tx];
+            __syncthreads();
+            for (int y = ty; y < 32; y += 8) C[size_t(tj * BN + bc + y) * ldc + ti * BM + br + tx] = t[tx][y];
+            __syncthreads();
+        }
+}
+
+struct GemmPlan {
+    int n_tiles, tiles_n, splits, kchunk;
+};
+
+GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri) {
+    GemmPlan p;
+    const int tm = M / BM, tn = N / BN;
+    p.tiles_n = tn;
+    p.n_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
+    const int nk = K / BK;
+    const int target = ctx->cu_count * 2;  // 2 resident workgroups per CU
+    int splits = 1;
+    if (p.n_tiles < target / 2 && nk >= 16) {
+        splits = (target + p.n_tiles - 1) / p.n_tiles;
+        splits = (splits + 7) / 8 * 8;
+        const int max_splits = (nk / 4) / 8 * 8;  // keep >= 4 k-stages per split
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 8) splits = 1;
+    }
+    if (splits > 1) {
+        const int per = (nk + splits - 1) / splits;
+        p.kchunk = per * BK;
+    } else {
+        p.kchunk = K;
+    }
+    p.splits = splits;
+    return p;
+}
+
+}  // namespace
+
+size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri) {
+    GemmPlan p = make_plan(ctx, M, N, K, tri);
+    return p.splits > 1 ? size_t(p.splits) * M * N * sizeof(double) + 256 : 0;
+}
+
+int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
+                   int ldb, double beta, double *C, int ldc, int tri) {
+    if (M <= 0 || N <= 0) return CP_OK;
+    if (M % BM || N % BN || K % BK || (lda & 1) || (ldb & 1) || (tri != CP_TRI_NONE && M != N))
+        return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn: unaligned shape M=%d N=%d K=%d lda=%d ldb=%d", M, N, K, lda,
+                            ldb);
+    GemmPlan p = make_plan(ctx, M, N, K, tri);
+    double *P = nullptr;
+    const size_t arena_mark = ctx->arena_used;  // P is transient: stream order makes reuse safe
+    if (p.splits > 1) {
+        P = cp_arena_take_t<double>(ctx, size_t(p.splits) * M * N);
+        if (!P) return cp_set_error(ctx, CP_ERR_NOMEM, "gemm_tn: arena exhausted (split-K partials)");
+    }
+    const int grid = p.n_tiles * p.splits;
+#define CP_GEMM_LAUNCH(T)                                                                                     \
+    k_gemm_tn_f64<T><<<grid, NTHREADS, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, P,      \
+                                                           p.splits, p.kchunk, p.n_tiles, p.tiles_n)
+    if (tri == CP_TRI_NONE)
+        CP_GEMM_LAUNCH(CP_TRI_NONE);
+    else if (tri == CP_TRI_LOWER_MIRROR)
+        CP_GEMM_LAUNCH(CP_TRI_LOWER_MIRROR);
+    else
+        CP_GEMM_LAUNCH(CP_TRI_UPPER);
+#undef CP_GEMM_LAUNCH
+    CP_LAUNCH_CHECK(ctx);
+    if (p.splits > 1) {
+        if (tri == CP_TRI_NONE)
+            k_gemm_reduce<CP_TRI_NONE><<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,
+                                                                                  ldc, p.tiles_n);
+        else if (tri == CP_TRI_LOWER_MIRROR)
+            k_gemm_reduce<CP_TRI_LOWER_MIRROR><<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits,
+                                                                                          beta, C, ldc, p.tiles_n);
+        else
+            k_gemm_reduce<CP_TRI_UPPER><<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,
+                                                                                   ldc, p.tiles_n);
+        CP_LAUNCH_CHECK(ctx);
+    } else if (tri == CP_TRI_LOWER_MIRROR && p.n_tiles > 1) {
+        k_mirror_lower<<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(C, ldc, p.tiles_n);
+        CP_LAUNCH_CHECK(ctx);
+    }
+    ctx->arena_used = arena_mark;
+    return CP_OK;
+}

@@ -1,0 +1,433 @@
+// Least-squares reconstruction on the kept channels, replacing
+//   fc_kernel(X[:, idxs].reshape(N, -1), Y)                      lib/decompose.py:622, 636-669
+//   -> LinearRegression(fit_intercept=True).fit -> scipy.linalg.lstsq (gelsd)
+//                                                                 sklearn/linear_model/_base.py:591-706
+// i.e. centre X and Y by their column means, coef = argmin ||Xc coef^T - Yc||_F (minimum norm),
+// intercept = ybar - xbar . coef^T (_base.py:300-316); ridge > 0 = the Ridge branch (decompose.py:662).
+//
+// Device formulation (p = kept * kk columns, all float64):
+//   column means (two-stage deterministic reduction)                         HBM bound
+//   Xs = gather(X, kept channels) - xbar,  Yc = Y - ybar  (tile-padded)      HBM bound
+//   G = Xs^T Xs (p x p, f64 MFMA, symmetric half),  R = Xs^T Yc (p x n)      MFMA bound
+//   Cholesky G = U^T U, blocked by 128: diagonal block factorised + inverted in LDS by one
+//   workgroup, panel solve and trailing update are cp_gemm_tn_f64 calls      MFMA / launch bound
+//   block forward / backward substitution with the inverted diagonal blocks  MFMA / launch bound
+// Rank deficiency (dead channels, N < p): a pivot below 1e-10 of its original diagonal flags the
+// factorisation; the solve is then redone as the regularised sandwich
+//   W = (G + eI)^-1 G (G + eI)^-1 R,   e = 1e-11 * max diag(G),
+// which converges to the minimum-norm solution G^+ R that gelsd returns (eigen-directions with
+// lambda >> e are reproduced to 2e/lambda, directions with lambda << e are annihilated; exactly
+// zero columns give exactly zero weights).
+#include "cp_common.h"
+
+namespace {
+
+constexpr int RT = 256;
+constexpr int NB = 128;  // Cholesky block = GEMM tile
+
+template <typename T>
+__device__ __forceinline__ double ldv(const T *p, size_t i) {
+    return double(p[i]);
+}
+
+// ---- column means ----------------------------------------------------------------------
+// part[rb][col] = sum over rows of block rb.  X columns are gathered through chan[].
+template <typename TX>
+__global__ void __launch_bounds__(RT) k_colsum_x(const TX *__restrict__ X, int64_t N, int c, int kk,
+                                                 const int *__restrict__ chan, int p, int rows_per_block,
+                                                 double *__restrict__ part, int ldp) {
+    const int col = blockIdx.x * RT + threadIdx.x;
+    if (col >= p) return;
+    const int a = col / kk, t = col - a * kk;
+    const size_t src = size_t(chan[a]) * kk + t, stride = size_t(c) * kk;
+    const int64_t r0 = int64_t(blockIdx.y) * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    double s = 0;
+    for (int64_t r = r0; r < r1; ++r) s += ldv(X, size_t(r) * stride + src);
+    part[size_t(blockIdx.y) * ldp + col] = s;
+}
+
+__global__ void __launch_bounds__(RT) k_colsum_y(const double *__restrict__ Y, int64_t N, int n, int rows_per_block,
+                                                 double *__restrict__ part, int ldp) {
+    const int col = blockIdx.x * RT + threadIdx.x;
+    if (col >= n) return;
+    const int64_t r0 = int64_t(blockIdx.y) * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    double s = 0;
+    for (int64_t r = r0; r < r1; ++r) s += Y[size_t(r) * n + col];
+    part[size_t(blockIdx.y) * ldp + col] = s;
+}
+
+__global__ void __launch_bounds__(RT) k_mean_finish(const double *__restrict__ part, int nparts, int ldp, int cols,
+                                                    double inv_n, double *__restrict__ mean) {
+    const int col = blockIdx.x * RT + threadIdx.x;
+    if (col >= cols) return;
+    double s = 0;
+    for (int b = 0; b < nparts; ++b) s += part[size_t(b) * ldp + col];
+    mean[col] = s * inv_n;
+}
+
+// ---- gather + centre ---------------------------------------------------------------------
+template <typename TX>
+__global__ void __launch_bounds__(RT) k_gather_center(const TX *__restrict__ X, int64_t N, int c, int kk,
+                                                      const int *__restrict__ chan, int p, int p_pad,
+                                                      const double *__restrict__ xmean, double *__restrict__ Xs) {
+    const int64_t r = blockIdx.x;
+    const size_t stride = size_t(c) * kk;
+    for (int col = threadIdx.x; col < p_pad; col += RT) {
+        double v = 0.0;
+        if (r < N && col < p) {
+            const int a = col / kk, t = col - a * kk;
+            v = ldv(X, size_t(r) * stride + size_t(chan[a]) * kk + t) - xmean[col];
+        }
+        Xs[size_t(r) * p_pad + col] = v;
+    }
+}
+
+__global__ void __launch_bounds__(RT) k_center_y(const double *__restrict__ Y, int64_t N, int n, int n_pad,
+                                                 const double *__restrict__ ymean, double *__restrict__ Yc) {
+    const int64_t r = blockIdx.x;
+    for (int col = threadIdx.x; col < n_pad; col += RT)
+        Yc[size_t(r) * n_pad + col] = (r < N && col < n) ? Y[size_t(r) * n + col] - ymean[col] : 0.0;
+}
+
+// ---- diagonal handling -------------------------------------------------------------------
+// dg0[i] = G[i,i] (original), gmax[0] = max_i dg0[i]; pad rows get G[i,i] = 1.
+__global__ void __launch_bounds__(1024) k_diag_prepare(double *__restrict__ G, int ld, int p, int p_pad, double ridge,
+                                                       double *__restrict__ dg0, double *__restrict__ gmax) {
+    __shared__ double red[16];
+    double m = 0;
+    for (int i = threadIdx.x; i < p_pad; i += blockDim.x) {
+        double d;
+        if (i < p) {
+            d = G[size_t(i) * ld + i] + ridge;
+        } else {
+            d = 1.0;
+        }
+        G[size_t(i) * ld + i] = d;
+        dg0[i] = d;
+        if (i < p) m = fmax(m, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double mm = 0;
+        for (int i = 0; i < int(blockDim.x >> 6); ++i) mm = fmax(mm, red[i]);
+        gmax[0] = mm;
+    }
+}
+
+__global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, int ld, int p,
+                                                        const double *__restrict__ gmax, double rel,
+                                                        double *__restrict__ dg0) {
+    const int i = blockIdx.x * RT + threadIdx.x;
+    if (i >= p) return;
+    const double d = G[size_t(i) * ld + i] + rel * gmax[0];
+    G[size_t(i) * ld + i] = d;
+    dg0[i] = d;
+}
+
+// ---- Cholesky diagonal block: U^T U = A (128 x 128), TI = U^-1, TIT = U^-T ----------------
+// One workgroup; the block lives in LDS (128 x 129 doubles = 132 KB).  Right-looking, column by
+// column, upper triangle only; the strictly-lower triangle of the LDS image then receives
+// (U^-1)^T, one row per thread pair.  info[0] receives 1 + global column of the first pivot
+// <= piv_tol * original diagonal.
+__global__ void __launch_bounds__(RT) k_potrf_diag(double *__restrict__ G, int ld, int blk,
+                                                   const double *__restrict__ dg0, double piv_tol,
+                                                   double *__restrict__ TI, double *__restrict__ TIT,
+                                                   int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int LD = NB + 1;
+    double *A = sm;  // NB x LD
+    const int tid = threadIdx.x;
+    double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
+    for (int e = tid; e < NB * NB; e += RT) {
+        const int r = e / NB, cc = e - r * NB;
+        A[r * LD + cc] = Gb[size_t(r) * ld + cc];
+    }
+    __syncthreads();
+    for (int k = 0; k < NB; ++k) {
+        double piv = A[k * LD + k];
+        const double ref = dg0[blk * NB + k];
+        if (!(piv > piv_tol * ref)) {  // also catches NaN
+            if (tid == 0) atomicCAS(info, 0, blk * NB + k + 1);
+            piv = ref > 0 ? ref : 1.0;  // keep going with a harmless pivot; the result is discarded
+        }
+        const double ukk = sqrt(piv);
+        const double inv = 1.0 / ukk;
+        __syncthreads();
+        // row k of U: U[k, j] = A[k, j] / ukk  (j > k)
+        for (int j = k + 1 + tid; j < NB; j += RT) A[k * LD + j] *= inv;
+        if (tid == 0) A[k * LD + k] = ukk;
+        __syncthreads();
+        // trailing update A[i, j] -= U[k, i] U[k, j], k < i <= j
+        const int rem = NB - k - 1;
+        for (int e = tid; e < rem * rem; e += RT) {
+            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+            if (j >= i) A[i * LD + j] -= A[k * LD + i] * A[k * LD + j];
+        }
+        __syncthreads();
+    }
+    // V = U^-1 (upper): U V = I -> V[i,j] = (delta_ij - sum_{k=i+1..j} U[i,k] V[k,j]) / U[i,i].
+    // Column j is owned by threads (j, j+128): they split the k-sum by parity and combine through
+    // a register exchange (both in the same wave? no: 128 apart) -> use LDS row NB.. instead:
+    // keep it simple and exact-order: ONE thread per column, V[k,j] (k < j) stored at A[j, k].
+    if (tid < NB) {
+        const int j = tid;
+        const double vjj = 1.0 / A[j * LD + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double s = -A[i * LD + j] * vjj;
+            for (int k = i + 1; k < j; ++k) s -= A[i * LD + k] * A[j * LD + k];
+            A[j * LD + i] = s / A[i * LD + i];
+        }
+    }
+    __syncthreads();
+    double *TIb = TI + size_t(blk) * NB * NB, *TITb = TIT + size_t(blk) * NB * NB;
+    for (int e = tid; e < NB * NB; e += RT) {
+        const int r = e / NB, cc = e - r * NB;
+        // V[r, cc] for cc > r lives at A[cc, r]; V[r, r] = 1 / U[r, r]
+        const double v_rc = cc > r ? A[cc * LD + r] : (cc == r ? 1.0 / A[r * LD + r] : 0.0);
+        const double v_cr = r > cc ? A[r * LD + cc] : (cc == r ? 1.0 / A[r * LD + r] : 0.0);
+        Gb[size_t(r) * ld + cc] = cc >= r ? A[r * LD + cc] : 0.0;  // U, strictly-lower part zeroed
+        TIb[e] = v_rc;   // U^-1   (upper)
+        TITb[e] = v_cr;  // U^-T   (lower): TIT[r, cc] = V[cc, r]
+    }
+}
+
+// Lt = U^T (only the upper triangle of U is meaningful; the rest of G holds stale data)
+__global__ void __launch_bounds__(RT) k_transpose_upper(const double *__restrict__ U, int ld, int p_pad,
+                                                        double *__restrict__ Lt) {
+    __shared__ double t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // source tile rows by.., cols bx..
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int y = ty; y < 32; y += 8) {
+        const int r = by + y, cc = bx + tx;
+        t[y][tx] = (cc >= r) ? U[size_t(r) * ld + cc] : 0.0;
+    }
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) Lt[size_t(bx + y) * ld + by + tx] = t[tx][y];
+    (void)p_pad;
+}
+
+// coef[j, col] = W[col, j];  b[j] = ymean[j] - sum_col xmean[col] coef[j, col]
+__global__ void __launch_bounds__(RT) k_finalize(const double *__restrict__ W, int ldw, int p, int n,
+                                                 const double *__restrict__ xmean, const double *__restrict__ ymean,
+                                                 double *__restrict__ coef, double *__restrict__ b) {
+    __shared__ double red[RT / 64];
+    const int j = blockIdx.x;
+    double s = 0;
+    for (int col = threadIdx.x; col < p; col += RT) {
+        const double v = W[size_t(col) * ldw + j];
+        coef[size_t(j) * p + col] = v;
+        s += xmean[col] * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0;
+        for (int i = 0; i < RT / 64; ++i) tot += red[i];
+        b[j] = ymean[j] - tot;
+    }
+    (void)n;
+}
+
+struct Chol {
+    double *G;   // p_pad x p_pad, overwritten by U (upper)
+    double *Lt;  // U^T
+    double *TI, *TIT;
+    double *dg0, *gmax;
+    int *info;
+    int p, p_pad, nblk;
+};
+
+// G = U^T U in place (upper), plus TI/TIT per diagonal block and Lt = U^T.
+int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
+    const int ld = ch.p_pad;
+    CP_HIP(ctx, hipMemsetAsync(ch.info, 0, sizeof(int), ctx->stream));
+    const size_t lds = size_t(NB) * (NB + 1) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KB of dynamic LDS needs an explicit opt-in
+        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_diag),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    for (int b = 0; b < ch.nblk; ++b) {
+        k_potrf_diag<<<1, RT, lds, ctx->stream>>>(ch.G, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
+        CP_LAUNCH_CHECK(ctx);
+        const int rest = (ch.nblk - b - 1) * NB;
+        if (rest > 0) {
+            double *G12 = ch.G + size_t(b) * NB * ld + size_t(b + 1) * NB;
+            // U12 = U11^-T G12 (in place)
+            CP_TRY(cp_gemm_tn_f64(ctx, NB, rest, NB, 1.0, ch.TI + size_t(b) * NB * NB, NB, G12, ld, 0.0, G12, ld,
+                                  CP_TRI_NONE));
+            // G22 -= U12^T U12 (upper tiles)
+            double *G22 = ch.G + size_t(b + 1) * NB * ld + size_t(b + 1) * NB;
+            CP_TRY(cp_gemm_tn_f64(ctx, rest, rest, NB, -1.0, G12, ld, G12, ld, 1.0, G22, ld, CP_TRI_UPPER));
+        }
+    }
+    dim3 tg(ch.p_pad / 32, ch.p_pad / 32);
+    k_transpose_upper<<<tg, RT, 0, ctx->stream>>>(ch.G, ld, ch.p_pad, ch.Lt);
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}
+
+// In place: Rm <- (U^T U)^-1 Rm, Rm is p_pad x n_pad.
+int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, int n_pad) {
+    const int ld = ch.p_pad;
+    for (int b = 0; b < ch.nblk; ++b) {  // U^T y = r
+        double *Rb = Rm + size_t(b) * NB * n_pad;
+        CP_TRY(cp_gemm_tn_f64(ctx, NB, n_pad, NB, 1.0, ch.TI + size_t(b) * NB * NB, NB, Rb, n_pad, 0.0, Rb, n_pad,
+                              CP_TRI_NONE));
+        const int rest = (ch.nblk - b - 1) * NB;
+        if (rest > 0)
+            CP_TRY(cp_gemm_tn_f64(ctx, rest, n_pad, NB, -1.0, ch.G + size_t(b) * NB * ld + size_t(b + 1) * NB, ld, Rb,
+                                  n_pad, 1.0, Rb + size_t(NB) * n_pad, n_pad, CP_TRI_NONE));
+    }
+    for (int b = ch.nblk - 1; b >= 0; --b) {  // U w = y
+        double *Rb = Rm + size_t(b) * NB * n_pad;
+        CP_TRY(cp_gemm_tn_f64(ctx, NB, n_pad, NB, 1.0, ch.TIT + size_t(b) * NB * NB, NB, Rb, n_pad, 0.0, Rb, n_pad,
+                              CP_TRI_NONE));
+        const int above = b * NB;
+        if (above > 0)
+            CP_TRY(cp_gemm_tn_f64(ctx, above, n_pad, NB, -1.0, ch.Lt + size_t(b) * NB * ld, ld, Rb, n_pad, 1.0, Rm,
+                                  n_pad, CP_TRI_NONE));
+    }
+    return CP_OK;
+}
+
+}  // namespace
+
+extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
+                              const double *Y, int n, double ridge, double *W_out, double *b_out,
+                              cp_refit_info *info) {
+    if (!ctx || !X || !mask || !Y || !W_out || !b_out || !info) return CP_ERR_ARG;
+    if (N <= 0 || c <= 0 || kk <= 0 || n <= 0 || ridge < 0) return cp_set_error(ctx, CP_ERR_ARG, "refit: bad sizes");
+    if (x_dtype != CP_F32 && x_dtype != CP_F64) return cp_set_error(ctx, CP_ERR_ARG, "refit: bad dtype");
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int> chan;
+    for (int i = 0; i < c; ++i)
+        if (mask[i]) chan.push_back(i);
+    const int kept = int(chan.size());
+    if (kept == 0) return cp_set_error(ctx, CP_ERR_ARG, "refit: empty mask");
+    const int p = kept * kk;
+    const int p_pad = int(cp_align_up(size_t(p), NB)), n_pad = int(cp_align_up(size_t(n), 128));
+    const int64_t N_pad = int64_t(cp_align_up(size_t(N), 16));
+    const int nblk = p_pad / NB;
+    const int RB = 64;
+    const int rows_per_block = int((N + RB - 1) / RB);
+
+    const size_t xs_b = size_t(N_pad) * p_pad * 8, yc_b = size_t(N_pad) * n_pad * 8, g_b = size_t(p_pad) * p_pad * 8,
+                 r_b = size_t(p_pad) * n_pad * 8, ti_b = size_t(nblk) * NB * NB * 8,
+                 part_b = size_t(RB) * size_t(std::max(p_pad, n_pad)) * 8;
+    size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
+                         cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE));
+    const size_t need = xs_b + yc_b + 3 * g_b + 2 * r_b + 2 * ti_b + part_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 +
+                        size_t(kept) * 4 + ws + (1 << 16);
+    CP_TRY(cp_arena_reserve(ctx, need));
+    double *Xs = cp_arena_take_t<double>(ctx, size_t(N_pad) * p_pad);
+    double *Yc = cp_arena_take_t<double>(ctx, size_t(N_pad) * n_pad);
+    double *G = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
+    double *G0 = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);  // copy of G for the fallback
+    double *Lt = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
+    double *Rm = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
+    double *R2 = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
+    double *TI = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB);
+    double *TIT = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB);
+    double *part = cp_arena_take_t<double>(ctx, size_t(RB) * std::max(p_pad, n_pad));
+    double *xmean = cp_arena_take_t<double>(ctx, p_pad);
+    double *dg0 = cp_arena_take_t<double>(ctx, p_pad);
+    double *gmax = cp_arena_take_t<double>(ctx, 8);
+    double *ymean = cp_arena_take_t<double>(ctx, n_pad);
+    int *dchan = cp_arena_take_t<int>(ctx, kept);
+    int *dinfo = cp_arena_take_t<int>(ctx, 16);
+    if (!Xs || !Yc || !G || !G0 || !Lt || !Rm || !R2 || !TI || !TIT || !part || !xmean || !dg0 || !gmax || !ymean ||
+        !dchan || !dinfo)
+        return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena");
+
+    cp_stage_begin(ctx);
+    CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
+    // column means
+    {
+        dim3 gx((p + RT - 1) / RT, RB), gy((n + RT - 1) / RT, RB);
+        if (x_dtype == CP_F32)
+            k_colsum_x<float><<<gx, RT, 0, ctx->stream>>>(static_cast<const float *>(X), N, c, kk, dchan, p,
+                                                          rows_per_block, part, p_pad);
+        else
+            k_colsum_x<double><<<gx, RT, 0, ctx->stream>>>(static_cast<const double *>(X), N, c, kk, dchan, p,
+                                                           rows_per_block, part, p_pad);
+        CP_LAUNCH_CHECK(ctx);
+        k_mean_finish<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(part, RB, p_pad, p, 1.0 / double(N), xmean);
+        CP_LAUNCH_CHECK(ctx);
+        k_colsum_y<<<gy, RT, 0, ctx->stream>>>(Y, N, n, rows_per_block, part, n_pad);
+        CP_LAUNCH_CHECK(ctx);
+        k_mean_finish<<<(n + RT - 1) / RT, RT, 0, ctx->stream>>>(part, RB, n_pad, n, 1.0 / double(N), ymean);
+        CP_LAUNCH_CHECK(ctx);
+    }
+    cp_stage_mark(ctx, "refit_means");
+    if (x_dtype == CP_F32)
+        k_gather_center<float><<<unsigned(N_pad), RT, 0, ctx->stream>>>(static_cast<const float *>(X), N, c, kk, dchan,
+                                                                        p, p_pad, xmean, Xs);
+    else
+        k_gather_center<double><<<unsigned(N_pad), RT, 0, ctx->stream>>>(static_cast<const double *>(X), N, c, kk,
+                                                                         dchan, p, p_pad, xmean, Xs);
+    CP_LAUNCH_CHECK(ctx);
+    k_center_y<<<unsigned(N_pad), RT, 0, ctx->stream>>>(Y, N, n, n_pad, ymean, Yc);
+    CP_LAUNCH_CHECK(ctx);
+    cp_stage_mark(ctx, "refit_gather_center");
+    CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, G, p_pad,
+                          CP_TRI_LOWER_MIRROR));
+    cp_stage_mark(ctx, "refit_gram_gemm");
+    CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rm, n_pad, CP_TRI_NONE));
+    cp_stage_mark(ctx, "refit_xty_gemm");
+    k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(G, p_pad, p, p_pad, ridge, dg0, gmax);
+    CP_LAUNCH_CHECK(ctx);
+    CP_HIP(ctx, hipMemcpyAsync(G0, G, g_b, hipMemcpyDeviceToDevice, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(R2, Rm, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+
+    Chol ch{G, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
+    int hinfo = 0;
+    bool fallback = (ridge == 0.0) && (N - 1 < p);  // centred X has rank <= N-1
+    if (!fallback) {
+        CP_TRY(chol_factor(ctx, ch, 1e-10));
+        cp_stage_mark(ctx, "refit_cholesky");
+        CP_TRY(chol_solve(ctx, ch, Rm, n_pad));
+        cp_stage_mark(ctx, "refit_solve");
+        CP_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hinfo != 0) fallback = true;
+    }
+    int rank = p;
+    if (fallback) {
+        // W = (G + eI)^-1 G (G + eI)^-1 R  with the untouched copies G0, R2
+        CP_HIP(ctx, hipMemcpyAsync(G, G0, g_b, hipMemcpyDeviceToDevice, ctx->stream));
+        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-11, dg0);
+        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(chol_factor(ctx, ch, 0.0));
+        CP_HIP(ctx, hipMemcpyAsync(Rm, R2, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+        CP_TRY(chol_solve(ctx, ch, Rm, n_pad));                       // V = (G+eI)^-1 R
+        // R2 <- G0^T V = G0 V (symmetric)
+        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, p_pad, 1.0, G0, p_pad, Rm, n_pad, 0.0, R2, n_pad, CP_TRI_NONE));
+        CP_TRY(chol_solve(ctx, ch, R2, n_pad));                       // W = (G+eI)^-1 G V
+        CP_HIP(ctx, hipMemcpyAsync(Rm, R2, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+        cp_stage_mark(ctx, "refit_minnorm_fallback");
+        CP_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hinfo != 0)
+            return cp_set_error(ctx, CP_ERR_NUMERIC, "refit: regularised factorisation broke down at column %d",
+                                hinfo - 1);
+        rank = -1;  // not determined on this path
+    }
+    k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, ymean, W_out, b_out);
+    CP_LAUNCH_CHECK(ctx);
+    cp_stage_mark(ctx, "refit_finalize");
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    cp_stage_finish(ctx);
+    info->p = p;
+    info->rank = rank;
+    info->fallback = fallback ? 1 : 0;
+    info->reserved = 0;
+    return CP_OK;
+}

@@ -1,0 +1,112 @@
+"""Drop-in for the pruning entry points of the reference's lib/decompose.py, computed on
+MI355X through libcpmi355.so (no scikit-learn / SciPy call on this path, no CPU fallback).
+
+    dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, verbose=0)
+        -> (idxs bool[c], newW2 float64[n, nnz, k, k], newB2 float64[n])     decompose.py:386-634
+    fc_kernel(X, Y, copy_X=True, W=None, B=None, ret_reg=False, fit_intercept=True)
+        -> (coef_[n, p], intercept_[n]) or an estimator-like object           decompose.py:636-669
+    rel_error, relu                                                           decompose.py:22-32
+
+Same argument meaning, same side effects as the reference: consumes numpy's GLOBAL RNG
+(one draw for the sample subset + one per LASSO fit, decompose.py:425 / _cd_fast.pyx:164),
+reads ``dcfgs.dic.rank_tol`` / ``dcfgs.fc_ridge`` / ``dcfgs.autodet`` and the module global
+``cfgs.alpha``, writes ``cfgs.alpha`` back (decompose.py:626-627); inputs are not modified.
+Branches of the reference that depend on modules absent from its own tree (lightning, keras,
+theanols, GDsolver; decompose.py:12-20, 641-660) raise NotImplementedError here.
+"""
+import numpy as np
+
+from cpmi355 import LayerProblem, default_context, prune_layer
+from cpmi355 import capi as _capi
+
+from . import cfgs
+from .cfgs import c as dcfgs
+
+# filled by every dictionary() call: per-fit (alpha, nnz, n_iter), the sample subset, refit path
+last_call_info = {}
+
+
+def relu(x):
+    return np.maximum(x, 0.)
+
+
+def rel_error(A, B):
+    return np.mean((A - B) ** 2) ** .5 / np.mean(A ** 2) ** .5
+
+
+def _flags():
+    return _capi.CP_CD_RECIPROCAL if dcfgs.cd_reciprocal else 0
+
+
+def dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, verbose=0):
+    """Channel selection by LASSO + least-squares reconstruction of W2 on the kept channels."""
+    rank_tol = dcfgs.dic.rank_tol                       # decompose.py:393
+    if dcfgs.autodet:
+        raise NotImplementedError("dcfgs.autodet (single LASSO solve at fixed alpha) is not on the "
+                                  "accelerated path")
+    if dcfgs.dic.alter or dcfgs.nonlinear_fc or dcfgs.nofc or dcfgs.ls != 'linear' \
+            or dcfgs.solver != cfgs.solvers.sk or dcfgs.dic.debug:
+        raise NotImplementedError("only the default pruning configuration of the reference is accelerated "
+                                  "(dic.alter=0, nonlinear_fc=0, nofc=0, ls='linear', solver='sklearn')")
+    X = np.asarray(X)
+    W2 = np.asarray(W2)
+    if X.shape[2] != X.shape[-1]:
+        raise ValueError("square kernels only (the reference assumes w = h, decompose.py:401-402)")
+    prob = LayerProblem(default_context(), X, W2, Y, flags=_flags())
+    try:
+        idxs, newW2, newB2, alpha_out = prune_layer(prob, rank, cfgs.alpha, rank_tol=rank_tol, rng=np.random,
+                                                    ridge=float(dcfgs.fc_ridge), mode=dcfgs.cd_mode,
+                                                    alpha_arg=alpha)
+        last_call_info.clear()
+        last_call_info.update(fits=list(prob.fits), samples=prob.samples,
+                              fallback=int(prob.refit_info.fallback), p=int(prob.refit_info.p))
+    finally:
+        prob.free()
+    cfgs.alpha = alpha_out                               # decompose.py:626-627
+    if DEBUG:
+        return X[:, idxs, ...], newW2, newB2             # decompose.py:629-632
+    return idxs, newW2, newB2
+
+
+class _FittedLinear:
+    """What ``ret_reg=True`` callers use of the sklearn estimator (decompose.py:667-668, 681-685)."""
+
+    def __init__(self, coef, intercept):
+        self.coef_ = coef
+        self.intercept_ = intercept
+
+    def predict(self, X):
+        return np.asarray(X) @ self.coef_.T + self.intercept_
+
+
+def fc_kernel(X, Y, copy_X=True, W=None, B=None, ret_reg=False, fit_intercept=True):
+    """OLS with intercept (or Ridge when dcfgs.fc_ridge > 0) of Y[N,n] on X[N,p]: returns n x p."""
+    assert copy_X == True  # noqa: E712  (decompose.py:640)
+    assert len(X.shape) == 2
+    if dcfgs.ls != 'linear':
+        raise NotImplementedError("dcfgs.ls=%r needs modules that are not in the reference tree" % dcfgs.ls)
+    if not fit_intercept:
+        raise NotImplementedError("fit_intercept=False is never used on the pruning path")
+    X = np.ascontiguousarray(X)
+    N, p = X.shape
+    Y2 = np.ascontiguousarray(Y, dtype=np.float64).reshape(N, -1)
+    n = Y2.shape[1]
+    ctx = default_context()
+    # every column is a "channel" with a 1x1 kernel: the refit entry point then solves exactly this
+    prob = LayerProblem(ctx, X.reshape(N, p, 1, 1), np.zeros((1, p, 1, 1), dtype=np.float32), np.zeros((N, 1)))
+    try:
+        prob.Yd.free()
+        prob.Yd = ctx.to_device(Y2)
+        prob.n = n
+        prob.Wout.free()
+        prob.bout.free()
+        prob.Wout = ctx.empty(n * p * 8)
+        prob.bout = ctx.empty(n * 8)
+        coef, intercept = prob.refit(np.ones(p, dtype=bool), ridge=float(dcfgs.fc_ridge))
+    finally:
+        prob.free()
+    if np.ndim(Y) == 1:
+        coef, intercept = coef[0], intercept[0]
+    if ret_reg:
+        return _FittedLinear(coef, intercept)
+    return coef, intercept

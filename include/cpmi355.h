@@ -1,0 +1,161 @@
+/*
+ * cpmi355.h -- C ABI of libcpmi355.so: the MI355X (gfx950) implementation of the
+ * channel-pruning hot path of ethanhe42/channel-pruning.
+ *
+ * The reference has NO FFI layer for this path: it is plain Python calling
+ * scikit-learn / SciPy (lib/decompose.py:386-669, lib/net.py:534-684,1685-1735).  This
+ * header is therefore the boundary a maintainer would bind with ctypes from the bodies of
+ * those functions (binding shown in INTEGRATION.md; shipped binding:
+ * channel-pruning_amd/cpmi355/capi.py).  Each entry point cites what it replaces.
+ *
+ * Conventions
+ *  - extern "C", every function returns int: CP_OK (0) or a negative CP_ERR_* code; no
+ *    exception crosses the boundary.  cp_last_error(ctx) gives the detail string.
+ *  - cp_ctx binds one device and one HIP stream; one ctx per thread/process.  Create it
+ *    AFTER fork() (the reference likewise creates its GPU context inside the child,
+ *    lib/net.py:55-58, lib/worker.py:33).
+ *  - Pointers marked DEVICE are device addresses valid on the ctx's device (hipMalloc,
+ *    cp_malloc, or a torch tensor's data_ptr()); pointers marked HOST are ordinary host
+ *    memory.  Inputs are never modified.  Calls are asynchronous on the ctx stream
+ *    unless they return HOST outputs, in which case they synchronise the stream.
+ *  - Row-major (C order) everywhere; dtype codes CP_F32 / CP_F64.
+ */
+#ifndef CPMI355_H
+#define CPMI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CP_VERSION 100 /* 0.1.0 */
+
+#define CP_OK 0
+#define CP_ERR_ARG (-1)         /* bad argument (null pointer, size, dtype) */
+#define CP_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define CP_ERR_NOMEM (-3)       /* device allocation failed */
+#define CP_ERR_UNSUPPORTED (-4) /* shape outside what the kernels support */
+#define CP_ERR_NUMERIC (-5)     /* factorisation broke down and no fallback applied */
+#define CP_ERR_NODEVICE (-6)    /* no gfx950 device visible */
+
+#define CP_F32 0
+#define CP_F64 1
+
+typedef struct cp_ctx cp_ctx;
+
+/* ---- library / context ---------------------------------------------------------- */
+int cp_version(void);
+const char *cp_strerror(int code);
+const char *cp_last_error(const cp_ctx *ctx);
+int cp_device_count(int *count);
+int cp_ctx_create(int device, cp_ctx **out);
+int cp_ctx_destroy(cp_ctx *ctx);
+/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the ctx's own stream. */
+int cp_ctx_set_stream(cp_ctx *ctx, void *hip_stream);
+int cp_sync(cp_ctx *ctx);
+
+/* ---- device memory helpers (so a ctypes-only host needs nothing else) ------------ */
+int cp_malloc(cp_ctx *ctx, size_t bytes, void **dptr);
+int cp_free(cp_ctx *ctx, void *dptr);
+int cp_memcpy_h2d(cp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int cp_memcpy_d2h(cp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* syncs */
+int cp_memset(cp_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* ---- a1: sampled-point im2col --------------------------------------------------- */
+/* Replaces the window copy of Net.extract_XY (lib/net.py:629-657, non-gw1 branch)
+ * + the reshape/rollaxis of lib/net.py:1702 + the VGG ReLU of lib/net.py:1720, for ONE
+ * batch: fmap DEVICE [B,C,H,W] f32 (bottom blob, unpadded), xs/ys HOST int32[P] sampled
+ * TOP coordinates.  Writes rows [row0, row0+P*B) of X_out DEVICE [*, C, k, k] f32 in the
+ * reference's row order [point][image]; zero padding `pad`, window origin x*stride-pad. */
+int cp_patch_gather(cp_ctx *ctx, const float *fmap, int B, int C, int H, int W, const int32_t *xs,
+                    const int32_t *ys, int P, int k, int pad, int stride, int relu, float *X_out,
+                    int64_t row0);
+
+/* ---- a2: target assembly -------------------------------------------------------- */
+/* Y = feats - bias (+ resY): lib/net.py:1707,1716-1722.  feats DEVICE [N,n] f32,
+ * bias DEVICE [n] f32, resY DEVICE [N,n] f64 or NULL, Y DEVICE [N,n] f64. */
+int cp_assemble_y(cp_ctx *ctx, const float *feats, const float *bias, const double *resY, int64_t N,
+                  int n, double *Y);
+
+/* ---- a3 (first half): LASSO operands -------------------------------------------- */
+/* Replaces lib/decompose.py:428-437 (Z = matmul(reX, reW2).reshape(c,-1).T; reY) and
+ * the centring + Gram that sklearn's Lasso.fit needs (_base.py:108-205): with
+ * Z[(s,j),i] = sum_t X[samples[s],i,t] W2[j,i,t], zc = Z - colmean, yc = y - mean:
+ *   Q = zc^T zc  DEVICE [c,c] f64,  q = zc^T yc DEVICE [c] f64,
+ *   stats DEVICE f64[4] = {yc^T yc, mean(y), M = S*n, 0}.
+ * Z itself is never returned.  X DEVICE [N,c,kk] (x_dtype), W2 DEVICE [n,c,kk]
+ * (w_dtype), Y DEVICE [N,n] f64, samples HOST int64[S] (rows may repeat). */
+int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const void *W2,
+                  int w_dtype, int n, const double *Y, const int64_t *samples, int S, double *Q,
+                  double *q, double *stats);
+
+/* ---- a4: one LASSO fit = sklearn enet_coordinate_descent_gram -------------------- */
+typedef struct cp_cd_result {
+    double gap;        /* duality gap at exit (unscaled, as _cd_fast returns it) */
+    double tol_scaled; /* tol * yc^T yc */
+    int32_t n_iter;    /* epochs run (sklearn's n_iter_) */
+    int32_t nnz;       /* count of w != 0 (the reference's sum(idxs), decompose.py:465) */
+} cp_cd_result;
+
+#define CP_CD_RECIPROCAL 1 /* multiply by 1/(Qii+l2) instead of dividing (<=1 ulp/step) */
+
+/* Replaces Lasso.fit as called by solve() (lib/decompose.py:453-466):
+ * sklearn/_cd_fast.pyx:564-737 with random coordinate order from our_rand_r
+ * (sklearn/utils/_random.pxd:20-35) seeded by `seed` (the value the host drew with
+ * rng.randint(0, 2147483647), _cd_fast.pyx:626).  Q DEVICE [c,c] (row stride ldq), q
+ * DEVICE [c], stats DEVICE (stats[0] = yc^T yc), w DEVICE [c] in/out (warm start),
+ * result HOST.  l1_reg = alpha*M, l2_reg = 0 for Lasso. */
+int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c,
+                    double l1_reg, double l2_reg, uint32_t seed, int max_iter, double tol, int flags,
+                    double *w, cp_cd_result *result);
+
+/* The whole alpha search of lib/decompose.py:490-525 in ONE launch (bracket doubling
+ * then bisection; acceptance lbound <= nnz <= rbound), warm-starting every fit from
+ * the previous one exactly as Lasso(warm_start=True) does.  seeds HOST uint32[max_fits]
+ * are the values the host pre-drew from the RNG; *fits_used tells it how many draws
+ * the reference would have consumed (the host rewinds its RNG accordingly).
+ * M = S*n (alpha -> l1_reg = alpha*M).  fit_log HOST [max_fits] (alpha per fit in
+ * fit_alpha HOST double[max_fits]) may be NULL.  w DEVICE [c] out (start = 0). */
+int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats,
+                          int c, double M, double alpha_right0, double rank, double lbound,
+                          double rbound, const uint32_t *seeds, int max_fits, int max_iter, double tol,
+                          int flags, double *w, int *fits_used, double *alpha_out,
+                          cp_cd_result *fit_log, double *fit_alpha);
+
+/* ---- a5: least-squares refit ---------------------------------------------------- */
+typedef struct cp_refit_info {
+    int32_t p;        /* columns = kept channels * kk */
+    int32_t rank;     /* numerical rank found (== p on the Cholesky path) */
+    int32_t fallback; /* 0 = Cholesky, 1 = rank-revealing minimum-norm path */
+    int32_t reserved;
+} cp_refit_info;
+
+/* Replaces fc_kernel(X[:,idxs].reshape(N,-1), Y) (lib/decompose.py:622, 636-669):
+ * LinearRegression(fit_intercept=True) -> centre, minimum-norm least squares
+ * (scipy gelsd, cut-off max(N,p)*eps), intercept = ybar - xbar.coef^T; ridge > 0 selects
+ * the Ridge branch (decompose.py:662-663).  X DEVICE [N,c,kk] (x_dtype), mask HOST
+ * uint8[c] (non-zero = keep), Y DEVICE [N,n] f64.  Outputs DEVICE: W_out [n, p] f64
+ * (p = kept*kk, caller reshapes to [n, kept, k, k]), b_out [n] f64; info HOST. */
+int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk,
+                   const uint8_t *mask, const double *Y, int n, double ridge, double *W_out,
+                   double *b_out, cp_refit_info *info);
+
+/* ---- micro-benchmarks used by bench.py for roofline denominators ---------------- */
+/* Sustained v_mfma_f64_16x16x4_f64 rate (TFLOP/s) and float4-copy HBM bandwidth (GB/s). */
+int cp_probe_mfma_f64(cp_ctx *ctx, double *tflops);
+int cp_probe_hbm_copy(cp_ctx *ctx, size_t bytes, double *gbps);
+
+/* Per-stage device timings (ms, HIP events on the ctx stream) of the most recent
+ * cp_lasso_gram / cp_lstsq_refit call; names in cp_stage_name().  Used by bench.py. */
+#define CP_MAX_STAGES 32
+int cp_last_stage_times(cp_ctx *ctx, int *count, float *ms /* [CP_MAX_STAGES] */);
+const char *cp_stage_name(cp_ctx *ctx, int index);
+int cp_enable_stage_timing(cp_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPMI355_H */

@@ -1,0 +1,361 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and against the
+golden vectors produced by the unmodified reference.
+
+Bars (BASELINE.json north_star): channel masks bit-identical; reconstructed weights within 1e-5
+relative Frobenius error.  Kernel-level checks are tighter (stated per test).
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+REL_W = 1e-5  # north_star tolerance for reconstructed weights / bias
+
+
+def relfro(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / nb if nb > 0 else np.linalg.norm(a - b)
+
+
+def golden_cases(prefixes):
+    out = []
+    for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
+        name = os.path.basename(path)[:-4]
+        if name[0] in prefixes:
+            out.append(name)
+    return out
+
+
+def load_case(name):
+    import cp_oracle
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    p = json.loads(str(g["params"]))
+    X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"], dead=p.get("dead", 0),
+                                         residual=p.get("residual", False))
+    return g, p, X, W2, Y, B2
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel level
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,c,n,k,xdt", [(400, 32, 24, 3, np.float32), (300, 48, 40, 1, np.float64),
+                                          (500, 96, 64, 3, np.float32), (260, 130, 20, 3, np.float64),
+                                          (2000, 256, 128, 3, np.float32)])
+def test_lasso_gram_matches_oracle(ctx, N, c, n, k, xdt):
+    """Q, q, yc^T yc of cp_lasso_gram vs the C restatement: rel. Frobenius <= 1e-12."""
+    import cp_oracle
+    from cpmi355 import capi
+    rs = np.random.RandomState(5)
+    X = np.maximum(rs.randn(N, c, k, k), 0).astype(xdt)
+    W2 = (rs.randn(n, c, k, k) * 0.05).astype(np.float32)
+    Y = rs.randn(N, n)
+    samples = rs.randint(0, N, min(400, N // 20))
+    ref = cp_oracle.lasso_operands(X.astype(np.float64), W2.astype(np.float64), Y, samples, want_Z=False)
+    Xd, Wd, Yd = ctx.to_device(X), ctx.to_device(W2), ctx.to_device(Y)
+    Qd, qd, sd = ctx.empty(c * c * 8), ctx.empty(c * 8), ctx.empty(32)
+    ctx.lasso_gram(Xd, capi.CP_F32 if xdt == np.float32 else capi.CP_F64, N, c, k * k, Wd, capi.CP_F32, n, Yd,
+                   samples, Qd, qd, sd)
+    Q = ctx.to_host(Qd, (c, c), np.float64)
+    q = ctx.to_host(qd, (c,), np.float64)
+    st = ctx.to_host(sd, (4,), np.float64)
+    assert relfro(Q, ref["Q"]) <= 1e-12
+    assert relfro(q, ref["q"]) <= 1e-11
+    assert abs(st[0] - ref["yty"]) <= 1e-12 * ref["yty"]
+    assert abs(st[1] - ref["ymean"]) <= 1e-12 * max(1.0, abs(ref["ymean"]))
+    assert st[2] == samples.shape[0] * n
+    assert np.array_equal(Q, Q.T)  # mirrored, exactly symmetric
+
+
+def _cd_problem(c, M=4000, seed=3):
+    rs = np.random.RandomState(seed)
+    Z = rs.randn(M, c) * (0.2 + rs.rand(c))
+    wtrue = np.where(rs.rand(c) < 0.4, rs.randn(c), 0.0)
+    y = Z @ wtrue + 0.1 * rs.randn(M)
+    Zc = Z - Z.mean(0)
+    yc = y - y.mean()
+    return np.ascontiguousarray(Zc.T @ Zc), Zc.T @ yc, float(yc @ yc), M
+
+
+@pytest.mark.parametrize("c", [16, 55, 64, 96, 128, 222, 256, 512])
+@pytest.mark.parametrize("recip", [0, 1])
+def test_cd_fit_bit_exact_vs_oracle(ctx, c, recip):
+    """cp_enet_cd_gram vs cpo_enet_cd_gram on the same Q, q, seed: identical n_iter and
+    bit-identical w (same fma sequence), for cold and warm starts."""
+    import cp_oracle
+    from cpmi355 import capi
+    Q, q, yty, M = _cd_problem(c)
+    Qd, qd = ctx.to_device(Q), ctx.to_device(q)
+    sd = ctx.to_device(np.array([yty, 0, M, 0], dtype=np.float64))
+    w_ref = np.zeros(c)
+    wd = ctx.zeros(c * 8)
+    flags = capi.CP_CD_RECIPROCAL if recip else 0
+    amax = np.abs(q).max() / M
+    for i, (frac, seed) in enumerate([(0.5, 12345), (0.2, 987654321), (0.05, 1), (0.3, 2147483646)]):
+        l1 = frac * amax * M
+        _, stats, n_ref = cp_oracle.enet_cd_gram(w_ref, l1, 0.0, Q, q, yty, 1000, 1e-4, seed, recip=bool(recip))
+        r = ctx.enet_cd_gram(Qd, c, qd, sd, c, l1, 0.0, seed, wd, flags=flags)
+        w = ctx.to_host(wd, (c,), np.float64)
+        assert r.n_iter == n_ref, "fit %d: n_iter %d vs oracle %d" % (i, r.n_iter, n_ref)
+        assert r.nnz == int(np.sum(w_ref != 0))
+        assert np.array_equal(w, w_ref), "fit %d: max |dw| = %g" % (i, np.abs(w - w_ref).max())
+        assert abs(r.gap - stats[0]) <= 1e-9 * max(1.0, abs(stats[1]))
+
+
+def test_cd_zero_diagonal_and_zero_seed(ctx):
+    """Q[ii,ii] == 0 features are skipped but still consume a draw (_cd_fast.pyx:651); seed 0 -> 1."""
+    import cp_oracle
+    c = 64
+    Q, q, yty, M = _cd_problem(c)
+    dead = [3, 17, 40]
+    for d in dead:
+        Q[d, :] = 0
+        Q[:, d] = 0
+        q[d] = 0
+    Qd, qd = ctx.to_device(Q), ctx.to_device(q)
+    sd = ctx.to_device(np.array([yty, 0, M, 0], dtype=np.float64))
+    for seed in (0, 77):
+        w_ref = np.zeros(c)
+        wd = ctx.zeros(c * 8)
+        l1 = 0.1 * np.abs(q).max()
+        _, _, n_ref = cp_oracle.enet_cd_gram(w_ref, l1, 0.0, Q, q, yty, 1000, 1e-4, seed)
+        r = ctx.enet_cd_gram(Qd, c, qd, sd, c, l1, 0.0, seed, wd)
+        w = ctx.to_host(wd, (c,), np.float64)
+        assert r.n_iter == n_ref and np.array_equal(w, w_ref)
+        assert np.all(w[dead] == 0)
+
+
+def test_cd_max_iter_and_l2(ctx):
+    """max_iter cap (for/else path) and a non-zero l2 term follow the oracle."""
+    import cp_oracle
+    c = 96
+    Q, q, yty, M = _cd_problem(c)
+    Qd, qd = ctx.to_device(Q), ctx.to_device(q)
+    sd = ctx.to_device(np.array([yty, 0, M, 0], dtype=np.float64))
+    w_ref = np.zeros(c)
+    wd = ctx.zeros(c * 8)
+    l1 = 0.01 * np.abs(q).max()
+    _, _, n_ref = cp_oracle.enet_cd_gram(w_ref, l1, 0.5, Q, q, yty, 3, 1e-9, 4242)
+    r = ctx.enet_cd_gram(Qd, c, qd, sd, c, l1, 0.5, 4242, wd, max_iter=3, tol=1e-9)
+    assert n_ref == 3 and r.n_iter == 3
+    assert np.array_equal(ctx.to_host(wd, (c,), np.float64), w_ref)
+
+
+@pytest.mark.parametrize("N,c,n,k,keep,xdt", [(600, 32, 24, 3, 0.5, np.float32), (900, 64, 48, 3, 0.6, np.float64),
+                                               (500, 64, 130, 1, 0.5, np.float32), (3000, 128, 64, 3, 0.5, np.float32)])
+def test_refit_matches_lstsq(ctx, N, c, n, k, keep, xdt):
+    """cp_lstsq_refit vs the numpy restatement of LinearRegression/gelsd: rel. Frobenius <= 1e-9."""
+    import cp_oracle
+    from cpmi355 import capi
+    rs = np.random.RandomState(11)
+    X = np.maximum(rs.randn(N, c, k, k), 0).astype(xdt)
+    Y = rs.randn(N, n) + 3.0
+    mask = rs.rand(c) < keep
+    mask[0] = True
+    p = int(mask.sum()) * k * k
+    coef_ref, b_ref, _ = cp_oracle.lstsq_min_norm(X[:, mask].reshape(N, -1).astype(np.float64), Y)
+    Xd, Yd = ctx.to_device(X), ctx.to_device(Y)
+    Wd, bd = ctx.empty(n * p * 8), ctx.empty(n * 8)
+    info = ctx.lstsq_refit(Xd, capi.CP_F32 if xdt == np.float32 else capi.CP_F64, N, c, k * k, mask, Yd, n, 0.0,
+                           Wd, bd)
+    assert info.p == p and info.fallback == 0
+    assert relfro(ctx.to_host(Wd, (n, p), np.float64), coef_ref) <= 1e-9
+    assert relfro(ctx.to_host(bd, (n,), np.float64), b_ref) <= 1e-9
+
+
+def test_refit_rank_deficient_min_norm(ctx):
+    """Dead (all-zero) channels and N < p take the minimum-norm path and match gelsd to 1e-5."""
+    import cp_oracle
+    from cpmi355 import capi
+    rs = np.random.RandomState(12)
+    # (a) dead channels
+    N, c, n, k = 500, 24, 16, 3
+    X = np.maximum(rs.randn(N, c, k, k), 0).astype(np.float32)
+    X[:, [2, 9]] = 0
+    Y = rs.randn(N, n)
+    mask = np.ones(c, dtype=bool)
+    coef_ref, b_ref, rank = cp_oracle.lstsq_min_norm(X.reshape(N, -1).astype(np.float64), Y)
+    assert rank == (c - 2) * k * k
+    p = c * k * k
+    Xd, Yd, Wd, bd = ctx.to_device(X), ctx.to_device(Y), ctx.empty(n * p * 8), ctx.empty(n * 8)
+    info = ctx.lstsq_refit(Xd, capi.CP_F32, N, c, k * k, mask, Yd, n, 0.0, Wd, bd)
+    W = ctx.to_host(Wd, (n, p), np.float64)
+    assert info.fallback == 1
+    assert relfro(W, coef_ref) <= REL_W and relfro(ctx.to_host(bd, (n,), np.float64), b_ref) <= REL_W
+    assert np.all(W.reshape(n, c, k * k)[:, [2, 9]] == 0)
+    # (b) N < p
+    N = 150
+    X = np.maximum(rs.randn(N, c, k, k), 0).astype(np.float32)
+    Y = rs.randn(N, n)
+    coef_ref, b_ref, rank = cp_oracle.lstsq_min_norm(X.reshape(N, -1).astype(np.float64), Y)
+    assert rank == N - 1
+    Xd, Yd = ctx.to_device(X), ctx.to_device(Y)
+    info = ctx.lstsq_refit(Xd, capi.CP_F32, N, c, k * k, mask, Yd, n, 0.0, Wd, bd)
+    assert info.fallback == 1
+    assert relfro(ctx.to_host(Wd, (n, p), np.float64), coef_ref) <= REL_W
+    assert relfro(ctx.to_host(bd, (n,), np.float64), b_ref) <= REL_W
+
+
+def test_refit_ridge(ctx):
+    import cp_oracle
+    from cpmi355 import capi
+    rs = np.random.RandomState(13)
+    N, c, n, k = 400, 16, 8, 3
+    X = rs.randn(N, c, k, k)
+    Y = rs.randn(N, n)
+    mask = np.ones(c, dtype=bool)
+    p = c * k * k
+    coef_ref, b_ref, _ = cp_oracle.lstsq_min_norm(X.reshape(N, -1), Y, ridge=0.7)
+    Xd, Yd, Wd, bd = ctx.to_device(X), ctx.to_device(Y), ctx.empty(n * p * 8), ctx.empty(n * 8)
+    ctx.lstsq_refit(Xd, capi.CP_F64, N, c, k * k, mask, Yd, n, 0.7, Wd, bd)
+    assert relfro(ctx.to_host(Wd, (n, p), np.float64), coef_ref) <= 1e-10
+    assert relfro(ctx.to_host(bd, (n,), np.float64), b_ref) <= 1e-10
+
+
+def test_patch_gather_and_assemble_y(ctx):
+    """a1/a2 kernels are bit-exact copies: compare with the C restatement of net.py:629-657,1707."""
+    import cp_oracle
+    rs = np.random.RandomState(14)
+    B, C, H, W, k, P = 4, 20, 14, 14, 3, 10
+    out_rows = 0
+    for pad, stride, relu in ((1, 1, 1), (0, 1, 0), (1, 2, 1)):
+        fmap = rs.randn(B, C, H, W).astype(np.float32)
+        top = (H + 2 * pad - k) // stride + 1
+        xs, ys = rs.randint(0, top, P), rs.randint(0, top, P)
+        ref = cp_oracle.patch_gather(fmap, xs, ys, k, pad, stride, relu)
+        fd = ctx.to_device(fmap)
+        od = ctx.zeros((P * B + 3) * C * k * k * 4)
+        ctx.patch_gather(fd, B, C, H, W, xs, ys, k, pad, stride, relu, od, 3)
+        got = ctx.to_host(od, (P * B + 3, C, k, k), np.float32)
+        assert np.array_equal(got[3:], ref) and np.all(got[:3] == 0)
+        out_rows += P * B
+    feats = rs.randn(300, 40).astype(np.float32)
+    bias = rs.randn(40).astype(np.float32)
+    res = rs.randn(300, 40)
+    for r in (None, res):
+        Yd = ctx.empty(300 * 40 * 8)
+        ctx.assemble_y(ctx.to_device(feats), ctx.to_device(bias), None if r is None else ctx.to_device(r), 300, 40, Yd)
+        assert np.array_equal(ctx.to_host(Yd, (300, 40), np.float64), cp_oracle.assemble_y(feats, bias, r))
+
+
+# ---------------------------------------------------------------------------------------------
+# whole path through the drop-in API, against the reference's golden vectors
+# ---------------------------------------------------------------------------------------------
+def _run_dropin(p, X, W2, Y, B2, mode):
+    import lib.cfgs as cfgs
+    import lib.decompose as D
+    from lib.cfgs import c as dcfgs
+    cfgs.alpha = p.get("alpha_in", 1e-3)
+    dcfgs.dic.rank_tol = p.get("rank_tol", .1)
+    dcfgs.fc_ridge = p.get("fc_ridge", 0)
+    dcfgs.cd_mode = mode
+    np.random.seed(1234 + p["layer_id"])
+    try:
+        idxs, newW2, newB2 = D.dictionary(X.astype(np.float64), W2, Y, rank=p["rank"], B2=B2)
+    finally:
+        dcfgs.fc_ridge = 0
+        dcfgs.dic.rank_tol = .1
+        dcfgs.cd_mode = 'device'
+    rng_next = int(np.random.randint(0, 2147483647))
+    return idxs, newW2, newB2, float(cfgs.alpha), rng_next, dict(D.last_call_info)
+
+
+def _check_against_golden(g, p, got):
+    idxs, newW2, newB2, alpha_out, rng_next, info = got
+    assert np.array_equal(idxs, g["idxs"]), "channel mask differs from the reference"
+    fits = np.array(info["fits"], dtype=np.float64).reshape(-1, 3)
+    assert fits.shape == g["fits"].shape and np.array_equal(fits, g["fits"]), "per-fit (alpha, nnz, n_iter) differ"
+    assert np.array_equal(info["samples"], g["samples"])
+    assert alpha_out == float(g["alpha_out"])
+    assert rng_next == int(g["rng_next"]), "numpy global RNG stream consumed differently"
+    assert newW2.shape == g["newW2"].shape
+    assert relfro(newW2, g["newW2"]) <= REL_W
+    assert relfro(newB2, g["newB2"]) <= REL_W
+
+
+@pytest.mark.parametrize("name", golden_cases("sm"))
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_dictionary_matches_reference_golden(ctx, name, mode):
+    g, p, X, W2, Y, B2 = load_case(name)
+    _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, mode))
+
+
+@pytest.mark.parametrize("name", golden_cases("L"))
+def test_dictionary_matches_reference_golden_full_size(ctx, name):
+    """BASELINE.json configs[1] sizes (N=5000, c up to 256): masks identical, weights <= 1e-5."""
+    g, p, X, W2, Y, B2 = load_case(name)
+    got = _run_dropin(p, X, W2, Y, B2, "device")
+    _check_against_golden(g, p, got)
+    # size-independent property: the refit is the least-squares optimum, so the residual is
+    # orthogonal to the centred kept columns (normal equations), and beats the unrefitted weights.
+    idxs, newW2, newB2 = got[0], got[1], got[2]
+    N = X.shape[0]
+    Xs = X[:, idxs].reshape(N, -1).astype(np.float64)
+    res = Xs @ newW2.reshape(newW2.shape[0], -1).T + newB2 - Y
+    Xc = Xs - Xs.mean(0)
+    assert np.abs(Xc.T @ res).max() <= 1e-7 * np.linalg.norm(Xc) * np.linalg.norm(Y) / np.sqrt(N)
+    assert np.abs(res.mean(0)).max() <= 1e-9
+    naive = Xs @ W2[:, idxs].reshape(W2.shape[0], -1).T.astype(np.float64) - Y
+    assert np.linalg.norm(res) < np.linalg.norm(naive)
+
+
+def test_f32_and_f64_storage_agree(ctx):
+    """X handed over as float32 (exactly representable) or float64 gives the same result."""
+    import cp_oracle
+    from cpmi355 import LayerProblem, prune_layer
+    X, W2, Y, B2 = cp_oracle.synth_layer(2, 600, 64, 48, 3)
+    outs = []
+    for dt in (np.float32, np.float64):
+        prob = LayerProblem(ctx, X.astype(dt), W2, Y)
+        outs.append(prune_layer(prob, 32, 1e-3, rng=np.random.RandomState(99)))
+        prob.free()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_run_to_run_reproducible(ctx):
+    """No atomics anywhere: two runs of the same problem are bitwise identical."""
+    import cp_oracle
+    from cpmi355 import LayerProblem, prune_layer
+    X, W2, Y, B2 = cp_oracle.synth_layer(12, 800, 96, 40, 3)
+    outs = []
+    for _ in range(2):
+        prob = LayerProblem(ctx, X, W2, Y)
+        outs.append(prune_layer(prob, 24, 1e-3, rng=np.random.RandomState(5)))
+        prob.free()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_fc_kernel_dropin(ctx):
+    import cp_oracle
+    import lib.decompose as D
+    rs = np.random.RandomState(21)
+    X = rs.randn(700, 90)
+    Y = rs.randn(700, 33)
+    coef, b = D.fc_kernel(X, Y)
+    cr, br, _ = cp_oracle.lstsq_min_norm(X, Y)
+    assert relfro(coef, cr) <= 1e-9 and relfro(b, br) <= 1e-9
+    reg = D.fc_kernel(X, Y, ret_reg=True)
+    assert relfro(reg.predict(X), X @ cr.T + br) <= 1e-9
+
+
+def test_inputs_not_modified_and_empty_cases(ctx):
+    import cp_oracle
+    import lib.cfgs as cfgs
+    import lib.decompose as D
+    X, W2, Y, B2 = cp_oracle.synth_layer(1, 400, 32, 24, 3)
+    X64 = X.astype(np.float64)
+    Xc, Wc, Yc = X64.copy(), W2.copy(), Y.copy()
+    cfgs.alpha = 1e-3
+    np.random.seed(1)
+    D.dictionary(X64, W2, Y, rank=16, B2=B2)
+    assert np.array_equal(X64, Xc) and np.array_equal(W2, Wc) and np.array_equal(Y, Yc)
+    with pytest.raises(Exception):
+        D.dictionary(X64[:0], W2, Y[:0], rank=16, B2=B2)  # empty input: error, as in the reference
