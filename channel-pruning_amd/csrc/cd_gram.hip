@@ -432,8 +432,10 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     DevResult *dres = reinterpret_cast<DevResult *>(cp_arena_take(ctx, sizeof(DevResult)));
     const size_t lds = size_t(5) * c * sizeof(double);
     const int R = pick_R(c);
+    cp_stage_begin(ctx);
     CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
     CP_LAUNCH_CHECK(ctx);
+    cp_stage_mark(ctx, "cd_fit");
     static_assert(sizeof(DevResult) == sizeof(cp_cd_result), "layout");
     CP_TRY(cp_pinned_reserve(ctx, 4096));
     CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dres, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
@@ -463,9 +465,11 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     CP_HIP(ctx, hipMemcpyAsync(dseeds, seeds, seed_bytes, hipMemcpyHostToDevice, ctx->stream));
     const size_t lds = size_t(5) * c * sizeof(double);
     const int R = pick_R(c);
+    cp_stage_begin(ctx);
     CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound, dseeds, max_fits,
                    max_iter, tol, flags, w, dlog, dal, dfits, dalpha);
     CP_LAUNCH_CHECK(ctx);
+    cp_stage_mark(ctx, "cd_alpha_search");
     const size_t total = log_bytes + al_bytes + 128;
     CP_TRY(cp_pinned_reserve(ctx, total));
     char *h = ctx->pinned;

@@ -24,12 +24,16 @@ struct cp_ctx {
     char *pinned = nullptr;
     size_t pinned_bytes = 0;
     char err[512] = {0};
-    // stage timing
+    // stage timing: a list of (name, event); name == nullptr marks the start of a call
     bool timing = false;
+    int n_marks = 0;
+    hipEvent_t ev[2 * CP_MAX_STAGES] = {};
+    const char *mark_names[2 * CP_MAX_STAGES] = {};
     int n_stages = 0;
-    hipEvent_t ev[CP_MAX_STAGES + 1] = {};
     const char *stage_names[CP_MAX_STAGES] = {};
     float stage_ms[CP_MAX_STAGES] = {};
+    const char *gemm_mark = nullptr;  // if set, cp_gemm_tn_f64 marks this stage right after its main kernel
+    int gemm_tag = 0;                 // selects a distinctly named instantiation of the GEMM kernel
     int cu_count = 256;
 };
 
@@ -62,9 +66,9 @@ static inline size_t cp_align_up(size_t v, size_t a) { return (v + a - 1) / a * 
 int cp_pinned_reserve(cp_ctx *ctx, size_t bytes);
 
 // stage timing -----------------------------------------------------------------------
-void cp_stage_begin(cp_ctx *ctx);                   // resets the stage list, records ev[0]
+void cp_stage_begin(cp_ctx *ctx);                   // start of a top-level call
 void cp_stage_mark(cp_ctx *ctx, const char *name);  // closes the stage that just ran
-void cp_stage_finish(cp_ctx *ctx);                  // after a stream sync: compute ms
+void cp_stage_finish(cp_ctx *ctx);                  // kept for symmetry (times are resolved lazily)
 
 // f64 GEMM (gemm_f64.hip) --------------------------------------------------------------
 // C[M,N] = alpha * sum_k A[k,m] * B[k,n] + beta * C   (both operands k-major, "TN").
@@ -73,6 +77,8 @@ void cp_stage_finish(cp_ctx *ctx);                  // after a stream sync: comp
 // part (A and B must then describe the same matrix), 2 upper tiles only (no mirror).
 // Deterministic: split-K partials are reduced in a fixed order.
 enum { CP_TRI_NONE = 0, CP_TRI_LOWER_MIRROR = 1, CP_TRI_UPPER = 2 };
+// kernel-name tags (ctx->gemm_tag) so that a profiler lists the big contractions separately
+enum { CP_GEMM_GENERIC = 0, CP_GEMM_LASSO_GRAM = 1, CP_GEMM_REFIT_GRAM = 2, CP_GEMM_REFIT_XTY = 3 };
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda,
                    const double *B, int ldb, double beta, double *C, int ldc, int tri);
 size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri);

@@ -66,7 +66,7 @@ extern "C" int cp_ctx_create(int device, cp_ctx **out) {
         return CP_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    for (int i = 0; i <= CP_MAX_STAGES; ++i) hipEventCreate(&ctx->ev[i]);
+    for (int i = 0; i < 2 * CP_MAX_STAGES; ++i) hipEventCreate(&ctx->ev[i]);
     *out = ctx;
     return CP_OK;
 }
@@ -77,7 +77,7 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->pinned) hipHostFree(ctx->pinned);
-    for (int i = 0; i <= CP_MAX_STAGES; ++i)
+    for (int i = 0; i < 2 * CP_MAX_STAGES; ++i)
         if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -175,34 +175,43 @@ int cp_pinned_reserve(cp_ctx *ctx, size_t bytes) {
 
 // ---- stage timing ----------------------------------------------------------------------
 void cp_stage_begin(cp_ctx *ctx) {
-    ctx->n_stages = 0;
-    if (ctx->timing) hipEventRecord(ctx->ev[0], ctx->stream);
+    if (!ctx->timing || ctx->n_marks >= 2 * CP_MAX_STAGES) return;
+    ctx->mark_names[ctx->n_marks] = nullptr;
+    hipEventRecord(ctx->ev[ctx->n_marks], ctx->stream);
+    ++ctx->n_marks;
 }
 
 void cp_stage_mark(cp_ctx *ctx, const char *name) {
-    if (!ctx->timing || ctx->n_stages >= CP_MAX_STAGES) return;
-    ctx->stage_names[ctx->n_stages] = name;
-    ++ctx->n_stages;
-    hipEventRecord(ctx->ev[ctx->n_stages], ctx->stream);
+    if (!ctx->timing || ctx->n_marks >= 2 * CP_MAX_STAGES) return;
+    ctx->mark_names[ctx->n_marks] = name;
+    hipEventRecord(ctx->ev[ctx->n_marks], ctx->stream);
+    ++ctx->n_marks;
 }
 
-void cp_stage_finish(cp_ctx *ctx) {
-    if (!ctx->timing) return;
-    for (int i = 0; i < ctx->n_stages; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]) != hipSuccess) ms = -1.f;
-        ctx->stage_ms[i] = ms;
-    }
-}
+void cp_stage_finish(cp_ctx *) {}
 
 extern "C" int cp_enable_stage_timing(cp_ctx *ctx, int on) {
     if (!ctx) return CP_ERR_ARG;
     ctx->timing = on != 0;
+    ctx->n_marks = 0;
+    ctx->n_stages = 0;
     return CP_OK;
 }
 
+// Resolves and clears the marks recorded since the previous call (synchronises the stream).
 extern "C" int cp_last_stage_times(cp_ctx *ctx, int *count, float *ms) {
     if (!ctx || !count || !ms) return CP_ERR_ARG;
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_stages = 0;
+    for (int i = 1; i < ctx->n_marks && ctx->n_stages < CP_MAX_STAGES; ++i) {
+        if (!ctx->mark_names[i]) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ctx->ev[i - 1], ctx->ev[i]) != hipSuccess) t = -1.f;
+        ctx->stage_names[ctx->n_stages] = ctx->mark_names[i];
+        ctx->stage_ms[ctx->n_stages] = t;
+        ++ctx->n_stages;
+    }
+    ctx->n_marks = 0;
     *count = ctx->n_stages;
     for (int i = 0; i < ctx->n_stages; ++i) ms[i] = ctx->stage_ms[i];
     return CP_OK;

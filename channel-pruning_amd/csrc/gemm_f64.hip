@@ -42,7 +42,7 @@ __device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int 
     }
 }
 
-template <int TRI>
+template <int TRI, int TAG>
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
               const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
@@ -248,17 +248,32 @@ int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double 
         if (!P) return cp_set_error(ctx, CP_ERR_NOMEM, "gemm_tn: arena exhausted (split-K partials)");
     }
     const int grid = p.n_tiles * p.splits;
-#define CP_GEMM_LAUNCH(T)                                                                                     \
-    k_gemm_tn_f64<T><<<grid, NTHREADS, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, P,      \
-                                                           p.splits, p.kchunk, p.n_tiles, p.tiles_n)
-    if (tri == CP_TRI_NONE)
-        CP_GEMM_LAUNCH(CP_TRI_NONE);
-    else if (tri == CP_TRI_LOWER_MIRROR)
-        CP_GEMM_LAUNCH(CP_TRI_LOWER_MIRROR);
-    else
-        CP_GEMM_LAUNCH(CP_TRI_UPPER);
+#define CP_GEMM_LAUNCH(T, G)                                                                                  \
+    k_gemm_tn_f64<T, G><<<grid, NTHREADS, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, P,   \
+                                                              p.splits, p.kchunk, p.n_tiles, p.tiles_n)
+    const int tag = ctx->gemm_tag;
+    ctx->gemm_tag = CP_GEMM_GENERIC;
+    if (tri == CP_TRI_NONE) {
+        if (tag == CP_GEMM_REFIT_XTY)
+            CP_GEMM_LAUNCH(CP_TRI_NONE, CP_GEMM_REFIT_XTY);
+        else
+            CP_GEMM_LAUNCH(CP_TRI_NONE, CP_GEMM_GENERIC);
+    } else if (tri == CP_TRI_LOWER_MIRROR) {
+        if (tag == CP_GEMM_LASSO_GRAM)
+            CP_GEMM_LAUNCH(CP_TRI_LOWER_MIRROR, CP_GEMM_LASSO_GRAM);
+        else if (tag == CP_GEMM_REFIT_GRAM)
+            CP_GEMM_LAUNCH(CP_TRI_LOWER_MIRROR, CP_GEMM_REFIT_GRAM);
+        else
+            CP_GEMM_LAUNCH(CP_TRI_LOWER_MIRROR, CP_GEMM_GENERIC);
+    } else {
+        CP_GEMM_LAUNCH(CP_TRI_UPPER, CP_GEMM_GENERIC);
+    }
 #undef CP_GEMM_LAUNCH
     CP_LAUNCH_CHECK(ctx);
+    if (ctx->gemm_mark) {
+        cp_stage_mark(ctx, ctx->gemm_mark);
+        ctx->gemm_mark = nullptr;
+    }
     if (p.splits > 1) {
         if (tri == CP_TRI_NONE)
             k_gemm_reduce<CP_TRI_NONE><<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,

@@ -217,16 +217,14 @@ extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N,
     CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "lasso_build_z");
     double *Qdst = c_pad == c ? Q : Qpad;
+    ctx->gemm_tag = CP_GEMM_LASSO_GRAM;
+    ctx->gemm_mark = "lasso_gram_gemm";
     CP_TRY(cp_gemm_tn_f64(ctx, c_pad, c_pad, int(M_pad), 1.0, Zc, c_pad, Zc, c_pad, 0.0, Qdst, c_pad,
                           CP_TRI_LOWER_MIRROR));
     if (Qdst != Q) {
         k_copy2d<<<c, ZT, 0, ctx->stream>>>(Qpad, c_pad, Q, c, c, c);
         CP_LAUNCH_CHECK(ctx);
     }
-    cp_stage_mark(ctx, "lasso_gram_gemm");
-    if (ctx->timing) {
-        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        cp_stage_finish(ctx);
-    }
+    cp_stage_mark(ctx, "lasso_gram_reduce");
     return CP_OK;
 }

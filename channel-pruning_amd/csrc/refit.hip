@@ -13,11 +13,12 @@
 //   workgroup, panel solve and trailing update are cp_gemm_tn_f64 calls      MFMA / launch bound
 //   block forward / backward substitution with the inverted diagonal blocks  MFMA / launch bound
 // Rank deficiency (dead channels, N < p): a pivot below 1e-10 of its original diagonal flags the
-// factorisation; the solve is then redone as the regularised sandwich
-//   W = (G + eI)^-1 G (G + eI)^-1 R,   e = 1e-11 * max diag(G),
-// which converges to the minimum-norm solution G^+ R that gelsd returns (eigen-directions with
-// lambda >> e are reproduced to 2e/lambda, directions with lambda << e are annihilated; exactly
-// zero columns give exactly zero weights).
+// factorisation; the solve is then redone by iterated Tikhonov regularisation
+//   W_0 = 0,  W_{k+1} = W_k + (G + eI)^-1 (R - G W_k),   e = 1e-9 * max diag(G),  5 sweeps,
+// which stays in range(G) and converges to the minimum-norm solution G^+ R that gelsd returns:
+// an eigen-direction lambda is reproduced up to (e/(lambda+e))^5, directions with lambda << e
+// (numerical null space) are left at zero; exactly zero columns give exactly zero weights.
+// Each sweep also acts as iterative refinement for the (moderately conditioned) G + eI solve.
 #include "cp_common.h"
 
 namespace {
@@ -209,6 +210,12 @@ __global__ void __launch_bounds__(RT) k_transpose_upper(const double *__restrict
     (void)p_pad;
 }
 
+__global__ void __launch_bounds__(RT) k_axpy(double *__restrict__ y, const double *__restrict__ x, size_t count) {
+    size_t i = blockIdx.x * size_t(RT) + threadIdx.x;
+    const size_t step = size_t(gridDim.x) * RT;
+    for (; i < count; i += step) y[i] += x[i];
+}
+
 // coef[j, col] = W[col, j];  b[j] = ymean[j] - sum_col xmean[col] coef[j, col]
 __global__ void __launch_bounds__(RT) k_finalize(const double *__restrict__ W, int ldw, int p, int n,
                                                  const double *__restrict__ xmean, const double *__restrict__ ymean,
@@ -324,7 +331,7 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
                          cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE));
-    const size_t need = xs_b + yc_b + 3 * g_b + 2 * r_b + 2 * ti_b + part_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 +
+    const size_t need = xs_b + yc_b + 3 * g_b + 3 * r_b + 2 * ti_b + part_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 +
                         size_t(kept) * 4 + ws + (1 << 16);
     CP_TRY(cp_arena_reserve(ctx, need));
     double *Xs = cp_arena_take_t<double>(ctx, size_t(N_pad) * p_pad);
@@ -377,11 +384,15 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     k_center_y<<<unsigned(N_pad), RT, 0, ctx->stream>>>(Y, N, n, n_pad, ymean, Yc);
     CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "refit_gather_center");
+    ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
+    ctx->gemm_mark = "refit_gram_gemm";
     CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, G, p_pad,
                           CP_TRI_LOWER_MIRROR));
-    cp_stage_mark(ctx, "refit_gram_gemm");
+    cp_stage_mark(ctx, "refit_gram_reduce");
+    ctx->gemm_tag = CP_GEMM_REFIT_XTY;
+    ctx->gemm_mark = "refit_xty_gemm";
     CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rm, n_pad, CP_TRI_NONE));
-    cp_stage_mark(ctx, "refit_xty_gemm");
+    cp_stage_mark(ctx, "refit_xty_reduce");
     k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(G, p_pad, p, p_pad, ridge, dg0, gmax);
     CP_LAUNCH_CHECK(ctx);
     CP_HIP(ctx, hipMemcpyAsync(G0, G, g_b, hipMemcpyDeviceToDevice, ctx->stream));
@@ -401,17 +412,26 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     }
     int rank = p;
     if (fallback) {
-        // W = (G + eI)^-1 G (G + eI)^-1 R  with the untouched copies G0, R2
+        // iterated Tikhonov on the untouched copies G0 (Gram) and R2 (right-hand side)
+        double *Wacc = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
+        if (!Wacc) return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena (fallback)");
         CP_HIP(ctx, hipMemcpyAsync(G, G0, g_b, hipMemcpyDeviceToDevice, ctx->stream));
-        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-11, dg0);
+        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0);
         CP_LAUNCH_CHECK(ctx);
         CP_TRY(chol_factor(ctx, ch, 0.0));
-        CP_HIP(ctx, hipMemcpyAsync(Rm, R2, r_b, hipMemcpyDeviceToDevice, ctx->stream));
-        CP_TRY(chol_solve(ctx, ch, Rm, n_pad));                       // V = (G+eI)^-1 R
-        // R2 <- G0^T V = G0 V (symmetric)
-        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, p_pad, 1.0, G0, p_pad, Rm, n_pad, 0.0, R2, n_pad, CP_TRI_NONE));
-        CP_TRY(chol_solve(ctx, ch, R2, n_pad));                       // W = (G+eI)^-1 G V
-        CP_HIP(ctx, hipMemcpyAsync(Rm, R2, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+        CP_HIP(ctx, hipMemsetAsync(Wacc, 0, r_b, ctx->stream));
+        const size_t cnt = size_t(p_pad) * n_pad;
+        const int ab = int(std::min<size_t>((cnt + RT - 1) / RT, size_t(ctx->cu_count) * 8));
+        for (int sweep = 0; sweep < 5; ++sweep) {
+            CP_HIP(ctx, hipMemcpyAsync(Rm, R2, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+            if (sweep > 0)  // Rm = R - G0 W   (G0 symmetric: G0^T W)
+                CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, p_pad, -1.0, G0, p_pad, Wacc, n_pad, 1.0, Rm, n_pad,
+                                      CP_TRI_NONE));
+            CP_TRY(chol_solve(ctx, ch, Rm, n_pad));
+            k_axpy<<<ab, RT, 0, ctx->stream>>>(Wacc, Rm, cnt);
+            CP_LAUNCH_CHECK(ctx);
+        }
+        CP_HIP(ctx, hipMemcpyAsync(Rm, Wacc, r_b, hipMemcpyDeviceToDevice, ctx->stream));
         cp_stage_mark(ctx, "refit_minnorm_fallback");
         CP_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -424,7 +444,6 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "refit_finalize");
     CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    cp_stage_finish(ctx);
     info->p = p;
     info->rank = rank;
     info->fallback = fallback ? 1 : 0;
