@@ -22,6 +22,17 @@
 #include "cp_common.h"
 #include "xorshift_jump.h"
 
+// tuning switches (tools/cd_bench.py builds variants with -D...)
+#ifndef CD_UNCOND_R
+#define CD_UNCOND_R 4  // R <= this: the "!= 0" guards of the two daxpy are dropped
+#endif
+#ifndef CD_TOUCH
+#define CD_TOUCH 1     // 1: one explicit wait per step for the slot's rows
+#endif
+#ifndef CD_BRANCH_SEL
+#define CD_BRANCH_SEL 1  // 1: w_cur patch through a (rarely taken) scalar branch
+#endif
+
 namespace {
 
 constexpr int WAVE = 64;
@@ -116,11 +127,14 @@ struct Slot {
 };
 
 // One fit.  w_lds holds the warm start on entry and the solution on exit.
-// feat[4 j + {0,1,2}] = { q[j], Q[j,j], Q[j,j] + beta (or its reciprocal, CP_CD_RECIPROCAL) }.
-template <int R>
+// feat[4 j + {0,1,2}] = { q[j], Q[j,j], Q[j,j] + beta (or its reciprocal when RECIP) }.
+// RECIP: multiply by 1/(Qii + beta) instead of dividing (CP_CD_RECIPROCAL).
+// ALIGNED: c is a multiple of 2*D, so an epoch ends exactly on a group boundary and the
+// end-of-epoch test is hoisted out of the per-step code.
+template <int R, bool RECIP, bool ALIGNED>
 __device__ __forceinline__ FitOut cd_fit(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
                                          uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
-                                         double y_norm2, int recip, double *w_lds, const double *feat) {
+                                         double y_norm2, double *w_lds, const double *feat) {
     constexpr int D = Ring<R>::D;
     const int lane = threadIdx.x;
     const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
@@ -245,53 +259,85 @@ __device__ __forceinline__ FitOut cd_fit(const double *__restrict__ Q, int ldq, 
     fill(A);
     double w_cur = w_lds[A[0].ii];  // w_ii of the step about to run
 
-    // one coordinate update (_cd_fast.pyx:644-682); `nx` is the slot of the following step
-    auto step = [&](const Slot<R> &S, const Slot<R> &nx) -> bool {
+    // One coordinate update (_cd_fast.pyx:644-682); `nx` is the slot of the following step.
+    // The two daxpy of the original are guarded by "!= 0" tests there; an fma with a zero
+    // multiplier returns its addend unchanged, so for narrow problems (R <= 2) the guards are
+    // dropped (same values, fewer instructions on the serial path); wider ones branch.
+    auto step = [&](const Slot<R> &S, const Slot<R> &nx) {
         const int ii = S.ii;
-        const int ii_next = nx.ii;
-        const double w_pre = w_lds[ii_next];  // issued early; patched below if ii_next == ii
+        const double w_pre = w_lds[nx.ii];  // issued early; patched below if nx.ii == ii
         const double Qii = S.Qii;
-        double w_next = w_pre;
+#if CD_TOUCH
+        double rowv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rowv[r] = S.row[r];
+        asm volatile("" : "+v"(rowv[R - 1]));
+#else
+        const double *rowv = S.row;
+#endif
         if (Qii != 0.0) {  // _cd_fast.pyx:651
             const double w_ii = w_cur;
-            const int r_ii = ii >> 6, l_ii = ii & 63;
             double hsel = H[0];
+            if (R > 1) {
+                const int r_ii = ii >> 6;
 #pragma unroll
-            for (int r = 1; r < R; ++r) hsel = (r == r_ii) ? H[r] : hsel;
-            double H_ii = read_lane(hsel, l_ii);
-            if (w_ii != 0.0) {  // H -= w_ii * Q[ii]
-#pragma unroll
-                for (int r = 0; r < R; ++r) H[r] = fma(-w_ii, S.row[r], H[r]);
-                H_ii = fma(-w_ii, Qii, H_ii);
+                for (int r = 1; r < R; ++r) hsel = (r == r_ii) ? H[r] : hsel;
             }
+            const double H_ii = fma(-w_ii, Qii, read_lane(hsel, ii & 63));
             const double tmp = S.qi - H_ii;
             // fsign(tmp) * fmax(|tmp| - alpha, 0)
             const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
-            const double w_new = recip ? thr * S.den : thr / S.den;
-            if (w_new != 0.0) {  // H += w[ii] * Q[ii]
+            const double w_new = RECIP ? thr * S.den : thr / S.den;
+            if (R <= CD_UNCOND_R) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) H[r] = fma(w_new, S.row[r], H[r]);
+                for (int r = 0; r < R; ++r) H[r] = fma(w_new, rowv[r], fma(-w_ii, rowv[r], H[r]));
+            } else {
+                if (w_ii != 0.0) {  // H -= w_ii * Q[ii]
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(-w_ii, rowv[r], H[r]);
+                }
+                if (w_new != 0.0) {  // H += w[ii] * Q[ii]
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(w_new, rowv[r], H[r]);
+                }
             }
             if (lane == 0) w_lds[ii] = w_new;
             d_w_max = fmax(d_w_max, fabs(w_new - w_ii));
             w_max = fmax(w_max, fabs(w_new));
-            w_next = (ii_next == ii) ? w_new : w_pre;
+#if CD_BRANCH_SEL
+            w_cur = w_pre;
+            if (__builtin_expect(nx.ii == ii, 0)) w_cur = w_new;
+#else
+            w_cur = (nx.ii == ii) ? w_new : w_pre;
+#endif
+        } else {
+            w_cur = w_pre;
         }
-        w_cur = w_next;
-        if (++f == c) return epoch_end();
-        return false;
     };
 
     for (;;) {
         fill(B);
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (step(A[d], d + 1 < D ? A[d + 1] : B[0])) goto fit_done;
+        for (int d = 0; d < D; ++d) {
+            step(A[d], d + 1 < D ? A[d + 1] : B[0]);
+            if (!ALIGNED)
+                if (++f == c)
+                    if (epoch_end()) goto fit_done;
+        }
         fill(A);
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (step(B[d], d + 1 < D ? B[d + 1] : A[0])) goto fit_done;
+        for (int d = 0; d < D; ++d) {
+            step(B[d], d + 1 < D ? B[d + 1] : A[0]);
+            if (!ALIGNED)
+                if (++f == c)
+                    if (epoch_end()) goto fit_done;
+        }
         settle(A);
+        if (ALIGNED) {
+            f += 2 * D;
+            if (f == c)
+                if (epoch_end()) goto fit_done;
+        }
     }
 fit_done:
     out.n_iter = n_iter;
@@ -305,6 +351,25 @@ fit_done:
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
     out.nnz = cnt;
     return out;
+}
+
+// run-time -> compile-time dispatch of (RECIP, ALIGNED)
+template <int R>
+__device__ __forceinline__ FitOut cd_fit_any(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
+                                             uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
+                                             double y_norm2, int recip, double *w_lds, const double *feat) {
+    const bool aligned = (c % (2 * Ring<R>::D)) == 0;
+    if (recip) {
+        if (aligned)
+            return cd_fit<R, true, true>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds,
+                                         feat);
+        return cd_fit<R, true, false>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds,
+                                      feat);
+    }
+    if (aligned)
+        return cd_fit<R, false, true>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds,
+                                      feat);
+    return cd_fit<R, false, false>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds, feat);
 }
 
 // LDS image shared by both kernels: w[c] | feat[4 c]
@@ -321,6 +386,10 @@ __device__ __forceinline__ void load_features(const double *__restrict__ Q, int 
     }
     __syncthreads();
 }
+
+// debug/bench aid: shader-clock cycles spent inside the last cd_fit of the last launch and the
+// number of coordinate steps it ran (read back by cp_debug_cd_cycles; not part of the public ABI)
+__device__ unsigned long long g_cd_debug[2];
 
 struct DevResult {  // mirrors cp_cd_result
     double gap;
@@ -339,8 +408,14 @@ __global__ void __launch_bounds__(WAVE) k_cd_fit(const double *__restrict__ Q, i
     load_features(Q, ldq, q, w, c, l2, flags, w_lds, feat);
     const double y_norm2 = stats[0];
     const double tol_scaled = tol * y_norm2;
-    FitOut o = cd_fit<R>(Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, flags & CP_CD_RECIPROCAL,
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    FitOut o = cd_fit_any<R>(Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, flags & CP_CD_RECIPROCAL,
                          w_lds, feat);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        g_cd_debug[0] = t1 - t0;
+        g_cd_debug[1] = (unsigned long long)o.n_iter * (unsigned long long)c;
+    }
     __syncthreads();
     for (int j = threadIdx.x; j < c; j += WAVE) w[j] = w_lds[j];
     if (threadIdx.x == 0) {
@@ -369,7 +444,7 @@ k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
     bool bracketing = true, ok = false;
     while (fit < max_fits) {
         alpha = bracketing ? right : (left + right) / 2;
-        FitOut o = cd_fit<R>(Q, ldq, c, alpha * M, 0.0, seeds[fit], max_iter, tol_scaled, tol, y_norm2,
+        FitOut o = cd_fit_any<R>(Q, ldq, c, alpha * M, 0.0, seeds[fit], max_iter, tol_scaled, tol, y_norm2,
                              flags & CP_CD_RECIPROCAL, w_lds, feat);
         if (threadIdx.x == 0) {
             log[fit].gap = o.gap;
@@ -441,6 +516,13 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dres, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
     CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(result, ctx->pinned, sizeof(cp_cd_result));
+    return CP_OK;
+}
+
+extern "C" int cp_debug_cd_cycles(cp_ctx *ctx, unsigned long long *out2) {
+    if (!ctx || !out2) return CP_ERR_ARG;
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CP_HIP(ctx, hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_cd_debug), 2 * sizeof(unsigned long long)));
     return CP_OK;
 }
 

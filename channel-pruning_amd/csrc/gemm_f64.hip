@@ -147,38 +147,48 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     }
 }
 
-// Fixed-order reduction of the split-K partials: C = alpha * sum_z P[z] + beta * C, one
-// 128x128 tile per workgroup; TRI == lower-mirror also writes the transposed element.
+// Fixed-order reduction of the split-K partials: C = alpha * sum_z P[z] + beta * C.  One
+// workgroup per 4-row strip of a 128x128 tile (32 strips per tile), one double2 per thread;
+// TRI == lower-mirror also writes the transposed element.
+constexpr int RSTRIPS = BM / 4;
 template <int TRI>
 __global__ void __launch_bounds__(NTHREADS)
 k_gemm_reduce(int M, int N, double alpha, const double *__restrict__ P, int splits, double beta,
               double *__restrict__ C, int ldc, int tiles_n) {
     int ti, tj;
-    decode_tile(TRI, blockIdx.x, tiles_n, ti, tj);
+    decode_tile(TRI, blockIdx.x / RSTRIPS, tiles_n, ti, tj);
+    const int strip = blockIdx.x % RSTRIPS;
     const int m0 = ti * BM, n0 = tj * BN;
     const size_t plane = size_t(M) * N;
-    for (int e = threadIdx.x; e < BM * BN / 2; e += NTHREADS) {
-        const int r = e / (BN / 2), cc = (e % (BN / 2)) * 2;
-        const size_t off = size_t(m0 + r) * N + n0 + cc;
-        double2 s = {0., 0.};
-        for (int z = 0; z < splits; ++z) {
-            const double2 v = *reinterpret_cast<const double2 *>(P + size_t(z) * plane + off);
-            s.x += v.x;
-            s.y += v.y;
-        }
-        s.x *= alpha;
-        s.y *= alpha;
-        double *c = C + size_t(m0 + r) * ldc + n0 + cc;
-        if (beta != 0.0) {
-            s.x += beta * c[0];
-            s.y += beta * c[1];
-        }
-        c[0] = s.x;
-        c[1] = s.y;
-        if (TRI == CP_TRI_LOWER_MIRROR && ti != tj) {
-            C[size_t(n0 + cc) * ldc + m0 + r] = s.x;
-            C[size_t(n0 + cc + 1) * ldc + m0 + r] = s.y;
-        }
+    const int r = strip * 4 + threadIdx.x / (BN / 2), cc = (threadIdx.x % (BN / 2)) * 2;
+    const size_t off = size_t(m0 + r) * N + n0 + cc;
+    double2 s = {0., 0.};
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {  // 4 loads in flight, summed in index order
+        const double2 v0 = *reinterpret_cast<const double2 *>(P + size_t(z) * plane + off);
+        const double2 v1 = *reinterpret_cast<const double2 *>(P + size_t(z + 1) * plane + off);
+        const double2 v2 = *reinterpret_cast<const double2 *>(P + size_t(z + 2) * plane + off);
+        const double2 v3 = *reinterpret_cast<const double2 *>(P + size_t(z + 3) * plane + off);
+        s.x = ((s.x + v0.x) + v1.x) + v2.x + v3.x;
+        s.y = ((s.y + v0.y) + v1.y) + v2.y + v3.y;
+    }
+    for (; z < splits; ++z) {
+        const double2 v = *reinterpret_cast<const double2 *>(P + size_t(z) * plane + off);
+        s.x += v.x;
+        s.y += v.y;
+    }
+    s.x *= alpha;
+    s.y *= alpha;
+    double *c = C + size_t(m0 + r) * ldc + n0 + cc;
+    if (beta != 0.0) {
+        s.x += beta * c[0];
+        s.y += beta * c[1];
+    }
+    c[0] = s.x;
+    c[1] = s.y;
+    if (TRI == CP_TRI_LOWER_MIRROR && ti != tj) {
+        C[size_t(n0 + cc) * ldc + m0 + r] = s.x;
+        C[size_t(n0 + cc + 1) * ldc + m0 + r] = s.y;
     }
 }
 
@@ -208,7 +218,7 @@ GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri) {
     p.tiles_n = tn;
     p.n_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
     const int nk = K / BK;
-    const int target = ctx->cu_count * 2;  // 2 resident workgroups per CU
+    const int target = ctx->cu_count + ctx->cu_count / 2;  // ~1.5 workgroups per CU
     int splits = 1;
     if (p.n_tiles < target / 2 && nk >= 16) {
         splits = (target + p.n_tiles - 1) / p.n_tiles;
@@ -276,13 +286,13 @@ int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double 
     }
     if (p.splits > 1) {
         if (tri == CP_TRI_NONE)
-            k_gemm_reduce<CP_TRI_NONE><<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,
+            k_gemm_reduce<CP_TRI_NONE><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,
                                                                                   ldc, p.tiles_n);
         else if (tri == CP_TRI_LOWER_MIRROR)
-            k_gemm_reduce<CP_TRI_LOWER_MIRROR><<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits,
+            k_gemm_reduce<CP_TRI_LOWER_MIRROR><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits,
                                                                                           beta, C, ldc, p.tiles_n);
         else
-            k_gemm_reduce<CP_TRI_UPPER><<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,
+            k_gemm_reduce<CP_TRI_UPPER><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,
                                                                                    ldc, p.tiles_n);
         CP_LAUNCH_CHECK(ctx);
     } else if (tri == CP_TRI_LOWER_MIRROR && p.n_tiles > 1) {

@@ -117,13 +117,24 @@ k_build_z(const TX *__restrict__ X, const int64_t *__restrict__ samples, int c, 
     }
 }
 
-__global__ void __launch_bounds__(ZT) k_reduce_q(const double *__restrict__ qpart, int nparts, int c_pad, int c,
-                                                 double *__restrict__ q) {
-    const int i = blockIdx.x * ZT + threadIdx.x;
-    if (i >= c) return;
+// q[i] = sum_b qpart[b][i]: 64 columns x 16 row-groups per workgroup, groups combined in order
+__global__ void __launch_bounds__(1024) k_reduce_q(const double *__restrict__ qpart, int nparts, int c_pad, int c,
+                                                   double *__restrict__ q) {
+    __shared__ double red[16][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    const int per = (nparts + 15) / 16;
+    const int b0 = g * per, b1 = min(nparts, b0 + per);
     double s = 0;
-    for (int b = 0; b < nparts; ++b) s += qpart[size_t(b) * c_pad + i];
-    q[i] = s;
+    if (i < c_pad)
+        for (int b = b0; b < b1; ++b) s += qpart[size_t(b) * c_pad + i];
+    red[g][col] = s;
+    __syncthreads();
+    if (g == 0 && i < c) {
+        double t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k][col];
+        q[i] = t;
+    }
 }
 
 __global__ void __launch_bounds__(ZT) k_copy2d(const double *__restrict__ src, int lds_, double *__restrict__ dst,
@@ -213,7 +224,7 @@ extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N,
     else
         CP_TRY(launch_build_z<double>(ctx, kk, grid, static_cast<const double *>(X), dsamples, c, Wt, n, c_pad, Y,
                                       stats, zmean, jchunk, Zc, qpart));
-    k_reduce_q<<<(c + ZT - 1) / ZT, ZT, 0, ctx->stream>>>(qpart, S * JS, c_pad, c, q);
+    k_reduce_q<<<(c + 63) / 64, 1024, 0, ctx->stream>>>(qpart, S * JS, c_pad, c, q);
     CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "lasso_build_z");
     double *Qdst = c_pad == c ? Q : Qpad;
