@@ -42,13 +42,22 @@ __device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int 
     }
 }
 
-template <int TRI, int TAG>
+// WT = per-wave output tile (64 -> 128x128 workgroup tile, 32 -> 64x64).  The small tile is
+// used for the skinny K = 128 products of the blocked Cholesky / substitutions, where the
+// large one would leave most CUs idle and make every call as long as one 128^3 tile.
+template <int TRI, int TAG, int WT>
 __global__ void __launch_bounds__(NTHREADS, 2)
 k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
               const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
               double *__restrict__ P, int splits, int kchunk, int n_tiles, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) double As[BK * LLD];
-    __shared__ __attribute__((aligned(16))) double Bs[BK * LLD];
+    constexpr int TM = 2 * WT;              // workgroup tile edge
+    constexpr int TLD = TM + LPAD;          // padded LDS row
+    constexpr int TPR = TM / 2;             // threads per tile row (one double2 each)
+    constexpr int RPP = NTHREADS / TPR;     // rows per pass
+    constexpr int NPASS = BK / RPP;
+    constexpr int FR = WT / 16;             // MFMA tiles per wave edge
+    __shared__ __attribute__((aligned(16))) double As[BK * TLD];
+    __shared__ __attribute__((aligned(16))) double Bs[BK * TLD];
 
     const int tid = threadIdx.x;
     int tile, z;
@@ -62,58 +71,58 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     }
     int ti, tj;
     decode_tile(TRI, tile, tiles_n, ti, tj);
-    const int m0 = ti * BM, n0 = tj * BN;
+    const int m0 = ti * TM, n0 = tj * TM;
     const int k0 = z * kchunk;
     int k1 = k0 + kchunk;
     if (k1 > K) k1 = K;
     const int nk = k1 > k0 ? (k1 - k0) / BK : 0;
 
-    // global -> register staging: thread loads rows (lrow + 4 i), 2 doubles at column lcol
-    const int lrow = tid >> 6, lcol = (tid & 63) * 2;
+    // global -> register staging: thread loads rows (lrow + RPP i), 2 doubles at column lcol
+    const int lrow = tid / TPR, lcol = (tid % TPR) * 2;
     const double *Ag = A + size_t(k0 + lrow) * lda + m0 + lcol;
     const double *Bg = B + size_t(k0 + lrow) * ldb + n0 + lcol;
-    double2 ar[4], br[4];
+    double2 ar[NPASS], br[NPASS];
     auto load_tile = [&](int kt) {
         const double *a = Ag + size_t(kt) * BK * lda;
         const double *b = Bg + size_t(kt) * BK * ldb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ar[i] = *reinterpret_cast<const double2 *>(a + size_t(4 * i) * lda);
-            br[i] = *reinterpret_cast<const double2 *>(b + size_t(4 * i) * ldb);
+        for (int i = 0; i < NPASS; ++i) {
+            ar[i] = *reinterpret_cast<const double2 *>(a + size_t(RPP * i) * lda);
+            br[i] = *reinterpret_cast<const double2 *>(b + size_t(RPP * i) * ldb);
         }
     };
 
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
     const int fk = lane >> 4, fi = lane & 15;
 
-    v4f64 acc[4][4];
+    v4f64 acc[FR][FR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FR; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0., 0., 0., 0.};
+        for (int j = 0; j < FR; ++j) acc[i][j] = v4f64{0., 0., 0., 0.};
 
     if (nk > 0) load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<double2 *>(&As[(lrow + 4 * i) * LLD + lcol]) = ar[i];
-            *reinterpret_cast<double2 *>(&Bs[(lrow + 4 * i) * LLD + lcol]) = br[i];
+        for (int i = 0; i < NPASS; ++i) {
+            *reinterpret_cast<double2 *>(&As[(lrow + RPP * i) * TLD + lcol]) = ar[i];
+            *reinterpret_cast<double2 *>(&Bs[(lrow + RPP * i) * TLD + lcol]) = br[i];
         }
         __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            double a[4], b[4];
+            double a[FR], b[FR];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = As[(kk * 4 + fk) * LLD + wm + i * 16 + fi];
-                b[i] = Bs[(kk * 4 + fk) * LLD + wn + i * 16 + fi];
+            for (int i = 0; i < FR; ++i) {
+                a[i] = As[(kk * 4 + fk) * TLD + wm + i * 16 + fi];
+                b[i] = Bs[(kk * 4 + fk) * TLD + wn + i * 16 + fi];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FR; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < FR; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -123,9 +132,9 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     if (splits > 1) {
         double *dst = P + size_t(z) * M * N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FR; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < FR; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
@@ -133,9 +142,9 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
                 }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FR; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < FR; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
@@ -210,17 +219,25 @@ __global__ void __launch_bounds__(NTHREADS) k_mirror_lower(double *__restrict__ 
 
 struct GemmPlan {
     int n_tiles, tiles_n, splits, kchunk;
+    bool small;  // 64x64 tiles
 };
 
 GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri) {
     GemmPlan p;
-    const int tm = M / BM, tn = N / BN;
+    int tm = M / BM, tn = N / BN;
+    const int big_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
+    // skinny products (few large tiles, short K, no mirroring needed): quarter-size tiles
+    p.small = tri != CP_TRI_LOWER_MIRROR && K <= 512 && big_tiles * 4 <= ctx->cu_count * 2;
+    if (p.small) {
+        tm *= 2;
+        tn *= 2;
+    }
     p.tiles_n = tn;
     p.n_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
     const int nk = K / BK;
     const int target = ctx->cu_count + ctx->cu_count / 2;  // ~1.5 workgroups per CU
     int splits = 1;
-    if (p.n_tiles < target / 2 && nk >= 16) {
+    if (!p.small && p.n_tiles < target / 2 && nk >= 16) {
         splits = (target + p.n_tiles - 1) / p.n_tiles;
         splits = (splits + 7) / 8 * 8;
         const int max_splits = (nk / 4) / 8 * 8;  // keep >= 4 k-stages per split
@@ -259,8 +276,14 @@ int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double 
     }
     const int grid = p.n_tiles * p.splits;
 #define CP_GEMM_LAUNCH(T, G)                                                                                  \
-    k_gemm_tn_f64<T, G><<<grid, NTHREADS, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, P,   \
-                                                              p.splits, p.kchunk, p.n_tiles, p.tiles_n)
+    do {                                                                                                      \
+        if (p.small)                                                                                          \
+            k_gemm_tn_f64<T, G, 32><<<grid, NTHREADS, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
+                                                                          P, p.splits, p.kchunk, p.n_tiles, p.tiles_n); \
+        else                                                                                                  \
+            k_gemm_tn_f64<T, G, 64><<<grid, NTHREADS, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
+                                                                          P, p.splits, p.kchunk, p.n_tiles, p.tiles_n); \
+    } while (0)
     const int tag = ctx->gemm_tag;
     ctx->gemm_tag = CP_GEMM_GENERIC;
     if (tri == CP_TRI_NONE) {

@@ -129,69 +129,176 @@ __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, 
 }
 
 // ---- Cholesky diagonal block: U^T U = A (128 x 128), TI = U^-1, TIT = U^-T ----------------
-// One workgroup; the block lives in LDS (128 x 129 doubles = 132 KB).  Right-looking, column by
-// column, upper triangle only; the strictly-lower triangle of the LDS image then receives
-// (U^-1)^T, one row per thread pair.  info[0] receives 1 + global column of the first pivot
-// <= piv_tol * original diagonal.
+// One 4-wave workgroup, block resident in LDS (128 x 136 doubles).  Eight 16-column panels:
+//   (1) wave 0 factors the 16x16 diagonal sub-block (rank-1 steps, rsq + 2 Newton steps per pivot)
+//   (2) all threads solve U12 = U11^-T A12 by forward substitution, one column per thread
+//   (3) all waves apply A22 -= U12^T U12 on v_mfma_f64_16x16x4_f64, one 16x16 tile at a time
+// then the 16x16 diagonal inverses (4 lanes per column, quad reductions) and the off-diagonal
+// blocks of U^-1 by block back-substitution on MFMA (V_ij = -T_ii sum_k U_ik V_kj), block columns
+// spread over the waves.  info[0] receives 1 + global column of the first pivot
+// <= piv_tol * original diagonal (also NaN).
+typedef double v4f64c __attribute__((ext_vector_type(4)));
+constexpr int PNB = 16, NPAN = NB / PNB, DLD = 136;
+
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
 __global__ void __launch_bounds__(RT) k_potrf_diag(double *__restrict__ G, int ld, int blk,
                                                    const double *__restrict__ dg0, double piv_tol,
                                                    double *__restrict__ TI, double *__restrict__ TIT,
                                                    int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    constexpr int LD = NB + 1;
-    double *A = sm;  // NB x LD
-    const int tid = threadIdx.x;
+    double *A = sm;                        // NB x DLD
+    double *Tl = sm + NB * DLD;            // NPAN x 16 x 16 : inverses of the diagonal sub-blocks
+    double *dinv = Tl + NPAN * PNB * PNB;  // NB : 1 / U[i,i]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fk = lane >> 4, fi = lane & 15;
     double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
-    for (int e = tid; e < NB * NB; e += RT) {
-        const int r = e / NB, cc = e - r * NB;
-        A[r * LD + cc] = Gb[size_t(r) * ld + cc];
+    for (int e = tid; e < NB * NB / 2; e += RT) {
+        const int r = e / (NB / 2), cc = (e % (NB / 2)) * 2;
+        *reinterpret_cast<double2 *>(&A[r * DLD + cc]) = *reinterpret_cast<const double2 *>(&Gb[size_t(r) * ld + cc]);
     }
     __syncthreads();
-    for (int k = 0; k < NB; ++k) {
-        double piv = A[k * LD + k];
-        const double ref = dg0[blk * NB + k];
-        if (!(piv > piv_tol * ref)) {  // also catches NaN
-            if (tid == 0) atomicCAS(info, 0, blk * NB + k + 1);
-            piv = ref > 0 ? ref : 1.0;  // keep going with a harmless pivot; the result is discarded
+
+    for (int p = 0; p < NPAN; ++p) {
+        const int k0 = p * PNB;
+        // (1) 16x16 diagonal sub-block, wave 0: lane (j = fi, g = fk) owns rows 4g..4g+3 of column j
+        if (wave == 0) {
+            for (int k = 0; k < PNB; ++k) {
+                double piv = A[(k0 + k) * DLD + k0 + k];
+                const double ref = dg0[blk * NB + k0 + k];
+                if (!(piv > piv_tol * ref)) {
+                    if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
+                    piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
+                }
+                const double inv = rsqrt_nr(piv), ukk = piv * inv;
+                const double u_j = A[(k0 + k) * DLD + k0 + fi] * inv;
+                const double2 a01 = *reinterpret_cast<const double2 *>(&A[(k0 + k) * DLD + k0 + 4 * fk]);
+                const double2 a23 = *reinterpret_cast<const double2 *>(&A[(k0 + k) * DLD + k0 + 4 * fk + 2]);
+                const double u_i[4] = {a01.x * inv, a01.y * inv, a23.x * inv, a23.y * inv};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int i = 4 * fk + m;
+                    if (i > k && fi >= i) A[(k0 + i) * DLD + k0 + fi] -= u_i[m] * u_j;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (fk == 0) {
+                    if (fi > k) A[(k0 + k) * DLD + k0 + fi] = u_j;
+                    if (fi == k) {
+                        A[(k0 + k) * DLD + k0 + k] = ukk;
+                        dinv[k0 + k] = inv;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        const double ukk = sqrt(piv);
-        const double inv = 1.0 / ukk;
         __syncthreads();
-        // row k of U: U[k, j] = A[k, j] / ukk  (j > k)
-        for (int j = k + 1 + tid; j < NB; j += RT) A[k * LD + j] *= inv;
-        if (tid == 0) A[k * LD + k] = ukk;
+        // (2) U12 = U11^-T A12: thread t owns column k0 + 16 + t
+        const int rest = NB - k0 - PNB;
+        if (tid < rest) {
+            const int col = k0 + PNB + tid;
+            double x[PNB];
+#pragma unroll
+            for (int i = 0; i < PNB; ++i) x[i] = A[(k0 + i) * DLD + col];
+#pragma unroll
+            for (int i = 0; i < PNB; ++i) {
+                double sacc = x[i];
+#pragma unroll
+                for (int k = 0; k < i; ++k) sacc = fma(-A[(k0 + k) * DLD + k0 + i], x[k], sacc);
+                x[i] = sacc * dinv[k0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < PNB; ++i) A[(k0 + i) * DLD + col] = x[i];
+        }
         __syncthreads();
-        // trailing update A[i, j] -= U[k, i] U[k, j], k < i <= j
-        const int rem = NB - k - 1;
-        for (int e = tid; e < rem * rem; e += RT) {
-            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-            if (j >= i) A[i * LD + j] -= A[k * LD + i] * A[k * LD + j];
+        // (3) A22 -= U12^T U12 on the upper tiles (ti <= tj) of the trailing (rest/16)^2 grid
+        const int rt = rest / PNB, ntile = rt * (rt + 1) / 2;
+        for (int e = wave; e < ntile; e += 4) {
+            int a = int((sqrtf(8.f * float(e) + 1.f) - 1.f) * 0.5f);
+            while ((a + 1) * (a + 2) / 2 <= e) ++a;
+            while (a * (a + 1) / 2 > e) --a;
+            const int b = e - a * (a + 1) / 2;  // b <= a
+            const int ci = k0 + PNB + b * PNB, cj = k0 + PNB + a * PNB;  // tile rows ci.., cols cj.. (ci <= cj)
+            v4f64c acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = A[(ci + fk + 4 * r) * DLD + cj + fi];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double av = -A[(k0 + kk * 4 + fk) * DLD + ci + fi];
+                const double bv = A[(k0 + kk * 4 + fk) * DLD + cj + fi];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(ci + fk + 4 * r) * DLD + cj + fi] = acc[r];
         }
         __syncthreads();
     }
-    // V = U^-1 (upper): U V = I -> V[i,j] = (delta_ij - sum_{k=i+1..j} U[i,k] V[k,j]) / U[i,i].
-    // Column j is owned by threads (j, j+128): they split the k-sum by parity and combine through
-    // a register exchange (both in the same wave? no: 128 apart) -> use LDS row NB.. instead:
-    // keep it simple and exact-order: ONE thread per column, V[k,j] (k < j) stored at A[j, k].
-    if (tid < NB) {
-        const int j = tid;
-        const double vjj = 1.0 / A[j * LD + j];
-        for (int i = j - 1; i >= 0; --i) {
-            double s = -A[i * LD + j] * vjj;
-            for (int k = i + 1; k < j; ++k) s -= A[i * LD + k] * A[j * LD + k];
-            A[j * LD + i] = s / A[i * LD + i];
+
+    // T_p = U_pp^-1 (upper 16x16): task = (panel, column j), 4 lanes per task split the k-sum
+    for (int pass = 0; pass < 2; ++pass) {
+        const int task = pass * 64 + (tid >> 2), g = tid & 3;
+        const int p = task >> 4, j = task & 15, k0 = p * PNB;
+        double *Tp = Tl + p * PNB * PNB;
+        for (int i = PNB - 1; i >= 0; --i) {
+            double sacc = 0.0;
+            for (int k = i + 1 + g; k <= j; k += 4) sacc = fma(A[(k0 + i) * DLD + k0 + k], Tp[k * PNB + j], sacc);
+            sacc += __shfl_xor(sacc, 1, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            const double t = i <= j ? ((i == j ? 1.0 : 0.0) - sacc) * dinv[k0 + i] : 0.0;
+            if (g == 0) Tp[i * PNB + j] = t;
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
+
+    // off-diagonal blocks of V = U^-1: V_ij = -T_ii * sum_{k=i+1..j} U_ik V_kj, stored (untransposed)
+    // at block position (j, i) of A's lower part.  Block columns per wave: {7}, {6,1}, {5,2}, {4,3}.
+    for (int which = 0; which < 2; ++which) {
+        const int jb = which == 0 ? 7 - wave : wave;
+        if (which == 1 && wave == 0) break;
+        for (int ib = jb - 1; ib >= 0; --ib) {
+            v4f64c S = {0., 0., 0., 0.};
+            for (int kb = ib + 1; kb <= jb; ++kb) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double av = A[(ib * PNB + fi) * DLD + kb * PNB + kk * 4 + fk];  // U_ik[i][k]
+                    const double bv = kb == jb ? Tl[jb * PNB * PNB + (kk * 4 + fk) * PNB + fi]
+                                               : A[(jb * PNB + kk * 4 + fk) * DLD + kb * PNB + fi];  // V_kj[k][j]
+                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, S, 0, 0, 0);
+                }
+            }
+            v4f64c V = {0., 0., 0., 0.};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double av = -Tl[ib * PNB * PNB + fi * PNB + kk * 4 + fk];  // -T_ii[i][k]
+                V = __builtin_amdgcn_mfma_f64_16x16x4f64(av, S[kk], V, 0, 0, 0);  // S rows 4kk.. sit in S[kk]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(jb * PNB + fk + 4 * r) * DLD + ib * PNB + fi] = V[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+
     double *TIb = TI + size_t(blk) * NB * NB, *TITb = TIT + size_t(blk) * NB * NB;
     for (int e = tid; e < NB * NB; e += RT) {
         const int r = e / NB, cc = e - r * NB;
-        // V[r, cc] for cc > r lives at A[cc, r]; V[r, r] = 1 / U[r, r]
-        const double v_rc = cc > r ? A[cc * LD + r] : (cc == r ? 1.0 / A[r * LD + r] : 0.0);
-        const double v_cr = r > cc ? A[r * LD + cc] : (cc == r ? 1.0 / A[r * LD + r] : 0.0);
-        Gb[size_t(r) * ld + cc] = cc >= r ? A[r * LD + cc] : 0.0;  // U, strictly-lower part zeroed
-        TIb[e] = v_rc;   // U^-1   (upper)
-        TITb[e] = v_cr;  // U^-T   (lower): TIT[r, cc] = V[cc, r]
+        const int rb = r >> 4, cb = cc >> 4, ri = r & 15, ci = cc & 15;
+        // V[r, cc] (upper): diagonal blocks in Tl, block (rb < cb) at A block position (cb, rb)
+        const double v_rc = rb < cb ? A[(cb * PNB + ri) * DLD + rb * PNB + ci]
+                                    : (rb == cb ? Tl[rb * PNB * PNB + ri * PNB + ci] : 0.0);
+        // V[cc, r] for the transposed copy
+        const double v_cr = cb < rb ? A[(rb * PNB + ci) * DLD + cb * PNB + ri]
+                                    : (rb == cb ? Tl[rb * PNB * PNB + ci * PNB + ri] : 0.0);
+        const bool up = cc > r || (cc == r);
+        const bool in_diag_lower = rb == cb && ci < ri;
+        Gb[size_t(r) * ld + cc] = (up && !in_diag_lower) ? A[r * DLD + cc] : 0.0;  // U, lower part zeroed
+        TIb[e] = v_rc;
+        TITb[e] = v_cr;
     }
 }
 
@@ -253,7 +360,7 @@ struct Chol {
 int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     const int ld = ch.p_pad;
     CP_HIP(ctx, hipMemsetAsync(ch.info, 0, sizeof(int), ctx->stream));
-    const size_t lds = size_t(NB) * (NB + 1) * sizeof(double);
+    const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + NB) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs an explicit opt-in
         CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_diag),
