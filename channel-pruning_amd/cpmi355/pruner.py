@@ -30,8 +30,43 @@ def _np_dtype_code(arr):
 class LayerProblem:
     """X[N,c,k,k], W2[n,c,k,k], Y[N,n] resident in HBM plus the small per-layer outputs."""
 
+    @classmethod
+    def from_device(cls, ctx, Xd, x_dtype, N, c, k, W2, Yd, flags=0):
+        """X[N,c,k,k] (x_dtype) and Y[N,n] float64 already resident (DevBuf / data_ptr owner);
+        W2 is the small host array [n,c,k,k]."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        W2 = np.ascontiguousarray(W2)
+        if W2.dtype not in (np.float32, np.float64):
+            W2 = W2.astype(np.float64)
+        self.N, self.c, self.k, self.kk = int(N), int(c), int(k), int(k) * int(k)
+        self.n = int(W2.shape[0])
+        if W2.shape[1] != self.c or int(np.prod(W2.shape[2:])) != self.kk:
+            raise ValueError("inconsistent shapes W2%s for c=%d k=%d" % (W2.shape, c, k))
+        self.x_dtype, self.w_dtype = x_dtype, _np_dtype_code(W2)
+        self.h2d_bytes = W2.nbytes
+        self.Xd, self.Yd = Xd, Yd
+        self._borrowed = ("Xd", "Yd")
+        self.W2d = ctx.to_device(W2)
+        self._alloc_outputs(flags)
+        return self
+
+    def _alloc_outputs(self, flags):
+        ctx, c, n = self.ctx, self.c, self.n
+        self.Qd = ctx.empty(c * c * 8)
+        self.qd = ctx.empty(c * 8)
+        self.statsd = ctx.empty(4 * 8)
+        self.wd = ctx.zeros(c * 8)
+        self.Wout = ctx.empty(n * c * self.kk * 8)
+        self.bout = ctx.empty(n * 8)
+        self.flags = flags
+        self.S = 0
+        self.fits = []          # [(alpha, nnz, n_iter)] of the last search
+        self.refit_info = None
+
     def __init__(self, ctx, X, W2, Y, flags=0):
         self.ctx = ctx
+        self._borrowed = ()
         X = np.ascontiguousarray(X)
         W2 = np.ascontiguousarray(W2)
         if X.dtype not in (np.float32, np.float64):
@@ -50,17 +85,7 @@ class LayerProblem:
         self.Xd = ctx.to_device(X)
         self.W2d = ctx.to_device(W2)
         self.Yd = ctx.to_device(Y)
-        c, n = self.c, self.n
-        self.Qd = ctx.empty(c * c * 8)
-        self.qd = ctx.empty(c * 8)
-        self.statsd = ctx.empty(4 * 8)
-        self.wd = ctx.zeros(c * 8)
-        self.Wout = ctx.empty(n * c * self.kk * 8)
-        self.bout = ctx.empty(n * 8)
-        self.flags = flags
-        self.S = 0
-        self.fits = []          # [(alpha, nnz, n_iter)] of the last search
-        self.refit_info = None
+        self._alloc_outputs(flags)
 
     # -- decompose.py:425-437 + Lasso.fit preprocessing ------------------------------
     def lasso_gram(self, samples):
@@ -147,7 +172,7 @@ class LayerProblem:
     def free(self):
         for name in ("Xd", "W2d", "Yd", "Qd", "qd", "statsd", "wd", "Wout", "bout"):
             buf = getattr(self, name, None)
-            if buf is not None:
+            if buf is not None and name not in self._borrowed and hasattr(buf, "free"):
                 buf.free()
 
 

@@ -1,0 +1,176 @@
+"""CPU: host-side logic of the product (no GPU compute): config mirror, Worker, layer sharding
+(world_size-2 gloo), RNG-stream bookkeeping of the alpha search, loud failure without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_cfgs_mirror_has_the_keys_the_path_reads():
+    import lib.cfgs as cfgs
+    from lib.cfgs import c as dcfgs
+    assert cfgs.alpha == 1e-3                                  # cfgs.py:18
+    assert dcfgs.dic.rank_tol == .1 and dcfgs.dic.keep == 3.   # cfgs.py:74-75
+    assert dcfgs.nBatches == 500 and dcfgs.nPointsPerLayer == 10
+    assert dcfgs.solver == cfgs.solvers.sk and dcfgs.ls == 'linear' and dcfgs.fc_ridge == 0
+    cfgs.set_nBatches(7)
+    assert dcfgs.nBatches == 7 and dcfgs.nBatches_fc == 7
+    cfgs.set_nBatches(500)
+
+
+def test_worker_runs_target_in_a_child_and_returns_its_dict():
+    from lib.worker import Worker
+
+    def target(a, b, queue=None):
+        return {"sum": a + b, "pid": os.getpid()}
+
+    w = Worker()
+    out = w.do(target, a=2, b=3)
+    assert out["sum"] == 5 and out["pid"] != os.getpid()
+    out = w.do(a=10, b=1)                                      # cached target (worker.py:13-18)
+    assert out["sum"] == 11
+
+
+def test_worker_propagates_child_failures_instead_of_hanging():
+    from lib.worker import Worker
+
+    def bad(queue=None):
+        raise ValueError("boom")
+
+    with pytest.raises(RuntimeError, match="boom"):
+        Worker().do(bad)
+
+    def not_a_dict(queue=None):
+        return 3
+
+    with pytest.raises(RuntimeError):
+        Worker().do(not_a_dict)
+
+
+def test_dictionary_without_gpu_fails_loudly():
+    """The product never falls back to a CPU path: no GPU -> CpError from context creation."""
+    from cpmi355 import capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    import lib.decompose as D
+    rs = np.random.RandomState(0)
+    X = rs.randn(100, 8, 3, 3)
+    W2 = rs.randn(4, 8, 3, 3).astype(np.float32)
+    with pytest.raises(capi.CpError):
+        D.dictionary(X, W2, rs.randn(100, 4), rank=4)
+    with pytest.raises(capi.CpError):
+        D.fc_kernel(rs.randn(50, 6), rs.randn(50, 2))
+
+
+def test_product_does_not_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under channel-pruning_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "channel-pruning_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "cp_oracle" not in text and "import oracle" not in text and "libcporacle" not in text, f
+
+
+def test_lpt_assignment_balances_layers():
+    from cpmi355.shard import assign_layers, layer_cost
+    vgg = [(64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 512), (512, 512),
+           (512, 512), (512, 512), (512, 512), (512, 512)]
+    costs = [layer_cost(5000, c, n, 3, c // 2) for c, n in vgg]
+    for world in (1, 2, 4, 8):
+        owner = assign_layers(costs, world)
+        assert set(owner) <= set(range(world)) and len(owner) == len(costs)
+        load = [sum(cst for cst, o in zip(costs, owner) if o == r) for r in range(world)]
+        assert max(load) <= sum(costs) / world + max(costs)   # LPT bound
+    assert assign_layers(costs, 2) == assign_layers(costs, 2)  # deterministic
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cp_oracle
+    from cpmi355.shard import prune_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = [dict(layer_id=i + 1, N=300, c=c, n=n, k=k, rank=r)
+             for i, (c, n, k, r) in enumerate([(16, 12, 3, 8), (24, 16, 3, 12), (32, 8, 1, 10), (16, 16, 3, 16)])]
+    calls = []
+
+    def compute(s):   # the checker stands in for the GPU here (CPU test of the sharding logic only)
+        calls.append(s["layer_id"])
+        X, W2, Y, B2 = cp_oracle.synth_layer(s["layer_id"], s["N"], s["c"], s["n"], s["k"])
+        rng = np.random.RandomState(1234 + s["layer_id"])
+        out = cp_oracle.dictionary_oracle(X.astype(np.float64), W2, Y, s["rank"], B2, rng=rng, lasso="c_gram",
+                                          ls="numpy")
+        return out[0], out[1], out[2]
+
+    res = prune_sharded(specs, compute, dist=dist)
+    q.put((rank, calls, [(r[0].tolist(), float(np.abs(r[1]).sum()), float(np.abs(r[2]).sum())) for r in res]))
+    dist.destroy_process_group()
+
+
+def test_sharded_pruning_world_size_2_gloo():
+    """Two ranks split four layers, then every rank holds every layer's (mask, W, b); the union of
+    the work is exactly one call per layer and the results equal a single-process run."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort()
+    calls = sorted(got[0][1] + got[1][1])
+    assert calls == [1, 2, 3, 4] and got[0][1] and got[1][1]
+    assert got[0][2] == got[1][2]
+    # single-process reference of the same sharding code path
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cp_oracle
+    from cpmi355.shard import prune_sharded
+    specs = [dict(layer_id=i + 1, N=300, c=c, n=n, k=k, rank=r)
+             for i, (c, n, k, r) in enumerate([(16, 12, 3, 8), (24, 16, 3, 12), (32, 8, 1, 10), (16, 16, 3, 16)])]
+
+    def compute(s):
+        X, W2, Y, B2 = cp_oracle.synth_layer(s["layer_id"], s["N"], s["c"], s["n"], s["k"])
+        out = cp_oracle.dictionary_oracle(X.astype(np.float64), W2, Y, s["rank"], B2,
+                                          rng=np.random.RandomState(1234 + s["layer_id"]), lasso="c_gram", ls="numpy")
+        return out[0], out[1], out[2]
+
+    single = prune_sharded(specs, compute)
+    for (m, sw, sb), r in zip(got[0][2], single):
+        assert m == r[0].tolist() and abs(sw - np.abs(r[1]).sum()) <= 1e-9 * sw and abs(sb - np.abs(r[2]).sum()) <= 1e-9
+
+
+def test_alpha_search_rng_rewind_matches_reference_consumption():
+    """The device-mode search pre-draws seeds, then rewinds and re-draws exactly F of them: the
+    stream position afterwards must equal 1 + F draws (what the reference consumes)."""
+    from cpmi355 import pruner
+
+    class FakeCtx:
+        def lasso_alpha_search(self, *a, **k):
+            return 5, 0.01, [(0.01, 3, 4)] * 5      # pretend the search used 5 fits
+
+    class P(pruner.LayerProblem):
+        def __init__(self):
+            self.ctx, self.c, self.n, self.S, self.flags = FakeCtx(), 8, 4, 10, 0
+            self.Qd = self.qd = self.statsd = self.wd = None
+            self.fits = []
+
+        def reset_w(self):
+            pass
+
+    rng = np.random.RandomState(42)
+    P().alpha_search(4, 1e-3, .1, rng, mode="device")
+    after = rng.randint(0, 2147483647)
+    ref = np.random.RandomState(42)
+    for _ in range(5):
+        ref.randint(0, pruner.RAND_R_MAX)
+    assert after == ref.randint(0, 2147483647)
