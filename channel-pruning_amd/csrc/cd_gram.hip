@@ -131,7 +131,7 @@ struct Slot {
 // RECIP: multiply by 1/(Qii + beta) instead of dividing (CP_CD_RECIPROCAL).
 // ALIGNED: c is a multiple of 2*D, so an epoch ends exactly on a group boundary and the
 // end-of-epoch test is hoisted out of the per-step code.
-template <int R, bool RECIP, bool ALIGNED>
+template <int R, bool RECIP, bool ALIGNED, bool DELTA>
 __device__ __forceinline__ FitOut cd_fit(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
                                          uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
                                          double y_norm2, double *w_lds, const double *feat) {
@@ -288,7 +288,13 @@ __device__ __forceinline__ FitOut cd_fit(const double *__restrict__ Q, int ldq, 
             // fsign(tmp) * fmax(|tmp| - alpha, 0)
             const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
             const double w_new = RECIP ? thr * S.den : thr / S.den;
-            if (R <= CD_UNCOND_R) {
+            if (DELTA) {  // CP_CD_DELTA: one axpy with the difference
+                const double dlt = w_new - w_ii;
+                if (R <= CD_UNCOND_R || dlt != 0.0) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(dlt, rowv[r], H[r]);
+                }
+            } else if (R <= CD_UNCOND_R) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) H[r] = fma(w_new, rowv[r], fma(-w_ii, rowv[r], H[r]));
             } else {
@@ -353,23 +359,286 @@ fit_done:
     return out;
 }
 
-// run-time -> compile-time dispatch of (RECIP, ALIGNED)
+// ---------------------------------------------------------------------------------------------
+// Blocked variant (c % B == 0, R <= 8).  A single wave issues one instruction every ~5-6.5 cycles
+// regardless of dependencies, so a step costs what its instruction count costs.  Here the
+// per-coordinate scalars of B consecutive steps live on B lanes: at block start every lane
+// fetches "its" H[ii] (through an LDS image of H), w[ii], and -- one block ahead -- the B
+// entries Q[ii_a, ii_lane] that couple it to the block's steps; the B updates then run as
+// straight vector code (lane a's result is latched at step a) with ONE readlane pair per step
+// to broadcast the step's (w_old, w_new) -- or just their difference with CP_CD_DELTA -- to the
+// full-width axpy on H.  No per-step register selects, LDS round trips or scalar bookkeeping.
+// The fma sequence applied to every H entry is unchanged, so w stays bit-identical to the oracle.
+// Blocks in which a coordinate repeats (detected per 64-value index batch) take a scalar path.
+template <int R>
+struct Blk {
+    static constexpr int B = R <= 4 ? 8 : 4;
+};
+
+template <int R, int B>
+struct BSet {
+    double row[B][R];  // Q[ii_a, lane + 64 r]
+    double qc[B];      // Q[ii_a, ii_lane]
+};
+
+template <int R, bool RECIP, bool DELTA>
+__device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, int ldq, int c, double alpha,
+                                                 double beta, uint32_t seed, int max_iter, double tol_scaled,
+                                                 double d_w_tol, double y_norm2, double *w_lds, const double *feat,
+                                                 double *h_lds) {
+    constexpr int B = Blk<R>::B, NBLK = 64 / B;
+    const int lane = threadIdx.x;
+    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    uint32_t colb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int col = r * WAVE + lane;
+        colb[r] = uint32_t(col < c ? col : c - 1) * 8u;
+    }
+    double H[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) H[r] = 0.0;
+    constexpr int U = R <= 4 ? 8 : 4;
+    for (int j0 = 0; j0 < c; j0 += U) {  // H = Q w in index order (as the oracle)
+        double row[U][R];
+        double wj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u;
+            wj[u] = j < c ? w_lds[j] : 0.0;
+            const uint32_t roff = uint32_t(j < c ? j : c - 1) * row_stride_bytes;
+#pragma unroll
+            for (int r = 0; r < R; ++r) row[u][r] = load_q(rsrc, colb[r], roff);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (wj[u] != 0.0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(wj[u], row[u][r], H[r]);
+            }
+    }
+
+    IdxStream rng;
+    rng.init(seed, uint32_t(c), row_stride_bytes, lane);
+
+    // per-lane data of the CURRENT 64-value batch (lane l <-> stream value 64*batch + l)
+    uint32_t ii_v, voff_v;
+    double q_v, Qd_v, den_v;
+    uint64_t dupmask;
+    auto adopt_batch = [&]() {
+        ii_v = rng.idx;
+        voff_v = ii_v * 8u;
+        const double2 qQ = *reinterpret_cast<const double2 *>(feat + 4 * ii_v);
+        q_v = qQ.x;
+        Qd_v = qQ.y;
+        den_v = feat[4 * ii_v + 2];
+        bool dup = false;
+#pragma unroll
+        for (int sft = 1; sft < B; ++sft) {
+            const int other = __shfl(int(ii_v), (lane & ~(B - 1)) | ((lane + sft) & (B - 1)), WAVE);
+            dup |= (uint32_t(other) == ii_v);
+        }
+        dupmask = __ballot(dup);
+    };
+
+    BSet<R, B> SA, SB;
+    // request the operands of block (base .. base+B-1) of the batch whose offsets are in (off_vec, voff_vec)
+    auto fill = [&](BSet<R, B> &S, uint32_t off_vec, uint32_t voff_vec, int base) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a));
+#pragma unroll
+            for (int r = 0; r < R; ++r) S.row[a][r] = load_q(rsrc, colb[r], roff);
+            S.qc[a] = load_q(rsrc, voff_vec, roff);
+        }
+    };
+    auto settle = [&](BSet<R, B> &S) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            asm volatile("" : "+v"(S.qc[a]));
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(S.row[a][r]));
+        }
+    };
+
+    FitOut out;
+    out.gap = tol_scaled + 1.0;
+    out.n_iter = 0;
+    int n_iter = 0, f = 0;
+    double wmax_v = 0.0, dmax_v = 0.0;  // per-lane running maxima, reduced at the end of an epoch
+
+    auto epoch_end = [&]() -> bool {
+        const double w_max = wave_max(wmax_v), d_w_max = wave_max(dmax_v);
+        bool done = false;
+        if (w_max == 0.0 || d_w_max / w_max < d_w_tol || n_iter == max_iter - 1) {
+            double s_qw = 0, s_wh = 0, s_ww = 0, s_l1 = 0, m_xta = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int col = r * WAVE + lane;
+                if (col < c) {
+                    const double wv = w_lds[col], qv = feat[4 * col];
+                    const double xta = qv - H[r] - beta * wv;
+                    s_qw += wv * qv;
+                    s_wh += wv * H[r];
+                    s_ww += wv * wv;
+                    s_l1 += fabs(wv);
+                    m_xta = fmax(m_xta, fabs(xta));
+                }
+            }
+            const double q_dot_w = wave_sum(s_qw), wh = wave_sum(s_wh), w_norm2 = wave_sum(s_ww),
+                         l1 = wave_sum(s_l1), dual_norm = wave_max(m_xta);
+            const double R_norm2 = y_norm2 + wh - 2.0 * q_dot_w;
+            double const_, gap;
+            if (dual_norm > alpha) {
+                const_ = alpha / dual_norm;
+                const double A_norm2 = R_norm2 * (const_ * const_);
+                gap = 0.5 * (R_norm2 + A_norm2);
+            } else {
+                const_ = 1.0;
+                gap = R_norm2;
+            }
+            gap += alpha * l1 - const_ * y_norm2 + const_ * q_dot_w + 0.5 * beta * (1.0 + const_ * const_) * w_norm2;
+            out.gap = gap;
+            if (gap < tol_scaled) done = true;
+        }
+        ++n_iter;
+        wmax_v = 0.0;
+        dmax_v = 0.0;
+        f = 0;
+        return done || n_iter == max_iter;
+    };
+
+    // B coordinate updates (_cd_fast.pyx:644-682) for the lanes base..base+B-1 of the current batch
+    auto compute = [&](const BSet<R, B> &S, int base) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) h_lds[r * WAVE + lane] = H[r];
+        double Hs_v = h_lds[ii_v];   // H[ii_lane] as of now
+        double wo_v = w_lds[ii_v];   // w[ii_lane]
+        double wn_keep = 0.0;        // lane a's new coefficient, latched at step a
+        const uint64_t blockmask = ((uint64_t(1) << B) - 1) << base;
+        uint64_t wmask = blockmask;  // lanes that write their coefficient back (later duplicate wins)
+        const bool has_dup = (dupmask & blockmask) != 0;
+        if (!has_dup) {
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const int la = base + a;
+                // every lane evaluates "its" update against its current H; lane la's is the real one
+                const double Hp = fma(-wo_v, Qd_v, Hs_v);
+                const double tmp = q_v - Hp;
+                const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+                const double wn_v = RECIP ? thr * den_v : thr / den_v;
+                wn_keep = lane == la ? wn_v : wn_keep;
+                if (DELTA) {
+                    const double d_a = read_lane(wn_v - wo_v, la);
+                    Hs_v = fma(d_a, S.qc[a], Hs_v);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(d_a, S.row[a][r], H[r]);
+                } else {
+                    const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
+                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S.row[a][r], fma(-wo_a, S.row[a][r], H[r]));
+                }
+            }
+        } else {  // a coordinate repeats inside the block: later visits must see the earlier result
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const int la = base + a;
+                const double Hp = fma(-wo_v, Qd_v, Hs_v);
+                const double tmp = q_v - Hp;
+                const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+                const double wn_v = RECIP ? thr * den_v : thr / den_v;
+                wn_keep = lane == la ? wn_v : wn_keep;
+                const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
+                if (DELTA) {
+                    const double d_a = read_lane(wn_v - wo_v, la);
+                    Hs_v = fma(d_a, S.qc[a], Hs_v);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(d_a, S.row[a][r], H[r]);
+                } else {
+                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S.row[a][r], fma(-wo_a, S.row[a][r], H[r]));
+                }
+                const uint32_t ii_a = uint32_t(__builtin_amdgcn_readlane(int(ii_v), la));
+                const bool later_same = ii_v == ii_a && lane > la && lane < base + B;
+                wo_v = later_same ? wn_a : wo_v;
+                if (__ballot(later_same) != 0) wmask &= ~(uint64_t(1) << la);
+            }
+        }
+        if ((blockmask >> lane) & 1) {
+            dmax_v = fmax(dmax_v, fabs(wn_keep - wo_v));
+            wmax_v = fmax(wmax_v, fabs(wn_keep));
+        }
+        if ((wmask >> lane) & 1) w_lds[ii_v] = wn_keep;
+    };
+
+    adopt_batch();
+    fill(SA, rng.off, voff_v, 0);
+    for (;;) {  // one 64-value batch per iteration
+        for (int g = 0; g < NBLK; g += 2) {
+            fill(SB, rng.off, voff_v, (g + 1) * B);
+            compute(SA, g * B);
+            f += B;
+            if (f == c)
+                if (epoch_end()) goto fit_done;
+            if (g + 2 < NBLK) {
+                fill(SA, rng.off, voff_v, (g + 2) * B);
+                compute(SB, (g + 1) * B);
+            } else {  // last block of the batch: request block 0 of the next batch first
+                rng.next_batch();  // only rng.idx / rng.off change; ii_v etc. still describe this batch
+                fill(SA, rng.off, rng.idx * 8u, 0);
+                compute(SB, (g + 1) * B);
+            }
+            f += B;
+            if (f == c)
+                if (epoch_end()) goto fit_done;
+            settle(SA);
+        }
+        adopt_batch();
+    }
+fit_done:
+    out.n_iter = n_iter;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int col = r * WAVE + lane;
+        cnt += (col < c && w_lds[col] != 0.0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+    out.nnz = cnt;
+    return out;
+}
+
+// run-time -> compile-time dispatch.  flags: CP_CD_RECIPROCAL | CP_CD_DELTA.
 template <int R>
 __device__ __forceinline__ FitOut cd_fit_any(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
                                              uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
-                                             double y_norm2, int recip, double *w_lds, const double *feat) {
+                                             double y_norm2, int flags, double *w_lds, const double *feat,
+                                             double *h_lds) {
+    const bool recip = flags & CP_CD_RECIPROCAL, delta = flags & CP_CD_DELTA;
+#define CP_FIT_ARGS Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds, feat
+    if constexpr (R <= 8) {
+        if (c % Blk<R>::B == 0) {
+            if (recip) {
+                if (delta) return cd_fit_blocked<R, true, true>(CP_FIT_ARGS, h_lds);
+                return cd_fit_blocked<R, true, false>(CP_FIT_ARGS, h_lds);
+            }
+            if (delta) return cd_fit_blocked<R, false, true>(CP_FIT_ARGS, h_lds);
+            return cd_fit_blocked<R, false, false>(CP_FIT_ARGS, h_lds);
+        }
+    }
     const bool aligned = (c % (2 * Ring<R>::D)) == 0;
     if (recip) {
-        if (aligned)
-            return cd_fit<R, true, true>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds,
-                                         feat);
-        return cd_fit<R, true, false>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds,
-                                      feat);
+        if (delta) return aligned ? cd_fit<R, true, true, true>(CP_FIT_ARGS) : cd_fit<R, true, false, true>(CP_FIT_ARGS);
+        return aligned ? cd_fit<R, true, true, false>(CP_FIT_ARGS) : cd_fit<R, true, false, false>(CP_FIT_ARGS);
     }
-    if (aligned)
-        return cd_fit<R, false, true>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds,
-                                      feat);
-    return cd_fit<R, false, false>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds, feat);
+    if (delta) return aligned ? cd_fit<R, false, true, true>(CP_FIT_ARGS) : cd_fit<R, false, false, true>(CP_FIT_ARGS);
+    return aligned ? cd_fit<R, false, true, false>(CP_FIT_ARGS) : cd_fit<R, false, false, false>(CP_FIT_ARGS);
+#undef CP_FIT_ARGS
 }
 
 // LDS image shared by both kernels: w[c] | feat[4 c]
@@ -381,7 +650,10 @@ __device__ __forceinline__ void load_features(const double *__restrict__ Q, int 
         w_lds[j] = w_in ? w_in[j] : 0.0;
         feat[4 * j + 0] = q[j];
         feat[4 * j + 1] = dj;
-        feat[4 * j + 2] = (flags & CP_CD_RECIPROCAL) ? 1.0 / (dj + l2) : dj + l2;
+        // zero-diagonal features are skipped by sklearn (_cd_fast.pyx:651); the blocked path makes their
+        // update a no-op through the denominator instead (their row of Q, q and H entry are all zero)
+        feat[4 * j + 2] = dj == 0.0 ? ((flags & CP_CD_RECIPROCAL) ? 0.0 : 1.0)
+                                    : ((flags & CP_CD_RECIPROCAL) ? 1.0 / (dj + l2) : dj + l2);
         feat[4 * j + 3] = 0.0;
     }
     __syncthreads();
@@ -404,13 +676,12 @@ __global__ void __launch_bounds__(WAVE) k_cd_fit(const double *__restrict__ Q, i
                                                  uint32_t seed, int max_iter, double tol, int flags,
                                                  double *__restrict__ w, DevResult *__restrict__ res) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *feat = smem, *w_lds = smem + 4 * c;
+    double *feat = smem, *w_lds = smem + 4 * c, *h_lds = smem + 5 * c;
     load_features(Q, ldq, q, w, c, l2, flags, w_lds, feat);
     const double y_norm2 = stats[0];
     const double tol_scaled = tol * y_norm2;
     const unsigned long long t0 = __builtin_readcyclecounter();
-    FitOut o = cd_fit_any<R>(Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, flags & CP_CD_RECIPROCAL,
-                         w_lds, feat);
+    FitOut o = cd_fit_any<R>(Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, flags, w_lds, feat, h_lds);
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) {
         g_cd_debug[0] = t1 - t0;
@@ -435,7 +706,7 @@ k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
             double *__restrict__ w, DevResult *__restrict__ log, double *__restrict__ log_alpha,
             int *__restrict__ fits_used, double *__restrict__ alpha_out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *feat = smem, *w_lds = smem + 4 * c;
+    double *feat = smem, *w_lds = smem + 4 * c, *h_lds = smem + 5 * c;
     load_features(Q, ldq, q, nullptr, c, 0.0, flags, w_lds, feat);
     const double y_norm2 = stats[0];
     const double tol_scaled = tol * y_norm2;
@@ -444,8 +715,8 @@ k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
     bool bracketing = true, ok = false;
     while (fit < max_fits) {
         alpha = bracketing ? right : (left + right) / 2;
-        FitOut o = cd_fit_any<R>(Q, ldq, c, alpha * M, 0.0, seeds[fit], max_iter, tol_scaled, tol, y_norm2,
-                             flags & CP_CD_RECIPROCAL, w_lds, feat);
+        FitOut o = cd_fit_any<R>(Q, ldq, c, alpha * M, 0.0, seeds[fit], max_iter, tol_scaled, tol, y_norm2, flags,
+                                 w_lds, feat, h_lds);
         if (threadIdx.x == 0) {
             log[fit].gap = o.gap;
             log[fit].tol_scaled = tol_scaled;
@@ -505,7 +776,7 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     CP_HIP(ctx, hipSetDevice(ctx->device));
     CP_TRY(cp_arena_reserve(ctx, 4096));
     DevResult *dres = reinterpret_cast<DevResult *>(cp_arena_take(ctx, sizeof(DevResult)));
-    const size_t lds = size_t(5) * c * sizeof(double);
+    const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
@@ -545,7 +816,7 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     int *dfits = reinterpret_cast<int *>(cp_arena_take(ctx, 64));
     double *dalpha = reinterpret_cast<double *>(cp_arena_take(ctx, 64));
     CP_HIP(ctx, hipMemcpyAsync(dseeds, seeds, seed_bytes, hipMemcpyHostToDevice, ctx->stream));
-    const size_t lds = size_t(5) * c * sizeof(double);
+    const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound, dseeds, max_fits,

@@ -222,12 +222,14 @@ struct GemmPlan {
     bool small;  // 64x64 tiles
 };
 
-GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri) {
+GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri, bool in_place = false) {
     GemmPlan p;
     int tm = M / BM, tn = N / BN;
     const int big_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
     // skinny products (few large tiles, short K, no mirroring needed): quarter-size tiles
-    p.small = tri != CP_TRI_LOWER_MIRROR && K <= 512 && big_tiles * 4 <= ctx->cu_count * 2;
+    // (never for in-place products C = A^T C: with more than one row tile per column strip, one
+    //  workgroup would overwrite rows another one still has to read)
+    p.small = !in_place && tri != CP_TRI_LOWER_MIRROR && K <= 512 && big_tiles * 4 <= ctx->cu_count * 2;
     if (p.small) {
         tm *= 2;
         tn *= 2;
@@ -267,7 +269,10 @@ int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double 
     if (M % BM || N % BN || K % BK || (lda & 1) || (ldb & 1) || (tri != CP_TRI_NONE && M != N))
         return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn: unaligned shape M=%d N=%d K=%d lda=%d ldb=%d", M, N, K, lda,
                             ldb);
-    GemmPlan p = make_plan(ctx, M, N, K, tri);
+    const bool in_place = (C == A || C == B);
+    if (in_place && (M > BM || tri != CP_TRI_NONE))
+        return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn: in-place product needs a single row tile (M <= %d)", BM);
+    GemmPlan p = make_plan(ctx, M, N, K, tri, in_place);
     double *P = nullptr;
     const size_t arena_mark = ctx->arena_used;  // P is transient: stream order makes reuse safe
     if (p.splits > 1) {

@@ -147,8 +147,8 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 
-__global__ void __launch_bounds__(RT) k_potrf_diag(double *__restrict__ G, int ld, int blk,
-                                                   const double *__restrict__ dg0, double piv_tol,
+__global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G, double *__restrict__ Uout, int ld,
+                                                   int blk, const double *__restrict__ dg0, double piv_tol,
                                                    double *__restrict__ TI, double *__restrict__ TIT,
                                                    int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(double *__restrict__ G, int l
     double *dinv = Tl + NPAN * PNB * PNB;  // NB : 1 / U[i,i]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fk = lane >> 4, fi = lane & 15;
-    double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
+    const double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
+    double *Ub = Uout + size_t(blk) * NB * ld + size_t(blk) * NB;
     for (int e = tid; e < NB * NB / 2; e += RT) {
         const int r = e / (NB / 2), cc = (e % (NB / 2)) * 2;
         *reinterpret_cast<double2 *>(&A[r * DLD + cc]) = *reinterpret_cast<const double2 *>(&Gb[size_t(r) * ld + cc]);
@@ -296,7 +297,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(double *__restrict__ G, int l
                                     : (rb == cb ? Tl[rb * PNB * PNB + ci * PNB + ri] : 0.0);
         const bool up = cc > r || (cc == r);
         const bool in_diag_lower = rb == cb && ci < ri;
-        Gb[size_t(r) * ld + cc] = (up && !in_diag_lower) ? A[r * DLD + cc] : 0.0;  // U, lower part zeroed
+        Ub[size_t(r) * ld + cc] = (up && !in_diag_lower) ? A[r * DLD + cc] : 0.0;  // U, lower part zeroed
         TIb[e] = v_rc;
         TITb[e] = v_cr;
     }
@@ -348,7 +349,9 @@ __global__ void __launch_bounds__(RT) k_finalize(const double *__restrict__ W, i
 }
 
 struct Chol {
-    double *G;   // p_pad x p_pad, overwritten by U (upper)
+    double *G;   // p_pad x p_pad working matrix (trailing Schur complements)
+    double *U;   // the factor (upper), written block row by block row (never in place: the panel
+                 // products then use 64x64 tiles and spread over 4x more CUs)
     double *Lt;  // U^T
     double *TI, *TIT;
     double *dg0, *gmax;
@@ -368,44 +371,46 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
         attr_set = true;
     }
     for (int b = 0; b < ch.nblk; ++b) {
-        k_potrf_diag<<<1, RT, lds, ctx->stream>>>(ch.G, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
+        k_potrf_diag<<<1, RT, lds, ctx->stream>>>(ch.G, ch.U, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
         CP_LAUNCH_CHECK(ctx);
         const int rest = (ch.nblk - b - 1) * NB;
         if (rest > 0) {
-            double *G12 = ch.G + size_t(b) * NB * ld + size_t(b + 1) * NB;
-            // U12 = U11^-T G12 (in place)
-            CP_TRY(cp_gemm_tn_f64(ctx, NB, rest, NB, 1.0, ch.TI + size_t(b) * NB * NB, NB, G12, ld, 0.0, G12, ld,
+            const double *G12 = ch.G + size_t(b) * NB * ld + size_t(b + 1) * NB;
+            double *U12 = ch.U + size_t(b) * NB * ld + size_t(b + 1) * NB;
+            // U12 = U11^-T G12
+            CP_TRY(cp_gemm_tn_f64(ctx, NB, rest, NB, 1.0, ch.TI + size_t(b) * NB * NB, NB, G12, ld, 0.0, U12, ld,
                                   CP_TRI_NONE));
             // G22 -= U12^T U12 (upper tiles)
             double *G22 = ch.G + size_t(b + 1) * NB * ld + size_t(b + 1) * NB;
-            CP_TRY(cp_gemm_tn_f64(ctx, rest, rest, NB, -1.0, G12, ld, G12, ld, 1.0, G22, ld, CP_TRI_UPPER));
+            CP_TRY(cp_gemm_tn_f64(ctx, rest, rest, NB, -1.0, U12, ld, U12, ld, 1.0, G22, ld, CP_TRI_UPPER));
         }
     }
     dim3 tg(ch.p_pad / 32, ch.p_pad / 32);
-    k_transpose_upper<<<tg, RT, 0, ctx->stream>>>(ch.G, ld, ch.p_pad, ch.Lt);
+    k_transpose_upper<<<tg, RT, 0, ctx->stream>>>(ch.U, ld, ch.p_pad, ch.Lt);
     CP_LAUNCH_CHECK(ctx);
     return CP_OK;
 }
 
-// In place: Rm <- (U^T U)^-1 Rm, Rm is p_pad x n_pad.
-int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, int n_pad) {
+// Rm <- (U^T U)^-1 Rm (p_pad x n_pad); Yt is scratch of the same shape.  The block results ping-pong
+// between the two arrays so that no product is in place.
+int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *Yt, int n_pad) {
     const int ld = ch.p_pad;
-    for (int b = 0; b < ch.nblk; ++b) {  // U^T y = r
-        double *Rb = Rm + size_t(b) * NB * n_pad;
-        CP_TRY(cp_gemm_tn_f64(ctx, NB, n_pad, NB, 1.0, ch.TI + size_t(b) * NB * NB, NB, Rb, n_pad, 0.0, Rb, n_pad,
+    for (int b = 0; b < ch.nblk; ++b) {  // U^T y = r : y_b -> Yt, updates applied to the rows of Rm below
+        double *Rb = Rm + size_t(b) * NB * n_pad, *Yb = Yt + size_t(b) * NB * n_pad;
+        CP_TRY(cp_gemm_tn_f64(ctx, NB, n_pad, NB, 1.0, ch.TI + size_t(b) * NB * NB, NB, Rb, n_pad, 0.0, Yb, n_pad,
                               CP_TRI_NONE));
         const int rest = (ch.nblk - b - 1) * NB;
         if (rest > 0)
-            CP_TRY(cp_gemm_tn_f64(ctx, rest, n_pad, NB, -1.0, ch.G + size_t(b) * NB * ld + size_t(b + 1) * NB, ld, Rb,
+            CP_TRY(cp_gemm_tn_f64(ctx, rest, n_pad, NB, -1.0, ch.U + size_t(b) * NB * ld + size_t(b + 1) * NB, ld, Yb,
                                   n_pad, 1.0, Rb + size_t(NB) * n_pad, n_pad, CP_TRI_NONE));
     }
-    for (int b = ch.nblk - 1; b >= 0; --b) {  // U w = y
-        double *Rb = Rm + size_t(b) * NB * n_pad;
-        CP_TRY(cp_gemm_tn_f64(ctx, NB, n_pad, NB, 1.0, ch.TIT + size_t(b) * NB * NB, NB, Rb, n_pad, 0.0, Rb, n_pad,
+    for (int b = ch.nblk - 1; b >= 0; --b) {  // U w = y : w_b -> Rm, updates applied to the rows of Yt above
+        double *Yb = Yt + size_t(b) * NB * n_pad, *Wb = Rm + size_t(b) * NB * n_pad;
+        CP_TRY(cp_gemm_tn_f64(ctx, NB, n_pad, NB, 1.0, ch.TIT + size_t(b) * NB * NB, NB, Yb, n_pad, 0.0, Wb, n_pad,
                               CP_TRI_NONE));
         const int above = b * NB;
         if (above > 0)
-            CP_TRY(cp_gemm_tn_f64(ctx, above, n_pad, NB, -1.0, ch.Lt + size_t(b) * NB * ld, ld, Rb, n_pad, 1.0, Rm,
+            CP_TRY(cp_gemm_tn_f64(ctx, above, n_pad, NB, -1.0, ch.Lt + size_t(b) * NB * ld, ld, Wb, n_pad, 1.0, Yt,
                                   n_pad, CP_TRI_NONE));
     }
     return CP_OK;
@@ -438,7 +443,7 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
                          cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE));
-    const size_t need = xs_b + yc_b + 3 * g_b + 3 * r_b + 2 * ti_b + part_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 +
+    const size_t need = xs_b + yc_b + 4 * g_b + 4 * r_b + 2 * ti_b + part_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 +
                         size_t(kept) * 4 + ws + (1 << 16);
     CP_TRY(cp_arena_reserve(ctx, need));
     double *Xs = cp_arena_take_t<double>(ctx, size_t(N_pad) * p_pad);
@@ -446,6 +451,8 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     double *G = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
     double *G0 = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);  // copy of G for the fallback
     double *Lt = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
+    double *Uf = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
+    double *Yt = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
     double *Rm = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
     double *R2 = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
     double *TI = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB);
@@ -457,7 +464,7 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     double *ymean = cp_arena_take_t<double>(ctx, n_pad);
     int *dchan = cp_arena_take_t<int>(ctx, kept);
     int *dinfo = cp_arena_take_t<int>(ctx, 16);
-    if (!Xs || !Yc || !G || !G0 || !Lt || !Rm || !R2 || !TI || !TIT || !part || !xmean || !dg0 || !gmax || !ymean ||
+    if (!Xs || !Yc || !G || !G0 || !Lt || !Uf || !Yt || !Rm || !R2 || !TI || !TIT || !part || !xmean || !dg0 || !gmax || !ymean ||
         !dchan || !dinfo)
         return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena");
 
@@ -505,13 +512,13 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     CP_HIP(ctx, hipMemcpyAsync(G0, G, g_b, hipMemcpyDeviceToDevice, ctx->stream));
     CP_HIP(ctx, hipMemcpyAsync(R2, Rm, r_b, hipMemcpyDeviceToDevice, ctx->stream));
 
-    Chol ch{G, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
+    Chol ch{G, Uf, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
     int hinfo = 0;
     bool fallback = (ridge == 0.0) && (N - 1 < p);  // centred X has rank <= N-1
     if (!fallback) {
         CP_TRY(chol_factor(ctx, ch, 1e-10));
         cp_stage_mark(ctx, "refit_cholesky");
-        CP_TRY(chol_solve(ctx, ch, Rm, n_pad));
+        CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad));
         cp_stage_mark(ctx, "refit_solve");
         CP_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -534,7 +541,7 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
             if (sweep > 0)  // Rm = R - G0 W   (G0 symmetric: G0^T W)
                 CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, p_pad, -1.0, G0, p_pad, Wacc, n_pad, 1.0, Rm, n_pad,
                                       CP_TRI_NONE));
-            CP_TRY(chol_solve(ctx, ch, Rm, n_pad));
+            CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad));
             k_axpy<<<ab, RT, 0, ctx->stream>>>(Wacc, Rm, cnt);
             CP_LAUNCH_CHECK(ctx);
         }

@@ -100,7 +100,11 @@ c.log = 'logs/'
 c.model = ''
 # knobs that only exist in this implementation
 c.cd_mode = 'device'             # 'device': whole alpha search in one launch; 'host': one launch per fit
-c.cd_reciprocal = 0              # 1: multiply by 1/(Qii+l2) in the CD update instead of dividing
+# rounding variants of the coordinate update (all reproduce every reference golden mask and per-fit
+# (nnz, n_iter) log; each is bit-identical to the matching mode of the CPU oracle):
+c.cd_reciprocal = 1              # 1: multiply by 1/(Qii+l2) instead of dividing (<= 1 ulp per step)
+c.cd_delta = 1                   # 1: one axpy with (w_new - w_old) instead of sklearn's two
+                                 # set both to 0 for sklearn's exact operation sequence
 
 
 def set_nBatches(n):

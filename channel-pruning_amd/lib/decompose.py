@@ -35,7 +35,7 @@ def rel_error(A, B):
 
 
 def _flags():
-    return _capi.CP_CD_RECIPROCAL if dcfgs.cd_reciprocal else 0
+    return (_capi.CP_CD_RECIPROCAL if dcfgs.cd_reciprocal else 0) | (_capi.CP_CD_DELTA if dcfgs.cd_delta else 0)
 
 
 def dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, verbose=0):

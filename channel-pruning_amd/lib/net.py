@@ -222,7 +222,8 @@ class Net(object):
         else:
             ctx.to_device(np.ascontiguousarray(feats - b2 + resY, dtype=np.float64), Yd)
         prob = LayerProblem.from_device(ctx, Xd, _capi.CP_F32, N, C, k, W2, Yd,
-                                        flags=_capi.CP_CD_RECIPROCAL if dcfgs.cd_reciprocal else 0)
+                                        flags=(_capi.CP_CD_RECIPROCAL if dcfgs.cd_reciprocal else 0)
+                                        | (_capi.CP_CD_DELTA if dcfgs.cd_delta else 0))
         try:
             idxs, newW2, newB2, alpha_out = prune_layer(prob, d_prime, cfgs.alpha, rank_tol=dcfgs.dic.rank_tol,
                                                         rng=np.random, ridge=float(dcfgs.fc_ridge),

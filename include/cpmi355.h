@@ -101,6 +101,7 @@ typedef struct cp_cd_result {
 } cp_cd_result;
 
 #define CP_CD_RECIPROCAL 1 /* multiply by 1/(Qii+l2) instead of dividing (<=1 ulp/step) */
+#define CP_CD_DELTA 2      /* one axpy H += (w_new - w_old) Q[ii] instead of sklearn's two (rounding-level) */
 
 /* Replaces Lasso.fit as called by solve() (lib/decompose.py:453-466):
  * sklearn/_cd_fast.pyx:564-737 with random coordinate order from our_rand_r

@@ -143,6 +143,9 @@ int cpo_enet_cd_data(double *w, double alpha, double beta, const double *X, cons
  * (channel-pruning_amd/csrc/cd_gram.hip) can reproduce w bit-for-bit.
  * recip != 0 replaces "/ (Q[ii,ii] + beta)" by "* (1 / (Q[ii,ii] + beta))" (a <=1 ulp
  * deviation offered by the device kernel as a latency option; default 0 = faithful).
+ * bit 1 of recip (value 2) selects the "delta" form: the two daxpy H -= w_ii Q[ii]; H += w_new Q[ii]
+ * become one, H += (w_new - w_ii) Q[ii], while tmp still uses H[ii] - w_ii Q[ii,ii] (again a
+ * rounding-level deviation offered as a device option).
  * stats_out (may be NULL) = {gap, tol_scaled, q_dot_w, dual_norm_XtA, R_norm2}.
  */
 int cpo_enet_cd_gram(double *w, double alpha, double beta, const double *Q, const double *q,
@@ -166,12 +169,22 @@ int cpo_enet_cd_gram(double *w, double alpha, double beta, const double *Q, cons
             const double *Qi = Q + (int64_t)ii * n_features;
             if (Qi[ii] == 0.0) continue;
             double w_ii = w[ii];
-            if (w_ii != 0.0)
-                for (int32_t i = 0; i < n_features; ++i) H[i] = fma(-w_ii, Qi[i], H[i]);
-            double tmp = q[ii] - H[ii];
+            const int delta = (recip & 2) != 0;
+            double tmp;
+            if (delta) {
+                tmp = q[ii] - fma(-w_ii, Qi[ii], H[ii]);
+            } else {
+                if (w_ii != 0.0)
+                    for (int32_t i = 0; i < n_features; ++i) H[i] = fma(-w_ii, Qi[i], H[i]);
+                tmp = q[ii] - H[ii];
+            }
             double thr = fsign(tmp) * fmax_(fabs(tmp) - alpha, 0);
-            w[ii] = recip ? thr * (1.0 / (Qi[ii] + beta)) : thr / (Qi[ii] + beta);
-            if (w[ii] != 0.0)
+            w[ii] = (recip & 1) ? thr * (1.0 / (Qi[ii] + beta)) : thr / (Qi[ii] + beta);
+            if (delta) {
+                const double d = w[ii] - w_ii;
+                if (d != 0.0)
+                    for (int32_t i = 0; i < n_features; ++i) H[i] = fma(d, Qi[i], H[i]);
+            } else if (w[ii] != 0.0)
                 for (int32_t i = 0; i < n_features; ++i) H[i] = fma(w[ii], Qi[i], H[i]);
             double d_w_ii = fabs(w[ii] - w_ii);
             if (d_w_ii > d_w_max) d_w_max = d_w_ii;

@@ -116,15 +116,16 @@ def enet_cd_data(w, l1_reg, l2_reg, Xc, yc, max_iter=1000, tol=1e-4, seed=1, ran
 
 
 def enet_cd_gram(w, l1_reg, l2_reg, Q, q, y_norm2, max_iter=1000, tol=1e-4, seed=1,
-                 random=True, recip=False):
-    """sklearn/_cd_fast.pyx:564-737.  Returns (w, stats[gap,tol,q.w,|XtA|inf,R2], n_iter)."""
+                 random=True, recip=False, delta=False):
+    """sklearn/_cd_fast.pyx:564-737.  Returns (w, stats[gap,tol,q.w,|XtA|inf,R2], n_iter).
+    recip / delta: the device kernel's CP_CD_RECIPROCAL / CP_CD_DELTA rounding variants."""
     Q = np.ascontiguousarray(Q, dtype=np.float64)
     q = np.ascontiguousarray(q, dtype=np.float64)
     assert w.dtype == np.float64 and w.flags.c_contiguous
     stats = np.zeros(5)
     n_iter = _c().cpo_enet_cd_gram(_dp(w), l1_reg, l2_reg, _dp(Q), _dp(q), float(y_norm2),
                                    Q.shape[0], max_iter, tol, int(seed), int(random),
-                                   int(recip), _dp(stats))
+                                   int(bool(recip)) | (2 if delta else 0), _dp(stats))
     return w, stats, n_iter
 
 

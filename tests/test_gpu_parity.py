@@ -84,11 +84,13 @@ def _cd_problem(c, M=4000, seed=3):
     return np.ascontiguousarray(Zc.T @ Zc), Zc.T @ yc, float(yc @ yc), M
 
 
-@pytest.mark.parametrize("c", [16, 55, 64, 96, 128, 222, 256, 512])
-@pytest.mark.parametrize("recip", [0, 1])
+@pytest.mark.parametrize("c", [8, 16, 55, 64, 96, 128, 222, 256, 264, 512, 1024])
+@pytest.mark.parametrize("recip", [0, 1, 2, 3])
 def test_cd_fit_bit_exact_vs_oracle(ctx, c, recip):
     """cp_enet_cd_gram vs cpo_enet_cd_gram on the same Q, q, seed: identical n_iter and
-    bit-identical w (same fma sequence), for cold and warm starts."""
+    bit-identical w (same fma sequence), for cold and warm starts, in all four rounding variants
+    (flags: 1 = CP_CD_RECIPROCAL, 2 = CP_CD_DELTA).  c covers the blocked kernel (c % 8 == 0,
+    c <= 512), the generic one (55, 222, 1024) and several register widths R = ceil(c/64)."""
     import cp_oracle
     from cpmi355 import capi
     Q, q, yty, M = _cd_problem(c)
@@ -96,11 +98,12 @@ def test_cd_fit_bit_exact_vs_oracle(ctx, c, recip):
     sd = ctx.to_device(np.array([yty, 0, M, 0], dtype=np.float64))
     w_ref = np.zeros(c)
     wd = ctx.zeros(c * 8)
-    flags = capi.CP_CD_RECIPROCAL if recip else 0
+    flags = recip
     amax = np.abs(q).max() / M
     for i, (frac, seed) in enumerate([(0.5, 12345), (0.2, 987654321), (0.05, 1), (0.3, 2147483646)]):
         l1 = frac * amax * M
-        _, stats, n_ref = cp_oracle.enet_cd_gram(w_ref, l1, 0.0, Q, q, yty, 1000, 1e-4, seed, recip=bool(recip))
+        _, stats, n_ref = cp_oracle.enet_cd_gram(w_ref, l1, 0.0, Q, q, yty, 1000, 1e-4, seed, recip=bool(recip & 1),
+                                                 delta=bool(recip & 2))
         r = ctx.enet_cd_gram(Qd, c, qd, sd, c, l1, 0.0, seed, wd, flags=flags)
         w = ctx.to_host(wd, (c,), np.float64)
         assert r.n_iter == n_ref, "fit %d: n_iter %d vs oracle %d" % (i, r.n_iter, n_ref)
@@ -248,10 +251,11 @@ def test_patch_gather_and_assemble_y(ctx):
 # ---------------------------------------------------------------------------------------------
 # whole path through the drop-in API, against the reference's golden vectors
 # ---------------------------------------------------------------------------------------------
-def _run_dropin(p, X, W2, Y, B2, mode):
+def _run_dropin(p, X, W2, Y, B2, mode, exact_ops=False):
     import lib.cfgs as cfgs
     import lib.decompose as D
     from lib.cfgs import c as dcfgs
+    dcfgs.cd_reciprocal = dcfgs.cd_delta = 0 if exact_ops else 1
     cfgs.alpha = p.get("alpha_in", 1e-3)
     dcfgs.dic.rank_tol = p.get("rank_tol", .1)
     dcfgs.fc_ridge = p.get("fc_ridge", 0)
@@ -263,6 +267,7 @@ def _run_dropin(p, X, W2, Y, B2, mode):
         dcfgs.fc_ridge = 0
         dcfgs.dic.rank_tol = .1
         dcfgs.cd_mode = 'device'
+        dcfgs.cd_reciprocal = dcfgs.cd_delta = 1
     rng_next = int(np.random.randint(0, 2147483647))
     return idxs, newW2, newB2, float(cfgs.alpha), rng_next, dict(D.last_call_info)
 
@@ -281,16 +286,17 @@ def _check_against_golden(g, p, got):
 
 
 @pytest.mark.parametrize("name", golden_cases("sm"))
-@pytest.mark.parametrize("mode", ["device", "host"])
+@pytest.mark.parametrize("mode", ["device", "host", "device-exact-ops"])
 def test_dictionary_matches_reference_golden(ctx, name, mode):
     g, p, X, W2, Y, B2 = load_case(name)
-    _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, mode))
+    _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, mode.split("-")[0], exact_ops=mode.endswith("exact-ops")))
 
 
 @pytest.mark.parametrize("name", golden_cases("L"))
 def test_dictionary_matches_reference_golden_full_size(ctx, name):
     """BASELINE.json configs[1] sizes (N=5000, c up to 256): masks identical, weights <= 1e-5."""
     g, p, X, W2, Y, B2 = load_case(name)
+    _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "device", exact_ops=True))
     got = _run_dropin(p, X, W2, Y, B2, "device")
     _check_against_golden(g, p, got)
     # size-independent property: the refit is the least-squares optimum, so the residual is
@@ -331,6 +337,44 @@ def test_run_to_run_reproducible(ctx):
         outs.append(prune_layer(prob, 24, 1e-3, rng=np.random.RandomState(5)))
         prob.free()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_concurrent_streams_full_size_bitwise(ctx):
+    """Three full-size problems driven from three host threads on three contexts (what bench.py
+    does) give bit-identical results to running them one after the other: guards against
+    inter-workgroup races that only show up when the GPU is shared (e.g. in-place panel products)."""
+    import threading
+    import cp_oracle
+    import cpmi355
+    specs = [(32, 256, 256, 128), (33, 256, 256, 128), (31, 128, 256, 64)]
+    data = [cp_oracle.synth_layer(lid, 5000, c, n, 3) for lid, c, n, _ in specs]
+
+    def run(i, out, cx):
+        lid, c, n, rank = specs[i]
+        X, W2, Y, _ = data[i]
+        prob = cpmi355.LayerProblem(cx, X, W2, Y)
+        for rep in range(3):
+            out[(i, rep)] = cpmi355.prune_layer(prob, rank, 1e-3, rng=np.random.RandomState(1234 + lid))
+        prob.free()
+
+    seq = {}
+    for i in range(3):
+        run(i, seq, ctx)
+    par = {}
+    ctxs = [cpmi355.Context(0) for _ in range(3)]
+    threads = [threading.Thread(target=run, args=(i, par, ctxs[i])) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for cx in ctxs:
+        cx.close()
+    assert sorted(par) == sorted(seq)
+    for key in seq:
+        assert np.array_equal(seq[key][0], par[key][0])
+        assert np.array_equal(seq[key][1], par[key][1]), "weights differ under concurrency %s" % (key,)
+        assert np.array_equal(seq[key][2], par[key][2])
+        assert np.array_equal(seq[key][1], seq[(key[0], 0)][1])   # and run to run
 
 
 def test_fc_kernel_dropin(ctx):

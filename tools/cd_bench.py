@@ -29,11 +29,11 @@ def problem(c, M=20000, seed=3):
     return np.ascontiguousarray(Zc.T @ Zc), Zc.T @ yc, float(yc @ yc), M
 
 
-for c in (64, 256, 512):
+for c in (64, 128, 256, 512):
     Q, q, yty, M = problem(c)
     Qd, qd = ctx.to_device(Q), ctx.to_device(q)
     sd = ctx.to_device(np.array([yty, 0, M, 0], dtype=np.float64))
-    for flags in (0, 1):
+    for flags in (0, 1, 2, 3):
         wd = ctx.zeros(c * 8)
         l1 = 0.05 * np.abs(q).max()
         ctx.enet_cd_gram(Qd, c, qd, sd, c, l1, 0.0, 7, wd, flags=flags)  # warm
