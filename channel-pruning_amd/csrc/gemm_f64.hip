@@ -45,17 +45,22 @@ __device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int 
 // WT = per-wave output tile (64 -> 128x128 workgroup tile, 32 -> 64x64).  The small tile is
 // used for the skinny K = 128 products of the blocked Cholesky / substitutions, where the
 // large one would leave most CUs idle and make every call as long as one 128^3 tile.
-template <int TRI, int TAG, int WT>
-__global__ void __launch_bounds__(NTHREADS, 2)
+template <int TRI, int TAG, int WT, int NTH>
+__global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
 k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
               const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
               double *__restrict__ P, int splits, int kchunk, int n_tiles, int tiles_n) {
+    // NTH = 256: 2 x 2 waves of WT x WT each; NTH = 512: 4 x 2 waves of (WT/2) x WT each (same
+    // workgroup tile, half the accumulators per wave -> 4 waves per SIMD, which is what it takes to
+    // keep the f64 MFMA pipe busy: one wave alone issues one v_mfma_f64_16x16x4 per ~140 cycles)
     constexpr int TM = 2 * WT;              // workgroup tile edge
     constexpr int TLD = TM + LPAD;          // padded LDS row
     constexpr int TPR = TM / 2;             // threads per tile row (one double2 each)
-    constexpr int RPP = NTHREADS / TPR;     // rows per pass
+    constexpr int RPP = NTH / TPR;          // rows per pass
     constexpr int NPASS = BK / RPP;
-    constexpr int FR = WT / 16;             // MFMA tiles per wave edge
+    constexpr int WROWS = NTH / 128;        // wave rows (2 or 4)
+    constexpr int WTM = TM / WROWS;         // wave tile rows
+    constexpr int FRM = WTM / 16, FRN = WT / 16;  // MFMA tiles per wave (rows, cols)
     __shared__ __attribute__((aligned(16))) double As[BK * TLD];
     __shared__ __attribute__((aligned(16))) double Bs[BK * TLD];
 
@@ -93,14 +98,14 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     };
 
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
+    const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WT;
     const int fk = lane >> 4, fi = lane & 15;
 
-    v4f64 acc[FR][FR];
+    v4f64 acc[FRM][FRN];
 #pragma unroll
-    for (int i = 0; i < FR; ++i)
+    for (int i = 0; i < FRM; ++i)
 #pragma unroll
-        for (int j = 0; j < FR; ++j) acc[i][j] = v4f64{0., 0., 0., 0.};
+        for (int j = 0; j < FRN; ++j) acc[i][j] = v4f64{0., 0., 0., 0.};
 
     if (nk > 0) load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -113,16 +118,15 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            double a[FR], b[FR];
+            double a[FRM], b[FRN];
 #pragma unroll
-            for (int i = 0; i < FR; ++i) {
-                a[i] = As[(kk * 4 + fk) * TLD + wm + i * 16 + fi];
-                b[i] = Bs[(kk * 4 + fk) * TLD + wn + i * 16 + fi];
-            }
+            for (int i = 0; i < FRM; ++i) a[i] = As[(kk * 4 + fk) * TLD + wm + i * 16 + fi];
 #pragma unroll
-            for (int i = 0; i < FR; ++i)
+            for (int j = 0; j < FRN; ++j) b[j] = Bs[(kk * 4 + fk) * TLD + wn + j * 16 + fi];
 #pragma unroll
-                for (int j = 0; j < FR; ++j)
+            for (int i = 0; i < FRM; ++i)
+#pragma unroll
+                for (int j = 0; j < FRN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -132,9 +136,9 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     if (splits > 1) {
         double *dst = P + size_t(z) * M * N;
 #pragma unroll
-        for (int i = 0; i < FR; ++i)
+        for (int i = 0; i < FRM; ++i)
 #pragma unroll
-            for (int j = 0; j < FR; ++j)
+            for (int j = 0; j < FRN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
@@ -142,9 +146,9 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
                 }
     } else {
 #pragma unroll
-        for (int i = 0; i < FR; ++i)
+        for (int i = 0; i < FRM; ++i)
 #pragma unroll
-            for (int j = 0; j < FR; ++j)
+            for (int j = 0; j < FRN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
@@ -237,7 +241,7 @@ GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri, bool in_plac
     p.tiles_n = tn;
     p.n_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
     const int nk = K / BK;
-    const int target = ctx->cu_count + ctx->cu_count / 2;  // ~1.5 workgroups per CU
+    const int target = ctx->cu_count * 2;  // 2 resident 8-wave workgroups per CU
     int splits = 1;
     if (!p.small && p.n_tiles < target / 2 && nk >= 16) {
         splits = (target + p.n_tiles - 1) / p.n_tiles;
@@ -283,10 +287,10 @@ int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double 
 #define CP_GEMM_LAUNCH(T, G)                                                                                  \
     do {                                                                                                      \
         if (p.small)                                                                                          \
-            k_gemm_tn_f64<T, G, 32><<<grid, NTHREADS, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
+            k_gemm_tn_f64<T, G, 32, 256><<<grid, 256, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
                                                                           P, p.splits, p.kchunk, p.n_tiles, p.tiles_n); \
         else                                                                                                  \
-            k_gemm_tn_f64<T, G, 64><<<grid, NTHREADS, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
+            k_gemm_tn_f64<T, G, 64, 512><<<grid, 512, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
                                                                           P, p.splits, p.kchunk, p.n_tiles, p.tiles_n); \
     } while (0)
     const int tag = ctx->gemm_tag;
