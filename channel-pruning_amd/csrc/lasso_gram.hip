@@ -43,24 +43,33 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
     return s;
 }
 
-// stats = { yc^T yc, mean(y), M, 0 }
+// stats = { yc^T yc, mean(y), M, 0 }.  One 1024-thread workgroup, two passes (mean, then centred
+// sum of squares); thread -> (sample s = tid / 32 + 32 it, columns j = tid % 32 + 32 jt): no
+// integer division in the loops, 32 consecutive doubles per sample row and wave.
 __global__ void __launch_bounds__(1024) k_y_stats(const double *__restrict__ Y, const int64_t *__restrict__ samples,
                                                   int S, int n, double *__restrict__ stats) {
     __shared__ double red[16];
-    const int64_t M = int64_t(S) * n;
+    const int js = threadIdx.x & 31, ss = threadIdx.x >> 5;
     double s = 0;
-    for (int64_t e = threadIdx.x; e < M; e += blockDim.x) s += Y[samples[e / n] * n + e % n];
-    const double mean = block_sum(s, red) / double(M);
+    for (int si = ss; si < S; si += 32) {
+        const double *row = Y + samples[si] * n;
+        for (int j = js; j < n; j += 32) s += row[j];
+    }
+    const double M = double(S) * double(n);
+    const double mean = block_sum(s, red) / M;
     double v = 0;
-    for (int64_t e = threadIdx.x; e < M; e += blockDim.x) {
-        const double d = Y[samples[e / n] * n + e % n] - mean;
-        v += d * d;
+    for (int si = ss; si < S; si += 32) {
+        const double *row = Y + samples[si] * n;
+        for (int j = js; j < n; j += 32) {
+            const double d = row[j] - mean;
+            v += d * d;
+        }
     }
     const double yty = block_sum(v, red);
     if (threadIdx.x == 0) {
         stats[0] = yty;
         stats[1] = mean;
-        stats[2] = double(M);
+        stats[2] = M;
         stats[3] = 0.0;
     }
 }

@@ -140,6 +140,14 @@ __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, 
 typedef double v4f64c __attribute__((ext_vector_type(4)));
 constexpr int PNB = 16, NPAN = NB / PNB, DLD = 136;
 
+__device__ unsigned long long g_potrf_debug[8];  // phase cycle counters of the last diagonal-block kernel
+
+__device__ __forceinline__ double read_lane_c(double v, int lane) {  // lane: compile-time constant after unrolling
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
     y = y * fma(-0.5 * x * y, y, 1.5);
@@ -155,6 +163,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
     double *A = sm;                        // NB x DLD
     double *Tl = sm + NB * DLD;            // NPAN x 16 x 16 : inverses of the diagonal sub-blocks
     double *dinv = Tl + NPAN * PNB * PNB;  // NB : 1 / U[i,i]
+    double *dref = dinv + NB;              // NB : original diagonal (pivot reference)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fk = lane >> 4, fi = lane & 15;
     const double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
@@ -163,41 +172,46 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
         const int r = e / (NB / 2), cc = (e % (NB / 2)) * 2;
         *reinterpret_cast<double2 *>(&A[r * DLD + cc]) = *reinterpret_cast<const double2 *>(&Gb[size_t(r) * ld + cc]);
     }
+    if (tid < NB) dref[tid] = dg0[blk * NB + tid];
     __syncthreads();
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+#define CP_PH(i) { const unsigned long long tn_ = __builtin_readcyclecounter(); tph[i] += tn_ - tlast; tlast = tn_; }
+    CP_PH(0)
 
     for (int p = 0; p < NPAN; ++p) {
         const int k0 = p * PNB;
-        // (1) 16x16 diagonal sub-block, wave 0: lane (j = fi, g = fk) owns rows 4g..4g+3 of column j
+        // (1) 16x16 diagonal sub-block on wave 0, in registers: lane j (< 16; the other lanes shadow
+        // them harmlessly) owns column j.  Per pivot: broadcast the pivot (readlane), scale row k,
+        // then for every later row i broadcast U[k,i] and apply a[i] -= U[k,i] U[k,j].
         if (wave == 0) {
+            double a[PNB];
+#pragma unroll
+            for (int i = 0; i < PNB; ++i) a[i] = A[(k0 + i) * DLD + k0 + fi];
+            const double refv = dref[k0 + fi];
+#pragma unroll
             for (int k = 0; k < PNB; ++k) {
-                double piv = A[(k0 + k) * DLD + k0 + k];
-                const double ref = dg0[blk * NB + k0 + k];
+                double piv = read_lane_c(a[k], k);
+                const double ref = read_lane_c(refv, k);
                 if (!(piv > piv_tol * ref)) {
                     if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
                     piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
                 }
-                const double inv = rsqrt_nr(piv), ukk = piv * inv;
-                const double u_j = A[(k0 + k) * DLD + k0 + fi] * inv;
-                const double2 a01 = *reinterpret_cast<const double2 *>(&A[(k0 + k) * DLD + k0 + 4 * fk]);
-                const double2 a23 = *reinterpret_cast<const double2 *>(&A[(k0 + k) * DLD + k0 + 4 * fk + 2]);
-                const double u_i[4] = {a01.x * inv, a01.y * inv, a23.x * inv, a23.y * inv};
+                const double inv = rsqrt_nr(piv);
+                const double u = a[k] * inv;  // U[k, j] for j > k
+                a[k] = fi == k ? piv * inv : u;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int i = 4 * fk + m;
-                    if (i > k && fi >= i) A[(k0 + i) * DLD + k0 + fi] -= u_i[m] * u_j;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (fk == 0) {
-                    if (fi > k) A[(k0 + k) * DLD + k0 + fi] = u_j;
-                    if (fi == k) {
-                        A[(k0 + k) * DLD + k0 + k] = ukk;
-                        dinv[k0 + k] = inv;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
+                for (int i = k + 1; i < PNB; ++i) a[i] = fma(-read_lane_c(u, i), u, a[i]);
+                if (lane == 0) dinv[k0 + k] = inv;
+            }
+            if (lane < PNB) {
+#pragma unroll
+                for (int i = 0; i < PNB; ++i)
+                    if (fi >= i) A[(k0 + i) * DLD + k0 + fi] = a[i];
             }
         }
         __syncthreads();
+        CP_PH(1)
         // (2) U12 = U11^-T A12: thread t owns column k0 + 16 + t
         const int rest = NB - k0 - PNB;
         if (tid < rest) {
@@ -216,6 +230,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
             for (int i = 0; i < PNB; ++i) A[(k0 + i) * DLD + col] = x[i];
         }
         __syncthreads();
+        CP_PH(2)
         // (3) A22 -= U12^T U12 on the upper tiles (ti <= tj) of the trailing (rest/16)^2 grid
         const int rt = rest / PNB, ntile = rt * (rt + 1) / 2;
         for (int e = wave; e < ntile; e += 4) {
@@ -237,6 +252,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
             for (int r = 0; r < 4; ++r) A[(ci + fk + 4 * r) * DLD + cj + fi] = acc[r];
         }
         __syncthreads();
+        CP_PH(3)
     }
 
     // T_p = U_pp^-1 (upper 16x16): task = (panel, column j), 4 lanes per task split the k-sum
@@ -255,6 +271,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
         }
     }
     __syncthreads();
+    CP_PH(4)
 
     // off-diagonal blocks of V = U^-1: V_ij = -T_ii * sum_{k=i+1..j} U_ik V_kj, stored (untransposed)
     // at block position (j, i) of A's lower part.  Block columns per wave: {7}, {6,1}, {5,2}, {4,3}.
@@ -284,6 +301,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
         }
     }
     __syncthreads();
+    CP_PH(5)
 
     double *TIb = TI + size_t(blk) * NB * NB, *TITb = TIT + size_t(blk) * NB * NB;
     for (int e = tid; e < NB * NB; e += RT) {
@@ -301,6 +319,10 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
         TIb[e] = v_rc;
         TITb[e] = v_cr;
     }
+    CP_PH(6)
+#undef CP_PH
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) g_potrf_debug[i] = tph[i];
 }
 
 // Lt = U^T (only the upper triangle of U is meaningful; the rest of G holds stale data)
@@ -363,7 +385,7 @@ struct Chol {
 int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     const int ld = ch.p_pad;
     CP_HIP(ctx, hipMemsetAsync(ch.info, 0, sizeof(int), ctx->stream));
-    const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + NB) * sizeof(double);
+    const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs an explicit opt-in
         CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_diag),
@@ -417,6 +439,13 @@ int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *Yt, int n_pad) {
 }
 
 }  // namespace
+
+extern "C" int cp_debug_potrf_cycles(cp_ctx *ctx, unsigned long long *out8) {
+    if (!ctx || !out8) return CP_ERR_ARG;
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CP_HIP(ctx, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_potrf_debug), 8 * sizeof(unsigned long long)));
+    return CP_OK;
+}
 
 extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
                               const double *Y, int n, double ridge, double *W_out, double *b_out,

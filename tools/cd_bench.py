@@ -44,10 +44,11 @@ for c in (64, 128, 256, 512):
             t0 = time.perf_counter()
             r = ctx.enet_cd_gram(Qd, c, qd, sd, c, l1, 0.0, 7 + rep, wd, flags=flags, tol=0.0, max_iter=20)
             dt = time.perf_counter() - t0
-            dbg = (ctypes.c_ulonglong * 2)()
+            dbg = (ctypes.c_ulonglong * 8)()
             lib.cp_debug_cd_cycles(ctx.h, dbg)
             steps = r.n_iter * c
             rows.append((dt / steps * 1e9, dbg[0] / max(dbg[1], 1), dbg[0] / dt / 1e9, r.n_iter, r.nnz))
+            phases = [dbg[2 + i] / max(dbg[1], 1) for i in range(4)]
         best = min(rows)
         print("c=%4d flags=%d  ns/step %.1f  cycles/step %.1f  implied GHz %.2f  n_iter %d nnz %d" % (
-            (c, flags) + best), flush=True)
+            (c, flags) + best), " phases/step fill %.1f compute %.1f batch %.1f other %.1f" % tuple(phases), flush=True)
