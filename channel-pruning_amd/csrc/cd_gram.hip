@@ -35,10 +35,6 @@
 
 namespace {
 
-// debug/bench aid: shader-clock cycles spent inside the last cd_fit of the last launch and the
-// number of coordinate steps it ran (read back by cp_debug_cd_cycles; not part of the public ABI)
-__device__ unsigned long long g_cd_debug[8];
-
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -389,7 +385,7 @@ template <int R, bool RECIP, bool DELTA>
 __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, int ldq, int c, double alpha,
                                                  double beta, uint32_t seed, int max_iter, double tol_scaled,
                                                  double d_w_tol, double y_norm2, double *w_lds, const double *feat,
-                                                 double *h_lds, uint32_t *tag_lds, uint32_t &stamp) {
+                                                 double *h_lds) {
     constexpr int B = Blk<R>::B, NBLK = 64 / B;
     const int lane = threadIdx.x;
     const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
@@ -427,13 +423,10 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
     IdxStream rng;
     rng.init(seed, uint32_t(c), row_stride_bytes, lane);
 
-    // per-lane data of the CURRENT 64-value batch (lane l <-> stream value 64*batch + l).  Gathered
-    // ONCE per batch: every step updates Hs_v of all 64 lanes (through qc = Q[ii_step, ii_lane]), so
-    // a lane's copy of H[ii] stays current until its own step comes; only a coordinate that repeats
-    // inside the batch needs its w patched (latermask marks lanes with a later twin).
+    // per-lane data of the CURRENT 64-value batch (lane l <-> stream value 64*batch + l)
     uint32_t ii_v, voff_v;
-    double q_v, Qd_v, den_v, Hs_v, wo_v;
-    uint64_t latermask;
+    double q_v, Qd_v, den_v;
+    uint64_t dupmask;
     auto adopt_batch = [&]() {
         ii_v = rng.idx;
         voff_v = ii_v * 8u;
@@ -441,22 +434,18 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
         q_v = qQ.x;
         Qd_v = qQ.y;
         den_v = feat[4 * ii_v + 2];
+        bool dup = false;
 #pragma unroll
-        for (int r = 0; r < R; ++r) h_lds[r * WAVE + lane] = H[r];
-        stamp += 64;  // tags of older batches are smaller: no reset of the tag array needed
-        atomicMax(&tag_lds[ii_v], stamp | uint32_t(lane));
-        Hs_v = h_lds[ii_v];
-        wo_v = w_lds[ii_v];
-        latermask = __ballot(tag_lds[ii_v] != (stamp | uint32_t(lane)));
+        for (int sft = 1; sft < B; ++sft) {
+            const int other = __shfl(int(ii_v), (lane & ~(B - 1)) | ((lane + sft) & (B - 1)), WAVE);
+            dup |= (uint32_t(other) == ii_v);
+        }
+        dupmask = __ballot(dup);
     };
 
     BSet<R, B> SA, SB;
     // request the operands of block (base .. base+B-1) of the batch whose offsets are in (off_vec, voff_vec)
-    int nfills = 0;
     auto fill = [&](BSet<R, B> &S, uint32_t off_vec, uint32_t voff_vec, int base) {
-#ifdef CD_EXP_NOLOAD
-        if (++nfills > 4) return;   // experiment: stale operands, no memory traffic
-#endif
 #pragma unroll
         for (int a = 0; a < B; ++a) {
             const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a));
@@ -523,35 +512,60 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
 
     // B coordinate updates (_cd_fast.pyx:644-682) for the lanes base..base+B-1 of the current batch
     auto compute = [&](const BSet<R, B> &S, int base) {
-        double wn_keep = 0.0;  // lane a's new coefficient, latched at step a
+#pragma unroll
+        for (int r = 0; r < R; ++r) h_lds[r * WAVE + lane] = H[r];
+        double Hs_v = h_lds[ii_v];   // H[ii_lane] as of now
+        double wo_v = w_lds[ii_v];   // w[ii_lane]
+        double wn_keep = 0.0;        // lane a's new coefficient, latched at step a
         const uint64_t blockmask = ((uint64_t(1) << B) - 1) << base;
-        uint64_t wmask = blockmask;  // lanes that write their coefficient back (a later twin in the block wins)
+        uint64_t wmask = blockmask;  // lanes that write their coefficient back (later duplicate wins)
+        const bool has_dup = (dupmask & blockmask) != 0;
+        if (!has_dup) {
 #pragma unroll
-        for (int a = 0; a < B; ++a) {
-            const int la = base + a;
-            // every lane evaluates "its" update against its current H; lane la's is the real one
-            const double Hp = fma(-wo_v, Qd_v, Hs_v);
-            const double tmp = q_v - Hp;
-            const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
-            const double wn_v = RECIP ? thr * den_v : thr / den_v;
-            wn_keep = lane == la ? wn_v : wn_keep;
-            if (DELTA) {
-                const double d_a = read_lane(wn_v - wo_v, la);
-                Hs_v = fma(d_a, S.qc[a], Hs_v);
+            for (int a = 0; a < B; ++a) {
+                const int la = base + a;
+                // every lane evaluates "its" update against its current H; lane la's is the real one
+                const double Hp = fma(-wo_v, Qd_v, Hs_v);
+                const double tmp = q_v - Hp;
+                const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+                const double wn_v = RECIP ? thr * den_v : thr / den_v;
+                wn_keep = lane == la ? wn_v : wn_keep;
+                if (DELTA) {
+                    const double d_a = read_lane(wn_v - wo_v, la);
+                    Hs_v = fma(d_a, S.qc[a], Hs_v);
 #pragma unroll
-                for (int r = 0; r < R; ++r) H[r] = fma(d_a, S.row[a][r], H[r]);
-            } else {
-                const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
-                Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+                    for (int r = 0; r < R; ++r) H[r] = fma(d_a, S.row[a][r], H[r]);
+                } else {
+                    const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
+                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
 #pragma unroll
-                for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S.row[a][r], fma(-wo_a, S.row[a][r], H[r]));
+                    for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S.row[a][r], fma(-wo_a, S.row[a][r], H[r]));
+                }
             }
-            if ((latermask >> la) & 1) {  // this coordinate comes back later in the batch: hand its new w over
-                const double wn_a = read_lane(wn_v, la);
+        } else {  // a coordinate repeats inside the block: later visits must see the earlier result
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const int la = base + a;
+                const double Hp = fma(-wo_v, Qd_v, Hs_v);
+                const double tmp = q_v - Hp;
+                const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+                const double wn_v = RECIP ? thr * den_v : thr / den_v;
+                wn_keep = lane == la ? wn_v : wn_keep;
+                const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
+                if (DELTA) {
+                    const double d_a = read_lane(wn_v - wo_v, la);
+                    Hs_v = fma(d_a, S.qc[a], Hs_v);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(d_a, S.row[a][r], H[r]);
+                } else {
+                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S.row[a][r], fma(-wo_a, S.row[a][r], H[r]));
+                }
                 const uint32_t ii_a = uint32_t(__builtin_amdgcn_readlane(int(ii_v), la));
-                const bool later_same = ii_v == ii_a && lane > la;
+                const bool later_same = ii_v == ii_a && lane > la && lane < base + B;
                 wo_v = later_same ? wn_a : wo_v;
-                if (__ballot(later_same && lane < base + B) != 0) wmask &= ~(uint64_t(1) << la);
+                if (__ballot(later_same) != 0) wmask &= ~(uint64_t(1) << la);
             }
         }
         if ((blockmask >> lane) & 1) {
@@ -561,53 +575,31 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
         if ((wmask >> lane) & 1) w_lds[ii_v] = wn_keep;
     };
 
-#ifdef CD_PHASE_TIMERS
-    unsigned long long tph[4] = {0, 0, 0, 0}, tl = __builtin_readcyclecounter();
-#define CD_PH(i) { const unsigned long long tn_ = __builtin_readcyclecounter(); tph[i] += tn_ - tl; tl = tn_; }
-#else
-#define CD_PH(i)
-#endif
     adopt_batch();
     fill(SA, rng.off, voff_v, 0);
     for (;;) {  // one 64-value batch per iteration
         for (int g = 0; g < NBLK; g += 2) {
-            CD_PH(3)
             fill(SB, rng.off, voff_v, (g + 1) * B);
-            CD_PH(0)
             compute(SA, g * B);
-            CD_PH(1)
             f += B;
             if (f == c)
                 if (epoch_end()) goto fit_done;
-            CD_PH(3)
             if (g + 2 < NBLK) {
                 fill(SA, rng.off, voff_v, (g + 2) * B);
-                CD_PH(0)
                 compute(SB, (g + 1) * B);
-                CD_PH(1)
             } else {  // last block of the batch: request block 0 of the next batch first
                 rng.next_batch();  // only rng.idx / rng.off change; ii_v etc. still describe this batch
-                CD_PH(2)
                 fill(SA, rng.off, rng.idx * 8u, 0);
-                CD_PH(0)
                 compute(SB, (g + 1) * B);
-                CD_PH(1)
             }
             f += B;
             if (f == c)
                 if (epoch_end()) goto fit_done;
             settle(SA);
         }
-        CD_PH(3)
         adopt_batch();
-        CD_PH(2)
     }
 fit_done:
-#ifdef CD_PHASE_TIMERS
-    if (lane == 0)
-        for (int i = 0; i < 4; ++i) g_cd_debug[2 + i] = tph[i];
-#endif
-#undef CD_PH
     out.n_iter = n_iter;
     int cnt = 0;
 #pragma unroll
@@ -626,17 +618,17 @@ template <int R>
 __device__ __forceinline__ FitOut cd_fit_any(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
                                              uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
                                              double y_norm2, int flags, double *w_lds, const double *feat,
-                                             double *h_lds, uint32_t *tag_lds, uint32_t &stamp) {
+                                             double *h_lds) {
     const bool recip = flags & CP_CD_RECIPROCAL, delta = flags & CP_CD_DELTA;
 #define CP_FIT_ARGS Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds, feat
     if constexpr (R <= 8) {
         if (c % Blk<R>::B == 0) {
             if (recip) {
-                if (delta) return cd_fit_blocked<R, true, true>(CP_FIT_ARGS, h_lds, tag_lds, stamp);
-                return cd_fit_blocked<R, true, false>(CP_FIT_ARGS, h_lds, tag_lds, stamp);
+                if (delta) return cd_fit_blocked<R, true, true>(CP_FIT_ARGS, h_lds);
+                return cd_fit_blocked<R, true, false>(CP_FIT_ARGS, h_lds);
             }
-            if (delta) return cd_fit_blocked<R, false, true>(CP_FIT_ARGS, h_lds, tag_lds, stamp);
-            return cd_fit_blocked<R, false, false>(CP_FIT_ARGS, h_lds, tag_lds, stamp);
+            if (delta) return cd_fit_blocked<R, false, true>(CP_FIT_ARGS, h_lds);
+            return cd_fit_blocked<R, false, false>(CP_FIT_ARGS, h_lds);
         }
     }
     const bool aligned = (c % (2 * Ring<R>::D)) == 0;
@@ -667,6 +659,10 @@ __device__ __forceinline__ void load_features(const double *__restrict__ Q, int 
     __syncthreads();
 }
 
+// debug/bench aid: shader-clock cycles spent inside the last cd_fit of the last launch and the
+// number of coordinate steps it ran (read back by cp_debug_cd_cycles; not part of the public ABI)
+__device__ unsigned long long g_cd_debug[8];
+
 struct DevResult {  // mirrors cp_cd_result
     double gap;
     double tol_scaled;
@@ -681,15 +677,11 @@ __global__ void __launch_bounds__(WAVE) k_cd_fit(const double *__restrict__ Q, i
                                                  double *__restrict__ w, DevResult *__restrict__ res) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *feat = smem, *w_lds = smem + 4 * c, *h_lds = smem + 5 * c;
-    uint32_t *tag_lds = reinterpret_cast<uint32_t *>(h_lds + WAVE * R);
-    for (int j = threadIdx.x; j < c; j += WAVE) tag_lds[j] = 0;
-    uint32_t stamp = 0;
     load_features(Q, ldq, q, w, c, l2, flags, w_lds, feat);
     const double y_norm2 = stats[0];
     const double tol_scaled = tol * y_norm2;
     const unsigned long long t0 = __builtin_readcyclecounter();
-    FitOut o = cd_fit_any<R>(Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, flags, w_lds, feat, h_lds,
-                             tag_lds, stamp);
+    FitOut o = cd_fit_any<R>(Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, flags, w_lds, feat, h_lds);
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) {
         g_cd_debug[0] = t1 - t0;
@@ -715,9 +707,6 @@ k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
             int *__restrict__ fits_used, double *__restrict__ alpha_out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *feat = smem, *w_lds = smem + 4 * c, *h_lds = smem + 5 * c;
-    uint32_t *tag_lds = reinterpret_cast<uint32_t *>(h_lds + WAVE * R);
-    for (int j = threadIdx.x; j < c; j += WAVE) tag_lds[j] = 0;
-    uint32_t stamp = 0;
     load_features(Q, ldq, q, nullptr, c, 0.0, flags, w_lds, feat);
     const double y_norm2 = stats[0];
     const double tol_scaled = tol * y_norm2;
@@ -727,7 +716,7 @@ k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
     while (fit < max_fits) {
         alpha = bracketing ? right : (left + right) / 2;
         FitOut o = cd_fit_any<R>(Q, ldq, c, alpha * M, 0.0, seeds[fit], max_iter, tol_scaled, tol, y_norm2, flags,
-                                 w_lds, feat, h_lds, tag_lds, stamp);
+                                 w_lds, feat, h_lds);
         if (threadIdx.x == 0) {
             log[fit].gap = o.gap;
             log[fit].tol_scaled = tol_scaled;
@@ -787,7 +776,7 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     CP_HIP(ctx, hipSetDevice(ctx->device));
     CP_TRY(cp_arena_reserve(ctx, 4096));
     DevResult *dres = reinterpret_cast<DevResult *>(cp_arena_take(ctx, sizeof(DevResult)));
-    const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double) + size_t(c) * 4;
+    const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
@@ -827,7 +816,7 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     int *dfits = reinterpret_cast<int *>(cp_arena_take(ctx, 64));
     double *dalpha = reinterpret_cast<double *>(cp_arena_take(ctx, 64));
     CP_HIP(ctx, hipMemcpyAsync(dseeds, seeds, seed_bytes, hipMemcpyHostToDevice, ctx->stream));
-    const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double) + size_t(c) * 4;
+    const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound, dseeds, max_fits,

@@ -92,6 +92,7 @@ extern "C" int cp_ctx_set_stream(cp_ctx *ctx, void *hip_stream) {
 
 extern "C" int cp_sync(cp_ctx *ctx) {
     if (!ctx) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
     CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CP_OK;
 }
@@ -106,12 +107,14 @@ extern "C" int cp_malloc(cp_ctx *ctx, size_t bytes, void **dptr) {
 
 extern "C" int cp_free(cp_ctx *ctx, void *dptr) {
     if (!ctx) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
     if (dptr) CP_HIP(ctx, hipFree(dptr));
     return CP_OK;
 }
 
 extern "C" int cp_memcpy_h2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx || (bytes && (!dst || !src))) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));  // the calling thread may never have selected this device
     // pageable source: hipMemcpyAsync stages it before returning, so the caller may reuse src.
     CP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return CP_OK;
@@ -119,6 +122,7 @@ extern "C" int cp_memcpy_h2d(cp_ctx *ctx, void *dst, const void *src, size_t byt
 
 extern "C" int cp_memcpy_d2h(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx || (bytes && (!dst || !src))) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
     CP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CP_OK;
@@ -126,6 +130,7 @@ extern "C" int cp_memcpy_d2h(cp_ctx *ctx, void *dst, const void *src, size_t byt
 
 extern "C" int cp_memset(cp_ctx *ctx, void *dst, int value, size_t bytes) {
     if (!ctx || (bytes && !dst)) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
     CP_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
     return CP_OK;
 }
