@@ -13,6 +13,8 @@
 // Small outputs are split along K (multiples of 8 splits; split z of every tile is placed
 // on XCD z % 8 so the tiles that share a k-chunk share an L2) and reduced by a second
 // kernel in a fixed order -> bitwise run-to-run reproducible, no atomics.
+#include <cstdlib>
+
 #include "cp_common.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -241,7 +243,10 @@ GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri, bool in_plac
     p.tiles_n = tn;
     p.n_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
     const int nk = K / BK;
-    const int target = ctx->cu_count * 2;  // 2 resident 8-wave workgroups per CU
+    // Workgroups to aim for when splitting K.  Every split writes a full partial plane (PMC: the
+    // refit Gram wrote ~3x its input bytes with 16 planes), so stay near one workgroup per CU.
+    static const int mult4 = getenv("CP_GEMM_SPLIT_X4") ? atoi(getenv("CP_GEMM_SPLIT_X4")) : 6;
+    const int target = ctx->cu_count * mult4 / 4;
     int splits = 1;
     if (!p.small && p.n_tiles < target / 2 && nk >= 16) {
         splits = (target + p.n_tiles - 1) / p.n_tiles;
