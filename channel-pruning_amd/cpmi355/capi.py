@@ -30,6 +30,16 @@ class RefitInfo(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+CP_MAX_FITS = 64
+
+
+class PruneResult(ctypes.Structure):
+    _fields_ = [("fits_used", ctypes.c_int32), ("nnz", ctypes.c_int32), ("p", ctypes.c_int32),
+                ("refit_rank", ctypes.c_int32), ("fallback", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("alpha", ctypes.c_double), ("fit_log", CdResult * CP_MAX_FITS),
+                ("fit_alpha", ctypes.c_double * CP_MAX_FITS)]
+
+
 class CpError(RuntimeError):
     def __init__(self, code, what, detail=""):
         self.code = code
@@ -64,6 +74,9 @@ SIGNATURES = {
                                        ctypes.POINTER(_c_dbl), _vp, _vp]),
     "cp_lstsq_refit": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _c_dbl, _vp, _vp,
                                 ctypes.POINTER(RefitInfo)]),
+    "cp_prune_layer": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
+                                _c_dbl, _c_dbl, _c_dbl, _c_dbl, _vp, _c_int, _c_int, _c_dbl, _c_int, _c_dbl,
+                                _vp, _vp, _vp, ctypes.POINTER(PruneResult)]),
     "cp_probe_mfma_f64": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
     "cp_probe_hbm_copy": (_c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_c_dbl)]),
     "cp_last_stage_times": (_c_int, [_vp, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_float)]),
@@ -81,6 +94,10 @@ def load():
         if not os.path.isfile(LIB_PATH):
             raise ImportError("libcpmi355.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C channel-pruning_amd/csrc` (expected at %s)" % LIB_PATH)
+        # Independent layers run on their own HIP streams.  With the runtime's default of 4 hardware
+        # queues several streams share one, and a multi-millisecond single-wave CD kernel then holds up
+        # every kernel queued behind it; has to be in the environment before the HIP runtime starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -239,6 +256,26 @@ class Context:
                                             _ptr(Y), int(n), float(ridge), _ptr(W_out), _ptr(b_out),
                                             ctypes.byref(info)), "cp_lstsq_refit")
         return info
+
+    def prune_layer(self, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, alpha_right0, rank, lbound, rbound,
+                    seeds, ridge, flags=0, max_iter=1000, tol=1e-4):
+        """One dictionary() worth of device work in a single foreign call (cp_prune_layer).
+        -> (PruneResult, mask bool[c], W f64[n, p], b f64[n]); res.fits_used == -1: search did not settle."""
+        samples = np.ascontiguousarray(samples, dtype=np.int64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        mask = np.zeros(int(c), dtype=np.uint8)
+        W = np.empty(int(n) * int(c) * int(kk), dtype=np.float64)
+        b = np.empty(int(n), dtype=np.float64)
+        res = PruneResult()
+        self._check(self.lib.cp_prune_layer(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), _ptr(W2), w_dtype,
+                                            int(n), _ptr(Y), samples.ctypes.data, int(samples.shape[0]),
+                                            float(alpha_right0), float(rank), float(lbound), float(rbound),
+                                            seeds.ctypes.data, int(seeds.shape[0]), int(max_iter), float(tol),
+                                            int(flags), float(ridge), mask.ctypes.data, W.ctypes.data, b.ctypes.data,
+                                            ctypes.byref(res)), "cp_prune_layer")
+        if res.fits_used < 0:
+            return res, None, None, None
+        return res, mask.astype(bool), W[:int(n) * int(res.p)].reshape(int(n), int(res.p)), b
 
     # -- measurement ------------------------------------------------------------------
     def probe_mfma_f64(self):

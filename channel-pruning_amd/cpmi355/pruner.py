@@ -111,8 +111,9 @@ class LayerProblem:
         w = self.ctx.to_host(self.wd, (self.c,), np.float64)
         return w != 0.
 
-    # -- decompose.py:490-525 -----------------------------------------------------------
-    def alpha_search(self, rank, alpha_right0, rank_tol, rng, mode="device"):
+    @staticmethod
+    def rank_bounds(rank, rank_tol):
+        """Acceptance window of the alpha search (decompose.py:493-501)."""
         lbound = rank
         if rank_tol >= 1:
             rbound = rank + rank_tol
@@ -121,6 +122,34 @@ class LayerProblem:
             if rank_tol == .2:            # decompose.py:498-501
                 lbound = rank + 0.1 * rank
                 rbound = rank + 0.2 * rank
+        return lbound, rbound
+
+    # -- the whole call in one foreign call (cp_prune_layer) ------------------------------
+    def prune_fused(self, rank, alpha_right0, rank_tol, rng, samples, ridge=0.0):
+        """-> (idxs, W[n,p], b, alpha) or None when the device search did not settle within MAX_FITS
+        (the RNG is then back where it was before the seeds were drawn)."""
+        lbound, rbound = self.rank_bounds(rank, rank_tol)
+        self.S = int(len(samples))
+        state = rng.get_state()
+        seeds = np.array([rng.randint(0, RAND_R_MAX) for _ in range(MAX_FITS)], dtype=np.uint32)
+        res, idxs, W, b = self.ctx.prune_layer(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype,
+                                               self.n, self.Yd, samples, alpha_right0, rank, lbound, rbound, seeds,
+                                               ridge, flags=self.flags)
+        rng.set_state(state)
+        if res.fits_used < 0:
+            return None
+        for _ in range(res.fits_used):     # consume exactly what the reference would have
+            rng.randint(0, RAND_R_MAX)
+        self.fits = [(float(res.fit_alpha[i]), int(res.fit_log[i].nnz), int(res.fit_log[i].n_iter))
+                     for i in range(res.fits_used)]
+        info = capi.RefitInfo()
+        info.p, info.rank, info.fallback = res.p, res.refit_rank, res.fallback
+        self.refit_info = info
+        return idxs, W, b, float(res.alpha)
+
+    # -- decompose.py:490-525 -----------------------------------------------------------
+    def alpha_search(self, rank, alpha_right0, rank_tol, rng, mode="device"):
+        lbound, rbound = self.rank_bounds(rank, rank_tol)
         self.fits = []
         self.reset_w()
         if mode == "device":
@@ -180,7 +209,11 @@ GLOBAL_RNG = np.random  # module-level legacy RandomState: randint / get_state /
 
 
 def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="device", alpha_arg=1e-4):
-    """dictionary() on a resident LayerProblem -> (idxs, newW2[n,nnz,k,k], newB2, alpha_out)."""
+    """dictionary() on a resident LayerProblem -> (idxs, newW2[n,nnz,k,k], newB2, alpha_out).
+
+    mode "device": the whole call is ONE foreign call (cp_prune_layer); "steps": the same device
+    search through the individual entry points (lasso_gram / alpha search / refit); "host": one
+    launch per LASSO fit, the host deciding the next alpha."""
     rng = GLOBAL_RNG if rng is None else rng
     N, c, n, k = prob.N, prob.c, prob.n, prob.k
     samples = rng.randint(0, N, min(400, N // 20))               # decompose.py:425
@@ -190,8 +223,14 @@ def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="de
         alpha = alpha_arg
         prob.fits = []
     else:
+        if mode == "device":
+            fused = prob.prune_fused(rank, alpha_in, rank_tol, rng, samples, ridge)
+            if fused is not None:
+                idxs, W, b, alpha = fused
+                return idxs, W.reshape((n, int(idxs.sum()), k, k)), b, alpha
+            mode = "host"                                         # did not settle within MAX_FITS
         prob.lasso_gram(samples)
-        alpha = prob.alpha_search(rank, alpha_in, rank_tol, rng, mode=mode)
+        alpha = prob.alpha_search(rank, alpha_in, rank_tol, rng, mode="device" if mode == "steps" else mode)
         idxs = prob.mask()
     W, b = prob.refit(idxs, ridge=ridge)
     nnz = int(idxs.sum())

@@ -68,6 +68,19 @@ __device__ __forceinline__ double load_q(__amdgpu_buffer_rsrc_t rsrc, uint32_t c
     return __hiloint2double(int(v[1]), int(v[0]));
 }
 
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+// 16-byte variant: two consecutive row elements per lane (one vector-memory issue instead of two)
+__device__ __forceinline__ void load_q2(__amdgpu_buffer_rsrc_t rsrc, uint32_t col_bytes, uint32_t row_bytes, double &a,
+                                        double &b) {
+    const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col_bytes, row_bytes, 0);
+    a = __hiloint2double(int(v[1]), int(v[0]));
+    b = __hiloint2double(int(v[3]), int(v[2]));
+}
+
+#ifndef CP_CD_PACKED
+#define CP_CD_PACKED 1
+#endif
+
 // Coordinate stream rand_int(c) of _cd_fast.pyx:30-32, produced 64 values at a time
 // (xorshift_jump.h): lane l of `idx`/`off` holds the coordinate / row byte offset of value
 // 64*batch + l; `pos` (wave-uniform) is the next lane to hand out.
@@ -391,12 +404,25 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
     const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    // register r of lane l holds column colof(r): 64 r + l, or -- packed -- 128 (r/2) + 2 l + (r&1), so
+    // that one 16-byte load fetches two of a lane's row elements
+    constexpr bool PK = CP_CD_PACKED && (R % 2 == 0);
+    auto colof = [&](int r) -> int { return PK ? (r >> 1) * 2 * WAVE + 2 * lane + (r & 1) : r * WAVE + lane; };
     uint32_t colb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int col = r * WAVE + lane;
-        colb[r] = uint32_t(col < c ? col : c - 1) * 8u;
+        const int col = colof(r);
+        colb[r] = uint32_t(col < c ? col : (PK ? c - 2 + (r & 1) : c - 1)) * 8u;
     }
+    auto load_row = [&](double (&dst)[R], uint32_t roff) {
+        if (PK) {
+#pragma unroll
+            for (int r = 0; r < R; r += 2) load_q2(rsrc, colb[r], roff, dst[r], dst[r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = load_q(rsrc, colb[r], roff);
+        }
+    };
     double H[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) H[r] = 0.0;
@@ -409,8 +435,7 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
             const int j = j0 + u;
             wj[u] = j < c ? w_lds[j] : 0.0;
             const uint32_t roff = uint32_t(j < c ? j : c - 1) * row_stride_bytes;
-#pragma unroll
-            for (int r = 0; r < R; ++r) row[u][r] = load_q(rsrc, colb[r], roff);
+            load_row(row[u], roff);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -449,8 +474,7 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
 #pragma unroll
         for (int a = 0; a < B; ++a) {
             const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a));
-#pragma unroll
-            for (int r = 0; r < R; ++r) S.row[a][r] = load_q(rsrc, colb[r], roff);
+            load_row(S.row[a], roff);
             S.qc[a] = load_q(rsrc, voff_vec, roff);
         }
     };
@@ -476,7 +500,7 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
             double s_qw = 0, s_wh = 0, s_ww = 0, s_l1 = 0, m_xta = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int col = r * WAVE + lane;
+                const int col = colof(r);
                 if (col < c) {
                     const double wv = w_lds[col], qv = feat[4 * col];
                     const double xta = qv - H[r] - beta * wv;
@@ -512,8 +536,14 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
 
     // B coordinate updates (_cd_fast.pyx:644-682) for the lanes base..base+B-1 of the current batch
     auto compute = [&](const BSet<R, B> &S, int base) {
+        if (PK) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) h_lds[r * WAVE + lane] = H[r];
+            for (int r = 0; r < R; r += 2)
+                *reinterpret_cast<double2 *>(h_lds + r * WAVE + 2 * lane) = make_double2(H[r], H[r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) h_lds[r * WAVE + lane] = H[r];
+        }
         double Hs_v = h_lds[ii_v];   // H[ii_lane] as of now
         double wo_v = w_lds[ii_v];   // w[ii_lane]
         double wn_keep = 0.0;        // lane a's new coefficient, latched at step a
@@ -604,7 +634,7 @@ fit_done:
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int col = r * WAVE + lane;
+        const int col = colof(r);
         cnt += (col < c && w_lds[col] != 0.0) ? 1 : 0;
     }
 #pragma unroll
@@ -785,14 +815,14 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     static_assert(sizeof(DevResult) == sizeof(cp_cd_result), "layout");
     CP_TRY(cp_pinned_reserve(ctx, 4096));
     CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dres, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
-    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
     memcpy(result, ctx->pinned, sizeof(cp_cd_result));
     return CP_OK;
 }
 
 extern "C" int cp_debug_cd_cycles(cp_ctx *ctx, unsigned long long *out2) {
     if (!ctx || !out2) return CP_ERR_ARG;
-    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
     CP_HIP(ctx, hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_cd_debug), 8 * sizeof(unsigned long long)));
     return CP_OK;
 }
@@ -830,7 +860,7 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     CP_HIP(ctx, hipMemcpyAsync(h + 64, dalpha, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CP_HIP(ctx, hipMemcpyAsync(h + 128, dlog, log_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CP_HIP(ctx, hipMemcpyAsync(h + 128 + log_bytes, dal, al_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
     memcpy(fits_used, h, sizeof(int));
     memcpy(alpha_out, h + 64, sizeof(double));
     if (fit_log) memcpy(fit_log, h + 128, log_bytes);

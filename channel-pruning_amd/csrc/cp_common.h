@@ -20,6 +20,11 @@ struct cp_ctx {
     char *arena = nullptr;
     size_t arena_bytes = 0;
     size_t arena_used = 0;
+    // per-layer outputs of cp_prune_layer (Q, q, stats, w, W, b): persistent across its sub-calls
+    char *layer_ws = nullptr;
+    size_t layer_ws_bytes = 0;
+    double host_ms[4] = {0, 0, 0, 0};  // host wall time of the phases of the last cp_prune_layer
+    double wait_ms = 0;                // of which: blocked in cp_stream_wait (running total)
     // pinned host staging for small D2H results
     char *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -54,6 +59,9 @@ int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
     } while (0)
 
 #define CP_LAUNCH_CHECK(ctx) CP_HIP(ctx, hipGetLastError())
+
+// hipStreamSynchronize(ctx->stream), with the time spent blocked added to ctx->wait_ms
+hipError_t cp_stream_wait(cp_ctx *ctx);
 
 // arena ------------------------------------------------------------------------------
 int cp_arena_reserve(cp_ctx *ctx, size_t bytes);  // ensure capacity (may sync + realloc); resets used=0

@@ -2,6 +2,8 @@
 // micro-probes of libcpmi355.so.
 #include "cp_common.h"
 
+#include <chrono>
+
 int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
         va_list ap;
@@ -76,6 +78,7 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->layer_ws) hipFree(ctx->layer_ws);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     for (int i = 0; i < 2 * CP_MAX_STAGES; ++i)
         if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
@@ -133,6 +136,13 @@ extern "C" int cp_memset(cp_ctx *ctx, void *dst, int value, size_t bytes) {
     CP_HIP(ctx, hipSetDevice(ctx->device));
     CP_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
     return CP_OK;
+}
+
+hipError_t cp_stream_wait(cp_ctx *ctx) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    ctx->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return e;
 }
 
 // ---- arena ---------------------------------------------------------------------------

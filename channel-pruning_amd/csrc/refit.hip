@@ -148,6 +148,35 @@ __device__ __forceinline__ double read_lane_c(double v, int lane) {  // lane: co
     return __hiloint2double(hi, lo);
 }
 
+// value of lane (16 * (l / 16) + I) for every lane l: one DPP move per half instead of a
+// v_readlane round trip through an SGPR pair (half the issue slots, no SGPR -> VALU hazard)
+template <int I>
+__device__ __forceinline__ double row_bcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + I, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + I, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_bcast_i(double v, int i) {  // i: constant after unrolling
+    switch (i) {
+        case 0: return row_bcast<0>(v);
+        case 1: return row_bcast<1>(v);
+        case 2: return row_bcast<2>(v);
+        case 3: return row_bcast<3>(v);
+        case 4: return row_bcast<4>(v);
+        case 5: return row_bcast<5>(v);
+        case 6: return row_bcast<6>(v);
+        case 7: return row_bcast<7>(v);
+        case 8: return row_bcast<8>(v);
+        case 9: return row_bcast<9>(v);
+        case 10: return row_bcast<10>(v);
+        case 11: return row_bcast<11>(v);
+        case 12: return row_bcast<12>(v);
+        case 13: return row_bcast<13>(v);
+        case 14: return row_bcast<14>(v);
+        default: return row_bcast<15>(v);
+    }
+}
+
 __device__ __forceinline__ double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
     y = y * fma(-0.5 * x * y, y, 1.5);
@@ -191,8 +220,8 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
             const double refv = dref[k0 + fi];
 #pragma unroll
             for (int k = 0; k < PNB; ++k) {
-                double piv = read_lane_c(a[k], k);
-                const double ref = read_lane_c(refv, k);
+                double piv = row_bcast_i(a[k], k);
+                const double ref = row_bcast_i(refv, k);
                 if (!(piv > piv_tol * ref)) {
                     if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
                     piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
@@ -201,7 +230,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
                 const double u = a[k] * inv;  // U[k, j] for j > k
                 a[k] = fi == k ? piv * inv : u;
 #pragma unroll
-                for (int i = k + 1; i < PNB; ++i) a[i] = fma(-read_lane_c(u, i), u, a[i]);
+                for (int i = k + 1; i < PNB; ++i) a[i] = fma(-row_bcast_i(u, i), u, a[i]);
                 if (lane == 0) dinv[k0 + k] = inv;
             }
             if (lane < PNB) {
@@ -442,7 +471,7 @@ int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *Yt, int n_pad) {
 
 extern "C" int cp_debug_potrf_cycles(cp_ctx *ctx, unsigned long long *out8) {
     if (!ctx || !out8) return CP_ERR_ARG;
-    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
     CP_HIP(ctx, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_potrf_debug), 8 * sizeof(unsigned long long)));
     return CP_OK;
 }
@@ -497,6 +526,7 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
         !dchan || !dinfo)
         return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena");
 
+    CP_TRY(cp_pinned_reserve(ctx, 4096));
     cp_stage_begin(ctx);
     CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
     // column means
@@ -544,13 +574,21 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     Chol ch{G, Uf, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
     int hinfo = 0;
     bool fallback = (ridge == 0.0) && (N - 1 < p);  // centred X has rank <= N-1
+    auto finalize = [&]() -> int {
+        k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, ymean, W_out, b_out);
+        CP_LAUNCH_CHECK(ctx);
+        cp_stage_mark(ctx, "refit_finalize");
+        CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CP_HIP(ctx, cp_stream_wait(ctx));
+        memcpy(&hinfo, ctx->pinned, sizeof(int));
+        return CP_OK;
+    };
     if (!fallback) {
         CP_TRY(chol_factor(ctx, ch, 1e-10));
         cp_stage_mark(ctx, "refit_cholesky");
         CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad));
         cp_stage_mark(ctx, "refit_solve");
-        CP_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CP_TRY(finalize());  // one wait for the whole call; the outputs are overwritten below if a pivot failed
         if (hinfo != 0) fallback = true;
     }
     int rank = p;
@@ -576,17 +614,12 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
         }
         CP_HIP(ctx, hipMemcpyAsync(Rm, Wacc, r_b, hipMemcpyDeviceToDevice, ctx->stream));
         cp_stage_mark(ctx, "refit_minnorm_fallback");
-        CP_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CP_TRY(finalize());
         if (hinfo != 0)
             return cp_set_error(ctx, CP_ERR_NUMERIC, "refit: regularised factorisation broke down at column %d",
                                 hinfo - 1);
         rank = -1;  // not determined on this path
     }
-    k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, ymean, W_out, b_out);
-    CP_LAUNCH_CHECK(ctx);
-    cp_stage_mark(ctx, "refit_finalize");
-    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     info->p = p;
     info->rank = rank;
     info->fallback = fallback ? 1 : 0;

@@ -99,7 +99,8 @@ c.shm = '/tmp'
 c.log = 'logs/'
 c.model = ''
 # knobs that only exist in this implementation
-c.cd_mode = 'device'             # 'device': whole alpha search in one launch; 'host': one launch per fit
+c.cd_mode = 'device'             # 'device': one foreign call per dictionary() (cp_prune_layer, alpha search in one
+                                 # launch); 'steps': same search via the individual entry points; 'host': one launch per fit
 # rounding variants of the coordinate update (all reproduce every reference golden mask and per-fit
 # (nnz, n_iter) log; each is bit-identical to the matching mode of the CPU oracle):
 c.cd_reciprocal = 1              # 1: multiply by 1/(Qii+l2) instead of dividing (<= 1 ulp per step)

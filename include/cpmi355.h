@@ -144,6 +144,35 @@ int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, in
                    const uint8_t *mask, const double *Y, int n, double ridge, double *W_out,
                    double *b_out, cp_refit_info *info);
 
+/* ---- a3: one whole dictionary() call -------------------------------------------- */
+#define CP_MAX_FITS 64
+typedef struct cp_prune_result {
+    int32_t fits_used;  /* LASSO fits consumed (= RNG draws the host replays); 0 when rank >= c;
+                           -1: the search did not settle within max_fits (nothing else is valid) */
+    int32_t nnz;        /* kept channels = sum(mask) */
+    int32_t p;          /* nnz * kk: columns of W_out */
+    int32_t refit_rank; /* cp_refit_info.rank */
+    int32_t fallback;   /* cp_refit_info.fallback */
+    int32_t reserved;
+    double alpha;       /* alpha of the accepted fit (decompose.py:525) */
+    cp_cd_result fit_log[CP_MAX_FITS];
+    double fit_alpha[CP_MAX_FITS];
+} cp_prune_result;
+
+/* Replaces the device work of one dictionary() call (lib/decompose.py:425-437, 453-466,
+ * 487-525, 622-623) in one foreign call: cp_lasso_gram -> cp_lasso_alpha_search -> mask = (w != 0)
+ * -> cp_lstsq_refit -> copies back.  X / W2 / Y DEVICE as for cp_lasso_gram; samples HOST
+ * int64[S]; seeds HOST uint32[max_fits] pre-drawn by the caller, who rewinds its RNG and
+ * re-draws res->fits_used of them; lbound/rbound as decompose.py:493-501 computes them.
+ * rank >= c skips the LASSO (decompose.py:487-488).  Outputs HOST: mask_out uint8[c],
+ * W_out f64 [n, p] (capacity n*c*kk), b_out f64 [n], res.  Synchronises the stream. */
+int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const void *W2,
+                   int w_dtype, int n, const double *Y, const int64_t *samples, int S,
+                   double alpha_right0, double rank, double lbound, double rbound,
+                   const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
+                   double ridge, uint8_t *mask_out, double *W_out, double *b_out,
+                   cp_prune_result *res);
+
 /* ---- micro-benchmarks used by bench.py for roofline denominators ---------------- */
 /* Sustained v_mfma_f64_16x16x4_f64 rate (TFLOP/s) and float4-copy HBM bandwidth (GB/s). */
 int cp_probe_mfma_f64(cp_ctx *ctx, double *tflops);

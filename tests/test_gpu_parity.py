@@ -286,7 +286,7 @@ def _check_against_golden(g, p, got):
 
 
 @pytest.mark.parametrize("name", golden_cases("sm"))
-@pytest.mark.parametrize("mode", ["device", "host", "device-exact-ops"])
+@pytest.mark.parametrize("mode", ["device", "steps", "host", "device-exact-ops"])
 def test_dictionary_matches_reference_golden(ctx, name, mode):
     g, p, X, W2, Y, B2 = load_case(name)
     _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, mode.split("-")[0], exact_ops=mode.endswith("exact-ops")))
