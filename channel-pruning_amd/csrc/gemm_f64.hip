@@ -235,7 +235,7 @@ GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri, bool in_plac
     // skinny products (few large tiles, short K, no mirroring needed): quarter-size tiles
     // (never for in-place products C = A^T C: with more than one row tile per column strip, one
     //  workgroup would overwrite rows another one still has to read)
-    p.small = !in_place && tri != CP_TRI_LOWER_MIRROR && K <= 512 && big_tiles * 4 <= ctx->cu_count * 2;
+    p.small = !in_place && tri != CP_TRI_LOWER_MIRROR && K <= 512 && big_tiles <= ctx->cu_count;
     if (p.small) {
         tm *= 2;
         tn *= 2;

@@ -3,15 +3,19 @@
 //   Z[(s,j), i] = sum_t X[samples[s], i, t] * W2[j, i, t]      M = S*n rows, c columns
 //   zc = Z - colmean(Z),  yc = Y[samples].ravel() - mean
 //   Q = zc^T zc (c x c),  q = zc^T yc,  yc^T yc
-// Stages (all float64 arithmetic, deterministic reductions):
-//   k_w_transpose  W2[n,c,kk] (f32/f64) -> Wt[t][j][c_pad] f64, so that a wave reading
-//                  consecutive channels reads consecutive addresses          (HBM/L2 bound)
-//   k_y_stats      mean and centred sum of squares of the sampled targets
-//   k_z_means      colmean(Z)[i] = (sum_t (sum_s x[s,i,t]) (sum_j w[j,i,t])) / M  -- the mean is
-//                  separable, so Z is written already centred and never re-read for it
-//   k_build_z      zc rows (thread = channel, coalesced 8-B stores) + per-block partials of q
-//   cp_gemm_tn_f64 Q = zc^T zc on the f64 MFMA pipe                          (MFMA bound)
+// Z (M x c, 131 MB at c = n = 256) is never formed.  With P = c*kk columns (i,t):
+//   Xs[s, (i,t)] = X[samples[s], i, t]   (S x P)        Wf[j, (i,t)] = W2[j, i, t]   (n x P)
+//   GX = Xs^T Xs,  GW = Wf^T Wf  (P x P, upper tiles)   T = Ys Wf  (S x P),  Ys = Y[samples]
+//   Z^T Z [i,i'] = sum_{t,t'} GX[(i,t),(i',t')] * GW[(i,t),(i',t')]         (k_hadamard_q)
+//   Z^T y [i]    = sum_t sum_s Xs[s,(i,t)] * T[s,(i,t)]                      (k_q_finish)
+//   colmean(Z)[i] = sum_t (sum_s Xs[s,(i,t)]) (sum_j Wf[j,(i,t)]) / M
+//   Q = Z^T Z - M zbar zbar^T,   q = Z^T y - M zbar ybar
+// i.e. (S + n) P^2 / 2 MFMA flops instead of S n c^2 (1.6x fewer at k = 3, S n / (S + n) ~ 126x fewer
+// at k = 1) and 2 x 21 MB of Gram tiles instead of the 131 MB of Z written and read back.
+// All float64, deterministic reductions (fixed order, no atomics).
 #include "cp_common.h"
+
+#include <algorithm>
 
 namespace {
 
@@ -20,15 +24,6 @@ constexpr int ZT = 256;  // threads per block in the element-wise stages
 template <typename T>
 __device__ __forceinline__ double ld(const T *p, size_t i) {
     return double(p[i]);
-}
-
-template <typename TW>
-__global__ void __launch_bounds__(ZT) k_w_transpose(const TW *__restrict__ W2, int n, int c, int kk, int c_pad,
-                                                    double *__restrict__ Wt) {
-    // Wt[(t*n + j)*c_pad + i]; grid.x over (t*n + j), threads over i
-    const int tj = blockIdx.x, t = tj / n, j = tj - t * n;
-    for (int i = threadIdx.x; i < c_pad; i += ZT)
-        Wt[size_t(tj) * c_pad + i] = i < c ? ld(W2, (size_t(j) * c + i) * kk + t) : 0.0;
 }
 
 __device__ __forceinline__ double block_sum(double v, double *red) {
@@ -74,102 +69,88 @@ __global__ void __launch_bounds__(1024) k_y_stats(const double *__restrict__ Y, 
     }
 }
 
-template <typename TX>
-__global__ void __launch_bounds__(ZT) k_z_means(const TX *__restrict__ X, const int64_t *__restrict__ samples, int S,
-                                                int c, int kk, const double *__restrict__ Wt, int n, int c_pad,
-                                                double *__restrict__ zmean) {
+// dst[r, col] = r < rows && col < cols ? src[(idx ? idx[r] : r) * cols + col] : 0   (row gather + f64 + zero pad)
+template <typename T>
+__global__ void __launch_bounds__(ZT) k_gather_rows(const T *__restrict__ src, const int64_t *__restrict__ idx,
+                                                    int rows, int cols, int ld_dst, double *__restrict__ dst) {
+    const int r = blockIdx.x;
+    const bool live = r < rows;
+    const size_t base = live ? size_t(idx ? idx[r] : r) * cols : 0;
+    for (int col = threadIdx.x; col < ld_dst; col += ZT)
+        dst[size_t(r) * ld_dst + col] = (live && col < cols) ? ld(src, base + col) : 0.0;
+}
+
+// Yst[j, s] = Y[samples[s], j] (n_pad x S_pad, zero padded): 32 x 32 tiles through LDS
+__global__ void __launch_bounds__(ZT) k_gather_yt(const double *__restrict__ Y, const int64_t *__restrict__ samples,
+                                                  int S, int n, int S_pad, double *__restrict__ Yst) {
+    __shared__ double t[32][33];
+    const int s0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int y = ty; y < 32; y += 8) {
+        const int s = s0 + y, j = j0 + tx;
+        t[y][tx] = (s < S && j < n) ? Y[samples[s] * n + j] : 0.0;
+    }
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) Yst[size_t(j0 + y) * S_pad + s0 + tx] = t[tx][y];
+}
+
+// One workgroup per channel i: column sums of Xs and Wf over its kk columns, the products with T,
+// then zmean[i] and q[i].  Thread = row (sample s, then filter j), kk consecutive doubles each.
+__global__ void __launch_bounds__(ZT) k_q_finish(const double *__restrict__ Xs, const double *__restrict__ Tm,
+                                                 const double *__restrict__ Wf, int S_pad, int n_pad, int ldp, int kk,
+                                                 const double *__restrict__ stats, double *__restrict__ zmean,
+                                                 double *__restrict__ q) {
     __shared__ double red[ZT / 64];
+    __shared__ double cx[64], cw[64];
     const int i = blockIdx.x;
-    double acc = 0;
+    const size_t c0 = size_t(i) * kk;
+    double dot = 0.0;
     for (int t = 0; t < kk; ++t) {
-        double xs = 0, ws = 0;
-        for (int s = threadIdx.x; s < S; s += ZT) xs += ld(X, (size_t(samples[s]) * c + i) * kk + t);
-        for (int j = threadIdx.x; j < n; j += ZT) ws += Wt[(size_t(t) * n + j) * c_pad + i];
+        double xs = 0.0, ws = 0.0;
+        for (int s = threadIdx.x; s < S_pad; s += ZT) {
+            const double x = Xs[size_t(s) * ldp + c0 + t];
+            xs += x;
+            dot = fma(x, Tm[size_t(s) * ldp + c0 + t], dot);
+        }
+        for (int j = threadIdx.x; j < n_pad; j += ZT) ws += Wf[size_t(j) * ldp + c0 + t];
         xs = block_sum(xs, red);
         ws = block_sum(ws, red);
-        acc += xs * ws;
-    }
-    if (threadIdx.x == 0) zmean[i] = acc / (double(S) * double(n));
-}
-
-// grid (S, JS): block handles sample s and target rows [j0, j1); thread = channel.
-template <typename TX, int KK>
-__global__ void __launch_bounds__(ZT)
-k_build_z(const TX *__restrict__ X, const int64_t *__restrict__ samples, int c, const double *__restrict__ Wt, int n,
-          int c_pad, const double *__restrict__ Y, const double *__restrict__ stats,
-          const double *__restrict__ zmean, int jchunk, double *__restrict__ Zc, double *__restrict__ qpart) {
-    const int s = blockIdx.x, js = blockIdx.y;
-    const int j0 = js * jchunk, j1 = min(n, j0 + jchunk);
-    const int64_t row = samples[s];
-    const double ymean = stats[1];
-    for (int i = threadIdx.x; i < c_pad; i += ZT) {
-        double x[KK];
-        double mu = 0.0;
-        if (i < c) {
-#pragma unroll
-            for (int t = 0; t < KK; ++t) x[t] = ld(X, (size_t(row) * c + i) * KK + t);
-            mu = zmean[i];
-        } else {
-#pragma unroll
-            for (int t = 0; t < KK; ++t) x[t] = 0.0;
+        if (threadIdx.x == 0) {
+            cx[t] = xs;
+            cw[t] = ws;
         }
-        double qacc = 0.0;
-        for (int j = j0; j < j1; ++j) {
-            double z = 0.0;
-#pragma unroll
-            for (int t = 0; t < KK; ++t) z = fma(x[t], Wt[(size_t(t) * n + j) * c_pad + i], z);
-            z -= mu;  // pad channels: 0 - 0
-            Zc[(size_t(s) * n + j) * c_pad + i] = z;
-            qacc = fma(z, Y[row * n + j] - ymean, qacc);
+    }
+    dot = block_sum(dot, red);
+    if (threadIdx.x == 0) {
+        const double M = stats[2];
+        double acc = 0.0;
+        for (int t = 0; t < kk; ++t) acc = fma(cx[t], cw[t], acc);
+        const double zm = acc / M;
+        zmean[i] = zm;
+        q[i] = dot - M * zm * stats[1];
+    }
+}
+
+// Q[i,i'] = sum_{t,t'} GX[(i,t),(i',t')] GW[(i,t),(i',t')] - M zbar_i zbar_i'  for i <= i', mirrored.
+// Only the upper tiles of GX / GW exist: element (r, col) is read at (min, max).  Block = one i,
+// threads over i' (a thread reads kk consecutive doubles per row: adjacent threads, adjacent segments).
+__global__ void __launch_bounds__(ZT) k_hadamard_q(const double *__restrict__ GX, const double *__restrict__ GW,
+                                                   int ldp, int c, int kk, const double *__restrict__ zmean,
+                                                   const double *__restrict__ stats, double *__restrict__ Q, int ldq) {
+    const int i = blockIdx.x, ip = blockIdx.y * ZT + threadIdx.x;
+    if (ip >= c || ip < i) return;
+    double acc = 0.0;
+    for (int t = 0; t < kk; ++t) {
+        const int r = i * kk + t;
+        for (int u = 0; u < kk; ++u) {
+            const int col = ip * kk + u;
+            const size_t off = r <= col ? size_t(r) * ldp + col : size_t(col) * ldp + r;
+            acc = fma(GX[off], GW[off], acc);
         }
-        qpart[(size_t(s) * gridDim.y + js) * c_pad + i] = qacc;
     }
-}
-
-// q[i] = sum_b qpart[b][i]: 64 columns x 16 row-groups per workgroup, groups combined in order
-__global__ void __launch_bounds__(1024) k_reduce_q(const double *__restrict__ qpart, int nparts, int c_pad, int c,
-                                                   double *__restrict__ q) {
-    __shared__ double red[16][64];
-    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + col;
-    const int per = (nparts + 15) / 16;
-    const int b0 = g * per, b1 = min(nparts, b0 + per);
-    double s = 0;
-    if (i < c_pad)
-        for (int b = b0; b < b1; ++b) s += qpart[size_t(b) * c_pad + i];
-    red[g][col] = s;
-    __syncthreads();
-    if (g == 0 && i < c) {
-        double t = 0;
-        for (int k = 0; k < 16; ++k) t += red[k][col];
-        q[i] = t;
-    }
-}
-
-__global__ void __launch_bounds__(ZT) k_copy2d(const double *__restrict__ src, int lds_, double *__restrict__ dst,
-                                               int ldd, int rows, int cols) {
-    const int r = blockIdx.x;
-    for (int cidx = threadIdx.x; cidx < cols; cidx += ZT) dst[size_t(r) * ldd + cidx] = src[size_t(r) * lds_ + cidx];
-}
-
-template <typename TX>
-int launch_build_z(cp_ctx *ctx, int kk, dim3 grid, const TX *X, const int64_t *samples, int c, const double *Wt, int n,
-                   int c_pad, const double *Y, const double *stats, const double *zmean, int jchunk, double *Zc,
-                   double *qpart) {
-#define CP_BZ(K)                                                                                             \
-    k_build_z<TX, K><<<grid, ZT, 0, ctx->stream>>>(X, samples, c, Wt, n, c_pad, Y, stats, zmean, jchunk, Zc, \
-                                                    qpart)
-    switch (kk) {
-        case 1: CP_BZ(1); break;
-        case 4: CP_BZ(4); break;
-        case 9: CP_BZ(9); break;
-        case 25: CP_BZ(25); break;
-        case 49: CP_BZ(49); break;
-        default: return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "kernel size k*k=%d not in {1,4,9,25,49}", kk);
-    }
-#undef CP_BZ
-    CP_LAUNCH_CHECK(ctx);
-    return CP_OK;
+    const double v = fma(-stats[2] * zmean[i], zmean[ip], acc);
+    Q[size_t(i) * ldq + ip] = v;
+    Q[size_t(ip) * ldq + i] = v;
 }
 
 }  // namespace
@@ -179,72 +160,62 @@ extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N,
                              double *stats) {
     if (!ctx || !X || !W2 || !Y || !samples || !Q || !q || !stats) return CP_ERR_ARG;
     if (N <= 0 || c <= 0 || kk <= 0 || n <= 0 || S <= 0) return cp_set_error(ctx, CP_ERR_ARG, "lasso_gram: bad sizes");
+    if (kk > 64) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "lasso_gram: kernel size k*k=%d > 64", kk);
     if ((x_dtype != CP_F32 && x_dtype != CP_F64) || (w_dtype != CP_F32 && w_dtype != CP_F64))
         return cp_set_error(ctx, CP_ERR_ARG, "lasso_gram: bad dtype");
     for (int s = 0; s < S; ++s)
         if (samples[s] < 0 || samples[s] >= N) return cp_set_error(ctx, CP_ERR_ARG, "lasso_gram: sample out of range");
     CP_HIP(ctx, hipSetDevice(ctx->device));
 
-    const int c_pad = int(cp_align_up(size_t(c), 128));
-    const int64_t M = int64_t(S) * n;
-    const int64_t M_pad = int64_t(cp_align_up(size_t(M), 16));
-    if (M_pad > (int64_t(1) << 30)) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "lasso_gram: S*n too large");
-    int JS = 1;
-    while (int64_t(S) * JS < 1024 && JS * 2 <= n) JS *= 2;
-    const int jchunk = (n + JS - 1) / JS;
-    JS = (n + jchunk - 1) / jchunk;
-
-    const size_t z_bytes = size_t(M_pad) * c_pad * 8, wt_bytes = size_t(kk) * n * c_pad * 8,
-                 qp_bytes = size_t(S) * JS * c_pad * 8, qpad_bytes = size_t(c_pad) * c_pad * 8;
-    const size_t need = z_bytes + wt_bytes + qp_bytes + qpad_bytes + size_t(S) * 8 + size_t(c_pad) * 8 +
-                        cp_gemm_tn_workspace(ctx, c_pad, c_pad, int(M_pad), CP_TRI_LOWER_MIRROR) + (1 << 16);
+    const int64_t P64 = int64_t(c) * kk;
+    if (P64 > 32768) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "lasso_gram: c*k*k = %lld too large", (long long)P64);
+    const int P = int(P64), P_pad = int(cp_align_up(size_t(P), 128));
+    const int S_pad = int(cp_align_up(size_t(S), 128)), n_pad = int(cp_align_up(size_t(n), 32));
+    const size_t g_cnt = size_t(P_pad) * P_pad;
+    size_t ws = std::max(cp_gemm_tn_workspace(ctx, P_pad, P_pad, S_pad, CP_TRI_UPPER),
+                         cp_gemm_tn_workspace(ctx, P_pad, P_pad, n_pad, CP_TRI_UPPER));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, S_pad, P_pad, n_pad, CP_TRI_NONE));
+    const size_t need = (2 * g_cnt + (2 * size_t(S_pad) + n_pad) * P_pad + size_t(n_pad) * S_pad + size_t(c) + 64) * 8 +
+                        size_t(S) * 8 + ws + (1 << 16);
     CP_TRY(cp_arena_reserve(ctx, need));
-    double *Zc = cp_arena_take_t<double>(ctx, size_t(M_pad) * c_pad);
-    double *Wt = cp_arena_take_t<double>(ctx, size_t(kk) * n * c_pad);
-    double *qpart = cp_arena_take_t<double>(ctx, size_t(S) * JS * c_pad);
-    double *Qpad = cp_arena_take_t<double>(ctx, size_t(c_pad) * c_pad);
+    double *GX = cp_arena_take_t<double>(ctx, g_cnt);
+    double *GW = cp_arena_take_t<double>(ctx, g_cnt);
+    double *Xs = cp_arena_take_t<double>(ctx, size_t(S_pad) * P_pad);
+    double *Tm = cp_arena_take_t<double>(ctx, size_t(S_pad) * P_pad);
+    double *Wf = cp_arena_take_t<double>(ctx, size_t(n_pad) * P_pad);
+    double *Yst = cp_arena_take_t<double>(ctx, size_t(n_pad) * S_pad);
+    double *zmean = cp_arena_take_t<double>(ctx, c);
     int64_t *dsamples = cp_arena_take_t<int64_t>(ctx, S);
-    double *zmean = cp_arena_take_t<double>(ctx, c_pad);
-    if (!Zc || !Wt || !qpart || !Qpad || !dsamples || !zmean) return cp_set_error(ctx, CP_ERR_NOMEM, "lasso_gram: arena");
+    if (!GX || !GW || !Xs || !Tm || !Wf || !Yst || !zmean || !dsamples)
+        return cp_set_error(ctx, CP_ERR_NOMEM, "lasso_gram: arena");
 
     cp_stage_begin(ctx);
     CP_HIP(ctx, hipMemcpyAsync(dsamples, samples, size_t(S) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (M_pad > M)
-        CP_HIP(ctx, hipMemsetAsync(Zc + size_t(M) * c_pad, 0, size_t(M_pad - M) * c_pad * 8, ctx->stream));
-    if (w_dtype == CP_F32)
-        k_w_transpose<float><<<kk * n, ZT, 0, ctx->stream>>>(static_cast<const float *>(W2), n, c, kk, c_pad, Wt);
+    if (x_dtype == CP_F32)
+        k_gather_rows<float><<<S_pad, ZT, 0, ctx->stream>>>(static_cast<const float *>(X), dsamples, S, P, P_pad, Xs);
     else
-        k_w_transpose<double><<<kk * n, ZT, 0, ctx->stream>>>(static_cast<const double *>(W2), n, c, kk, c_pad, Wt);
+        k_gather_rows<double><<<S_pad, ZT, 0, ctx->stream>>>(static_cast<const double *>(X), dsamples, S, P, P_pad, Xs);
+    CP_LAUNCH_CHECK(ctx);
+    if (w_dtype == CP_F32)
+        k_gather_rows<float><<<n_pad, ZT, 0, ctx->stream>>>(static_cast<const float *>(W2), nullptr, n, P, P_pad, Wf);
+    else
+        k_gather_rows<double><<<n_pad, ZT, 0, ctx->stream>>>(static_cast<const double *>(W2), nullptr, n, P, P_pad, Wf);
+    CP_LAUNCH_CHECK(ctx);
+    k_gather_yt<<<dim3(S_pad / 32, n_pad / 32), ZT, 0, ctx->stream>>>(Y, dsamples, S, n, S_pad, Yst);
     CP_LAUNCH_CHECK(ctx);
     k_y_stats<<<1, 1024, 0, ctx->stream>>>(Y, dsamples, S, n, stats);
     CP_LAUNCH_CHECK(ctx);
-    if (x_dtype == CP_F32)
-        k_z_means<float><<<c, ZT, 0, ctx->stream>>>(static_cast<const float *>(X), dsamples, S, c, kk, Wt, n, c_pad,
-                                                     zmean);
-    else
-        k_z_means<double><<<c, ZT, 0, ctx->stream>>>(static_cast<const double *>(X), dsamples, S, c, kk, Wt, n, c_pad,
-                                                      zmean);
-    CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "lasso_prep");
-    dim3 grid(S, JS);
-    if (x_dtype == CP_F32)
-        CP_TRY(launch_build_z<float>(ctx, kk, grid, static_cast<const float *>(X), dsamples, c, Wt, n, c_pad, Y, stats,
-                                     zmean, jchunk, Zc, qpart));
-    else
-        CP_TRY(launch_build_z<double>(ctx, kk, grid, static_cast<const double *>(X), dsamples, c, Wt, n, c_pad, Y,
-                                      stats, zmean, jchunk, Zc, qpart));
-    k_reduce_q<<<(c + 63) / 64, 1024, 0, ctx->stream>>>(qpart, S * JS, c_pad, c, q);
-    CP_LAUNCH_CHECK(ctx);
-    cp_stage_mark(ctx, "lasso_build_z");
-    double *Qdst = c_pad == c ? Q : Qpad;
     ctx->gemm_tag = CP_GEMM_LASSO_GRAM;
     ctx->gemm_mark = "lasso_gram_gemm";
-    CP_TRY(cp_gemm_tn_f64(ctx, c_pad, c_pad, int(M_pad), 1.0, Zc, c_pad, Zc, c_pad, 0.0, Qdst, c_pad,
-                          CP_TRI_LOWER_MIRROR));
-    if (Qdst != Q) {
-        k_copy2d<<<c, ZT, 0, ctx->stream>>>(Qpad, c_pad, Q, c, c, c);
-        CP_LAUNCH_CHECK(ctx);
-    }
+    CP_TRY(cp_gemm_tn_f64(ctx, P_pad, P_pad, S_pad, 1.0, Xs, P_pad, Xs, P_pad, 0.0, GX, P_pad, CP_TRI_UPPER));
+    CP_TRY(cp_gemm_tn_f64(ctx, P_pad, P_pad, n_pad, 1.0, Wf, P_pad, Wf, P_pad, 0.0, GW, P_pad, CP_TRI_UPPER));
+    CP_TRY(cp_gemm_tn_f64(ctx, S_pad, P_pad, n_pad, 1.0, Yst, S_pad, Wf, P_pad, 0.0, Tm, P_pad, CP_TRI_NONE));
+    cp_stage_mark(ctx, "lasso_gram_gemms");
+    k_q_finish<<<c, ZT, 0, ctx->stream>>>(Xs, Tm, Wf, S_pad, n_pad, P_pad, kk, stats, zmean, q);
+    CP_LAUNCH_CHECK(ctx);
+    k_hadamard_q<<<dim3(c, (c + ZT - 1) / ZT), ZT, 0, ctx->stream>>>(GX, GW, P_pad, c, kk, zmean, stats, Q, c);
+    CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "lasso_gram_reduce");
     return CP_OK;
 }
