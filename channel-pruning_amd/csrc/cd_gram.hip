@@ -733,8 +733,8 @@ __global__ void __launch_bounds__(WAVE)
 k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
             int c, double M, double right0, double rank, double lbound, double rbound,
             const uint32_t *__restrict__ seeds, int max_fits, int max_iter, double tol, int flags,
-            double *__restrict__ w, DevResult *__restrict__ log, double *__restrict__ log_alpha,
-            int *__restrict__ fits_used, double *__restrict__ alpha_out) {
+            double *__restrict__ w, double *__restrict__ w_host, DevResult *__restrict__ log,
+            double *__restrict__ log_alpha, int *__restrict__ fits_used, double *__restrict__ alpha_out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *feat = smem, *w_lds = smem + 4 * c, *h_lds = smem + 5 * c;
     load_features(Q, ldq, q, nullptr, c, 0.0, flags, w_lds, feat);
@@ -773,7 +773,10 @@ k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < c; j += WAVE) w[j] = w_lds[j];
+    for (int j = threadIdx.x; j < c; j += WAVE) {
+        w[j] = w_lds[j];
+        w_host[j] = w_lds[j];
+    }
     if (threadIdx.x == 0) {
         *fits_used = ok ? fit : -fit;  // negative: ran out of pre-drawn seeds
         *alpha_out = alpha;
@@ -837,34 +840,33 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
         return CP_ERR_ARG;
     if (c > 32 * WAVE) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d > %d channels", c, 32 * WAVE);
     CP_HIP(ctx, hipSetDevice(ctx->device));
+    // Everything small the kernel reads or reports lives in pinned host memory that the device
+    // addresses directly: no copy packets before or after the launch -- with many layers in
+    // flight every extra packet in the stream costs tens of microseconds of dispatch latency.
     const size_t log_bytes = size_t(max_fits) * sizeof(DevResult), al_bytes = size_t(max_fits) * sizeof(double),
-                 seed_bytes = size_t(max_fits) * sizeof(uint32_t);
-    CP_TRY(cp_arena_reserve(ctx, log_bytes + al_bytes + seed_bytes + 4096));
-    DevResult *dlog = reinterpret_cast<DevResult *>(cp_arena_take(ctx, log_bytes));
-    double *dal = reinterpret_cast<double *>(cp_arena_take(ctx, al_bytes));
-    uint32_t *dseeds = reinterpret_cast<uint32_t *>(cp_arena_take(ctx, seed_bytes));
-    int *dfits = reinterpret_cast<int *>(cp_arena_take(ctx, 64));
-    double *dalpha = reinterpret_cast<double *>(cp_arena_take(ctx, 64));
-    CP_HIP(ctx, hipMemcpyAsync(dseeds, seeds, seed_bytes, hipMemcpyHostToDevice, ctx->stream));
+                 seed_bytes = cp_align_up(size_t(max_fits) * sizeof(uint32_t), 64), w_bytes = size_t(c) * sizeof(double);
+    const size_t off_log = 128, off_al = off_log + log_bytes, off_seed = off_al + al_bytes, off_w = off_seed + seed_bytes;
+    CP_TRY(cp_pinned_reserve(ctx, off_w + w_bytes));
+    char *h = ctx->pinned;
+    int *hfits = reinterpret_cast<int *>(h);
+    double *halpha = reinterpret_cast<double *>(h + 64);
+    *hfits = 0;
+    memcpy(h + off_seed, seeds, size_t(max_fits) * sizeof(uint32_t));
     const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound, dseeds, max_fits,
-                   max_iter, tol, flags, w, dlog, dal, dfits, dalpha);
+    CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
+                   reinterpret_cast<const uint32_t *>(h + off_seed), max_fits, max_iter, tol, flags, w,
+                   reinterpret_cast<double *>(h + off_w), reinterpret_cast<DevResult *>(h + off_log),
+                   reinterpret_cast<double *>(h + off_al), hfits, halpha);
     CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "cd_alpha_search");
-    const size_t total = log_bytes + al_bytes + 128;
-    CP_TRY(cp_pinned_reserve(ctx, total));
-    char *h = ctx->pinned;
-    CP_HIP(ctx, hipMemcpyAsync(h, dfits, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    CP_HIP(ctx, hipMemcpyAsync(h + 64, dalpha, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CP_HIP(ctx, hipMemcpyAsync(h + 128, dlog, log_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    CP_HIP(ctx, hipMemcpyAsync(h + 128 + log_bytes, dal, al_bytes, hipMemcpyDeviceToHost, ctx->stream));
     CP_HIP(ctx, cp_stream_wait(ctx));
-    memcpy(fits_used, h, sizeof(int));
-    memcpy(alpha_out, h + 64, sizeof(double));
-    if (fit_log) memcpy(fit_log, h + 128, log_bytes);
-    if (fit_alpha) memcpy(fit_alpha, h + 128 + log_bytes, al_bytes);
+    ctx->pinned_w = reinterpret_cast<const double *>(h + off_w);
+    memcpy(fits_used, hfits, sizeof(int));
+    memcpy(alpha_out, halpha, sizeof(double));
+    if (fit_log) memcpy(fit_log, h + off_log, log_bytes);
+    if (fit_alpha) memcpy(fit_alpha, h + off_al, al_bytes);
     if (*fits_used < 0)
         return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search did not terminate within %d fits", max_fits);
     return CP_OK;

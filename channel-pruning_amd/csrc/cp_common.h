@@ -28,6 +28,7 @@ struct cp_ctx {
     // pinned host staging for small D2H results
     char *pinned = nullptr;
     size_t pinned_bytes = 0;
+    const double *pinned_w = nullptr;  // host copy of w written by the last alpha-search kernel
     char err[512] = {0};
     // stage timing: a list of (name, event); name == nullptr marks the start of a call
     bool timing = false;
@@ -90,3 +91,8 @@ enum { CP_GEMM_GENERIC = 0, CP_GEMM_LASSO_GRAM = 1, CP_GEMM_REFIT_GRAM = 2, CP_G
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda,
                    const double *B, int ldb, double beta, double *C, int ldc, int tri);
 size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri);
+
+// cp_lstsq_refit with optional host-visible outputs: b (n doubles) then W (n x p) at ctx->pinned + 64
+int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
+                        const double *Y, int n, double ridge, double *W_out, double *b_out, cp_refit_info *info,
+                        bool host_out);

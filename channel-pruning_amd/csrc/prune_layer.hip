@@ -71,7 +71,6 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
         CP_TRY(cp_lasso_gram(ctx, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, S, Q, q, stats));
         const double t1 = now_ms();
         ctx->host_ms[0] = t1 - t0;
-        CP_HIP(ctx, hipMemsetAsync(w, 0, cc * sizeof(double), ctx->stream));
         int fits_used = 0;
         double alpha = 0.0;
         const int rc = cp_lasso_alpha_search(ctx, Q, c, q, stats, c, double(S) * double(n), alpha_right0, rank, lbound,
@@ -84,10 +83,7 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
         CP_TRY(rc);
         res->fits_used = fits_used;
         res->alpha = alpha;
-        CP_TRY(cp_pinned_reserve(ctx, cc * sizeof(double)));
-        CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, w, cc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        CP_HIP(ctx, cp_stream_wait(ctx));
-        memcpy(w_host.data(), ctx->pinned, cc * sizeof(double));
+        memcpy(w_host.data(), ctx->pinned_w, cc * sizeof(double));  // written by the search kernel itself
         for (size_t i = 0; i < cc; ++i) mask_out[i] = w_host[i] != 0.0 ? 1 : 0;  // decompose.py:463
         ctx->host_ms[1] = now_ms() - t1 - (ctx->wait_ms - w0);  // host work only (enqueue + copies)
     }
@@ -96,16 +92,16 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     res->nnz = nnz;
     cp_refit_info info;
     const double t2 = now_ms(), w2 = ctx->wait_ms;
-    CP_TRY(cp_lstsq_refit(ctx, X, x_dtype, N, c, kk, mask_out, Y, n, ridge, Wd, bd, &info));
+    CP_TRY(cp_lstsq_refit_impl(ctx, X, x_dtype, N, c, kk, mask_out, Y, n, ridge, Wd, bd, &info, true));
     const double t3 = now_ms();
     ctx->host_ms[2] = t3 - t2 - (ctx->wait_ms - w2);  // host work only
     res->p = info.p;
     res->refit_rank = info.rank;
     res->fallback = info.fallback;
-    CP_HIP(ctx, hipMemcpyAsync(W_out, Wd, size_t(n) * size_t(info.p) * sizeof(double), hipMemcpyDeviceToHost,
-                               ctx->stream));
-    CP_HIP(ctx, hipMemcpyAsync(b_out, bd, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CP_HIP(ctx, cp_stream_wait(ctx));
+    // the last kernel of the refit wrote b and W into the pinned block itself
+    const double *b_host = reinterpret_cast<const double *>(ctx->pinned + 64);
+    memcpy(b_out, b_host, size_t(n) * sizeof(double));
+    memcpy(W_out, b_host + n, size_t(n) * size_t(info.p) * sizeof(double));
     ctx->host_ms[3] = now_ms() - t3;  // copies back + last wait
     return CP_OK;
 }

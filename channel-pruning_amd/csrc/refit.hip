@@ -31,46 +31,53 @@ __device__ __forceinline__ double ldv(const T *p, size_t i) {
     return double(p[i]);
 }
 
-// ---- column means ----------------------------------------------------------------------
-// part[rb][col] = sum over rows of block rb.  X columns are gathered through chan[].
+// ---- column means, gather + centre -------------------------------------------------------
+// Column sums of the kept X columns (gathered through chan[]) and of Y in one launch:
+// blockIdx.x < gx covers 256 X columns, the rest 256 Y columns; blockIdx.y = row block.
 template <typename TX>
-__global__ void __launch_bounds__(RT) k_colsum_x(const TX *__restrict__ X, int64_t N, int c, int kk,
-                                                 const int *__restrict__ chan, int p, int rows_per_block,
-                                                 double *__restrict__ part, int ldp) {
-    const int col = blockIdx.x * RT + threadIdx.x;
-    if (col >= p) return;
-    const int a = col / kk, t = col - a * kk;
-    const size_t src = size_t(chan[a]) * kk + t, stride = size_t(c) * kk;
+__global__ void __launch_bounds__(RT) k_colsum_xy(const TX *__restrict__ X, const double *__restrict__ Y, int64_t N,
+                                                  int c, int kk, int n, const int *__restrict__ chan, int p, int gx,
+                                                  int rows_per_block, double *__restrict__ part_x, int ldx,
+                                                  double *__restrict__ part_y, int ldy) {
     const int64_t r0 = int64_t(blockIdx.y) * rows_per_block, r1 = min(N, r0 + rows_per_block);
     double s = 0;
-    for (int64_t r = r0; r < r1; ++r) s += ldv(X, size_t(r) * stride + src);
-    part[size_t(blockIdx.y) * ldp + col] = s;
+    if (int(blockIdx.x) < gx) {
+        const int col = blockIdx.x * RT + threadIdx.x;
+        if (col >= p) return;
+        const int a = col / kk, t = col - a * kk;
+        const size_t src = size_t(chan[a]) * kk + t, stride = size_t(c) * kk;
+        for (int64_t r = r0; r < r1; ++r) s += ldv(X, size_t(r) * stride + src);
+        part_x[size_t(blockIdx.y) * ldx + col] = s;
+    } else {
+        const int col = (blockIdx.x - gx) * RT + threadIdx.x;
+        if (col >= n) return;
+        for (int64_t r = r0; r < r1; ++r) s += Y[size_t(r) * n + col];
+        part_y[size_t(blockIdx.y) * ldy + col] = s;
+    }
 }
 
-__global__ void __launch_bounds__(RT) k_colsum_y(const double *__restrict__ Y, int64_t N, int n, int rows_per_block,
-                                                 double *__restrict__ part, int ldp) {
-    const int col = blockIdx.x * RT + threadIdx.x;
-    if (col >= n) return;
-    const int64_t r0 = int64_t(blockIdx.y) * rows_per_block, r1 = min(N, r0 + rows_per_block);
-    double s = 0;
-    for (int64_t r = r0; r < r1; ++r) s += Y[size_t(r) * n + col];
-    part[size_t(blockIdx.y) * ldp + col] = s;
-}
-
-__global__ void __launch_bounds__(RT) k_mean_finish(const double *__restrict__ part, int nparts, int ldp, int cols,
-                                                    double inv_n, double *__restrict__ mean) {
-    const int col = blockIdx.x * RT + threadIdx.x;
-    if (col >= cols) return;
+// xmean / ymean from the row-block partials (fixed order)
+__global__ void __launch_bounds__(RT) k_mean_finish_xy(const double *__restrict__ part_x, int ldx, int p,
+                                                       const double *__restrict__ part_y, int ldy, int n, int gx,
+                                                       int nparts, double inv_n, double *__restrict__ xmean,
+                                                       double *__restrict__ ymean) {
+    const bool is_x = int(blockIdx.x) < gx;
+    const int col = (is_x ? blockIdx.x : blockIdx.x - gx) * RT + threadIdx.x;
+    if (col >= (is_x ? p : n)) return;
+    const double *part = is_x ? part_x : part_y;
+    const int ldp = is_x ? ldx : ldy;
     double s = 0;
     for (int b = 0; b < nparts; ++b) s += part[size_t(b) * ldp + col];
-    mean[col] = s * inv_n;
+    (is_x ? xmean : ymean)[col] = s * inv_n;
 }
 
-// ---- gather + centre ---------------------------------------------------------------------
+// Xs[r, :] = X[r, kept columns] - xmean and Yc[r, :] = Y[r, :] - ymean, zero padded (row r = blockIdx.x)
 template <typename TX>
-__global__ void __launch_bounds__(RT) k_gather_center(const TX *__restrict__ X, int64_t N, int c, int kk,
-                                                      const int *__restrict__ chan, int p, int p_pad,
-                                                      const double *__restrict__ xmean, double *__restrict__ Xs) {
+__global__ void __launch_bounds__(RT) k_gather_center_xy(const TX *__restrict__ X, const double *__restrict__ Y,
+                                                         int64_t N, int c, int kk, int n, const int *__restrict__ chan,
+                                                         int p, int p_pad, int n_pad, const double *__restrict__ xmean,
+                                                         const double *__restrict__ ymean, double *__restrict__ Xs,
+                                                         double *__restrict__ Yc) {
     const int64_t r = blockIdx.x;
     const size_t stride = size_t(c) * kk;
     for (int col = threadIdx.x; col < p_pad; col += RT) {
@@ -81,11 +88,6 @@ __global__ void __launch_bounds__(RT) k_gather_center(const TX *__restrict__ X, 
         }
         Xs[size_t(r) * p_pad + col] = v;
     }
-}
-
-__global__ void __launch_bounds__(RT) k_center_y(const double *__restrict__ Y, int64_t N, int n, int n_pad,
-                                                 const double *__restrict__ ymean, double *__restrict__ Yc) {
-    const int64_t r = blockIdx.x;
     for (int col = threadIdx.x; col < n_pad; col += RT)
         Yc[size_t(r) * n_pad + col] = (r < N && col < n) ? Y[size_t(r) * n + col] - ymean[col] : 0.0;
 }
@@ -93,8 +95,10 @@ __global__ void __launch_bounds__(RT) k_center_y(const double *__restrict__ Y, i
 // ---- diagonal handling -------------------------------------------------------------------
 // dg0[i] = G[i,i] (original), gmax[0] = max_i dg0[i]; pad rows get G[i,i] = 1.
 __global__ void __launch_bounds__(1024) k_diag_prepare(double *__restrict__ G, int ld, int p, int p_pad, double ridge,
-                                                       double *__restrict__ dg0, double *__restrict__ gmax) {
+                                                       double *__restrict__ dg0, double *__restrict__ gmax,
+                                                       int *__restrict__ info) {
     __shared__ double red[16];
+    if (threadIdx.x == 0) info[0] = 0;  // first failed pivot of the factorisation that follows
     double m = 0;
     for (int i = threadIdx.x; i < p_pad; i += blockDim.x) {
         double d;
@@ -120,8 +124,9 @@ __global__ void __launch_bounds__(1024) k_diag_prepare(double *__restrict__ G, i
 
 __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, int ld, int p,
                                                         const double *__restrict__ gmax, double rel,
-                                                        double *__restrict__ dg0) {
+                                                        double *__restrict__ dg0, int *__restrict__ info) {
     const int i = blockIdx.x * RT + threadIdx.x;
+    if (i == 0) info[0] = 0;
     if (i >= p) return;
     const double d = G[size_t(i) * ld + i] + rel * gmax[0];
     G[size_t(i) * ld + i] = d;
@@ -376,15 +381,21 @@ __global__ void __launch_bounds__(RT) k_axpy(double *__restrict__ y, const doubl
 }
 
 // coef[j, col] = W[col, j];  b[j] = ymean[j] - sum_col xmean[col] coef[j, col]
+// coef_host / b_host / info_host: optional copies in pinned host memory the device writes directly
+// (no copy packets after the last kernel); info_host[0] = first failed pivot + 1 of the factorisation.
 __global__ void __launch_bounds__(RT) k_finalize(const double *__restrict__ W, int ldw, int p, int n,
                                                  const double *__restrict__ xmean, const double *__restrict__ ymean,
-                                                 double *__restrict__ coef, double *__restrict__ b) {
+                                                 double *__restrict__ coef, double *__restrict__ b,
+                                                 double *__restrict__ coef_host, double *__restrict__ b_host,
+                                                 const int *__restrict__ info, int *__restrict__ info_host) {
     __shared__ double red[RT / 64];
     const int j = blockIdx.x;
+    if (j == 0 && threadIdx.x == 0) info_host[0] = info[0];
     double s = 0;
     for (int col = threadIdx.x; col < p; col += RT) {
         const double v = W[size_t(col) * ldw + j];
         coef[size_t(j) * p + col] = v;
+        if (coef_host) coef_host[size_t(j) * p + col] = v;
         s += xmean[col] * v;
     }
 #pragma unroll
@@ -395,6 +406,7 @@ __global__ void __launch_bounds__(RT) k_finalize(const double *__restrict__ W, i
         double tot = 0;
         for (int i = 0; i < RT / 64; ++i) tot += red[i];
         b[j] = ymean[j] - tot;
+        if (b_host) b_host[j] = ymean[j] - tot;
     }
     (void)n;
 }
@@ -413,7 +425,6 @@ struct Chol {
 // G = U^T U in place (upper), plus TI/TIT per diagonal block and Lt = U^T.
 int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     const int ld = ch.p_pad;
-    CP_HIP(ctx, hipMemsetAsync(ch.info, 0, sizeof(int), ctx->stream));
     const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs an explicit opt-in
@@ -442,28 +453,59 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     return CP_OK;
 }
 
-// Rm <- (U^T U)^-1 Rm (p_pad x n_pad); Yt is scratch of the same shape.  The block results ping-pong
-// between the two arrays so that no product is in place.
-int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *Yt, int n_pad) {
-    const int ld = ch.p_pad;
-    for (int b = 0; b < ch.nblk; ++b) {  // U^T y = r : y_b -> Yt, updates applied to the rows of Rm below
-        double *Rb = Rm + size_t(b) * NB * n_pad, *Yb = Yt + size_t(b) * NB * n_pad;
-        CP_TRY(cp_gemm_tn_f64(ctx, NB, n_pad, NB, 1.0, ch.TI + size_t(b) * NB * NB, NB, Rb, n_pad, 0.0, Yb, n_pad,
-                              CP_TRI_NONE));
-        const int rest = (ch.nblk - b - 1) * NB;
-        if (rest > 0)
-            CP_TRY(cp_gemm_tn_f64(ctx, rest, n_pad, NB, -1.0, ch.U + size_t(b) * NB * ld + size_t(b + 1) * NB, ld, Yb,
-                                  n_pad, 1.0, Rb + size_t(NB) * n_pad, n_pad, CP_TRI_NONE));
+// Rm <- (U^T U)^-1 Rm (p_pad x n_pad), in place, ONE launch.  Triangular solves are independent per
+// right-hand-side column: workgroup g owns columns [16 g, 16 g + 16) and runs the whole forward
+// (U^T y = r) and backward (U w = y) block substitution for them -- no inter-workgroup traffic, no
+// per-block launches (the launch-per-block version was 40 dependent GEMM launches, 0.7 ms alone and
+// 3 ms with other layers in flight).  Per 128-row block b:
+//   S   = R_b - sum_{k<b} U[k,b]^T Y_k      wave m accumulates its 16 x 16 row tile on MFMA (K = 128 b)
+//   Y_b = U_bb^-T S                          through LDS, with the inverted diagonal block TI_b
+// and the mirror image with Lt = U^T / TIT_b for the backward sweep.  8 waves = 8 row tiles.
+__global__ void __launch_bounds__(512) k_solve_strips(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
+                                                      const double *__restrict__ TI, const double *__restrict__ TIT,
+                                                      int nblk, double *R, int n_pad) {
+    __shared__ double S[NB][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fk = lane >> 4, fi = lane & 15;
+    const int col0 = blockIdx.x * 16, row0 = wave * 16;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const double *Tri = sweep == 0 ? U : Lt;      // element (kk of block k, m of block b) at Tri[(k NB + kk) ld + b NB + m]
+        const double *Dinv = sweep == 0 ? TI : TIT;   // a-operand of the diagonal solve: Dinv_b[j, m]
+        for (int step = 0; step < nblk; ++step) {
+            const int b = sweep == 0 ? step : nblk - 1 - step;
+            double *Rb = R + (size_t(b) * NB + row0) * n_pad + col0 + fi;
+            v4f64c acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = Rb[size_t(fk + 4 * r) * n_pad];
+            const int k_lo = sweep == 0 ? 0 : b + 1, k_hi = sweep == 0 ? b : nblk;
+            for (int k = k_lo; k < k_hi; ++k) {
+                const double *Ak = Tri + size_t(k) * NB * ld + size_t(b) * NB + row0 + fi;
+                const double *Yk = R + size_t(k) * NB * n_pad + col0 + fi;
+#pragma unroll 8
+                for (int q = 0; q < NB / 4; ++q) {
+                    const double av = -Ak[size_t(4 * q + fk) * ld];
+                    const double bv = Yk[size_t(4 * q + fk) * n_pad];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[row0 + fk + 4 * r][fi] = acc[r];
+            __syncthreads();
+            const double *Db = Dinv + size_t(b) * NB * NB + row0 + fi;
+            v4f64c o = {0., 0., 0., 0.};
+#pragma unroll 8
+            for (int q = 0; q < NB / 4; ++q)
+                o = __builtin_amdgcn_mfma_f64_16x16x4f64(Db[size_t(4 * q + fk) * NB], S[4 * q + fk][fi], o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Rb[size_t(fk + 4 * r) * n_pad] = o[r];
+            __syncthreads();  // block b of the strip is complete (and visible) before any wave reads it
+        }
     }
-    for (int b = ch.nblk - 1; b >= 0; --b) {  // U w = y : w_b -> Rm, updates applied to the rows of Yt above
-        double *Yb = Yt + size_t(b) * NB * n_pad, *Wb = Rm + size_t(b) * NB * n_pad;
-        CP_TRY(cp_gemm_tn_f64(ctx, NB, n_pad, NB, 1.0, ch.TIT + size_t(b) * NB * NB, NB, Yb, n_pad, 0.0, Wb, n_pad,
-                              CP_TRI_NONE));
-        const int above = b * NB;
-        if (above > 0)
-            CP_TRY(cp_gemm_tn_f64(ctx, above, n_pad, NB, -1.0, ch.Lt + size_t(b) * NB * ld, ld, Wb, n_pad, 1.0, Yt,
-                                  n_pad, CP_TRI_NONE));
-    }
+}
+
+int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad) {
+    k_solve_strips<<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad);
+    CP_LAUNCH_CHECK(ctx);
     return CP_OK;
 }
 
@@ -476,9 +518,10 @@ extern "C" int cp_debug_potrf_cycles(cp_ctx *ctx, unsigned long long *out8) {
     return CP_OK;
 }
 
-extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
-                              const double *Y, int n, double ridge, double *W_out, double *b_out,
-                              cp_refit_info *info) {
+// host_out: also leave b (n) and W (n x p) in the context's pinned block at offset 64 (cp_prune_layer)
+int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
+                        const double *Y, int n, double ridge, double *W_out, double *b_out, cp_refit_info *info,
+                        bool host_out) {
     if (!ctx || !X || !mask || !Y || !W_out || !b_out || !info) return CP_ERR_ARG;
     if (N <= 0 || c <= 0 || kk <= 0 || n <= 0 || ridge < 0) return cp_set_error(ctx, CP_ERR_ARG, "refit: bad sizes");
     if (x_dtype != CP_F32 && x_dtype != CP_F64) return cp_set_error(ctx, CP_ERR_ARG, "refit: bad dtype");
@@ -497,7 +540,7 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
 
     const size_t xs_b = size_t(N_pad) * p_pad * 8, yc_b = size_t(N_pad) * n_pad * 8, g_b = size_t(p_pad) * p_pad * 8,
                  r_b = size_t(p_pad) * n_pad * 8, ti_b = size_t(nblk) * NB * NB * 8,
-                 part_b = size_t(RB) * size_t(std::max(p_pad, n_pad)) * 8;
+                 part_b = size_t(RB) * size_t(p_pad + n_pad) * 8;
     size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
                          cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE));
@@ -507,7 +550,7 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     double *Xs = cp_arena_take_t<double>(ctx, size_t(N_pad) * p_pad);
     double *Yc = cp_arena_take_t<double>(ctx, size_t(N_pad) * n_pad);
     double *G = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
-    double *G0 = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);  // copy of G for the fallback
+    double *G0 = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);  // Gram kept intact for the fallback sweeps
     double *Lt = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
     double *Uf = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
     double *Yt = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
@@ -515,89 +558,94 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     double *R2 = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
     double *TI = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB);
     double *TIT = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB);
-    double *part = cp_arena_take_t<double>(ctx, size_t(RB) * std::max(p_pad, n_pad));
+    double *part_x = cp_arena_take_t<double>(ctx, size_t(RB) * p_pad);
+    double *part_y = cp_arena_take_t<double>(ctx, size_t(RB) * n_pad);
     double *xmean = cp_arena_take_t<double>(ctx, p_pad);
     double *dg0 = cp_arena_take_t<double>(ctx, p_pad);
     double *gmax = cp_arena_take_t<double>(ctx, 8);
     double *ymean = cp_arena_take_t<double>(ctx, n_pad);
     int *dchan = cp_arena_take_t<int>(ctx, kept);
     int *dinfo = cp_arena_take_t<int>(ctx, 16);
-    if (!Xs || !Yc || !G || !G0 || !Lt || !Uf || !Yt || !Rm || !R2 || !TI || !TIT || !part || !xmean || !dg0 || !gmax || !ymean ||
-        !dchan || !dinfo)
+    if (!Xs || !Yc || !G || !G0 || !Lt || !Uf || !Yt || !Rm || !R2 || !TI || !TIT || !part_x || !part_y || !xmean || !dg0 ||
+        !gmax || !ymean || !dchan || !dinfo)
         return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena");
 
-    CP_TRY(cp_pinned_reserve(ctx, 4096));
+    // pinned host block the last kernel writes: [info | b (n) | W (n x p)] when the caller wants host copies
+    const size_t pin_b = 64 + (host_out ? (size_t(n) + size_t(n) * p) * sizeof(double) : 0);
+    CP_TRY(cp_pinned_reserve(ctx, pin_b));
+    int *info_host = reinterpret_cast<int *>(ctx->pinned);
+    double *b_host = host_out ? reinterpret_cast<double *>(ctx->pinned + 64) : nullptr;
+    double *W_host = host_out ? b_host + n : nullptr;
     cp_stage_begin(ctx);
     CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
-    // column means
-    {
-        dim3 gx((p + RT - 1) / RT, RB), gy((n + RT - 1) / RT, RB);
+    {   // column means, then gather + centre (three launches)
+        const int gx = (p + RT - 1) / RT, gy = (n + RT - 1) / RT;
+        dim3 gs(gx + gy, RB);
         if (x_dtype == CP_F32)
-            k_colsum_x<float><<<gx, RT, 0, ctx->stream>>>(static_cast<const float *>(X), N, c, kk, dchan, p,
-                                                          rows_per_block, part, p_pad);
+            k_colsum_xy<float><<<gs, RT, 0, ctx->stream>>>(static_cast<const float *>(X), Y, N, c, kk, n, dchan, p, gx,
+                                                           rows_per_block, part_x, p_pad, part_y, n_pad);
         else
-            k_colsum_x<double><<<gx, RT, 0, ctx->stream>>>(static_cast<const double *>(X), N, c, kk, dchan, p,
-                                                           rows_per_block, part, p_pad);
+            k_colsum_xy<double><<<gs, RT, 0, ctx->stream>>>(static_cast<const double *>(X), Y, N, c, kk, n, dchan, p, gx,
+                                                            rows_per_block, part_x, p_pad, part_y, n_pad);
         CP_LAUNCH_CHECK(ctx);
-        k_mean_finish<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(part, RB, p_pad, p, 1.0 / double(N), xmean);
+        k_mean_finish_xy<<<gx + gy, RT, 0, ctx->stream>>>(part_x, p_pad, p, part_y, n_pad, n, gx, RB, 1.0 / double(N),
+                                                          xmean, ymean);
         CP_LAUNCH_CHECK(ctx);
-        k_colsum_y<<<gy, RT, 0, ctx->stream>>>(Y, N, n, rows_per_block, part, n_pad);
+        cp_stage_mark(ctx, "refit_means");
+        if (x_dtype == CP_F32)
+            k_gather_center_xy<float><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
+                static_cast<const float *>(X), Y, N, c, kk, n, dchan, p, p_pad, n_pad, xmean, ymean, Xs, Yc);
+        else
+            k_gather_center_xy<double><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
+                static_cast<const double *>(X), Y, N, c, kk, n, dchan, p, p_pad, n_pad, xmean, ymean, Xs, Yc);
         CP_LAUNCH_CHECK(ctx);
-        k_mean_finish<<<(n + RT - 1) / RT, RT, 0, ctx->stream>>>(part, RB, n_pad, n, 1.0 / double(N), ymean);
-        CP_LAUNCH_CHECK(ctx);
+        cp_stage_mark(ctx, "refit_gather_center");
     }
-    cp_stage_mark(ctx, "refit_means");
-    if (x_dtype == CP_F32)
-        k_gather_center<float><<<unsigned(N_pad), RT, 0, ctx->stream>>>(static_cast<const float *>(X), N, c, kk, dchan,
-                                                                        p, p_pad, xmean, Xs);
-    else
-        k_gather_center<double><<<unsigned(N_pad), RT, 0, ctx->stream>>>(static_cast<const double *>(X), N, c, kk,
-                                                                         dchan, p, p_pad, xmean, Xs);
-    CP_LAUNCH_CHECK(ctx);
-    k_center_y<<<unsigned(N_pad), RT, 0, ctx->stream>>>(Y, N, n, n_pad, ymean, Yc);
-    CP_LAUNCH_CHECK(ctx);
-    cp_stage_mark(ctx, "refit_gather_center");
-    ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
-    ctx->gemm_mark = "refit_gram_gemm";
-    CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, G, p_pad,
-                          CP_TRI_LOWER_MIRROR));
-    cp_stage_mark(ctx, "refit_gram_reduce");
-    ctx->gemm_tag = CP_GEMM_REFIT_XTY;
-    ctx->gemm_mark = "refit_xty_gemm";
-    CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rm, n_pad, CP_TRI_NONE));
-    cp_stage_mark(ctx, "refit_xty_reduce");
-    k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(G, p_pad, p, p_pad, ridge, dg0, gmax);
-    CP_LAUNCH_CHECK(ctx);
-    CP_HIP(ctx, hipMemcpyAsync(G0, G, g_b, hipMemcpyDeviceToDevice, ctx->stream));
-    CP_HIP(ctx, hipMemcpyAsync(R2, Rm, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+    // Gram and right-hand side into (Gd, Rd), diagonal prepared (ridge, unit pad diagonal, dg0, gmax, info = 0)
+    auto normal_equations = [&](double *Gd, double *Rd, bool mark) -> int {
+        ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
+        ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
+        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad,
+                              CP_TRI_LOWER_MIRROR));
+        if (mark) cp_stage_mark(ctx, "refit_gram_reduce");
+        ctx->gemm_tag = CP_GEMM_REFIT_XTY;
+        ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
+        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
+        if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
+        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo);
+        CP_LAUNCH_CHECK(ctx);
+        return CP_OK;
+    };
 
     Chol ch{G, Uf, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
     int hinfo = 0;
     bool fallback = (ridge == 0.0) && (N - 1 < p);  // centred X has rank <= N-1
     auto finalize = [&]() -> int {
-        k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, ymean, W_out, b_out);
+        k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo,
+                                              info_host);
         CP_LAUNCH_CHECK(ctx);
         cp_stage_mark(ctx, "refit_finalize");
-        CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        CP_HIP(ctx, cp_stream_wait(ctx));
-        memcpy(&hinfo, ctx->pinned, sizeof(int));
+        CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
+        hinfo = *info_host;
         return CP_OK;
     };
     if (!fallback) {
+        CP_TRY(normal_equations(G, Rm, true));
         CP_TRY(chol_factor(ctx, ch, 1e-10));
         cp_stage_mark(ctx, "refit_cholesky");
         CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad));
         cp_stage_mark(ctx, "refit_solve");
-        CP_TRY(finalize());  // one wait for the whole call; the outputs are overwritten below if a pivot failed
+        CP_TRY(finalize());  // the outputs are overwritten below if a pivot failed
         if (hinfo != 0) fallback = true;
     }
     int rank = p;
     if (fallback) {
-        // iterated Tikhonov on the untouched copies G0 (Gram) and R2 (right-hand side)
+        // iterated Tikhonov on an untouched Gram G0 and right-hand side R2 (recomputed: this path is rare)
         double *Wacc = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
         if (!Wacc) return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena (fallback)");
+        CP_TRY(normal_equations(G0, R2, false));
         CP_HIP(ctx, hipMemcpyAsync(G, G0, g_b, hipMemcpyDeviceToDevice, ctx->stream));
-        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0);
+        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0, dinfo);
         CP_LAUNCH_CHECK(ctx);
         CP_TRY(chol_factor(ctx, ch, 0.0));
         CP_HIP(ctx, hipMemsetAsync(Wacc, 0, r_b, ctx->stream));
@@ -625,4 +673,10 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     info->fallback = fallback ? 1 : 0;
     info->reserved = 0;
     return CP_OK;
+}
+
+extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
+                              const double *Y, int n, double ridge, double *W_out, double *b_out,
+                              cp_refit_info *info) {
+    return cp_lstsq_refit_impl(ctx, X, x_dtype, N, c, kk, mask, Y, n, ridge, W_out, b_out, info, false);
 }
