@@ -448,13 +448,24 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
     IdxStream rng;
     rng.init(seed, uint32_t(c), row_stride_bytes, lane);
 
+    // Coupling loads of step a are made out of range (-> 0.0) for the lanes at or before position a of
+    // their block: a lane's private H[ii] then stops changing once its own step is over, so the value
+    // its update chain recomputes in the remaining steps IS its final coefficient -- no per-step latch.
+    const uint32_t rel = uint32_t(lane) & uint32_t(B - 1);
+    constexpr uint32_t OOB = 0x80000000u;  // beyond num_records with or without the row offset, no 32-bit wrap
+    auto mask_offsets = [&](uint32_t voff, uint32_t (&vm)[B]) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) vm[a] = rel > uint32_t(a) ? voff : OOB;
+    };
     // per-lane data of the CURRENT 64-value batch (lane l <-> stream value 64*batch + l)
     uint32_t ii_v, voff_v;
+    uint32_t vm_cur[B], vm_nxt[B];
     double q_v, Qd_v, den_v;
     uint64_t dupmask;
     auto adopt_batch = [&]() {
         ii_v = rng.idx;
         voff_v = ii_v * 8u;
+        mask_offsets(voff_v, vm_cur);
         const double2 qQ = *reinterpret_cast<const double2 *>(feat + 4 * ii_v);
         q_v = qQ.x;
         Qd_v = qQ.y;
@@ -470,12 +481,12 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
 
     BSet<R, B> SA, SB;
     // request the operands of block (base .. base+B-1) of the batch whose offsets are in (off_vec, voff_vec)
-    auto fill = [&](BSet<R, B> &S, uint32_t off_vec, uint32_t voff_vec, int base) {
+    auto fill = [&](BSet<R, B> &S, uint32_t off_vec, const uint32_t (&vm)[B], int base) {
 #pragma unroll
         for (int a = 0; a < B; ++a) {
             const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a));
             load_row(S.row[a], roff);
-            S.qc[a] = load_q(rsrc, voff_vec, roff);
+            S.qc[a] = load_q(rsrc, vm[a], roff);
         }
     };
     auto settle = [&](BSet<R, B> &S) {
@@ -551,15 +562,16 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
         uint64_t wmask = blockmask;  // lanes that write their coefficient back (later duplicate wins)
         const bool has_dup = (dupmask & blockmask) != 0;
         if (!has_dup) {
+            double wn_v = 0.0;
 #pragma unroll
             for (int a = 0; a < B; ++a) {
                 const int la = base + a;
-                // every lane evaluates "its" update against its current H; lane la's is the real one
+                // every lane evaluates "its" update against its private H; lane la's is the one that counts now,
+                // lanes before it reproduce their final value (their couplings to this and later steps read 0)
                 const double Hp = fma(-wo_v, Qd_v, Hs_v);
                 const double tmp = q_v - Hp;
                 const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
-                const double wn_v = RECIP ? thr * den_v : thr / den_v;
-                wn_keep = lane == la ? wn_v : wn_keep;
+                wn_v = RECIP ? thr * den_v : thr / den_v;
                 if (DELTA) {
                     const double d_a = read_lane(wn_v - wo_v, la);
                     Hs_v = fma(d_a, S.qc[a], Hs_v);
@@ -572,6 +584,7 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
                     for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S.row[a][r], fma(-wo_a, S.row[a][r], H[r]));
                 }
             }
+            wn_keep = wn_v;
         } else {  // a coordinate repeats inside the block: later visits must see the earlier result
 #pragma unroll
             for (int a = 0; a < B; ++a) {
@@ -606,20 +619,21 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
     };
 
     adopt_batch();
-    fill(SA, rng.off, voff_v, 0);
+    fill(SA, rng.off, vm_cur, 0);
     for (;;) {  // one 64-value batch per iteration
         for (int g = 0; g < NBLK; g += 2) {
-            fill(SB, rng.off, voff_v, (g + 1) * B);
+            fill(SB, rng.off, vm_cur, (g + 1) * B);
             compute(SA, g * B);
             f += B;
             if (f == c)
                 if (epoch_end()) goto fit_done;
             if (g + 2 < NBLK) {
-                fill(SA, rng.off, voff_v, (g + 2) * B);
+                fill(SA, rng.off, vm_cur, (g + 2) * B);
                 compute(SB, (g + 1) * B);
             } else {  // last block of the batch: request block 0 of the next batch first
                 rng.next_batch();  // only rng.idx / rng.off change; ii_v etc. still describe this batch
-                fill(SA, rng.off, rng.idx * 8u, 0);
+                mask_offsets(rng.idx * 8u, vm_nxt);
+                fill(SA, rng.off, vm_nxt, 0);
                 compute(SB, (g + 1) * B);
             }
             f += B;
