@@ -658,6 +658,546 @@ fit_done:
 }
 
 // run-time -> compile-time dispatch.  flags: CP_CD_RECIPROCAL | CP_CD_DELTA.
+// debug/bench aid: shader-clock cycles spent inside the last cd_fit of the last launch and the
+// number of coordinate steps it ran (read back by cp_debug_cd_cycles; not part of the public ABI)
+__device__ unsigned long long g_cd_debug[8];
+
+// ---------------------------------------------------------------------------------------------
+// Two-wave form of the blocked variant (c % 8 == 0, R <= 8; 128-thread workgroup).  A single wave
+// issues one instruction per ~5-6.5 cycles whatever the dependencies, so the step costs its
+// instruction count; here the count is split between two waves on two SIMDs of the CU:
+//   chain wave  (wave 0): the scalar recurrence only -- per step the 7-op soft-threshold chain, one
+//                readlane pair and one fma on the lanes' private H[ii]; it never touches the full H.
+//   keeper wave (wave 1): owns H in registers, fetches the rows Q[ii,:], applies the block's 8 axpys
+//                with the differences the chain wave publishes, and exposes H as an LDS image after
+//                every block; it also runs the index stream (xorshift jump-ahead, duplicate scan).
+// The chain wave runs one block ahead of the keeper: the private H[ii] of block t+1 is taken from
+// the image after block t-1 plus the 8 updates of block t through the couplings Q[ii_a(t), ii_l(t+1)]
+// (same fma sequence as the keeper applies to that element, so w stays bit-identical).  Hand-offs are
+// sequence counters in LDS (acquire/release at workgroup scope), polled with a bound.
+struct DuoCtl {
+    int seqA;   // blocks published by the chain wave
+    int seqB;   // images published by the keeper (image k = H after the first k blocks; count = k + 1)
+    int batB;   // index batches published by the keeper
+    int stop;   // chain -> keeper: the fit is over
+    int err;    // a bounded wait ran out (never in a correct run)
+    int n_iter, nnz, pad;
+    double gap;
+};
+
+// Flags and payloads all live in LDS, and the LDS executes one wave's instructions in program order:
+// a flag written after its payload lands after it, a payload read after the flag read sees what the
+// flag announced.  So the hand-offs need no s_waitcnt of their own (an acquire / release atomic would
+// also drain the outstanding vector-memory prefetches) -- only the compiler must keep the order.
+// (explicit LDS address space: a volatile access through a generic pointer stays a FLAT instruction
+// with a full vmcnt(0) drain around it)
+typedef __attribute__((address_space(3))) volatile int duo_lds_vint;
+__device__ __forceinline__ int duo_load(int *p) {
+    const int v = *(duo_lds_vint *)p;
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void duo_store(int *p, int v) {
+    asm volatile("" ::: "memory");
+    *(duo_lds_vint *)p = v;
+}
+// wait until *p >= need (returns false if `stop` was raised or the bound ran out)
+__device__ __forceinline__ bool duo_wait(int *p, int need, DuoCtl *ctl, bool watch_stop) {
+    for (int spin = 0;; ++spin) {
+        if (duo_load(p) >= need) return true;
+        if (watch_stop && duo_load(&ctl->stop)) return false;
+        if (spin > (1 << 22)) {
+            duo_store(&ctl->err, 1);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int R>
+struct DuoLds {
+    static constexpr int B = 8, IMG = R * WAVE;
+    double *img;       // [2][IMG]
+    double *pub;       // [4][2 * B]
+    uint32_t *ii;      // [3][64]
+    uint64_t *dup;     // [4] lanes whose coordinate repeats inside their block
+    uint64_t *xdup;    // [4] lanes whose coordinate also occurs in the block before theirs
+    DuoCtl *ctl;
+    static __host__ __device__ constexpr int doubles() { return 2 * IMG + 4 * 2 * B + 3 * 32 + 8 + int(sizeof(DuoCtl) / 8) + 2; }
+    __device__ void bind(double *base) {
+        img = base;
+        pub = img + 2 * IMG;
+        ii = reinterpret_cast<uint32_t *>(pub + 4 * 2 * B);
+        dup = reinterpret_cast<uint64_t *>(ii + 3 * 64);
+        xdup = dup + 4;
+        ctl = reinterpret_cast<DuoCtl *>(xdup + 4);
+    }
+};
+
+template <int R, bool RECIP, bool DELTA>
+__device__ __forceinline__ void duo_keeper(const double *__restrict__ Q, int ldq, int c, uint32_t seed, const double *w_lds,
+                                           DuoLds<R> &L) {
+    constexpr int B = 8;
+    const int lane = threadIdx.x & 63;
+    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    constexpr bool PK = CP_CD_PACKED && (R % 2 == 0);
+    auto colof = [&](int r) -> int { return PK ? (r >> 1) * 2 * WAVE + 2 * lane + (r & 1) : r * WAVE + lane; };
+    uint32_t colb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int col = colof(r);
+        colb[r] = uint32_t(col < c ? col : (PK ? c - 2 + (r & 1) : c - 1)) * 8u;
+    }
+    auto load_row = [&](double (&dst)[R], uint32_t roff) {
+        if (PK) {
+#pragma unroll
+            for (int r = 0; r < R; r += 2) load_q2(rsrc, colb[r], roff, dst[r], dst[r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = load_q(rsrc, colb[r], roff);
+        }
+    };
+    double H[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) H[r] = 0.0;
+    constexpr int U = R <= 4 ? 8 : 4;
+    for (int j0 = 0; j0 < c; j0 += U) {  // H = Q w in index order (as the oracle)
+        double row[U][R];
+        double wj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u;
+            wj[u] = j < c ? w_lds[j] : 0.0;
+            load_row(row[u], uint32_t(j < c ? j : c - 1) * row_stride_bytes);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (wj[u] != 0.0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(wj[u], row[u][r], H[r]);
+            }
+    }
+    auto write_image = [&](int k) {
+        double *im = L.img + (k & 1) * DuoLds<R>::IMG;
+        if (PK) {
+#pragma unroll
+            for (int r = 0; r < R; r += 2) *reinterpret_cast<double2 *>(im + r * WAVE + 2 * lane) = make_double2(H[r], H[r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) im[r * WAVE + lane] = H[r];
+        }
+        duo_store(&L.ctl->seqB, k + 1);
+    };
+    write_image(0);
+
+    IdxStream rng;
+    rng.init(seed, uint32_t(c), row_stride_bytes, lane);
+    uint32_t prev_idx = 0xffffffffu;  // coordinates of the batch published before (none yet)
+    auto publish_batch = [&](int k) {
+        L.ii[(k % 3) * 64 + lane] = rng.idx;
+        bool dup = false, xd = false;
+        const int bs = lane & ~(B - 1);
+#pragma unroll
+        for (int sft = 1; sft < B; ++sft) {
+            const int other = __shfl(int(rng.idx), bs | ((lane + sft) & (B - 1)), WAVE);
+            dup |= (uint32_t(other) == rng.idx);
+        }
+#pragma unroll
+        for (int sft = 0; sft < B; ++sft) {  // the block before: lanes bs-8.. of this batch, or 56.. of the previous one
+            const int src = ((bs - B) & 63) + sft;
+            const int o_same = __shfl(int(rng.idx), src, WAVE), o_prev = __shfl(int(prev_idx), src, WAVE);
+            xd |= uint32_t(bs == 0 ? o_prev : o_same) == rng.idx;
+        }
+        const uint64_t m = __ballot(dup), mx = __ballot(xd);
+        if (lane == 0) {
+            L.dup[k & 3] = m;
+            L.xdup[k & 3] = mx;
+        }
+        prev_idx = rng.idx;
+        duo_store(&L.ctl->batB, k + 1);
+    };
+    publish_batch(0);  // the ring runs two batches ahead of the one being applied
+    uint32_t off_cur = rng.off;
+    rng.next_batch();
+    publish_batch(1);
+    uint32_t off_nxt = rng.off;
+    rng.next_batch();
+    publish_batch(2);
+    uint32_t off_n2 = rng.off;
+    int batch = 0;
+
+    double rowA[B][R], rowB[B][R];
+    auto fill = [&](double (&S)[B][R], uint32_t off_vec, int base) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) load_row(S[a], uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a)));
+    };
+    auto settle = [&](double (&S)[B][R]) {
+#pragma unroll
+        for (int a = 0; a < B; ++a)
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(S[a][r]));
+    };
+    // apply block t with the rows in S; returns false when the fit is over
+    unsigned long long waitB = 0, blocksB = 0;
+    auto apply = [&](const double (&S)[B][R], int t) -> bool {
+        const unsigned long long w0 = __builtin_readcyclecounter();
+        const bool okw = duo_wait(&L.ctl->seqA, t + 1, L.ctl, true);
+        waitB += __builtin_readcyclecounter() - w0;
+        ++blocksB;
+        if (!okw) {
+            if (lane == 0) {
+                g_cd_debug[4] = waitB;
+                g_cd_debug[5] = blocksB;
+            }
+            return false;
+        }
+        const double *pb = L.pub + (t & 3) * 2 * B;
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            if (DELTA) {
+                const double d_a = pb[a];  // same address in every lane: LDS broadcast
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(d_a, S[a][r], H[r]);
+            } else {
+                const double wo_a = pb[2 * a], wn_a = pb[2 * a + 1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S[a][r], fma(-wo_a, S[a][r], H[r]));
+            }
+        }
+        write_image(t + 1);
+        return true;
+    };
+    fill(rowA, off_cur, 0);
+    for (int t = 0;; t += 2) {  // two blocks per iteration (register sets A / B); 8 blocks per batch
+        const int g = t & 7;
+        fill(rowB, off_cur, (g + 1) * B);
+        if (!apply(rowA, t)) break;
+        if (g + 2 < 8) {
+            fill(rowA, off_cur, (g + 2) * B);
+        } else {
+            fill(rowA, off_nxt, 0);
+        }
+        if (!apply(rowB, t + 1)) break;
+        settle(rowA);
+        if (g + 2 >= 8) {  // batch roll-over
+            off_cur = off_nxt;
+            off_nxt = off_n2;
+            rng.next_batch();
+            ++batch;
+            publish_batch(batch + 2);
+            off_n2 = rng.off;
+        }
+    }
+}
+
+template <int R, bool RECIP, bool DELTA>
+__device__ __forceinline__ void duo_chain(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
+                                          int max_iter, double tol_scaled, double d_w_tol, double y_norm2, double *w_lds,
+                                          const double *feat, DuoLds<R> &L) {
+    constexpr int B = 8;
+    const int lane = threadIdx.x & 63;
+    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    const uint32_t rel = uint32_t(lane) & uint32_t(B - 1);
+    constexpr uint32_t OOB = 0x80000000u;
+    DuoCtl *ctl = L.ctl;
+
+    struct Batch {
+        uint32_t ii, off, voff;
+        uint32_t vm[B];  // coupling column offsets, out of range for lanes at or before position a of their block
+        double q, Qd, den;
+        uint64_t dupmask, xdupmask;
+    };
+    auto load_batch = [&](Batch &bt, int k) -> bool {
+        if (!duo_wait(&ctl->batB, k + 1, ctl, false)) return false;
+        bt.ii = L.ii[(k % 3) * 64 + lane];
+        bt.dupmask = L.dup[k & 3];
+        bt.xdupmask = L.xdup[k & 3];
+        bt.off = bt.ii * row_stride_bytes;
+        bt.voff = bt.ii * 8u;
+#pragma unroll
+        for (int a = 0; a < B; ++a) bt.vm[a] = rel > uint32_t(a) ? bt.voff : OOB;
+        const double2 qQ = *reinterpret_cast<const double2 *>(feat + 4 * bt.ii);
+        bt.q = qQ.x;
+        bt.Qd = qQ.y;
+        bt.den = feat[4 * bt.ii + 2];
+        return true;
+    };
+    struct CSet {
+        double qc[B];  // Q[ii_a, ii_lane] within the block (0 for finished lanes)
+        double qx[B];  // Q[ii_a(previous block), ii_lane]
+    };
+    // couplings of block `base` of batch `bt`; the block before it is block `prev_base` of batch `pb`
+    auto fill = [&](CSet &S, const Batch &bt, int base, const Batch &pb, int prev_base, bool has_prev) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(bt.off), base + a));
+            S.qc[a] = load_q(rsrc, bt.vm[a], roff);
+        }
+        if (has_prev) {
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(pb.off), prev_base + a));
+                S.qx[a] = load_q(rsrc, bt.voff, roff);
+            }
+        }
+    };
+    auto settle = [&](CSet &S) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            asm volatile("" : "+v"(S.qc[a]));
+            asm volatile("" : "+v"(S.qx[a]));
+        }
+    };
+
+    Batch cur, nxt;
+    if (!load_batch(cur, 0) || !load_batch(nxt, 1)) return;
+    int batch = 0;
+    int n_iter = 0, f = 0;
+    double wmax_v = 0.0, dmax_v = 0.0;
+    double gap_out = tol_scaled + 1.0;
+    double dp0[B], dp1[B];  // what the previous block published (DELTA: dp0 = differences; else dp0 = w_old, dp1 = w_new)
+#pragma unroll
+    for (int a = 0; a < B; ++a) dp0[a] = dp1[a] = 0.0;
+
+    // the image after t_done blocks is complete: dual gap from it (same arithmetic as the one-wave form)
+    auto epoch_end = [&](int t_done) -> bool {
+        const double w_max = wave_max(wmax_v), d_w_max = wave_max(dmax_v);
+        bool done = false;
+        if (w_max == 0.0 || d_w_max / w_max < d_w_tol || n_iter == max_iter - 1) {
+            if (!duo_wait(&ctl->seqB, t_done + 1, ctl, false)) return true;
+            const double *im = L.img + (t_done & 1) * DuoLds<R>::IMG;
+            double s_qw = 0, s_wh = 0, s_ww = 0, s_l1 = 0, m_xta = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int col = r * WAVE + lane;
+                if (col < c) {
+                    const double wv = w_lds[col], qv = feat[4 * col], hv = im[col];
+                    const double xta = qv - hv - beta * wv;
+                    s_qw += wv * qv;
+                    s_wh += wv * hv;
+                    s_ww += wv * wv;
+                    s_l1 += fabs(wv);
+                    m_xta = fmax(m_xta, fabs(xta));
+                }
+            }
+            const double q_dot_w = wave_sum(s_qw), wh = wave_sum(s_wh), w_norm2 = wave_sum(s_ww),
+                         l1 = wave_sum(s_l1), dual_norm = wave_max(m_xta);
+            const double R_norm2 = y_norm2 + wh - 2.0 * q_dot_w;
+            double const_, gap;
+            if (dual_norm > alpha) {
+                const_ = alpha / dual_norm;
+                const double A_norm2 = R_norm2 * (const_ * const_);
+                gap = 0.5 * (R_norm2 + A_norm2);
+            } else {
+                const_ = 1.0;
+                gap = R_norm2;
+            }
+            gap += alpha * l1 - const_ * y_norm2 + const_ * q_dot_w + 0.5 * beta * (1.0 + const_ * const_) * w_norm2;
+            gap_out = gap;
+            if (gap < tol_scaled) done = true;
+        }
+        ++n_iter;
+        wmax_v = 0.0;
+        dmax_v = 0.0;
+        f = 0;
+        return done || n_iter == max_iter;
+    };
+
+    unsigned long long waitA = 0, repairs = 0;
+    // per-lane inputs of a block, fetched while the block before it is still running
+    struct Pre {
+        double Hn;   // image part of H[ii] (the previous block's 8 updates are added through qx)
+        double wo;   // w[ii]
+        int seq;     // seqB as seen just before Hn was read
+    };
+    auto prefetch = [&](Pre &pr, const Batch &nb, int t_next) {  // for block t_next: image t_next - 1
+        pr.seq = duo_load(&ctl->seqB);
+        pr.Hn = (L.img + ((t_next - 1) & 1) * DuoLds<R>::IMG)[nb.ii];
+        pr.wo = w_lds[nb.ii];
+    };
+
+    // one block: lanes base..base+7 of `bt`; after step PF the inputs of the next block (lanes nbase.. of `nb`)
+    // are requested into `pn`
+    constexpr int PF = 5;
+    auto compute = [&](const CSet &S, const Batch &bt, int base, int t, const Pre &pc, bool has_prev, const Batch &nb,
+                       int nbase, Pre &pn) {
+        double Hs_v = pc.Hn;
+        if (has_prev) {
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                if (DELTA)
+                    Hs_v = fma(dp0[a], S.qx[a], Hs_v);
+                else
+                    Hs_v = fma(dp1[a], S.qx[a], fma(-dp0[a], S.qx[a], Hs_v));
+            }
+        }
+        double wo_v = pc.wo;
+        const uint64_t blockmask = ((uint64_t(1) << B) - 1) << base;
+        uint64_t wmask = blockmask;
+        const bool has_dup = (bt.dupmask & blockmask) != 0;
+        double wn_keep = 0.0, p0_v = 0.0, p1_v = 0.0;  // what this lane publishes for its own step
+        if (!has_dup) {
+            double wn_v = 0.0;
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const int la = base + a;
+                const double Hp = fma(-wo_v, bt.Qd, Hs_v);
+                const double tmp = bt.q - Hp;
+                const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+                wn_v = RECIP ? thr * bt.den : thr / bt.den;
+                if (DELTA) {
+                    const double d_a = read_lane(wn_v - wo_v, la);
+                    dp0[a] = d_a;
+                    Hs_v = fma(d_a, S.qc[a], Hs_v);
+                } else {
+                    const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
+                    dp0[a] = wo_a;
+                    dp1[a] = wn_a;
+                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+                }
+                if (a == PF) prefetch(pn, nb, t + 1);
+            }
+            wn_keep = wn_v;
+            p0_v = DELTA ? wn_v - wo_v : wo_v;
+            p1_v = wn_v;
+        } else {  // a coordinate repeats inside the block: later visits must see the earlier result
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const int la = base + a;
+                const double Hp = fma(-wo_v, bt.Qd, Hs_v);
+                const double tmp = bt.q - Hp;
+                const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+                const double wn_v = RECIP ? thr * bt.den : thr / bt.den;
+                const bool mine = lane == la;
+                wn_keep = mine ? wn_v : wn_keep;
+                const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
+                if (DELTA) {
+                    const double dv = wn_v - wo_v;
+                    const double d_a = read_lane(dv, la);
+                    p0_v = mine ? dv : p0_v;
+                    dp0[a] = d_a;
+                    Hs_v = fma(d_a, S.qc[a], Hs_v);
+                } else {
+                    p0_v = mine ? wo_v : p0_v;
+                    p1_v = mine ? wn_v : p1_v;
+                    dp0[a] = wo_a;
+                    dp1[a] = wn_a;
+                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+                }
+                const uint32_t ii_a = uint32_t(__builtin_amdgcn_readlane(int(bt.ii), la));
+                const bool later_same = bt.ii == ii_a && lane > la && lane < base + B;
+                wo_v = later_same ? wn_a : wo_v;
+                if (__ballot(later_same) != 0) wmask &= ~(uint64_t(1) << la);
+                if (a == PF) prefetch(pn, nb, t + 1);
+            }
+        }
+        if ((blockmask >> lane) & 1) {
+            double *pb = L.pub + (t & 3) * 2 * B;
+            if (DELTA) {
+                pb[rel] = p0_v;
+            } else {
+                pb[2 * rel] = p0_v;
+                pb[2 * rel + 1] = p1_v;
+            }
+            dmax_v = fmax(dmax_v, fabs(wn_keep - wo_v));
+            wmax_v = fmax(wmax_v, fabs(wn_keep));
+        }
+        if ((wmask >> lane) & 1) w_lds[bt.ii] = wn_keep;
+        duo_store(&ctl->seqA, t + 1);
+        // rare repairs of the prefetch: the keeper had not published image t yet, or the next block revisits
+        // a coordinate this block just changed
+        if (pn.seq < t + 1) {
+            const unsigned long long w0 = __builtin_readcyclecounter();
+            duo_wait(&ctl->seqB, t + 1, ctl, false);
+            pn.Hn = (L.img + (t & 1) * DuoLds<R>::IMG)[nb.ii];
+            waitA += __builtin_readcyclecounter() - w0;
+            ++repairs;
+        }
+        if ((nb.xdupmask >> nbase) & ((uint64_t(1) << B) - 1)) pn.wo = w_lds[nb.ii];
+    };
+
+    CSet SA, SB;
+    Pre pa, pb2;
+    fill(SA, cur, 0, cur, 0, false);
+    duo_wait(&ctl->seqB, 1, ctl, false);
+    pa.Hn = L.img[cur.ii];
+    pa.wo = w_lds[cur.ii];
+    pa.seq = 1;
+    for (int t = 0;; t += 2) {  // blocks t (set A) and t+1 (set B); 8 blocks per batch
+        const int g = t & 7;
+        // ---- block t ----
+        fill(SB, cur, (g + 1) * B, cur, g * B, true);
+        compute(SA, cur, g * B, t, pa, t > 0, cur, (g + 1) * B, pb2);
+        f += B;
+        if (f == c && epoch_end(t + 1)) break;
+        // ---- block t+1 ----
+        const bool roll = g + 2 >= 8;
+        if (!roll) {
+            fill(SA, cur, (g + 2) * B, cur, (g + 1) * B, true);
+            compute(SB, cur, (g + 1) * B, t + 1, pb2, true, cur, (g + 2) * B, pa);
+        } else {
+            fill(SA, nxt, 0, cur, (g + 1) * B, true);
+            compute(SB, cur, (g + 1) * B, t + 1, pb2, true, nxt, 0, pa);
+        }
+        f += B;
+        if (f == c && epoch_end(t + 2)) break;
+        settle(SA);
+        if (roll) {
+            cur = nxt;
+            ++batch;
+            if (!load_batch(nxt, batch + 1)) break;
+        }
+    }
+    duo_store(&ctl->stop, 1);
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int col = r * WAVE + lane;
+        cnt += (col < c && w_lds[col] != 0.0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+    if (lane == 0) {
+        g_cd_debug[2] = waitA;
+        g_cd_debug[3] = repairs;
+        ctl->gap = gap_out;
+        ctl->n_iter = duo_load(&ctl->err) ? -1 : n_iter;
+        ctl->nnz = cnt;
+    }
+}
+
+// both waves of the workgroup call this; returns the same FitOut in all threads
+template <int R, bool RECIP, bool DELTA>
+__device__ __forceinline__ FitOut cd_fit_duo(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
+                                             uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
+                                             double y_norm2, double *w_lds, const double *feat, double *duo_base) {
+    DuoLds<R> L;
+    L.bind(duo_base);
+    if (threadIdx.x == 0) {
+        L.ctl->seqA = 0;
+        L.ctl->seqB = 0;
+        L.ctl->batB = 0;
+        L.ctl->stop = 0;
+        L.ctl->err = 0;
+    }
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 1)
+        duo_keeper<R, RECIP, DELTA>(Q, ldq, c, seed, w_lds, L);
+    else
+        duo_chain<R, RECIP, DELTA>(Q, ldq, c, alpha, beta, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds, feat, L);
+    __syncthreads();
+    FitOut out;
+    out.gap = L.ctl->gap;
+    out.n_iter = L.ctl->n_iter;
+    out.nnz = L.ctl->nnz;
+    __syncthreads();
+    return out;
+}
+
 template <int R>
 __device__ __forceinline__ FitOut cd_fit_any(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
                                              uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
@@ -703,9 +1243,6 @@ __device__ __forceinline__ void load_features(const double *__restrict__ Q, int 
     __syncthreads();
 }
 
-// debug/bench aid: shader-clock cycles spent inside the last cd_fit of the last launch and the
-// number of coordinate steps it ran (read back by cp_debug_cd_cycles; not part of the public ABI)
-__device__ unsigned long long g_cd_debug[8];
 
 struct DevResult {  // mirrors cp_cd_result
     double gap;
@@ -797,6 +1334,115 @@ k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
     }
 }
 
+
+// ---- two-wave kernels (128 threads): same contracts as k_cd_fit / k_cd_search ---------------------
+template <int R, typename... A>
+__device__ __forceinline__ FitOut cd_fit_duo_any(int flags, A... args) {
+    const bool recip = flags & CP_CD_RECIPROCAL, delta = flags & CP_CD_DELTA;
+    if (recip) {
+        if (delta) return cd_fit_duo<R, true, true>(args...);
+        return cd_fit_duo<R, true, false>(args...);
+    }
+    if (delta) return cd_fit_duo<R, false, true>(args...);
+    return cd_fit_duo<R, false, false>(args...);
+}
+
+__device__ __forceinline__ void load_features_wg(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
+                                                 const double *__restrict__ w_in, int c, double l2, int flags,
+                                                 double *w_lds, double *feat) {
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        const double dj = Q[size_t(j) * ldq + j];
+        w_lds[j] = w_in ? w_in[j] : 0.0;
+        feat[4 * j + 0] = q[j];
+        feat[4 * j + 1] = dj;
+        feat[4 * j + 2] = dj == 0.0 ? ((flags & CP_CD_RECIPROCAL) ? 0.0 : 1.0)
+                                    : ((flags & CP_CD_RECIPROCAL) ? 1.0 / (dj + l2) : dj + l2);
+        feat[4 * j + 3] = 0.0;
+    }
+    __syncthreads();
+}
+
+template <int R>
+__global__ void __launch_bounds__(2 * WAVE) k_cd_fit_duo(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
+                                                         const double *__restrict__ stats, int c, double l1, double l2,
+                                                         uint32_t seed, int max_iter, double tol, int flags,
+                                                         double *__restrict__ w, DevResult *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *feat = smem, *w_lds = smem + 4 * c, *duo = smem + 5 * c;
+    load_features_wg(Q, ldq, q, w, c, l2, flags, w_lds, feat);
+    const double y_norm2 = stats[0];
+    const double tol_scaled = tol * y_norm2;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    FitOut o = cd_fit_duo_any<R>(flags, Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, w_lds, feat, duo);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        g_cd_debug[0] = t1 - t0;
+        g_cd_debug[1] = (unsigned long long)o.n_iter * (unsigned long long)c;
+    }
+    for (int j = threadIdx.x; j < c; j += blockDim.x) w[j] = w_lds[j];
+    if (threadIdx.x == 0) {
+        res->gap = o.gap;
+        res->tol_scaled = tol_scaled;
+        res->n_iter = o.n_iter;
+        res->nnz = o.nnz;
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(2 * WAVE)
+k_cd_search_duo(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
+                int c, double M, double right0, double rank, double lbound, double rbound,
+                const uint32_t *__restrict__ seeds, int max_fits, int max_iter, double tol, int flags,
+                double *__restrict__ w, double *__restrict__ w_host, DevResult *__restrict__ log,
+                double *__restrict__ log_alpha, int *__restrict__ fits_used, double *__restrict__ alpha_out) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *feat = smem, *w_lds = smem + 4 * c, *duo = smem + 5 * c;
+    load_features_wg(Q, ldq, q, nullptr, c, 0.0, flags, w_lds, feat);
+    const double y_norm2 = stats[0];
+    const double tol_scaled = tol * y_norm2;
+    int fit = 0;
+    double left = 0.0, right = right0, alpha = right0;
+    bool bracketing = true, ok = false;
+    while (fit < max_fits) {
+        alpha = bracketing ? right : (left + right) / 2;
+        FitOut o = cd_fit_duo_any<R>(flags, Q, ldq, c, alpha * M, 0.0, seeds[fit], max_iter, tol_scaled, tol, y_norm2,
+                                     w_lds, feat, duo);
+        if (threadIdx.x == 0) {
+            log[fit].gap = o.gap;
+            log[fit].tol_scaled = tol_scaled;
+            log[fit].n_iter = o.n_iter;
+            log[fit].nnz = o.nnz;
+            log_alpha[fit] = alpha;
+        }
+        ++fit;
+        const double tmp = double(o.nnz);
+        if (bracketing) {  // decompose.py:502-515
+            if (tmp < rank)
+                bracketing = false;
+            else
+                right *= 2;
+        } else {  // decompose.py:516-525
+            if (tmp > rbound)
+                left = alpha;
+            else if (tmp < lbound)
+                right = alpha;
+            else {
+                ok = true;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        w[j] = w_lds[j];
+        w_host[j] = w_lds[j];
+    }
+    if (threadIdx.x == 0) {
+        *fits_used = ok ? fit : -fit;  // negative: ran out of pre-drawn seeds
+        *alpha_out = alpha;
+    }
+}
+
 }  // namespace
 
 #define CP_CD_DISPATCH(KERNEL, R_, ...)                                      \
@@ -815,6 +1461,24 @@ static int pick_R(int c) {
     return R;
 }
 
+// two-wave kernels: c % 8 == 0 and 256 < c <= 512 (CP_CD_DUO=0 keeps the one-wave kernels)
+static bool use_duo(int c) {
+    static const bool on = !(getenv("CP_CD_DUO") && atoi(getenv("CP_CD_DUO")) == 0);
+    return on && c % 8 == 0 && c > 4 * WAVE && c <= 8 * WAVE;  // measured: 254 vs 327 cycles/step at c = 512, no gain below
+}
+static size_t duo_lds_bytes(int c) {
+    const int R = pick_R(c);
+    const int extra = R == 1 ? DuoLds<1>::doubles() : R == 2 ? DuoLds<2>::doubles() : R == 4 ? DuoLds<4>::doubles() : DuoLds<8>::doubles();
+    return (size_t(5) * c + size_t(extra)) * sizeof(double);
+}
+#define CP_CD_DISPATCH_DUO(KERNEL, R_, ...)                                              \
+    switch (R_) {                                                                        \
+        case 1: KERNEL<1><<<1, 2 * WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;         \
+        case 2: KERNEL<2><<<1, 2 * WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;         \
+        case 4: KERNEL<4><<<1, 2 * WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;         \
+        default: KERNEL<8><<<1, 2 * WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;        \
+    }
+
 extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c,
                                double l1_reg, double l2_reg, uint32_t seed, int max_iter, double tol, int flags,
                                double *w, cp_cd_result *result) {
@@ -823,10 +1487,15 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     CP_HIP(ctx, hipSetDevice(ctx->device));
     CP_TRY(cp_arena_reserve(ctx, 4096));
     DevResult *dres = reinterpret_cast<DevResult *>(cp_arena_take(ctx, sizeof(DevResult)));
-    const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
+    const bool duo = use_duo(c);
+    const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
+    if (duo) {
+        CP_CD_DISPATCH_DUO(k_cd_fit_duo, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
+    } else {
+        CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
+    }
     CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "cd_fit");
     static_assert(sizeof(DevResult) == sizeof(cp_cd_result), "layout");
@@ -866,13 +1535,21 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     double *halpha = reinterpret_cast<double *>(h + 64);
     *hfits = 0;
     memcpy(h + off_seed, seeds, size_t(max_fits) * sizeof(uint32_t));
-    const size_t lds = (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
+    const bool duo = use_duo(c);
+    const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
-                   reinterpret_cast<const uint32_t *>(h + off_seed), max_fits, max_iter, tol, flags, w,
-                   reinterpret_cast<double *>(h + off_w), reinterpret_cast<DevResult *>(h + off_log),
-                   reinterpret_cast<double *>(h + off_al), hfits, halpha);
+    if (duo) {
+        CP_CD_DISPATCH_DUO(k_cd_search_duo, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
+                           reinterpret_cast<const uint32_t *>(h + off_seed), max_fits, max_iter, tol, flags, w,
+                           reinterpret_cast<double *>(h + off_w), reinterpret_cast<DevResult *>(h + off_log),
+                           reinterpret_cast<double *>(h + off_al), hfits, halpha);
+    } else {
+        CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
+                       reinterpret_cast<const uint32_t *>(h + off_seed), max_fits, max_iter, tol, flags, w,
+                       reinterpret_cast<double *>(h + off_w), reinterpret_cast<DevResult *>(h + off_log),
+                       reinterpret_cast<double *>(h + off_al), hfits, halpha);
+    }
     CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(ctx, "cd_alpha_search");
     CP_HIP(ctx, cp_stream_wait(ctx));

@@ -51,4 +51,4 @@ for c in (64, 128, 256, 512):
             phases = [dbg[2 + i] / max(dbg[1], 1) for i in range(4)]
         best = min(rows)
         print("c=%4d flags=%d  ns/step %.1f  cycles/step %.1f  implied GHz %.2f  n_iter %d nnz %d" % (
-            (c, flags) + best), " phases/step fill %.1f compute %.1f batch %.1f other %.1f" % tuple(phases), flush=True)
+            (c, flags) + best), " dbg/step: %.2f %.4f %.2f %.4f" % tuple(phases), flush=True)
