@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, 
 // <= piv_tol * original diagonal (also NaN).
 typedef double v4f64c __attribute__((ext_vector_type(4)));
 constexpr int PNB = 16, NPAN = NB / PNB, DLD = 136;
+constexpr int PT = 512;  // threads of the diagonal-block kernel (8 waves)
 
 __device__ unsigned long long g_potrf_debug[8];  // phase cycle counters of the last diagonal-block kernel
 
@@ -189,7 +190,7 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 
-__global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G, double *__restrict__ Uout, int ld,
+__global__ void __launch_bounds__(PT) k_potrf_diag(const double *__restrict__ G, double *__restrict__ Uout, int ld,
                                                    int blk, const double *__restrict__ dg0, double piv_tol,
                                                    double *__restrict__ TI, double *__restrict__ TIT,
                                                    int *__restrict__ info) {
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
     const int fk = lane >> 4, fi = lane & 15;
     const double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
     double *Ub = Uout + size_t(blk) * NB * ld + size_t(blk) * NB;
-    for (int e = tid; e < NB * NB / 2; e += RT) {
+    for (int e = tid; e < NB * NB / 2; e += PT) {
         const int r = e / (NB / 2), cc = (e % (NB / 2)) * 2;
         *reinterpret_cast<double2 *>(&A[r * DLD + cc]) = *reinterpret_cast<const double2 *>(&Gb[size_t(r) * ld + cc]);
     }
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
         CP_PH(2)
         // (3) A22 -= U12^T U12 on the upper tiles (ti <= tj) of the trailing (rest/16)^2 grid
         const int rt = rest / PNB, ntile = rt * (rt + 1) / 2;
-        for (int e = wave; e < ntile; e += 4) {
+        for (int e = wave; e < ntile; e += PT / 64) {
             int a = int((sqrtf(8.f * float(e) + 1.f) - 1.f) * 0.5f);
             while ((a + 1) * (a + 2) / 2 <= e) ++a;
             while (a * (a + 1) / 2 > e) --a;
@@ -290,8 +291,8 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
     }
 
     // T_p = U_pp^-1 (upper 16x16): task = (panel, column j), 4 lanes per task split the k-sum
-    for (int pass = 0; pass < 2; ++pass) {
-        const int task = pass * 64 + (tid >> 2), g = tid & 3;
+    for (int pass = 0; pass < NPAN * PNB * 4 / PT; ++pass) {
+        const int task = pass * (PT / 4) + (tid >> 2), g = tid & 3;
         const int p = task >> 4, j = task & 15, k0 = p * PNB;
         double *Tp = Tl + p * PNB * PNB;
         for (int i = PNB - 1; i >= 0; --i) {
@@ -309,9 +310,10 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
 
     // off-diagonal blocks of V = U^-1: V_ij = -T_ii * sum_{k=i+1..j} U_ik V_kj, stored (untransposed)
     // at block position (j, i) of A's lower part.  Block columns per wave: {7}, {6,1}, {5,2}, {4,3}.
-    for (int which = 0; which < 2; ++which) {
-        const int jb = which == 0 ? 7 - wave : wave;
+    for (int which = 0; which < (PT == 256 ? 2 : 1); ++which) {
+        const int jb = which == 0 ? 7 - wave : wave;  // 4 waves: {7}, {6,1}, {5,2}, {4,3}; 8 waves: one block column each
         if (which == 1 && wave == 0) break;
+        if (jb < 1) break;
         for (int ib = jb - 1; ib >= 0; --ib) {
             v4f64c S = {0., 0., 0., 0.};
             for (int kb = ib + 1; kb <= jb; ++kb) {
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(RT) k_potrf_diag(const double *__restrict__ G,
     CP_PH(5)
 
     double *TIb = TI + size_t(blk) * NB * NB, *TITb = TIT + size_t(blk) * NB * NB;
-    for (int e = tid; e < NB * NB; e += RT) {
+    for (int e = tid; e < NB * NB; e += PT) {
         const int r = e / NB, cc = e - r * NB;
         const int rb = r >> 4, cb = cc >> 4, ri = r & 15, ci = cc & 15;
         // V[r, cc] (upper): diagonal blocks in Tl, block (rb < cb) at A block position (cb, rb)
@@ -433,7 +435,7 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
         attr_set = true;
     }
     for (int b = 0; b < ch.nblk; ++b) {
-        k_potrf_diag<<<1, RT, lds, ctx->stream>>>(ch.G, ch.U, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
+        k_potrf_diag<<<1, PT, lds, ctx->stream>>>(ch.G, ch.U, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
         CP_LAUNCH_CHECK(ctx);
         const int rest = (ch.nblk - b - 1) * NB;
         if (rest > 0) {
