@@ -96,9 +96,9 @@ __global__ void __launch_bounds__(RT) k_gather_center_xy(const TX *__restrict__ 
 // dg0[i] = G[i,i] (original), gmax[0] = max_i dg0[i]; pad rows get G[i,i] = 1.
 __global__ void __launch_bounds__(1024) k_diag_prepare(double *__restrict__ G, int ld, int p, int p_pad, double ridge,
                                                        double *__restrict__ dg0, double *__restrict__ gmax,
-                                                       int *__restrict__ info) {
+                                                       int *__restrict__ info, int n_info) {
     __shared__ double red[16];
-    if (threadIdx.x == 0) info[0] = 0;  // first failed pivot of the factorisation that follows
+    for (int i = threadIdx.x; i < n_info; i += blockDim.x) info[i] = 0;  // [0] first failed pivot, [1 + b] block b done
     double m = 0;
     for (int i = threadIdx.x; i < p_pad; i += blockDim.x) {
         double d;
@@ -124,9 +124,9 @@ __global__ void __launch_bounds__(1024) k_diag_prepare(double *__restrict__ G, i
 
 __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, int ld, int p,
                                                         const double *__restrict__ gmax, double rel,
-                                                        double *__restrict__ dg0, int *__restrict__ info) {
+                                                        double *__restrict__ dg0, int *__restrict__ info, int n_info) {
     const int i = blockIdx.x * RT + threadIdx.x;
-    if (i == 0) info[0] = 0;
+    if (i < n_info) info[i] = 0;  // n_info <= p: one entry per 128-column block + 1
     if (i >= p) return;
     const double d = G[size_t(i) * ld + i] + rel * gmax[0];
     G[size_t(i) * ld + i] = d;
@@ -190,11 +190,46 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 
-__global__ void __launch_bounds__(PT) k_potrf_diag(const double *__restrict__ G, double *__restrict__ Uout, int ld,
-                                                   int blk, const double *__restrict__ dg0, double piv_tol,
-                                                   double *__restrict__ TI, double *__restrict__ TIT,
-                                                   int *__restrict__ info) {
+// Workgroups 1.. of the same launch are the panel of this block step: workgroup j waits for the
+// diagonal workgroup's flag (info[1 + blk]; workgroup 0 is dispatched first, so it is never starved by
+// the waiters) and computes U[blk, blk + j] = U_bb^-T G[blk, blk + j] on MFMA (wave w: 16 rows x 128
+// columns).  One launch per block step instead of two: with many layers in flight every launch in
+// the chain costs tens of microseconds of dispatch latency.
+__global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout, int ld, int blk,
+                                                   const double *__restrict__ dg0, double piv_tol, double *TI,
+                                                   double *TIT, int *info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (blockIdx.x > 0) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
+        int *flag = info + 1 + blk;
+        if (tid == 0) {
+            for (int spin = 0; spin < (1 << 24); ++spin) {
+                if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int j = blk + int(blockIdx.x);
+        const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
+        const double *Gbj = G + size_t(blk) * NB * ld + size_t(j) * NB + fi;
+        double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
+        v4f64c acc[NB / 16];
+#pragma unroll
+        for (int t = 0; t < NB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
+#pragma unroll 2
+        for (int q = 0; q < NB / 4; ++q) {
+            const double av = TIb[size_t(4 * q + fk) * NB];
+#pragma unroll
+            for (int t = 0; t < NB / 16; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Gbj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NB / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
+        return;
+    }
     double *A = sm;                        // NB x DLD
     double *Tl = sm + NB * DLD;            // NPAN x 16 x 16 : inverses of the diagonal sub-blocks
     double *dinv = Tl + NPAN * PNB * PNB;  // NB : 1 / U[i,i]
@@ -357,8 +392,11 @@ __global__ void __launch_bounds__(PT) k_potrf_diag(const double *__restrict__ G,
     }
     CP_PH(6)
 #undef CP_PH
-    if (tid == 0)
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // TI_b is complete
         for (int i = 0; i < 8; ++i) g_potrf_debug[i] = tph[i];
+    }
 }
 
 // Lt = U^T (only the upper triangle of U is meaningful; the rest of G holds stale data)
@@ -435,15 +473,12 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
         attr_set = true;
     }
     for (int b = 0; b < ch.nblk; ++b) {
-        k_potrf_diag<<<1, PT, lds, ctx->stream>>>(ch.G, ch.U, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
+        // diagonal block + its panel U12 = U11^-T G12 (workgroups 1..)
+        k_potrf_diag<<<ch.nblk - b, PT, lds, ctx->stream>>>(ch.G, ch.U, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
         CP_LAUNCH_CHECK(ctx);
         const int rest = (ch.nblk - b - 1) * NB;
         if (rest > 0) {
-            const double *G12 = ch.G + size_t(b) * NB * ld + size_t(b + 1) * NB;
             double *U12 = ch.U + size_t(b) * NB * ld + size_t(b + 1) * NB;
-            // U12 = U11^-T G12
-            CP_TRY(cp_gemm_tn_f64(ctx, NB, rest, NB, 1.0, ch.TI + size_t(b) * NB * NB, NB, G12, ld, 0.0, U12, ld,
-                                  CP_TRI_NONE));
             // G22 -= U12^T U12 (upper tiles)
             double *G22 = ch.G + size_t(b + 1) * NB * ld + size_t(b + 1) * NB;
             CP_TRY(cp_gemm_tn_f64(ctx, rest, rest, NB, -1.0, U12, ld, U12, ld, 1.0, G22, ld, CP_TRI_UPPER));
@@ -567,7 +602,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     double *gmax = cp_arena_take_t<double>(ctx, 8);
     double *ymean = cp_arena_take_t<double>(ctx, n_pad);
     int *dchan = cp_arena_take_t<int>(ctx, kept);
-    int *dinfo = cp_arena_take_t<int>(ctx, 16);
+    int *dinfo = cp_arena_take_t<int>(ctx, nblk + 16);
     if (!Xs || !Yc || !G || !G0 || !Lt || !Uf || !Yt || !Rm || !R2 || !TI || !TIT || !part_x || !part_y || !xmean || !dg0 ||
         !gmax || !ymean || !dchan || !dinfo)
         return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena");
@@ -614,7 +649,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
         CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
         if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
-        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo);
+        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, nblk + 1);
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;
     };
@@ -647,7 +682,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         if (!Wacc) return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena (fallback)");
         CP_TRY(normal_equations(G0, R2, false));
         CP_HIP(ctx, hipMemcpyAsync(G, G0, g_b, hipMemcpyDeviceToDevice, ctx->stream));
-        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0, dinfo);
+        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0, dinfo, nblk + 1);
         CP_LAUNCH_CHECK(ctx);
         CP_TRY(chol_factor(ctx, ch, 0.0));
         CP_HIP(ctx, hipMemsetAsync(Wacc, 0, r_b, ctx->stream));

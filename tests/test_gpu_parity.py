@@ -403,3 +403,46 @@ def test_inputs_not_modified_and_empty_cases(ctx):
     assert np.array_equal(X64, Xc) and np.array_equal(W2, Wc) and np.array_equal(Y, Yc)
     with pytest.raises(Exception):
         D.dictionary(X64[:0], W2, Y[:0], rank=16, B2=B2)  # empty input: error, as in the reference
+
+
+# ---------------------------------------------------------------------------------------------
+# fused per-layer entry (cp_prune_layer)
+# ---------------------------------------------------------------------------------------------
+def test_prune_layer_reports_unsettled_search(ctx):
+    """With fewer pre-drawn seeds than the alpha search needs, cp_prune_layer reports fits_used = -1
+    (nothing else valid) instead of guessing."""
+    import cp_oracle
+    import cpmi355
+    X, W2, Y, _ = cp_oracle.synth_layer(1, 400, 32, 24, 3)
+    prob = cpmi355.LayerProblem(ctx, X, W2, Y, flags=3)
+    samples = np.random.RandomState(0).randint(0, 400, 20)
+    res, idxs, W, b = ctx.prune_layer(prob.Xd, prob.x_dtype, 400, 32, 9, prob.W2d, prob.w_dtype, 24, prob.Yd, samples,
+                                      1e-3, 16, 16, 17.6, np.array([123], dtype=np.uint32), 0.0, flags=3)
+    assert res.fits_used == -1 and idxs is None and W is None and b is None
+    prob.free()
+
+
+@pytest.mark.parametrize("name", golden_cases("s")[:4])
+def test_dictionary_replays_on_host_when_device_search_runs_out_of_seeds(ctx, name, monkeypatch):
+    """pruner.MAX_FITS seeds not enough -> RNG rewound, search replayed fit by fit: same mask, same per-fit
+    log, same RNG consumption as the reference."""
+    import cpmi355.pruner as pruner
+    monkeypatch.setattr(pruner, "MAX_FITS", 2)
+    g, p, X, W2, Y, B2 = load_case(name)
+    if len(g["fits"]) <= 2:
+        pytest.skip("search settles within two fits")
+    _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "device"))
+
+
+def test_prune_layer_rank_equal_c_skips_lasso(ctx):
+    """rank == c: every channel kept, no LASSO fit, no RNG draw beyond the sample subset (decompose.py:487-488)."""
+    import cp_oracle
+    import cpmi355
+    X, W2, Y, _ = cp_oracle.synth_layer(2, 300, 16, 12, 3)
+    prob = cpmi355.LayerProblem(ctx, X, W2, Y, flags=3)
+    res, idxs, W, b = ctx.prune_layer(prob.Xd, prob.x_dtype, 300, 16, 9, prob.W2d, prob.w_dtype, 12, prob.Yd,
+                                      np.arange(15), 1e-3, 16, 16, 17.6, np.zeros(0, dtype=np.uint32), 0.0, flags=3)
+    assert res.fits_used == 0 and idxs.all() and res.p == 16 * 9
+    Wref, bref, _ = cp_oracle.lstsq_min_norm(X.reshape(300, -1).astype(np.float64), Y)
+    assert relfro(W, Wref) <= 1e-9 and relfro(b, bref) <= 1e-9
+    prob.free()
