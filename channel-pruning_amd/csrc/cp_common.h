@@ -41,6 +41,7 @@ struct cp_ctx {
     const char *gemm_mark = nullptr;  // if set, cp_gemm_tn_f64 marks this stage right after its main kernel
     int gemm_tag = 0;                 // selects a distinctly named instantiation of the GEMM kernel
     int cu_count = 256;
+    bool potrf_lds_opt_in = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
 
 int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);

@@ -466,11 +466,10 @@ struct Chol {
 int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     const int ld = ch.p_pad;
     const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KB of dynamic LDS needs an explicit opt-in
+    if (!ctx->potrf_lds_opt_in) {  // > 64 KB of dynamic LDS needs an explicit opt-in (per device; idempotent)
         CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_diag),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_set = true;
+        ctx->potrf_lds_opt_in = true;
     }
     for (int b = 0; b < ch.nblk; ++b) {
         // diagonal block + its panel U12 = U11^-T G12 (workgroups 1..)
