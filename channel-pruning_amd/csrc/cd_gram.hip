@@ -372,6 +372,67 @@ fit_done:
     return out;
 }
 
+// ---- LDS hand-off primitives shared by the two-wave forms (see cd_fit_duo / cd_fit_assist below) ----
+struct DuoCtl {
+    int seqA;   // blocks published by the chain wave
+    int seqB;   // images published by the keeper (image k = H after the first k blocks; count = k + 1)
+    int batB;   // index batches published by the keeper
+    int stop;   // chain -> keeper: the fit is over
+    int err;    // a bounded wait ran out (never in a correct run)
+    int n_iter, nnz, pad;
+    double gap;
+};
+
+// Flags and payloads all live in LDS, and the LDS executes one wave's instructions in program order:
+// a flag written after its payload lands after it, a payload read after the flag read sees what the
+// flag announced.  So the hand-offs need no s_waitcnt of their own (an acquire / release atomic would
+// also drain the outstanding vector-memory prefetches) -- only the compiler must keep the order.
+// (explicit LDS address space: a volatile access through a generic pointer stays a FLAT instruction
+// with a full vmcnt(0) drain around it)
+typedef __attribute__((address_space(3))) volatile int duo_lds_vint;
+__device__ __forceinline__ int duo_load(int *p) {
+    const int v = *(duo_lds_vint *)p;
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void duo_store(int *p, int v) {
+    asm volatile("" ::: "memory");
+    *(duo_lds_vint *)p = v;
+}
+// wait until *p >= need (returns false if `stop` was raised or the bound ran out)
+__device__ __forceinline__ bool duo_wait(int *p, int need, DuoCtl *ctl, bool watch_stop) {
+    for (int spin = 0;; ++spin) {
+        if (duo_load(p) >= need) return true;
+        if (watch_stop && duo_load(&ctl->stop)) return false;
+        if (spin > (1 << 22)) {
+            duo_store(&ctl->err, 1);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int R>
+struct DuoLds {
+    static constexpr int B = 8, IMG = R * WAVE;
+    double *img;       // [2][IMG]
+    double *pub;       // [4][2 * B]
+    uint32_t *ii;      // [3][64]
+    uint64_t *dup;     // [4] lanes whose coordinate repeats inside their block
+    uint64_t *xdup;    // [4] lanes whose coordinate also occurs in the block before theirs
+    DuoCtl *ctl;
+    static __host__ __device__ constexpr int doubles() { return 2 * IMG + 4 * 2 * B + 3 * 32 + 8 + int(sizeof(DuoCtl) / 8) + 2; }
+    __device__ void bind(double *base) {
+        img = base;
+        pub = img + 2 * IMG;
+        ii = reinterpret_cast<uint32_t *>(pub + 4 * 2 * B);
+        dup = reinterpret_cast<uint64_t *>(ii + 3 * 64);
+        xdup = dup + 4;
+        ctl = reinterpret_cast<DuoCtl *>(xdup + 4);
+    }
+};
+
+
 // ---------------------------------------------------------------------------------------------
 // Blocked variant (c % B == 0, R <= 8).  A single wave issues one instruction every ~5-6.5 cycles
 // regardless of dependencies, so a step costs what its instruction count costs.  Here the
@@ -394,11 +455,14 @@ struct BSet {
     double qc[B];      // Q[ii_a, ii_lane]
 };
 
-template <int R, bool RECIP, bool DELTA>
+// ASSIST: a second wave of the workgroup (cd_assist_wave) runs the index stream and the duplicate scan and hands
+// every 64-value batch over through the LDS ring of `L`; this wave then spends ~30 instead of ~190 instructions
+// per batch on it.
+template <int R, bool RECIP, bool DELTA, bool ASSIST = false>
 __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, int ldq, int c, double alpha,
                                                  double beta, uint32_t seed, int max_iter, double tol_scaled,
                                                  double d_w_tol, double y_norm2, double *w_lds, const double *feat,
-                                                 double *h_lds) {
+                                                 double *h_lds, DuoLds<R> *L = nullptr) {
     constexpr int B = Blk<R>::B, NBLK = 64 / B;
     const int lane = threadIdx.x;
     const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
@@ -446,7 +510,17 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
     }
 
     IdxStream rng;
-    rng.init(seed, uint32_t(c), row_stride_bytes, lane);
+    int kb = 0;  // ASSIST: index of the batch `rng.idx / rng.off` describe
+    auto take_batch = [&]() {  // ASSIST: batch kb from the ring
+        duo_wait(&L->ctl->batB, kb + 1, L->ctl, false);
+        rng.idx = L->ii[(kb % 3) * 64 + lane];
+        rng.off = rng.idx * row_stride_bytes;
+        duo_store(&L->ctl->seqA, kb + 1);  // slot kb % 3 may be reused
+    };
+    if (ASSIST)
+        take_batch();
+    else
+        rng.init(seed, uint32_t(c), row_stride_bytes, lane);
 
     // Coupling loads of step a are made out of range (-> 0.0) for the lanes at or before position a of
     // their block: a lane's private H[ii] then stops changing once its own step is over, so the value
@@ -470,13 +544,17 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
         q_v = qQ.x;
         Qd_v = qQ.y;
         den_v = feat[4 * ii_v + 2];
-        bool dup = false;
+        if (ASSIST) {
+            dupmask = L->dup[kb & 3];
+        } else {
+            bool dup = false;
 #pragma unroll
-        for (int sft = 1; sft < B; ++sft) {
-            const int other = __shfl(int(ii_v), (lane & ~(B - 1)) | ((lane + sft) & (B - 1)), WAVE);
-            dup |= (uint32_t(other) == ii_v);
+            for (int sft = 1; sft < B; ++sft) {
+                const int other = __shfl(int(ii_v), (lane & ~(B - 1)) | ((lane + sft) & (B - 1)), WAVE);
+                dup |= (uint32_t(other) == ii_v);
+            }
+            dupmask = __ballot(dup);
         }
-        dupmask = __ballot(dup);
     };
 
     BSet<R, B> SA, SB;
@@ -631,7 +709,12 @@ __device__ __forceinline__ FitOut cd_fit_blocked(const double *__restrict__ Q, i
                 fill(SA, rng.off, vm_cur, (g + 2) * B);
                 compute(SB, (g + 1) * B);
             } else {  // last block of the batch: request block 0 of the next batch first
-                rng.next_batch();  // only rng.idx / rng.off change; ii_v etc. still describe this batch
+                if (ASSIST) {  // only rng.idx / rng.off change; ii_v etc. still describe this batch
+                    ++kb;
+                    take_batch();
+                } else {
+                    rng.next_batch();
+                }
                 mask_offsets(rng.idx * 8u, vm_nxt);
                 fill(SA, rng.off, vm_nxt, 0);
                 compute(SB, (g + 1) * B);
@@ -675,65 +758,6 @@ __device__ unsigned long long g_cd_debug[8];
 // the image after block t-1 plus the 8 updates of block t through the couplings Q[ii_a(t), ii_l(t+1)]
 // (same fma sequence as the keeper applies to that element, so w stays bit-identical).  Hand-offs are
 // sequence counters in LDS (acquire/release at workgroup scope), polled with a bound.
-struct DuoCtl {
-    int seqA;   // blocks published by the chain wave
-    int seqB;   // images published by the keeper (image k = H after the first k blocks; count = k + 1)
-    int batB;   // index batches published by the keeper
-    int stop;   // chain -> keeper: the fit is over
-    int err;    // a bounded wait ran out (never in a correct run)
-    int n_iter, nnz, pad;
-    double gap;
-};
-
-// Flags and payloads all live in LDS, and the LDS executes one wave's instructions in program order:
-// a flag written after its payload lands after it, a payload read after the flag read sees what the
-// flag announced.  So the hand-offs need no s_waitcnt of their own (an acquire / release atomic would
-// also drain the outstanding vector-memory prefetches) -- only the compiler must keep the order.
-// (explicit LDS address space: a volatile access through a generic pointer stays a FLAT instruction
-// with a full vmcnt(0) drain around it)
-typedef __attribute__((address_space(3))) volatile int duo_lds_vint;
-__device__ __forceinline__ int duo_load(int *p) {
-    const int v = *(duo_lds_vint *)p;
-    asm volatile("" ::: "memory");
-    return v;
-}
-__device__ __forceinline__ void duo_store(int *p, int v) {
-    asm volatile("" ::: "memory");
-    *(duo_lds_vint *)p = v;
-}
-// wait until *p >= need (returns false if `stop` was raised or the bound ran out)
-__device__ __forceinline__ bool duo_wait(int *p, int need, DuoCtl *ctl, bool watch_stop) {
-    for (int spin = 0;; ++spin) {
-        if (duo_load(p) >= need) return true;
-        if (watch_stop && duo_load(&ctl->stop)) return false;
-        if (spin > (1 << 22)) {
-            duo_store(&ctl->err, 1);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-template <int R>
-struct DuoLds {
-    static constexpr int B = 8, IMG = R * WAVE;
-    double *img;       // [2][IMG]
-    double *pub;       // [4][2 * B]
-    uint32_t *ii;      // [3][64]
-    uint64_t *dup;     // [4] lanes whose coordinate repeats inside their block
-    uint64_t *xdup;    // [4] lanes whose coordinate also occurs in the block before theirs
-    DuoCtl *ctl;
-    static __host__ __device__ constexpr int doubles() { return 2 * IMG + 4 * 2 * B + 3 * 32 + 8 + int(sizeof(DuoCtl) / 8) + 2; }
-    __device__ void bind(double *base) {
-        img = base;
-        pub = img + 2 * IMG;
-        ii = reinterpret_cast<uint32_t *>(pub + 4 * 2 * B);
-        dup = reinterpret_cast<uint64_t *>(ii + 3 * 64);
-        xdup = dup + 4;
-        ctl = reinterpret_cast<DuoCtl *>(xdup + 4);
-    }
-};
-
 template <int R, bool RECIP, bool DELTA>
 __device__ __forceinline__ void duo_keeper(const double *__restrict__ Q, int ldq, int c, uint32_t seed, const double *w_lds,
                                            DuoLds<R> &L) {
@@ -1170,6 +1194,67 @@ __device__ __forceinline__ void duo_chain(const double *__restrict__ Q, int ldq,
     }
 }
 
+// ---- one-wave kernel + assist wave (c <= 256, c % 8 == 0) -----------------------------------------
+// The second wave only runs the index stream: xorshift jump-ahead, rand_int, in-block duplicate scan,
+// published per 64-value batch through the ring (three batches ahead at most, paced by seqA = batches taken).
+template <int R>
+__device__ __forceinline__ void cd_assist_wave(int ldq, int c, uint32_t seed, DuoLds<R> &L) {
+    constexpr int B = 8;
+    const int lane = threadIdx.x & 63;
+    IdxStream rng;
+    rng.init(seed, uint32_t(c), uint32_t(ldq) * 8u, lane);
+    for (int k = 0;; ++k) {
+        if (k >= 3 && !duo_wait(&L.ctl->seqA, k - 2, L.ctl, true)) return;  // slot k % 3 free once batch k-3 is taken
+        if (k > 0) rng.next_batch();
+        L.ii[(k % 3) * 64 + lane] = rng.idx;
+        bool dup = false;
+#pragma unroll
+        for (int sft = 1; sft < B; ++sft) {
+            const int other = __shfl(int(rng.idx), (lane & ~(B - 1)) | ((lane + sft) & (B - 1)), WAVE);
+            dup |= (uint32_t(other) == rng.idx);
+        }
+        const uint64_t m = __ballot(dup);
+        if (lane == 0) L.dup[k & 3] = m;
+        duo_store(&L.ctl->batB, k + 1);
+        if (duo_load(&L.ctl->stop)) return;
+    }
+}
+
+template <int R, bool RECIP, bool DELTA>
+__device__ __forceinline__ FitOut cd_fit_assist(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
+                                                uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
+                                                double y_norm2, double *w_lds, const double *feat, double *duo_base) {
+    DuoLds<R> L;
+    L.bind(duo_base);
+    if (threadIdx.x == 0) {
+        L.ctl->seqA = 0;
+        L.ctl->seqB = 0;
+        L.ctl->batB = 0;
+        L.ctl->stop = 0;
+        L.ctl->err = 0;
+    }
+    __syncthreads();
+    if ((threadIdx.x >> 6) == 1) {
+        cd_assist_wave<R>(ldq, c, seed, L);
+    } else {
+        const FitOut o = cd_fit_blocked<R, RECIP, DELTA, true>(Q, ldq, c, alpha, beta, seed, max_iter, tol_scaled, d_w_tol,
+                                                               y_norm2, w_lds, feat, L.img /* H image */, &L);
+        duo_store(&L.ctl->stop, 1);
+        if ((threadIdx.x & 63) == 0) {
+            L.ctl->gap = o.gap;
+            L.ctl->n_iter = o.n_iter;
+            L.ctl->nnz = o.nnz;
+        }
+    }
+    __syncthreads();
+    FitOut out;
+    out.gap = L.ctl->gap;
+    out.n_iter = L.ctl->n_iter;
+    out.nnz = L.ctl->nnz;
+    __syncthreads();
+    return out;
+}
+
 // both waves of the workgroup call this; returns the same FitOut in all threads
 template <int R, bool RECIP, bool DELTA>
 __device__ __forceinline__ FitOut cd_fit_duo(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
@@ -1339,12 +1424,21 @@ k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
 template <int R, typename... A>
 __device__ __forceinline__ FitOut cd_fit_duo_any(int flags, A... args) {
     const bool recip = flags & CP_CD_RECIPROCAL, delta = flags & CP_CD_DELTA;
-    if (recip) {
-        if (delta) return cd_fit_duo<R, true, true>(args...);
-        return cd_fit_duo<R, true, false>(args...);
+    if constexpr (R <= 4) {  // c <= 256: one-wave kernel, the second wave only prepares the index batches
+        if (recip) {
+            if (delta) return cd_fit_assist<R, true, true>(args...);
+            return cd_fit_assist<R, true, false>(args...);
+        }
+        if (delta) return cd_fit_assist<R, false, true>(args...);
+        return cd_fit_assist<R, false, false>(args...);
+    } else {         // 256 < c <= 512: chain wave + keeper wave
+        if (recip) {
+            if (delta) return cd_fit_duo<R, true, true>(args...);
+            return cd_fit_duo<R, true, false>(args...);
+        }
+        if (delta) return cd_fit_duo<R, false, true>(args...);
+        return cd_fit_duo<R, false, false>(args...);
     }
-    if (delta) return cd_fit_duo<R, false, true>(args...);
-    return cd_fit_duo<R, false, false>(args...);
 }
 
 __device__ __forceinline__ void load_features_wg(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
@@ -1461,10 +1555,10 @@ static int pick_R(int c) {
     return R;
 }
 
-// two-wave kernels: c % 8 == 0 and 256 < c <= 512 (CP_CD_DUO=0 keeps the one-wave kernels)
+// 128-thread kernels: c % 8 == 0 and c <= 512 (CP_CD_DUO=0 keeps the 64-thread kernels)
 static bool use_duo(int c) {
     static const bool on = !(getenv("CP_CD_DUO") && atoi(getenv("CP_CD_DUO")) == 0);
-    return on && c % 8 == 0 && c > 4 * WAVE && c <= 8 * WAVE;  // measured: 254 vs 327 cycles/step at c = 512, no gain below
+    return on && c % 8 == 0 && c <= 8 * WAVE;  // c <= 256: one-wave kernel + assist wave; above: chain + keeper waves
 }
 static size_t duo_lds_bytes(int c) {
     const int R = pick_R(c);
