@@ -52,6 +52,9 @@ CASES = {
     "L02_conv3_1_conv3_2": dict(layer_id=32, N=5000, c=256, n=256, k=3, rank=128, large=True),
     "L03_conv3_2_conv3_3": dict(layer_id=33, N=5000, c=256, n=256, k=3, rank=128, large=True),
     "L04_conv3_1_dc222": dict(layer_id=34, N=5000, c=256, n=256, k=3, rank=222, large=True),
+    # conv4-sized layer (BASELINE.json configs[2]): c = 512 exercises the two-wave CD kernels and the
+    # split plans of the larger GEMMs end to end; N reduced so that the reference run stays in minutes
+    "L05_conv4_1_conv4_2": dict(layer_id=35, N=2400, c=512, n=512, k=3, rank=256, large=True),
 }
 
 
