@@ -55,6 +55,9 @@ CASES = {
     # conv4-sized layer (BASELINE.json configs[2]): c = 512 exercises the two-wave CD kernels and the
     # split plans of the larger GEMMs end to end; N reduced so that the reference run stays in minutes
     "L05_conv4_1_conv4_2": dict(layer_id=35, N=2400, c=512, n=512, k=3, rank=256, large=True),
+    # ResNet-50 bottleneck 1x1 with the residual-aware target (configs[3]) and the 20000-sample refit of configs[4]
+    "L06_res3_1x1_resid": dict(layer_id=36, N=5000, c=512, n=128, k=1, rank=256, residual=True, large=True),
+    "L07_conv3_N20000": dict(layer_id=37, N=20000, c=256, n=256, k=3, rank=102, large=True),
 }
 
 
