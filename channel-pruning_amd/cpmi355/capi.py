@@ -289,7 +289,8 @@ class Context:
         return v.value
 
     def enable_stage_timing(self, on=True):
-        self._check(self.lib.cp_enable_stage_timing(self.h, int(bool(on))), "cp_enable_stage_timing")
+        """False/0 off, True/1 every stage, 2 only the stage of the roofline kernel ("refit_gram_gemm")."""
+        self._check(self.lib.cp_enable_stage_timing(self.h, int(on)), "cp_enable_stage_timing")
 
     def last_stage_times(self):
         cnt = _c_int()

@@ -32,6 +32,7 @@ struct cp_ctx {
     char err[512] = {0};
     // stage timing: a list of (name, event); name == nullptr marks the start of a call
     bool timing = false;
+    bool timing_gram_only = false;  // cp_enable_stage_timing(ctx, 2)
     int n_marks = 0;
     hipEvent_t ev[2 * CP_MAX_STAGES] = {};
     const char *mark_names[2 * CP_MAX_STAGES] = {};

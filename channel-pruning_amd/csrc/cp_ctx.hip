@@ -190,7 +190,7 @@ int cp_pinned_reserve(cp_ctx *ctx, size_t bytes) {
 
 // ---- stage timing ----------------------------------------------------------------------
 void cp_stage_begin(cp_ctx *ctx) {
-    if (!ctx->timing || ctx->n_marks >= 2 * CP_MAX_STAGES) return;
+    if (!ctx->timing || ctx->timing_gram_only || ctx->n_marks >= 2 * CP_MAX_STAGES) return;
     ctx->mark_names[ctx->n_marks] = nullptr;
     hipEventRecord(ctx->ev[ctx->n_marks], ctx->stream);
     ++ctx->n_marks;
@@ -198,6 +198,8 @@ void cp_stage_begin(cp_ctx *ctx) {
 
 void cp_stage_mark(cp_ctx *ctx, const char *name) {
     if (!ctx->timing || ctx->n_marks >= 2 * CP_MAX_STAGES) return;
+    // mode 2: only the two events that bracket the roofline kernel (every event is a packet in the stream)
+    if (ctx->timing_gram_only && strcmp(name, "refit_gather_center") != 0 && strcmp(name, "refit_gram_gemm") != 0) return;
     ctx->mark_names[ctx->n_marks] = name;
     hipEventRecord(ctx->ev[ctx->n_marks], ctx->stream);
     ++ctx->n_marks;
@@ -208,6 +210,7 @@ void cp_stage_finish(cp_ctx *) {}
 extern "C" int cp_enable_stage_timing(cp_ctx *ctx, int on) {
     if (!ctx) return CP_ERR_ARG;
     ctx->timing = on != 0;
+    ctx->timing_gram_only = on == 2;
     ctx->n_marks = 0;
     ctx->n_stages = 0;
     return CP_OK;

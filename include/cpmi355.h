@@ -183,7 +183,8 @@ int cp_probe_hbm_copy(cp_ctx *ctx, size_t bytes, double *gbps);
 #define CP_MAX_STAGES 32
 int cp_last_stage_times(cp_ctx *ctx, int *count, float *ms /* [CP_MAX_STAGES] */);
 const char *cp_stage_name(cp_ctx *ctx, int index);
-int cp_enable_stage_timing(cp_ctx *ctx, int on);
+int cp_enable_stage_timing(cp_ctx *ctx, int on); /* 0 off, 1 every stage, 2 only "refit_gram_gemm" (two events per
+                                                   * call: each event is one more packet in the stream) */
 
 #ifdef __cplusplus
 }
