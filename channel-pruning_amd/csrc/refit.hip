@@ -195,7 +195,7 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // the waiters) and computes U[blk, blk + j] = U_bb^-T G[blk, blk + j] on MFMA (wave w: 16 rows x 128
 // columns).  One launch per block step instead of two: with many layers in flight every launch in
 // the chain costs tens of microseconds of dispatch latency.
-__global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout, int ld, int blk,
+__global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout, double *Lt, int ld, int blk,
                                                    const double *__restrict__ dg0, double piv_tol, double *TI,
                                                    double *TIT, int *info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -224,10 +224,15 @@ __global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout
             for (int t = 0; t < NB / 16; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Gbj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
         }
+        // U[blk, j] and its transpose Lt[j, blk] (what the backward substitution reads; no separate transpose pass)
+        double *Ltj = Lt + size_t(j) * NB * ld + size_t(blk) * NB + wave * 16;
 #pragma unroll
         for (int t = 0; t < NB / 16; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
+            for (int r = 0; r < 4; ++r) {
+                Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
+                Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
+            }
         return;
     }
     double *A = sm;                        // NB x DLD
@@ -399,21 +404,6 @@ __global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout
     }
 }
 
-// Lt = U^T (only the upper triangle of U is meaningful; the rest of G holds stale data)
-__global__ void __launch_bounds__(RT) k_transpose_upper(const double *__restrict__ U, int ld, int p_pad,
-                                                        double *__restrict__ Lt) {
-    __shared__ double t[32][33];
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // source tile rows by.., cols bx..
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int y = ty; y < 32; y += 8) {
-        const int r = by + y, cc = bx + tx;
-        t[y][tx] = (cc >= r) ? U[size_t(r) * ld + cc] : 0.0;
-    }
-    __syncthreads();
-    for (int y = ty; y < 32; y += 8) Lt[size_t(bx + y) * ld + by + tx] = t[tx][y];
-    (void)p_pad;
-}
-
 __global__ void __launch_bounds__(RT) k_axpy(double *__restrict__ y, const double *__restrict__ x, size_t count) {
     size_t i = blockIdx.x * size_t(RT) + threadIdx.x;
     const size_t step = size_t(gridDim.x) * RT;
@@ -462,7 +452,7 @@ struct Chol {
     int p, p_pad, nblk;
 };
 
-// G = U^T U in place (upper), plus TI/TIT per diagonal block and Lt = U^T.
+// G = U^T U (upper, into ch.U), TI/TIT per diagonal block, and the off-diagonal blocks of Lt = U^T.
 int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     const int ld = ch.p_pad;
     const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
@@ -473,7 +463,8 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     }
     for (int b = 0; b < ch.nblk; ++b) {
         // diagonal block + its panel U12 = U11^-T G12 (workgroups 1..)
-        k_potrf_diag<<<ch.nblk - b, PT, lds, ctx->stream>>>(ch.G, ch.U, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
+        k_potrf_diag<<<ch.nblk - b, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT,
+                                                            ch.info);
         CP_LAUNCH_CHECK(ctx);
         const int rest = (ch.nblk - b - 1) * NB;
         if (rest > 0) {
@@ -483,9 +474,6 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
             CP_TRY(cp_gemm_tn_f64(ctx, rest, rest, NB, -1.0, U12, ld, U12, ld, 1.0, G22, ld, CP_TRI_UPPER));
         }
     }
-    dim3 tg(ch.p_pad / 32, ch.p_pad / 32);
-    k_transpose_upper<<<tg, RT, 0, ctx->stream>>>(ch.U, ld, ch.p_pad, ch.Lt);
-    CP_LAUNCH_CHECK(ctx);
     return CP_OK;
 }
 
@@ -497,9 +485,18 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
 //   S   = R_b - sum_{k<b} U[k,b]^T Y_k      wave m accumulates its 16 x 16 row tile on MFMA (K = 128 b)
 //   Y_b = U_bb^-T S                          through LDS, with the inverted diagonal block TI_b
 // and the mirror image with Lt = U^T / TIT_b for the backward sweep.  8 waves = 8 row tiles.
+struct StripFinal {  // optional tail of k_solve_strips: what k_finalize does, for the strip's 16 columns
+    int p, n;                      // p == 0: no tail
+    const double *xmean, *ymean;
+    double *coef, *b;              // device outputs: coef[n, p], b[n]
+    double *coef_host, *b_host;    // pinned host copies (may be null)
+    const int *info;
+    int *info_host;
+};
+
 __global__ void __launch_bounds__(512) k_solve_strips(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
                                                       const double *__restrict__ TI, const double *__restrict__ TIT,
-                                                      int nblk, double *R, int n_pad) {
+                                                      int nblk, double *R, int n_pad, StripFinal fin) {
     __shared__ double S[NB][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fk = lane >> 4, fi = lane & 15;
@@ -537,10 +534,47 @@ __global__ void __launch_bounds__(512) k_solve_strips(const double *__restrict__
             __syncthreads();  // block b of the strip is complete (and visible) before any wave reads it
         }
     }
+    if (fin.p > 0) {  // coef[j, col] = W[col, j],  b[j] = ymean[j] - sum_col xmean[col] W[col, j]  for this strip's j
+        if (blockIdx.x == 0 && threadIdx.x == 0 && fin.info_host) fin.info_host[0] = fin.info[0];
+        double acc16[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) acc16[jj] = 0.0;
+        for (int col = threadIdx.x; col < fin.p; col += 512) {
+            const double xm = fin.xmean[col];
+            const double *wr = R + size_t(col) * n_pad + col0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = col0 + jj;
+                if (j < fin.n) {
+                    const double v = wr[jj];
+                    fin.coef[size_t(j) * fin.p + col] = v;
+                    if (fin.coef_host) fin.coef_host[size_t(j) * fin.p + col] = v;
+                    acc16[jj] = fma(xm, v, acc16[jj]);
+                }
+            }
+        }
+        double *red = &S[0][0];  // 8 waves x 16 partial sums
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            double v = acc16[jj];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) red[wave * 16 + jj] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 && col0 + int(threadIdx.x) < fin.n) {
+            double tot = 0;
+            for (int w8 = 0; w8 < 8; ++w8) tot += red[w8 * 16 + threadIdx.x];
+            const int j = col0 + threadIdx.x;
+            const double bj = fin.ymean[j] - tot;
+            fin.b[j] = bj;
+            if (fin.b_host) fin.b_host[j] = bj;
+        }
+    }
 }
 
-int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad) {
-    k_solve_strips<<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad);
+int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad, const StripFinal &fin = StripFinal{}) {
+    k_solve_strips<<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad, fin);
     CP_LAUNCH_CHECK(ctx);
     return CP_OK;
 }
@@ -669,9 +703,11 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         CP_TRY(normal_equations(G, Rm, true));
         CP_TRY(chol_factor(ctx, ch, 1e-10));
         cp_stage_mark(ctx, "refit_cholesky");
-        CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad));
+        StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
+        CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin));  // substitutions + coefficient lay-out + intercept in one launch
         cp_stage_mark(ctx, "refit_solve");
-        CP_TRY(finalize());  // the outputs are overwritten below if a pivot failed
+        CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
+        hinfo = *info_host;                // outputs are overwritten below if a pivot failed
         if (hinfo != 0) fallback = true;
     }
     int rank = p;
