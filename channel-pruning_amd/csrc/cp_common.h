@@ -93,6 +93,9 @@ enum { CP_GEMM_GENERIC = 0, CP_GEMM_LASSO_GRAM = 1, CP_GEMM_REFIT_GRAM = 2, CP_G
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda,
                    const double *B, int ldb, double beta, double *C, int ldc, int tri);
 size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri);
+// two products of the same shape (different operands / K), one launch when neither needs split-K
+int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const double *A1, const double *B1, double *C1,
+                        int K2, const double *A2, const double *B2, double *C2, int lda, int ldb, int ldc, int tri);
 
 // cp_lstsq_refit with optional host-visible outputs: b (n doubles) then W (n x p) at ctx->pinned + 64
 int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,

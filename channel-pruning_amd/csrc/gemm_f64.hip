@@ -47,11 +47,26 @@ __device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int 
 // WT = per-wave output tile (64 -> 128x128 workgroup tile, 32 -> 64x64).  The small tile is
 // used for the skinny K = 128 products of the blocked Cholesky / substitutions, where the
 // large one would leave most CUs idle and make every call as long as one 128^3 tile.
+// A second product of the same shape (other operands, other K, no split) can ride in the same launch
+// as blockIdx.y == 1: one launch instead of two for the two LASSO Grams.
+struct GemmSecond {
+    const double *A, *B;
+    double *C;
+    int K;
+};
+
 template <int TRI, int TAG, int WT, int NTH>
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
 k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
               const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
-              double *__restrict__ P, int splits, int kchunk, int n_tiles, int tiles_n) {
+              double *__restrict__ P, int splits, int kchunk, int n_tiles, int tiles_n, GemmSecond second) {
+    if (blockIdx.y == 1) {
+        A = second.A;
+        B = second.B;
+        C = second.C;
+        K = second.K;
+        kchunk = second.K;
+    }
     // NTH = 256: 2 x 2 waves of WT x WT each; NTH = 512: 4 x 2 waves of (WT/2) x WT each (same
     // workgroup tile, half the accumulators per wave -> 4 waves per SIMD, which is what it takes to
     // keep the f64 MFMA pipe busy: one wave alone issues one v_mfma_f64_16x16x4 per ~140 cycles)
@@ -272,8 +287,29 @@ size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri) {
     return p.splits > 1 ? size_t(p.splits) * M * N * sizeof(double) + 256 : 0;
 }
 
+static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
+                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second);
+
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
                    int ldb, double beta, double *C, int ldc, int tri) {
+    return gemm_launch(ctx, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, nullptr);
+}
+
+// C1 = alpha A1^T B1 (K1) and C2 = alpha A2^T B2 (K2), same M, N, leading dimensions and tri, in one launch when
+// neither product needs split-K (else two launches)
+int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const double *A1, const double *B1, double *C1,
+                        int K2, const double *A2, const double *B2, double *C2, int lda, int ldb, int ldc, int tri) {
+    const GemmPlan p1 = make_plan(ctx, M, N, K1, tri), p2 = make_plan(ctx, M, N, K2, tri);
+    if (p1.splits == 1 && p2.splits == 1 && p1.small == p2.small && K2 % BK == 0 && C1 != A1 && C1 != B1) {
+        const GemmSecond sec{A2, B2, C2, K2};
+        return gemm_launch(ctx, M, N, K1, alpha, A1, lda, B1, ldb, 0.0, C1, ldc, tri, &sec);
+    }
+    CP_TRY(gemm_launch(ctx, M, N, K1, alpha, A1, lda, B1, ldb, 0.0, C1, ldc, tri, nullptr));
+    return gemm_launch(ctx, M, N, K2, alpha, A2, lda, B2, ldb, 0.0, C2, ldc, tri, nullptr);
+}
+
+static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
+                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second) {
     if (M <= 0 || N <= 0) return CP_OK;
     if (M % BM || N % BN || K % BK || (lda & 1) || (ldb & 1) || (tri != CP_TRI_NONE && M != N))
         return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn: unaligned shape M=%d N=%d K=%d lda=%d ldb=%d", M, N, K, lda,
@@ -288,15 +324,16 @@ int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double 
         P = cp_arena_take_t<double>(ctx, size_t(p.splits) * M * N);
         if (!P) return cp_set_error(ctx, CP_ERR_NOMEM, "gemm_tn: arena exhausted (split-K partials)");
     }
-    const int grid = p.n_tiles * p.splits;
+    const dim3 grid(p.n_tiles * p.splits, second ? 2 : 1);
+    const GemmSecond sec = second ? *second : GemmSecond{nullptr, nullptr, nullptr, 0};
 #define CP_GEMM_LAUNCH(T, G)                                                                                  \
     do {                                                                                                      \
         if (p.small)                                                                                          \
             k_gemm_tn_f64<T, G, 32, 256><<<grid, 256, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
-                                                                          P, p.splits, p.kchunk, p.n_tiles, p.tiles_n); \
+                                                                          P, p.splits, p.kchunk, p.n_tiles, p.tiles_n, sec); \
         else                                                                                                  \
             k_gemm_tn_f64<T, G, 64, 512><<<grid, 512, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
-                                                                          P, p.splits, p.kchunk, p.n_tiles, p.tiles_n); \
+                                                                          P, p.splits, p.kchunk, p.n_tiles, p.tiles_n, sec); \
     } while (0)
     const int tag = ctx->gemm_tag;
     ctx->gemm_tag = CP_GEMM_GENERIC;

@@ -12,6 +12,8 @@
 //   Q = Z^T Z - M zbar zbar^T,   q = Z^T y - M zbar ybar
 // i.e. (S + n) P^2 / 2 MFMA flops instead of S n c^2 (1.6x fewer at k = 3, S n / (S + n) ~ 126x fewer
 // at k = 1) and 2 x 21 MB of Gram tiles instead of the 131 MB of Z written and read back.
+// Launches: k_lasso_prep (sampled rows of X, W2 and Y^T widened to f64 + target statistics), one paired
+// MFMA launch for GX and GW, one for T, k_q_finish, k_hadamard_q.
 // All float64, deterministic reductions (fixed order, no atomics).
 #include "cp_common.h"
 
@@ -38,71 +40,92 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
     return s;
 }
 
-// stats = { yc^T yc, mean(y), M, 0 }.  One 1024-thread workgroup, two passes (mean, then centred
-// sum of squares); thread -> (sample s = tid / 32 + 32 it, columns j = tid % 32 + 32 jt): no
-// integer division in the loops, 32 consecutive doubles per sample row and wave.
-__global__ void __launch_bounds__(1024) k_y_stats(const double *__restrict__ Y, const int64_t *__restrict__ samples,
-                                                  int S, int n, double *__restrict__ stats) {
-    __shared__ double red[16];
-    const int js = threadIdx.x & 31, ss = threadIdx.x >> 5;
-    double s = 0;
-    for (int si = ss; si < S; si += 32) {
-        const double *row = Y + samples[si] * n;
-        for (int j = js; j < n; j += 32) s += row[j];
+// All operand preparation in ONE launch (block ranges): S_pad blocks gather + widen the sampled rows of X,
+// n_pad blocks widen W2, the next (S_pad/32)(n_pad/32) blocks build Yst = Y[samples]^T, and the last YB blocks
+// accumulate the target statistics around a shift (the first sampled target): ypart[k] = {sum(y - shift),
+// sum((y - shift)^2)} over the samples s = k mod YB, combined in fixed order by k_q_finish --
+//   mean = shift + S1 / M,   yc^T yc = S2 - S1^2 / M
+// (a one-pass centred sum of squares; the shift keeps the cancellation harmless).
+constexpr int YB = 32;
+template <typename TX, typename TW>
+__global__ void __launch_bounds__(ZT) k_lasso_prep(const TX *__restrict__ X, const TW *__restrict__ W2,
+                                                   const double *__restrict__ Y, const int64_t *__restrict__ samples,
+                                                   int S, int n, int P, int S_pad, int n_pad, int P_pad,
+                                                   double *__restrict__ Xs, double *__restrict__ Wf,
+                                                   double *__restrict__ Yst, double *__restrict__ ypart) {
+    __shared__ double t[32][33];
+    int b = blockIdx.x;
+    if (b < S_pad) {  // Xs[b, :]
+        const bool live = b < S;
+        const size_t base = live ? size_t(samples[b]) * P : 0;
+        for (int col = threadIdx.x; col < P_pad; col += ZT)
+            Xs[size_t(b) * P_pad + col] = (live && col < P) ? ld(X, base + col) : 0.0;
+        return;
     }
-    const double M = double(S) * double(n);
-    const double mean = block_sum(s, red) / M;
-    double v = 0;
-    for (int si = ss; si < S; si += 32) {
-        const double *row = Y + samples[si] * n;
-        for (int j = js; j < n; j += 32) {
-            const double d = row[j] - mean;
-            v += d * d;
+    b -= S_pad;
+    if (b < n_pad) {  // Wf[b, :]
+        const bool live = b < n;
+        for (int col = threadIdx.x; col < P_pad; col += ZT)
+            Wf[size_t(b) * P_pad + col] = (live && col < P) ? ld(W2, size_t(b) * P + col) : 0.0;
+        return;
+    }
+    b -= n_pad;
+    const int tiles_s = S_pad / 32, tiles = tiles_s * (n_pad / 32);
+    if (b < tiles) {  // Yst tile
+        const int s0 = (b % tiles_s) * 32, j0 = (b / tiles_s) * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int y = ty; y < 32; y += 8) {
+            const int s = s0 + y, j = j0 + tx;
+            t[y][tx] = (s < S && j < n) ? Y[samples[s] * n + j] : 0.0;
+        }
+        __syncthreads();
+        for (int y = ty; y < 32; y += 8) Yst[size_t(j0 + y) * S_pad + s0 + tx] = t[tx][y];
+        return;
+    }
+    b -= tiles;  // target statistics, block b of YB
+    const double shift = Y[samples[0] * n];
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = b; s < S; s += YB) {
+        const double *row = Y + samples[s] * n;
+        for (int j = threadIdx.x; j < n; j += ZT) {
+            const double d = row[j] - shift;
+            s1 += d;
+            s2 = fma(d, d, s2);
         }
     }
-    const double yty = block_sum(v, red);
+    double *red = &t[0][0];
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
     if (threadIdx.x == 0) {
-        stats[0] = yty;
-        stats[1] = mean;
-        stats[2] = M;
-        stats[3] = 0.0;
+        ypart[2 * b] = s1;
+        ypart[2 * b + 1] = s2;
     }
-}
-
-// dst[r, col] = r < rows && col < cols ? src[(idx ? idx[r] : r) * cols + col] : 0   (row gather + f64 + zero pad)
-template <typename T>
-__global__ void __launch_bounds__(ZT) k_gather_rows(const T *__restrict__ src, const int64_t *__restrict__ idx,
-                                                    int rows, int cols, int ld_dst, double *__restrict__ dst) {
-    const int r = blockIdx.x;
-    const bool live = r < rows;
-    const size_t base = live ? size_t(idx ? idx[r] : r) * cols : 0;
-    for (int col = threadIdx.x; col < ld_dst; col += ZT)
-        dst[size_t(r) * ld_dst + col] = (live && col < cols) ? ld(src, base + col) : 0.0;
-}
-
-// Yst[j, s] = Y[samples[s], j] (n_pad x S_pad, zero padded): 32 x 32 tiles through LDS
-__global__ void __launch_bounds__(ZT) k_gather_yt(const double *__restrict__ Y, const int64_t *__restrict__ samples,
-                                                  int S, int n, int S_pad, double *__restrict__ Yst) {
-    __shared__ double t[32][33];
-    const int s0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int y = ty; y < 32; y += 8) {
-        const int s = s0 + y, j = j0 + tx;
-        t[y][tx] = (s < S && j < n) ? Y[samples[s] * n + j] : 0.0;
-    }
-    __syncthreads();
-    for (int y = ty; y < 32; y += 8) Yst[size_t(j0 + y) * S_pad + s0 + tx] = t[tx][y];
 }
 
 // One workgroup per channel i: column sums of Xs and Wf over its kk columns, the products with T,
 // then zmean[i] and q[i].  Thread = row (sample s, then filter j), kk consecutive doubles each.
 __global__ void __launch_bounds__(ZT) k_q_finish(const double *__restrict__ Xs, const double *__restrict__ Tm,
                                                  const double *__restrict__ Wf, int S_pad, int n_pad, int ldp, int kk,
-                                                 const double *__restrict__ stats, double *__restrict__ zmean,
+                                                 const double *__restrict__ ypart, const double *__restrict__ Y,
+                                                 const int64_t *__restrict__ samples, int n, double M,
+                                                 double *__restrict__ stats, double *__restrict__ zmean,
                                                  double *__restrict__ q) {
     __shared__ double red[ZT / 64];
     __shared__ double cx[64], cw[64];
     const int i = blockIdx.x;
+    // target statistics from the YB partials (every block recombines them in the same fixed order)
+    double S1 = 0.0, S2 = 0.0;
+    for (int k = 0; k < YB; ++k) {
+        S1 += ypart[2 * k];
+        S2 += ypart[2 * k + 1];
+    }
+    const double ymean = Y[samples[0] * n] + S1 / M;
+    if (i == 0 && threadIdx.x == 0) {
+        stats[0] = S2 - S1 * (S1 / M);
+        stats[1] = ymean;
+        stats[2] = M;
+        stats[3] = 0.0;
+    }
     const size_t c0 = size_t(i) * kk;
     double dot = 0.0;
     for (int t = 0; t < kk; ++t) {
@@ -122,12 +145,11 @@ __global__ void __launch_bounds__(ZT) k_q_finish(const double *__restrict__ Xs, 
     }
     dot = block_sum(dot, red);
     if (threadIdx.x == 0) {
-        const double M = stats[2];
         double acc = 0.0;
         for (int t = 0; t < kk; ++t) acc = fma(cx[t], cw[t], acc);
         const double zm = acc / M;
         zmean[i] = zm;
-        q[i] = dot - M * zm * stats[1];
+        q[i] = dot - M * zm * ymean;
     }
 }
 
@@ -185,34 +207,39 @@ extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N,
     double *Wf = cp_arena_take_t<double>(ctx, size_t(n_pad) * P_pad);
     double *Yst = cp_arena_take_t<double>(ctx, size_t(n_pad) * S_pad);
     double *zmean = cp_arena_take_t<double>(ctx, c);
+    double *ypart = cp_arena_take_t<double>(ctx, 2 * YB);
     int64_t *dsamples = cp_arena_take_t<int64_t>(ctx, S);
-    if (!GX || !GW || !Xs || !Tm || !Wf || !Yst || !zmean || !dsamples)
+    if (!GX || !GW || !Xs || !Tm || !Wf || !Yst || !zmean || !ypart || !dsamples)
         return cp_set_error(ctx, CP_ERR_NOMEM, "lasso_gram: arena");
 
     cp_stage_begin(ctx);
     CP_HIP(ctx, hipMemcpyAsync(dsamples, samples, size_t(S) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (x_dtype == CP_F32)
-        k_gather_rows<float><<<S_pad, ZT, 0, ctx->stream>>>(static_cast<const float *>(X), dsamples, S, P, P_pad, Xs);
-    else
-        k_gather_rows<double><<<S_pad, ZT, 0, ctx->stream>>>(static_cast<const double *>(X), dsamples, S, P, P_pad, Xs);
-    CP_LAUNCH_CHECK(ctx);
-    if (w_dtype == CP_F32)
-        k_gather_rows<float><<<n_pad, ZT, 0, ctx->stream>>>(static_cast<const float *>(W2), nullptr, n, P, P_pad, Wf);
-    else
-        k_gather_rows<double><<<n_pad, ZT, 0, ctx->stream>>>(static_cast<const double *>(W2), nullptr, n, P, P_pad, Wf);
-    CP_LAUNCH_CHECK(ctx);
-    k_gather_yt<<<dim3(S_pad / 32, n_pad / 32), ZT, 0, ctx->stream>>>(Y, dsamples, S, n, S_pad, Yst);
-    CP_LAUNCH_CHECK(ctx);
-    k_y_stats<<<1, 1024, 0, ctx->stream>>>(Y, dsamples, S, n, stats);
-    CP_LAUNCH_CHECK(ctx);
+    {
+        const unsigned nblk = unsigned(S_pad + n_pad + (S_pad / 32) * (n_pad / 32) + YB);
+        const float *Xf = static_cast<const float *>(X), *Wf32 = static_cast<const float *>(W2);
+        const double *Xd = static_cast<const double *>(X), *Wd64 = static_cast<const double *>(W2);
+#define CP_PREP(TXp, TWp) \
+    k_lasso_prep<<<nblk, ZT, 0, ctx->stream>>>(TXp, TWp, Y, dsamples, S, n, P, S_pad, n_pad, P_pad, Xs, Wf, Yst, ypart)
+        if (x_dtype == CP_F32 && w_dtype == CP_F32)
+            CP_PREP(Xf, Wf32);
+        else if (x_dtype == CP_F32)
+            CP_PREP(Xf, Wd64);
+        else if (w_dtype == CP_F32)
+            CP_PREP(Xd, Wf32);
+        else
+            CP_PREP(Xd, Wd64);
+#undef CP_PREP
+        CP_LAUNCH_CHECK(ctx);
+    }
     cp_stage_mark(ctx, "lasso_prep");
     ctx->gemm_tag = CP_GEMM_LASSO_GRAM;
     ctx->gemm_mark = "lasso_gram_gemm";
-    CP_TRY(cp_gemm_tn_f64(ctx, P_pad, P_pad, S_pad, 1.0, Xs, P_pad, Xs, P_pad, 0.0, GX, P_pad, CP_TRI_UPPER));
-    CP_TRY(cp_gemm_tn_f64(ctx, P_pad, P_pad, n_pad, 1.0, Wf, P_pad, Wf, P_pad, 0.0, GW, P_pad, CP_TRI_UPPER));
+    CP_TRY(cp_gemm_tn_f64_pair(ctx, P_pad, P_pad, 1.0, S_pad, Xs, Xs, GX, n_pad, Wf, Wf, GW, P_pad, P_pad, P_pad,
+                               CP_TRI_UPPER));
     CP_TRY(cp_gemm_tn_f64(ctx, S_pad, P_pad, n_pad, 1.0, Yst, S_pad, Wf, P_pad, 0.0, Tm, P_pad, CP_TRI_NONE));
     cp_stage_mark(ctx, "lasso_gram_gemms");
-    k_q_finish<<<c, ZT, 0, ctx->stream>>>(Xs, Tm, Wf, S_pad, n_pad, P_pad, kk, stats, zmean, q);
+    k_q_finish<<<c, ZT, 0, ctx->stream>>>(Xs, Tm, Wf, S_pad, n_pad, P_pad, kk, ypart, Y, dsamples, n,
+                                          double(S) * double(n), stats, zmean, q);
     CP_LAUNCH_CHECK(ctx);
     k_hadamard_q<<<dim3(c, (c + ZT - 1) / ZT), ZT, 0, ctx->stream>>>(GX, GW, P_pad, c, kk, zmean, stats, Q, c);
     CP_LAUNCH_CHECK(ctx);
