@@ -74,6 +74,8 @@ SIGNATURES = {
                                        ctypes.POINTER(_c_dbl), _vp, _vp]),
     "cp_lstsq_refit": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _c_dbl, _vp, _vp,
                                 ctypes.POINTER(RefitInfo)]),
+    "cp_nonlinear_fc": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp, _vp,
+                                 ctypes.POINTER(RefitInfo)]),
     "cp_prune_layer": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
                                 _c_dbl, _c_dbl, _c_dbl, _c_dbl, _vp, _c_int, _c_int, _c_dbl, _c_int, _c_dbl,
                                 _vp, _vp, _vp, ctypes.POINTER(PruneResult)]),
@@ -255,6 +257,17 @@ class Context:
         self._check(self.lib.cp_lstsq_refit(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), mask.ctypes.data,
                                             _ptr(Y), int(n), float(ridge), _ptr(W_out), _ptr(b_out),
                                             ctypes.byref(info)), "cp_lstsq_refit")
+        return info
+
+    def nonlinear_fc(self, X, x_dtype, N, c, kk, mask, Y, n, W_out, b_out, iters=(30, 20), lambdas=(0.1, 1.0)):
+        """ReLU-aware alternating reconstruction (cp_nonlinear_fc); defaults = the reference's schedule."""
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        it = np.ascontiguousarray(iters, dtype=np.int32)
+        lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+        info = RefitInfo()
+        self._check(self.lib.cp_nonlinear_fc(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), mask.ctypes.data, _ptr(Y),
+                                             int(n), it.ctypes.data, lam.ctypes.data, int(it.shape[0]), _ptr(W_out),
+                                             _ptr(b_out), ctypes.byref(info)), "cp_nonlinear_fc")
         return info
 
     def prune_layer(self, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, alpha_right0, rank, lbound, rbound,

@@ -198,6 +198,15 @@ class LayerProblem:
         b = self.ctx.to_host(self.bout, (self.n,), np.float64)
         return W, b
 
+    # -- decompose.py:615-617 -> nonlinear_fc ------------------------------------------------
+    def refit_nonlinear(self, idxs, iters=(30, 20), lambdas=(0.1, 1.0)):
+        idxs = np.asarray(idxs, dtype=bool)
+        info = self.ctx.nonlinear_fc(self.Xd, self.x_dtype, self.N, self.c, self.kk, idxs.astype(np.uint8), self.Yd,
+                                     self.n, self.Wout, self.bout, iters=iters, lambdas=lambdas)
+        self.refit_info = info
+        p = int(info.p)
+        return (self.ctx.to_host(self.Wout, (self.n, p), np.float64), self.ctx.to_host(self.bout, (self.n,), np.float64))
+
     def free(self):
         for name in ("Xd", "W2d", "Yd", "Qd", "qd", "statsd", "wd", "Wout", "bout"):
             buf = getattr(self, name, None)
@@ -208,10 +217,12 @@ class LayerProblem:
 GLOBAL_RNG = np.random  # module-level legacy RandomState: randint / get_state / set_state
 
 
-def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="device", alpha_arg=1e-4):
+def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="device", alpha_arg=1e-4,
+                refit="linear", W2_host=None):
     """dictionary() on a resident LayerProblem -> (idxs, newW2[n,nnz,k,k], newB2, alpha_out).
 
-    mode "device": the whole call is ONE foreign call (cp_prune_layer); "steps": the same device
+    refit: "linear" (fc_kernel), "nonlinear" (nonlinear_fc) or "none" (dcfgs.nofc: W2[:, idxs], zero bias).
+    mode "device": the whole call is ONE foreign call (cp_prune_layer; linear refit only); "steps": the same device
     search through the individual entry points (lasso_gram / alpha search / refit); "host": one
     launch per LASSO fit, the host deciding the next alpha."""
     rng = GLOBAL_RNG if rng is None else rng
@@ -223,7 +234,7 @@ def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="de
         alpha = alpha_arg
         prob.fits = []
     else:
-        if mode == "device":
+        if mode == "device" and refit == "linear":
             fused = prob.prune_fused(rank, alpha_in, rank_tol, rng, samples, ridge)
             if fused is not None:
                 idxs, W, b, alpha = fused
@@ -232,6 +243,11 @@ def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="de
         prob.lasso_gram(samples)
         alpha = prob.alpha_search(rank, alpha_in, rank_tol, rng, mode="device" if mode == "steps" else mode)
         idxs = prob.mask()
-    W, b = prob.refit(idxs, ridge=ridge)
     nnz = int(idxs.sum())
+    if refit == "none":                                           # dcfgs.nofc (decompose.py:618-620)
+        return idxs, np.asarray(W2_host)[:, idxs, :, :], np.zeros(n), alpha
+    if refit == "nonlinear":                                      # dcfgs.nonlinear_fc (decompose.py:615-617)
+        W, b = prob.refit_nonlinear(idxs)
+    else:
+        W, b = prob.refit(idxs, ridge=ridge)
     return idxs, W.reshape((n, nnz, k, k)), b, alpha

@@ -747,6 +747,186 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     return CP_OK;
 }
 
+// ---- nonlinear_fc: ReLU-aware reconstruction (lib/decompose.py:671-685, 51-59) -------------------------------
+namespace {
+
+// U = Y, Z = relu(Y) in the padded [Nr, n_pad] lay-out (zero outside N x n)
+__global__ void __launch_bounds__(RT) k_nl_init(const double *__restrict__ Y, int64_t N, int n, int n_pad,
+                                                double *__restrict__ U, double *__restrict__ Z) {
+    const int64_t r = blockIdx.x;
+    for (int j = threadIdx.x; j < n_pad; j += RT) {
+        const double y = (r < N && j < n) ? Y[size_t(r) * n + j] : 0.0;
+        U[size_t(r) * n_pad + j] = y;
+        Z[size_t(r) * n_pad + j] = fmax(y, 0.0);
+    }
+}
+
+// dst[col, r] = src[r, col]: 32 x 32 tiles through LDS
+__global__ void __launch_bounds__(RT) k_transpose_2d(const double *__restrict__ src, int ld_src, double *__restrict__ dst,
+                                                     int ld_dst) {
+    __shared__ double t[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int y = ty; y < 32; y += 8) t[y][tx] = src[size_t(r0 + y) * ld_src + c0 + tx];
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) dst[size_t(c0 + y) * ld_dst + r0 + tx] = t[tx][y];
+}
+
+// column sums of the padded U over row blocks (fixed order), then Uc = U - mean
+__global__ void __launch_bounds__(RT) k_colsum_u(const double *__restrict__ U, int64_t N, int n, int n_pad,
+                                                 int rows_per_block, double *__restrict__ part) {
+    const int col = blockIdx.x * RT + threadIdx.x;
+    if (col >= n) return;
+    const int64_t r0 = int64_t(blockIdx.y) * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    double s = 0;
+    for (int64_t r = r0; r < r1; ++r) s += U[size_t(r) * n_pad + col];
+    part[size_t(blockIdx.y) * n_pad + col] = s;
+}
+__global__ void __launch_bounds__(RT) k_center_u(const double *__restrict__ U, const double *__restrict__ part,
+                                                 int nparts, int64_t N, int n, int n_pad, double inv_n,
+                                                 double *__restrict__ umean, double *__restrict__ Uc) {
+    const int64_t r = blockIdx.x;
+    for (int j = threadIdx.x; j < n_pad; j += RT) {
+        double m = 0.0;
+        if (j < n) {
+            for (int b = 0; b < nparts; ++b) m += part[size_t(b) * n_pad + j];
+            m *= inv_n;
+            if (r == 0) umean[j] = m;
+        }
+        Uc[size_t(r) * n_pad + j] = (r < N && j < n) ? U[size_t(r) * n_pad + j] - m : 0.0;
+    }
+}
+
+// U <- solve_relu(RU + umean, Z, lambda)  (lib/decompose.py:51-59), zero outside N x n
+__global__ void __launch_bounds__(RT) k_solve_relu(const double *__restrict__ RUc, const double *__restrict__ umean,
+                                                   const double *__restrict__ Z, double lambda, int64_t N, int n,
+                                                   int n_pad, double *__restrict__ U) {
+    const int64_t r = blockIdx.x;
+    for (int j = threadIdx.x; j < n_pad; j += RT) {
+        double u = 0.0;
+        if (r < N && j < n) {
+            const double RU = RUc[size_t(r) * n_pad + j] + umean[j], z = Z[size_t(r) * n_pad + j];
+            const double U0 = fmin(RU, 0.0);
+            const double Cost0 = z * z + lambda * ((U0 - RU) * (U0 - RU));
+            const double U1 = fmax((lambda * RU + z) / (lambda + 1.0), 0.0);
+            const double Cost1 = (U1 - z) * (U1 - z) + lambda * ((U1 - RU) * (U1 - RU));
+            u = Cost0 <= Cost1 ? U0 : U1;
+        }
+        U[size_t(r) * n_pad + j] = u;
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
+                               const double *Y, int n, const int *iters, const double *lambdas, int n_stage,
+                               double *W_out, double *b_out, cp_refit_info *info) {
+    if (!ctx || !X || !mask || !Y || !iters || !lambdas || !W_out || !b_out || !info) return CP_ERR_ARG;
+    if (N <= 0 || c <= 0 || kk <= 0 || n <= 0 || n_stage <= 0) return cp_set_error(ctx, CP_ERR_ARG, "nonlinear_fc: bad sizes");
+    if (x_dtype != CP_F32 && x_dtype != CP_F64) return cp_set_error(ctx, CP_ERR_ARG, "nonlinear_fc: bad dtype");
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int> chan;
+    for (int i = 0; i < c; ++i)
+        if (mask[i]) chan.push_back(i);
+    const int kept = int(chan.size());
+    if (kept == 0) return cp_set_error(ctx, CP_ERR_ARG, "nonlinear_fc: empty mask");
+    const int p = kept * kk;
+    if (N - 1 < p)
+        return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "nonlinear_fc: needs N - 1 >= p (full column rank), N=%lld p=%d",
+                            (long long)N, p);
+    const int p_pad = int(cp_align_up(size_t(p), NB)), n_pad = int(cp_align_up(size_t(n), 128));
+    const int64_t Nr = int64_t(cp_align_up(size_t(N), 128));  // sample rows, also an M dimension here
+    const int nblk = p_pad / NB;
+    const int RB = 64, rows_per_block = int((N + RB - 1) / RB);
+    const size_t xs_c = size_t(Nr) * p_pad, u_c = size_t(Nr) * n_pad, g_c = size_t(p_pad) * p_pad, r_c = size_t(p_pad) * n_pad;
+    size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(Nr), CP_TRI_LOWER_MIRROR),
+                         cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(Nr), CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, int(Nr), n_pad, p_pad, CP_TRI_NONE));
+    const size_t need = (2 * xs_c + 4 * u_c + 3 * g_c + r_c + 2 * size_t(nblk) * NB * NB + size_t(RB) * (p_pad + n_pad) +
+                         3 * size_t(p_pad) + 2 * size_t(n_pad) + 64) * 8 + size_t(kept) * 4 + size_t(nblk + 16) * 4 + ws +
+                        (1 << 16);
+    CP_TRY(cp_arena_reserve(ctx, need));
+    double *Xs = cp_arena_take_t<double>(ctx, xs_c), *XsT = cp_arena_take_t<double>(ctx, xs_c);
+    double *Ub = cp_arena_take_t<double>(ctx, u_c), *Zb = cp_arena_take_t<double>(ctx, u_c);
+    double *Uc = cp_arena_take_t<double>(ctx, u_c), *RU = cp_arena_take_t<double>(ctx, u_c);
+    double *G = cp_arena_take_t<double>(ctx, g_c), *Uf = cp_arena_take_t<double>(ctx, g_c), *Lt = cp_arena_take_t<double>(ctx, g_c);
+    double *Rm = cp_arena_take_t<double>(ctx, r_c);
+    double *TI = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB), *TIT = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB);
+    double *part_x = cp_arena_take_t<double>(ctx, size_t(RB) * p_pad), *part_y = cp_arena_take_t<double>(ctx, size_t(RB) * n_pad);
+    double *xmean = cp_arena_take_t<double>(ctx, p_pad), *dg0 = cp_arena_take_t<double>(ctx, p_pad);
+    double *gmax = cp_arena_take_t<double>(ctx, 8), *umean = cp_arena_take_t<double>(ctx, n_pad);
+    double *ydummy = cp_arena_take_t<double>(ctx, n_pad);
+    int *dchan = cp_arena_take_t<int>(ctx, kept), *dinfo = cp_arena_take_t<int>(ctx, nblk + 16);
+    if (!Xs || !XsT || !Ub || !Zb || !Uc || !RU || !G || !Uf || !Lt || !Rm || !TI || !TIT || !part_x || !part_y || !xmean ||
+        !dg0 || !gmax || !umean || !ydummy || !dchan || !dinfo)
+        return cp_set_error(ctx, CP_ERR_NOMEM, "nonlinear_fc: arena");
+    CP_TRY(cp_pinned_reserve(ctx, 4096));
+    int *info_host = reinterpret_cast<int *>(ctx->pinned);
+
+    cp_stage_begin(ctx);
+    CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
+    {   // centred kept columns of X (constant over the iterations), its transpose, Gram, Cholesky -- once
+        const int gx = (p + RT - 1) / RT;
+        dim3 gs(gx, RB);
+        if (x_dtype == CP_F32)
+            k_colsum_xy<float><<<gs, RT, 0, ctx->stream>>>(static_cast<const float *>(X), Y, N, c, kk, n, dchan, p, gx,
+                                                           rows_per_block, part_x, p_pad, part_y, n_pad);
+        else
+            k_colsum_xy<double><<<gs, RT, 0, ctx->stream>>>(static_cast<const double *>(X), Y, N, c, kk, n, dchan, p, gx,
+                                                            rows_per_block, part_x, p_pad, part_y, n_pad);
+        CP_LAUNCH_CHECK(ctx);
+        k_mean_finish_xy<<<gx, RT, 0, ctx->stream>>>(part_x, p_pad, p, part_y, n_pad, 0, gx, RB, 1.0 / double(N), xmean,
+                                                     ydummy);
+        CP_LAUNCH_CHECK(ctx);
+        CP_HIP(ctx, hipMemsetAsync(ydummy, 0, size_t(n_pad) * 8, ctx->stream));  // gather below centres "Y" by 0: unused
+        if (x_dtype == CP_F32)
+            k_gather_center_xy<float><<<unsigned(Nr), RT, 0, ctx->stream>>>(static_cast<const float *>(X), Y, N, c, kk, 0,
+                                                                            dchan, p, p_pad, 0, xmean, ydummy, Xs, Uc);
+        else
+            k_gather_center_xy<double><<<unsigned(Nr), RT, 0, ctx->stream>>>(static_cast<const double *>(X), Y, N, c, kk, 0,
+                                                                             dchan, p, p_pad, 0, xmean, ydummy, Xs, Uc);
+        CP_LAUNCH_CHECK(ctx);
+        k_transpose_2d<<<dim3(unsigned(Nr / 32), p_pad / 32), RT, 0, ctx->stream>>>(Xs, p_pad, XsT, int(Nr));
+        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(Nr), 1.0, Xs, p_pad, Xs, p_pad, 0.0, G, p_pad, CP_TRI_LOWER_MIRROR));
+        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(G, p_pad, p, p_pad, 0.0, dg0, gmax, dinfo, nblk + 1);
+        CP_LAUNCH_CHECK(ctx);
+    }
+    Chol ch{G, Uf, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
+    CP_TRY(chol_factor(ctx, ch, 1e-10));
+    k_nl_init<<<unsigned(Nr), RT, 0, ctx->stream>>>(Y, N, n, n_pad, Ub, Zb);
+    CP_LAUNCH_CHECK(ctx);
+    cp_stage_mark(ctx, "nonlinear_setup");
+    const int gy = (n + RT - 1) / RT;
+    for (int st = 0; st < n_stage; ++st)
+        for (int it = 0; it < iters[st]; ++it) {
+            // reg = fc_kernel(X, U): centre U, normal equations with the factor computed above
+            k_colsum_u<<<dim3(gy, RB), RT, 0, ctx->stream>>>(Ub, N, n, n_pad, rows_per_block, part_y);
+            CP_LAUNCH_CHECK(ctx);
+            k_center_u<<<unsigned(Nr), RT, 0, ctx->stream>>>(Ub, part_y, RB, N, n, n_pad, 1.0 / double(N), umean, Uc);
+            CP_LAUNCH_CHECK(ctx);
+            CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(Nr), 1.0, Xs, p_pad, Uc, n_pad, 0.0, Rm, n_pad, CP_TRI_NONE));
+            CP_TRY(chol_solve(ctx, ch, Rm, nullptr, n_pad));
+            // RU = reg.predict(X) = Xc W + mean(U); U = solve_relu(RU, Z, lambda)
+            CP_TRY(cp_gemm_tn_f64(ctx, int(Nr), n_pad, p_pad, 1.0, XsT, int(Nr), Rm, n_pad, 0.0, RU, n_pad, CP_TRI_NONE));
+            k_solve_relu<<<unsigned(Nr), RT, 0, ctx->stream>>>(RU, umean, Zb, lambdas[st], N, n, n_pad, Ub);
+            CP_LAUNCH_CHECK(ctx);
+        }
+    cp_stage_mark(ctx, "nonlinear_iterations");
+    // coefficients and intercept of the LAST regression (decompose.py:685): W in Rm, mean(U) of that fit in umean
+    k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, umean, W_out, b_out, nullptr, nullptr, dinfo, info_host);
+    CP_LAUNCH_CHECK(ctx);
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    if (*info_host != 0)
+        return cp_set_error(ctx, CP_ERR_NUMERIC, "nonlinear_fc: X^T X is not positive definite at column %d (rank-deficient "
+                                                 "inputs are not supported on this path)", *info_host - 1);
+    info->p = p;
+    info->rank = p;
+    info->fallback = 0;
+    info->reserved = 0;
+    return CP_OK;
+}
+
 extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
                               const double *Y, int n, double ridge, double *W_out, double *b_out,
                               cp_refit_info *info) {

@@ -44,10 +44,12 @@ def dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, v
     if dcfgs.autodet:
         raise NotImplementedError("dcfgs.autodet (single LASSO solve at fixed alpha) is not on the "
                                   "accelerated path")
-    if dcfgs.dic.alter or dcfgs.nonlinear_fc or dcfgs.nofc or dcfgs.ls != 'linear' \
-            or dcfgs.solver != cfgs.solvers.sk or dcfgs.dic.debug:
-        raise NotImplementedError("only the default pruning configuration of the reference is accelerated "
-                                  "(dic.alter=0, nonlinear_fc=0, nofc=0, ls='linear', solver='sklearn')")
+    if dcfgs.dic.alter or dcfgs.ls != 'linear' or dcfgs.solver != cfgs.solvers.sk or dcfgs.dic.debug:
+        raise NotImplementedError("only the sklearn/linear configuration of the reference is accelerated "
+                                  "(dic.alter=0, ls='linear', solver='sklearn')")
+    if dcfgs.nonlinear_fc and dcfgs.fc_ridge:
+        raise NotImplementedError("nonlinear_fc with fc_ridge > 0")
+    refit = "nonlinear" if dcfgs.nonlinear_fc else ("none" if dcfgs.nofc else "linear")   # decompose.py:615-623
     X = np.asarray(X)
     W2 = np.asarray(W2)
     if X.shape[2] != X.shape[-1]:
@@ -56,10 +58,12 @@ def dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, v
     try:
         idxs, newW2, newB2, alpha_out = prune_layer(prob, rank, cfgs.alpha, rank_tol=rank_tol, rng=np.random,
                                                     ridge=float(dcfgs.fc_ridge), mode=dcfgs.cd_mode,
-                                                    alpha_arg=alpha)
+                                                    alpha_arg=alpha, refit=refit, W2_host=W2)
         last_call_info.clear()
+        ri = prob.refit_info
         last_call_info.update(fits=list(prob.fits), samples=prob.samples,
-                              fallback=int(prob.refit_info.fallback), p=int(prob.refit_info.p))
+                              fallback=int(ri.fallback) if ri is not None else 0,
+                              p=int(ri.p) if ri is not None else int(idxs.sum()) * prob.kk)
     finally:
         prob.free()
     cfgs.alpha = alpha_out                               # decompose.py:626-627
@@ -77,6 +81,23 @@ class _FittedLinear:
 
     def predict(self, X):
         return np.asarray(X) @ self.coef_.T + self.intercept_
+
+
+def nonlinear_fc(X, Y, copy_X=True, W=None, B=None):
+    """ReLU-aware reconstruction (decompose.py:671-685): 30 + 20 alternations of fc_kernel and solve_relu with
+    X[N,p] constant; returns (coef_[n, p], intercept_[n]) of the last regression."""
+    assert len(X.shape) == 2
+    assert copy_X == True  # noqa: E712
+    assert W is None
+    assert B is None
+    X = np.ascontiguousarray(X)
+    N, p = X.shape
+    Y2 = np.ascontiguousarray(Y, dtype=np.float64).reshape(N, -1)
+    prob = LayerProblem(default_context(), X.reshape(N, p, 1, 1), np.zeros((Y2.shape[1], p, 1, 1), dtype=np.float32), Y2)
+    try:
+        return prob.refit_nonlinear(np.ones(p, dtype=bool))
+    finally:
+        prob.free()
 
 
 def fc_kernel(X, Y, copy_X=True, W=None, B=None, ret_reg=False, fit_intercept=True):

@@ -144,6 +144,17 @@ int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, in
                    const uint8_t *mask, const double *Y, int n, double ridge, double *W_out,
                    double *b_out, cp_refit_info *info);
 
+/* Replaces nonlinear_fc(X[:, idxs].reshape(N, -1), Y) (lib/decompose.py:671-685; the dcfgs.nonlinear_fc
+ * branch of dictionary(), decompose.py:615-617): Z = relu(Y), U = Y, then for every stage s (reference: iters =
+ * {30, 20}, lambdas = {0.1, 1}) iters[s] times  reg = fc_kernel(X, U);  U = solve_relu(reg.predict(X), Z, lambdas[s])
+ * (decompose.py:51-59).  X is constant over the 50 regressions: it is centred, its Gram factorised once, each
+ * iteration is two GEMMs, one substitution launch and one element-wise pass.  Returns the coefficients /
+ * intercept of the LAST regression like the reference.  Arguments as cp_lstsq_refit (outputs DEVICE); needs
+ * N - 1 >= p and a positive definite Gram (CP_ERR_UNSUPPORTED / CP_ERR_NUMERIC otherwise). */
+int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
+                    const double *Y, int n, const int *iters, const double *lambdas, int n_stage,
+                    double *W_out, double *b_out, cp_refit_info *info);
+
 /* ---- a3: one whole dictionary() call -------------------------------------------- */
 #define CP_MAX_FITS 64
 typedef struct cp_prune_result {

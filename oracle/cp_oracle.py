@@ -272,8 +272,33 @@ class _LassoEngine:
         return idxs, int(idxs.sum()), int(n_iter), seed
 
 
+def solve_relu_oracle(RU, Z, Lambda):
+    """decompose.py:51-59, statement by statement."""
+    U0 = np.minimum(RU, 0.)
+    Cost0 = Z ** 2 + Lambda * (U0 - RU) ** 2
+    U1 = np.maximum((Lambda * RU + Z) / (Lambda + 1.), 0.)
+    Cost1 = (U1 - Z) ** 2 + Lambda * (U1 - RU) ** 2
+    return (Cost0 <= Cost1) * U0 + (Cost0 > Cost1) * U1
+
+
+def nonlinear_fc_oracle(X, Y, engine="sklearn"):
+    """decompose.py:671-685: U = Y, Z = relu(Y); 30 iterations with lambda = 0.1 then 20 with lambda = 1 of
+    reg = fc_kernel(X, U); U = solve_relu(reg.predict(X), Z, lambda); returns the last reg's (coef_, intercept_)."""
+    assert X.ndim == 2
+    U = Y.copy()
+    Z = np.maximum(Y, 0.)
+    its = [30, 20]
+    coef = b = None
+    for epoch, l in enumerate([10 ** i for i in range(-1, 1)]):
+        for _ in range(its[epoch]):
+            coef, b = fc_kernel_oracle(X, U, engine=engine)
+            RU = X @ coef.T + b
+            U = solve_relu_oracle(RU, Z, l)
+    return coef, b
+
+
 def dictionary_oracle(X, W2, Y, rank, B2=None, alpha=1e-4, alpha_in=1e-3, rank_tol=.1, rng=None,
-                      lasso="sklearn", ls="sklearn", ridge=0.0, log=None):
+                      lasso="sklearn", ls="sklearn", ridge=0.0, log=None, refit="linear"):
     """Restatement of lib/decompose.py:386-634 (live path).
 
     alpha_in plays the role of the module global ``cfgs.alpha`` on entry (decompose.py:491);
@@ -323,7 +348,12 @@ def dictionary_oracle(X, W2, Y, rank, B2=None, alpha=1e-4, alpha_in=1e-3, rank_t
             else:
                 break
         rank = tmp                                            # decompose.py:581
-    newW2, newB2 = fc_kernel_oracle(X[:, idxs, ...].reshape((N, -1)), Y, ridge=ridge, engine=ls)
+    if refit == "nonlinear":                                  # decompose.py:615-617
+        newW2, newB2 = nonlinear_fc_oracle(X[:, idxs, ...].reshape((N, -1)), Y, engine=ls)
+    elif refit == "none":                                     # decompose.py:618-620
+        return idxs, W2[:, idxs, :, :], np.zeros(n), alpha
+    else:
+        newW2, newB2 = fc_kernel_oracle(X[:, idxs, ...].reshape((N, -1)), Y, ridge=ridge, engine=ls)
     newW2 = newW2.reshape((n, rank, h, w))                    # decompose.py:622-623
     return idxs, newW2, newB2, alpha                          # decompose.py:626-627, 634
 

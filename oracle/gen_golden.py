@@ -48,6 +48,9 @@ CASES = {
     # BASELINE.json configs[0]
     "m01_config1": dict(layer_id=20, N=500, c=256, n=256, k=3, rank=128),
     # BASELINE.json configs[1] (the bench workload): VGG-16 conv3_x block, 5000 samples
+    # refit variants of dictionary(): ReLU-aware nonlinear_fc (decompose.py:615-617, 671-685) and nofc (618-620)
+    "s14_nonlinear_fc": dict(layer_id=14, N=1200, c=24, n=20, k=3, rank=12, nonlinear_fc=1),
+    "s15_nofc": dict(layer_id=15, N=400, c=32, n=24, k=3, rank=16, nofc=1),
     "L01_conv2_2_conv3_1": dict(layer_id=31, N=5000, c=128, n=256, k=3, rank=64, large=True),
     "L02_conv3_1_conv3_2": dict(layer_id=32, N=5000, c=256, n=256, k=3, rank=128, large=True),
     "L03_conv3_2_conv3_3": dict(layer_id=33, N=5000, c=256, n=256, k=3, rank=128, large=True),
@@ -86,6 +89,8 @@ def run_reference(p):
     cfgs.alpha = p.get("alpha_in", 1e-3)
     D.dcfgs.dic.rank_tol = p.get("rank_tol", .1)
     D.dcfgs.fc_ridge = p.get("fc_ridge", 0)
+    D.dcfgs.nonlinear_fc = p.get("nonlinear_fc", 0)
+    D.dcfgs.nofc = p.get("nofc", 0)
     np.random.seed(1234 + p["layer_id"])
     state0 = np.random.get_state()
     Lasso.fit = logging_fit
@@ -97,6 +102,8 @@ def run_reference(p):
         Lasso.fit = orig_fit
         D.dcfgs.fc_ridge = 0
         D.dcfgs.dic.rank_tol = .1
+        D.dcfgs.nonlinear_fc = 0
+        D.dcfgs.nofc = 0
     alpha_out = float(cfgs.alpha)
     rng_next = int(np.random.randint(0, 2147483647))
     # recover `samples` (first draw) by replaying the stream

@@ -259,12 +259,16 @@ def _run_dropin(p, X, W2, Y, B2, mode, exact_ops=False):
     cfgs.alpha = p.get("alpha_in", 1e-3)
     dcfgs.dic.rank_tol = p.get("rank_tol", .1)
     dcfgs.fc_ridge = p.get("fc_ridge", 0)
+    dcfgs.nonlinear_fc = p.get("nonlinear_fc", 0)
+    dcfgs.nofc = p.get("nofc", 0)
     dcfgs.cd_mode = mode
     np.random.seed(1234 + p["layer_id"])
     try:
         idxs, newW2, newB2 = D.dictionary(X.astype(np.float64), W2, Y, rank=p["rank"], B2=B2)
     finally:
         dcfgs.fc_ridge = 0
+        dcfgs.nonlinear_fc = 0
+        dcfgs.nofc = 0
         dcfgs.dic.rank_tol = .1
         dcfgs.cd_mode = 'device'
         dcfgs.cd_reciprocal = dcfgs.cd_delta = 1
@@ -446,3 +450,36 @@ def test_prune_layer_rank_equal_c_skips_lasso(ctx):
     Wref, bref, _ = cp_oracle.lstsq_min_norm(X.reshape(300, -1).astype(np.float64), Y)
     assert relfro(W, Wref) <= 1e-9 and relfro(b, bref) <= 1e-9
     prob.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# nonlinear_fc (ReLU-aware reconstruction, decompose.py:671-685)
+# ---------------------------------------------------------------------------------------------
+def test_nonlinear_fc_dropin_matches_oracle(ctx):
+    """lib.decompose.nonlinear_fc (50 regressions on one Cholesky factor) vs the numpy restatement
+    (50 x LinearRegression + solve_relu): rel. Frobenius <= 1e-8."""
+    import cp_oracle
+    import lib.decompose as D
+    rs = np.random.RandomState(5)
+    N, p, n = 1500, 150, 40
+    X = np.maximum(rs.randn(N, p), 0.)
+    Y = X @ (rs.randn(p, n) * 0.1) + 0.3 * rs.randn(N, n) - 0.2
+    coef, b = D.nonlinear_fc(X, Y)
+    cref, bref = cp_oracle.nonlinear_fc_oracle(X, Y, engine="numpy")
+    assert coef.shape == (n, p) and b.shape == (n,)
+    assert relfro(coef, cref) <= 1e-8 and relfro(b, bref) <= 1e-8
+    # the ReLU-aware fit beats plain least squares on the post-ReLU error it optimises
+    Wl, bl = D.fc_kernel(X, Y)
+    relu = lambda a: np.maximum(a, 0.)  # noqa: E731
+    err_nl = np.linalg.norm(relu(X @ coef.T + b) - relu(Y))
+    err_ls = np.linalg.norm(relu(X @ Wl.T + bl) - relu(Y))
+    assert err_nl <= err_ls * (1 + 1e-9)
+
+
+def test_nonlinear_fc_rejects_rank_deficient_input(ctx):
+    import cpmi355
+    import lib.decompose as D
+    rs = np.random.RandomState(6)
+    X = rs.randn(50, 80)          # N - 1 < p
+    with pytest.raises(cpmi355.CpError):
+        D.nonlinear_fc(X, rs.randn(50, 4))
