@@ -76,6 +76,9 @@ SIGNATURES = {
                                 ctypes.POINTER(RefitInfo)]),
     "cp_nonlinear_fc": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp, _vp,
                                  ctypes.POINTER(RefitInfo)]),
+    "cp_svd_rows": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_c_int)]),
+    "cp_vh_project": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
+    "cp_matmul_tn": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "cp_prune_layer": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
                                 _c_dbl, _c_dbl, _c_dbl, _c_dbl, _vp, _c_int, _c_int, _c_dbl, _c_int, _c_dbl,
                                 _vp, _vp, _vp, ctypes.POINTER(PruneResult)]),
@@ -269,6 +272,38 @@ class Context:
                                              int(n), it.ctypes.data, lam.ctypes.data, int(it.shape[0]), _ptr(W_out),
                                              _ptr(b_out), ctypes.byref(info)), "cp_nonlinear_fc")
         return info
+
+    # -- VH_decompose pieces -------------------------------------------------------------
+    def svd_rows(self, M, r):
+        """Leading r singular triplets of the host matrix M[m, n] (m <= n) -> (sigma[r], Vt[r, m], SH[r, n])
+        with SH = diag(sigma) H; computed on the device (cp_svd_rows)."""
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        m, n = M.shape
+        Md = self.to_device(M)
+        sd, Vd, Hd = self.empty(r * 8), self.empty(r * m * 8), self.empty(r * n * 8)
+        sweeps = _c_int()
+        try:
+            self._check(self.lib.cp_svd_rows(self.h, Md.ptr, m, n, int(r), sd.ptr, Vd.ptr, Hd.ptr, ctypes.byref(sweeps)),
+                        "cp_svd_rows")
+            return (self.to_host(sd, (r,), np.float64), self.to_host(Vd, (r, m), np.float64),
+                    self.to_host(Hd, (r, n), np.float64))
+        finally:
+            for bfr in (Md, sd, Vd, Hd):
+                bfr.free()
+
+    def matmul_tn(self, A, B):
+        """A[k, m]^T B[k, n] on the device (host arrays in, host array out)."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        k, m = A.shape
+        n = B.shape[1]
+        Ad, Bd, Cd = self.to_device(A), self.to_device(B), self.empty(m * n * 8)
+        try:
+            self._check(self.lib.cp_matmul_tn(self.h, Ad.ptr, Bd.ptr, m, n, k, Cd.ptr), "cp_matmul_tn")
+            return self.to_host(Cd, (m, n), np.float64)
+        finally:
+            for bfr in (Ad, Bd, Cd):
+                bfr.free()
 
     def prune_layer(self, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, alpha_right0, rank, lbound, rbound,
                     seeds, ridge, flags=0, max_iter=1000, tol=1e-4):

@@ -1,0 +1,234 @@
+// Thin SVD of a small dense matrix by one-sided (Hestenes) Jacobi on its ROWS, replacing
+// scipy.linalg.svd(x, full_matrices=False, lapack_driver='gesvd') as called by VH_decompose
+// (lib/decompose.py:45-47, 100).  For M (m x n, m <= n), left rotations J^T M make the rows mutually
+// orthogonal:  R M = Sigma H  with R = J^T orthogonal, so
+//   singular values  sigma_k = |row k of R M|,   V = R^T (column k = row k of R),   diag(sigma) H = R M
+// -- the reference needs exactly V[:, :rank] and diag(sigma) H[:rank] (decompose.py:105-112), so the rows are
+// never normalised.  High relative accuracy (no Gram squaring).
+// One launch per round of the round-robin ordering: m/2 disjoint row pairs, one workgroup per pair
+// (three dot products -> rotation -> both rows of the work matrix and of R).  A sweep is m-1 rounds; sweeps
+// repeat until no pair exceeds the orthogonality tolerance.  Rows are contiguous, so every access is coalesced.
+#include "cp_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace {
+
+constexpr int JT = 256;
+
+__device__ __forceinline__ double jblock_sum(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// round r of the tournament on m (even) players: pair k -> rows (i, j)
+__device__ __forceinline__ void round_pair(int m, int r, int k, int &i, int &j) {
+    if (k == 0) {
+        i = m - 1;
+        j = r;
+    } else {
+        i = (r + k) % (m - 1);
+        j = (r - k + m - 1) % (m - 1);
+    }
+}
+
+__global__ void __launch_bounds__(JT) k_jacobi_round(double *__restrict__ Wk, int n, double *__restrict__ R, int m,
+                                                     int round, double tol, int *__restrict__ rotated) {
+    __shared__ double red[4];
+    __shared__ double cs[2];
+    int i, j;
+    round_pair(m, round, blockIdx.x, i, j);
+    double *a = Wk + size_t(i) * n, *b = Wk + size_t(j) * n;
+    double saa = 0, sbb = 0, sab = 0;
+    for (int col = threadIdx.x; col < n; col += JT) {
+        const double x = a[col], y = b[col];
+        saa = fma(x, x, saa);
+        sbb = fma(y, y, sbb);
+        sab = fma(x, y, sab);
+    }
+    const double alpha = jblock_sum(saa, red), beta = jblock_sum(sbb, red), gamma = jblock_sum(sab, red);
+    if (threadIdx.x == 0) {
+        double c = 1.0, s = 0.0;
+        if (fabs(gamma) > tol * sqrt(alpha * beta) && gamma != 0.0) {
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = c * t;
+            atomicAdd(rotated, 1);
+        }
+        cs[0] = c;
+        cs[1] = s;
+    }
+    __syncthreads();
+    const double c = cs[0], s = cs[1];
+    if (s == 0.0) return;
+    for (int col = threadIdx.x; col < n; col += JT) {
+        const double x = a[col], y = b[col];
+        a[col] = c * x - s * y;
+        b[col] = s * x + c * y;
+    }
+    double *ra = R + size_t(i) * m, *rb = R + size_t(j) * m;
+    for (int col = threadIdx.x; col < m; col += JT) {
+        const double x = ra[col], y = rb[col];
+        ra[col] = c * x - s * y;
+        rb[col] = s * x + c * y;
+    }
+}
+
+__global__ void __launch_bounds__(JT) k_identity(double *__restrict__ R, int m) {
+    const int r = blockIdx.x;
+    for (int col = threadIdx.x; col < m; col += JT) R[size_t(r) * m + col] = col == r ? 1.0 : 0.0;
+}
+
+// dst[k, :cols] = src[order[k], :cols]
+__global__ void __launch_bounds__(JT) k_take_rows(const double *__restrict__ src, int ld_src, const int *__restrict__ order,
+                                                  int cols, double *__restrict__ dst, int ld_dst) {
+    const double *a = src + size_t(order[blockIdx.x]) * ld_src;
+    for (int col = threadIdx.x; col < cols; col += JT) dst[size_t(blockIdx.x) * ld_dst + col] = a[col];
+}
+
+__global__ void __launch_bounds__(JT) k_row_norms(const double *__restrict__ Wk, int n, double *__restrict__ sig) {
+    __shared__ double red[4];
+    const double *a = Wk + size_t(blockIdx.x) * n;
+    double s = 0;
+    for (int col = threadIdx.x; col < n; col += JT) s = fma(a[col], a[col], s);
+    s = jblock_sum(s, red);
+    if (threadIdx.x == 0) sig[blockIdx.x] = sqrt(s);
+}
+
+}  // namespace
+
+// M DEVICE [m, n] row-major f64 (m <= n, untouched).  Outputs DEVICE: sigma [r] descending, Vt [r, m] (row k =
+// k-th left singular vector, i.e. V[:, k]), SH [r, n] = diag(sigma) H[:r] (k-th right singular vector scaled by
+// sigma_k).  r <= m.  sweeps_out HOST (may be NULL).
+extern "C" int cp_svd_rows(cp_ctx *ctx, const double *M, int m, int n, int r, double *sigma, double *Vt, double *SH,
+                           int *sweeps_out) {
+    if (!ctx || !M || !sigma || !Vt || !SH || m <= 0 || n < m || r <= 0 || r > m)
+        return ctx ? cp_set_error(ctx, CP_ERR_ARG, "svd_rows: bad arguments (needs 0 < r <= m <= n)") : CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    const int me = m + (m & 1);  // even number of players: an all-zero row plays along if m is odd
+    CP_TRY(cp_arena_reserve(ctx, (size_t(me) * n + size_t(me) * me + size_t(me)) * 8 + size_t(me) * 4 + (1 << 16)));
+    double *Wk = cp_arena_take_t<double>(ctx, size_t(me) * n);
+    double *R = cp_arena_take_t<double>(ctx, size_t(me) * me);
+    double *sig = cp_arena_take_t<double>(ctx, me);
+    int *rotated = cp_arena_take_t<int>(ctx, 16);
+    if (!Wk || !R || !sig || !rotated) return cp_set_error(ctx, CP_ERR_NOMEM, "svd_rows: arena");
+    CP_TRY(cp_pinned_reserve(ctx, 4096));
+    CP_HIP(ctx, hipMemsetAsync(Wk, 0, size_t(me) * n * 8, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(Wk, M, size_t(m) * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    k_identity<<<me, JT, 0, ctx->stream>>>(R, me);
+    CP_LAUNCH_CHECK(ctx);
+    int sweeps = 0;
+    const double tol = std::max(1e-14, 4e-16 * std::sqrt(double(n)));  // |a.b| <= tol |a||b|: rows orthogonal to rounding
+    for (; sweeps < 40; ++sweeps) {
+        CP_HIP(ctx, hipMemsetAsync(rotated, 0, sizeof(int), ctx->stream));
+        for (int round = 0; round < me - 1; ++round) {
+            k_jacobi_round<<<me / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated);
+            CP_LAUNCH_CHECK(ctx);
+        }
+        CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, rotated, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CP_HIP(ctx, cp_stream_wait(ctx));
+        int nrot;
+        memcpy(&nrot, ctx->pinned, sizeof(int));
+        if (nrot == 0) break;
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    if (sweeps >= 40) return cp_set_error(ctx, CP_ERR_NUMERIC, "svd_rows: no convergence in 40 sweeps");
+    // singular values = row norms; order descending on the host (m numbers), gather the leading r rows
+    k_row_norms<<<me, JT, 0, ctx->stream>>>(Wk, n, sig);
+    CP_LAUNCH_CHECK(ctx);
+    std::vector<double> hs(me);
+    CP_HIP(ctx, hipMemcpyAsync(hs.data(), sig, size_t(me) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    std::vector<int> order(me);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hs[x] > hs[y]; });
+    std::vector<double> hsorted(r);
+    for (int k = 0; k < r; ++k) hsorted[k] = hs[order[k]];
+    int *dorder = reinterpret_cast<int *>(cp_arena_take(ctx, size_t(me) * sizeof(int)));
+    if (!dorder) return cp_set_error(ctx, CP_ERR_NOMEM, "svd_rows: arena");
+    CP_HIP(ctx, hipMemcpyAsync(dorder, order.data(), size_t(r) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    k_take_rows<<<r, JT, 0, ctx->stream>>>(R, me, dorder, m, Vt, m);
+    CP_LAUNCH_CHECK(ctx);
+    k_take_rows<<<r, JT, 0, ctx->stream>>>(Wk, n, dorder, n, SH, n);
+    CP_LAUNCH_CHECK(ctx);
+    CP_HIP(ctx, hipMemcpyAsync(sigma, hsorted.data(), size_t(r) * 8, hipMemcpyHostToDevice, ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    return CP_OK;
+}
+
+// ---- VH_decompose helpers (lib/decompose.py:85-146) ------------------------------------------------------
+namespace {
+
+// Xv[s, r * w + wi] = sum_{ci, hi} X[s, ci, hi, wi] * Vt[r, ci * h + hi]      (np.tensordot(X, V, [[1,2],[1,2]])
+// followed by the transpose / reshape of decompose.py:131-136).  One workgroup per sample, x[s] staged in LDS.
+template <typename TX>
+__global__ void __launch_bounds__(JT) k_vh_project(const TX *__restrict__ X, int ch, int w, const double *__restrict__ Vt,
+                                                   int ldv, int rank, double *__restrict__ Xv) {
+    extern __shared__ double xs[];  // [ch][w]
+    const size_t s = blockIdx.x;
+    for (int e = threadIdx.x; e < ch * w; e += JT) xs[e] = double(X[s * size_t(ch) * w + e]);
+    __syncthreads();
+    for (int o = threadIdx.x; o < rank * w; o += JT) {
+        const int r = o / w, wi = o - r * w;
+        const double *v = Vt + size_t(r) * ldv;
+        double acc = 0.0;
+        for (int k = 0; k < ch; ++k) acc = fma(xs[k * w + wi], v[k], acc);
+        Xv[s * size_t(rank) * w + o] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(JT) k_pad_copy(const double *__restrict__ src, int rows, int cols, int ld_src,
+                                                 double *__restrict__ dst, int ld_dst) {
+    const int r = blockIdx.x;
+    for (int col = threadIdx.x; col < ld_dst; col += JT)
+        dst[size_t(r) * ld_dst + col] = (r < rows && col < cols) ? src[size_t(r) * ld_src + col] : 0.0;
+}
+
+}  // namespace
+
+// Xv DEVICE [N, rank * w] f64 from X DEVICE [N, c, h, w] (x_dtype) and Vt DEVICE [rank, c*h] (rows = leading left
+// singular vectors, as cp_svd_rows returns them): decompose.py:131-136.
+extern "C" int cp_vh_project(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int h, int w, const double *Vt,
+                             int rank, double *Xv) {
+    if (!ctx || !X || !Vt || !Xv || N <= 0 || c <= 0 || h <= 0 || w <= 0 || rank <= 0) return CP_ERR_ARG;
+    if (x_dtype != CP_F32 && x_dtype != CP_F64) return cp_set_error(ctx, CP_ERR_ARG, "vh_project: bad dtype");
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    const int ch = c * h;
+    const size_t lds = size_t(ch) * w * sizeof(double);
+    if (lds > 60 * 1024) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "vh_project: c*h*w = %d too large", ch * w);
+    if (x_dtype == CP_F32)
+        k_vh_project<float><<<unsigned(N), JT, lds, ctx->stream>>>(static_cast<const float *>(X), ch, w, Vt, ch, rank, Xv);
+    else
+        k_vh_project<double><<<unsigned(N), JT, lds, ctx->stream>>>(static_cast<const double *>(X), ch, w, Vt, ch, rank, Xv);
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}
+
+// C[m, n] = A^T B with A DEVICE [k, m], B DEVICE [k, n] (row-major, any sizes): the f64 MFMA GEMM on zero-padded
+// copies.  Used for the small reconstructions V diag(sigma) H (decompose.py:114, 139).
+extern "C" int cp_matmul_tn(cp_ctx *ctx, const double *A, const double *B, int m, int n, int k, double *C) {
+    if (!ctx || !A || !B || !C || m <= 0 || n <= 0 || k <= 0) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    const int mp = int(cp_align_up(size_t(m), 128)), np_ = int(cp_align_up(size_t(n), 128)), kp = int(cp_align_up(size_t(k), 16));
+    const size_t ws = cp_gemm_tn_workspace(ctx, mp, np_, kp, CP_TRI_NONE);
+    CP_TRY(cp_arena_reserve(ctx, (size_t(kp) * mp + size_t(kp) * np_ + size_t(mp) * np_) * 8 + ws + (1 << 16)));
+    double *Ap = cp_arena_take_t<double>(ctx, size_t(kp) * mp), *Bp = cp_arena_take_t<double>(ctx, size_t(kp) * np_);
+    double *Cp = cp_arena_take_t<double>(ctx, size_t(mp) * np_);
+    if (!Ap || !Bp || !Cp) return cp_set_error(ctx, CP_ERR_NOMEM, "matmul_tn: arena");
+    k_pad_copy<<<kp, JT, 0, ctx->stream>>>(A, k, m, m, Ap, mp);
+    CP_LAUNCH_CHECK(ctx);
+    k_pad_copy<<<kp, JT, 0, ctx->stream>>>(B, k, n, n, Bp, np_);
+    CP_LAUNCH_CHECK(ctx);
+    CP_TRY(cp_gemm_tn_f64(ctx, mp, np_, kp, 1.0, Ap, mp, Bp, np_, 0.0, Cp, np_, CP_TRI_NONE));
+    CP_HIP(ctx, hipMemcpy2DAsync(C, size_t(n) * 8, Cp, size_t(np_) * 8, size_t(n) * 8, size_t(m), hipMemcpyDeviceToDevice,
+                                 ctx->stream));
+    return CP_OK;
+}

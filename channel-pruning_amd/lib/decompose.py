@@ -83,6 +83,77 @@ class _FittedLinear:
         return np.asarray(X) @ self.coef_.T + self.intercept_
 
 
+def epscheck(x, tol=5):
+    """decompose.py:158-161: warn when an entry exceeds 10**tol."""
+    if np.any(np.abs(x) > 10 ** tol):
+        print('1e' + str(tol) + ' exceed')
+
+
+def VH_decompose(weights, rank=None, DEBUG=0, X=None, Y=None):
+    """Spatial decomposition of a k x k convolution into (k x 1) then (1 x k) (decompose.py:85-146).
+
+        weights [n, c, h, w] -> V [rank, c, h, 1], H [n, rank, 1, w], VHr [n, c, h, w] (and b when X, Y are given)
+
+    The truncated SVD of the (c*h) x (n*w) matrix runs on the device (one-sided Jacobi, cp_svd_rows); with
+    X[N, c, h, w] and Y[N, n] the second factor is refit by nonlinear_fc on Xv = X * V exactly as the reference
+    does.  Singular vectors carry LAPACK's arbitrary sign in the reference and Jacobi's here: V[k] and H[:, k] may
+    both be negated, their product (VHr) is the same."""
+    weights = np.asarray(weights)
+    dim = weights.shape
+    ch, nw = dim[1] * dim[2], dim[0] * dim[3]
+    VH = np.transpose(weights, [1, 2, 0, 3]).reshape([ch, nw])          # decompose.py:96-99
+    if rank is None:
+        rank = ch
+    ctx = default_context()
+    if ch <= nw:
+        _, Vt, SH = ctx.svd_rows(VH, rank)                                # rows of Vt = V[:, k]; SH = diag(sigma) H
+    else:                                                                 # work on the transpose, swap the roles
+        sig, Ht, SV = ctx.svd_rows(VH.T, rank)
+        Vt, SH = SV / sig[:, None], Ht * sig[:, None]
+    V = Vt.T                                                              # ch x rank   (decompose.py:105-106)
+    H = SH                                                                # rank x nw   (decompose.py:108-112)
+    VHr = ctx.matmul_tn(Vt, H).reshape([dim[1], dim[2], dim[0], dim[3]])  # decompose.py:114
+    H = H.reshape([rank, dim[0], dim[3], 1])                              # decompose.py:120-122
+    H = np.transpose(H, [1, 0, 3, 2])
+    origV = V.copy()
+    V = V.reshape((dim[1], 1, dim[2], rank))                              # decompose.py:125-126
+    V = np.transpose(V, [3, 0, 2, 1])
+    b = None
+    if X is not None:                                                     # decompose.py:128-139
+        X = np.ascontiguousarray(X)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        N = X.shape[0]
+        o = H.shape[0]
+        w = dim[3]
+        Xd, Vd = ctx.to_device(X), ctx.to_device(np.ascontiguousarray(Vt))
+        Xvd = ctx.empty(N * rank * w * 8)
+        try:
+            ctx._check(ctx.lib.cp_vh_project(ctx.h, Xd.ptr, _capi.CP_F32 if X.dtype == np.float32 else _capi.CP_F64, N,
+                                             dim[1], dim[2], w, Vd.ptr, rank, Xvd.ptr), "cp_vh_project")
+            Y2 = np.ascontiguousarray(Y, dtype=np.float64).reshape(N, -1)
+            prob = LayerProblem.from_device(ctx, Xvd, _capi.CP_F64, N, rank * w, 1,
+                                            np.zeros((Y2.shape[1], rank * w, 1, 1), dtype=np.float32), ctx.to_device(Y2))
+            try:
+                H2, b = prob.refit_nonlinear(np.ones(rank * w, dtype=bool))
+            finally:
+                prob.Yd.free()
+                prob.free()
+        finally:
+            for bfr in (Xd, Vd, Xvd):
+                bfr.free()
+        H = H2.reshape([o, rank, 1, 3])                                   # decompose.py:137 (w = 3 hard-coded there)
+        reH = np.transpose(H, [1, 0, 2, 3]).reshape([rank, -1])
+        VHr = ctx.matmul_tn(Vt, reH).reshape([dim[1], dim[2], dim[0], dim[3]])
+    VHr = np.transpose(VHr, [2, 0, 1, 3])                                 # decompose.py:141
+    epscheck(V, 2)
+    epscheck(H, 2)
+    epscheck(VHr, 2)
+    if X is not None:
+        return V, H, VHr, b
+    return V, H, VHr
+
+
 def nonlinear_fc(X, Y, copy_X=True, W=None, B=None):
     """ReLU-aware reconstruction (decompose.py:671-685): 30 + 20 alternations of fc_kernel and solve_relu with
     X[N,p] constant; returns (coef_[n, p], intercept_[n]) of the last regression."""

@@ -155,6 +155,21 @@ int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, i
                     const double *Y, int n, const int *iters, const double *lambdas, int n_stage,
                     double *W_out, double *b_out, cp_refit_info *info);
 
+/* ---- f1: VH_decompose (spatial decomposition, lib/decompose.py:85-146) ---------------------------- */
+/* Replaces svd(VH) = scipy.linalg.svd(x, full_matrices=False, lapack_driver='gesvd') (decompose.py:45-47, 100)
+ * together with the truncation of decompose.py:105-112: one-sided Jacobi on the rows of M DEVICE [m, n]
+ * (row-major f64, m <= n, untouched).  Outputs DEVICE: sigma [r] descending, Vt [r, m] (row k = V[:, k], the
+ * k-th left singular vector; sign arbitrary as with LAPACK), SH [r, n] = diag(sigma) H[:r].  *sweeps HOST. */
+int cp_svd_rows(cp_ctx *ctx, const double *M, int m, int n, int r, double *sigma, double *Vt, double *SH,
+                int *sweeps);
+/* Xv[s, r*w + wi] = sum_{ci,hi} X[s,ci,hi,wi] V[(ci,hi), r]: np.tensordot(X, V, [[1,2],[1,2]]) + the transpose and
+ * reshape of decompose.py:131-136.  X DEVICE [N,c,h,w] (x_dtype), Vt DEVICE [rank, c*h], Xv DEVICE [N, rank*w]. */
+int cp_vh_project(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int h, int w, const double *Vt,
+                  int rank, double *Xv);
+/* C[m,n] = A^T B, A DEVICE [k,m], B DEVICE [k,n], C DEVICE [m,n] (row-major f64, any sizes): the small
+ * reconstructions V.dot(H) of decompose.py:114, 139. */
+int cp_matmul_tn(cp_ctx *ctx, const double *A, const double *B, int m, int n, int k, double *C);
+
 /* ---- a3: one whole dictionary() call -------------------------------------------- */
 #define CP_MAX_FITS 64
 typedef struct cp_prune_result {

@@ -297,6 +297,33 @@ def nonlinear_fc_oracle(X, Y, engine="sklearn"):
     return coef, b
 
 
+def vh_decompose_oracle(weights, rank=None, X=None, Y=None, engine="sklearn"):
+    """decompose.py:85-146 restated (scipy gesvd as the reference calls it): V[rank,c,h,1], H[n,rank,1,w],
+    VHr[n,c,h,w] (+ b with X, Y).  Singular-vector signs are LAPACK's."""
+    import scipy.linalg
+    dim = weights.shape
+    VH = np.transpose(weights, [1, 2, 0, 3]).reshape([dim[1] * dim[2], dim[0] * dim[3]])
+    V, s, H = scipy.linalg.svd(VH, full_matrices=False, lapack_driver='gesvd')
+    if rank is None:
+        rank = dim[1] * dim[2]
+    V = V[:, :rank]
+    H = np.diag(s[:rank]).dot(H[:rank, :])
+    VHr = (V.dot(H)).reshape([dim[1], dim[2], dim[0], dim[3]])
+    H = np.transpose(H.reshape([rank, dim[0], dim[3], 1]), [1, 0, 3, 2])
+    origV = V.copy()
+    V = np.transpose(V.reshape((dim[1], 1, dim[2], rank)), [3, 0, 2, 1])
+    b = None
+    if X is not None:
+        Xv = np.transpose(np.tensordot(X, V, [[1, 2], [1, 2]]), [0, 2, 3, 1])
+        N, o = Xv.shape[0], H.shape[0]
+        H, b = nonlinear_fc_oracle(Xv.reshape([N, -1]), Y, engine=engine)
+        H = H.reshape([o, rank, 1, 3])
+        reH = np.transpose(H, [1, 0, 2, 3]).reshape([rank, -1])
+        VHr = (origV.dot(reH)).reshape([dim[1], dim[2], dim[0], dim[3]])
+    VHr = np.transpose(VHr, [2, 0, 1, 3])
+    return (V, H, VHr, b) if X is not None else (V, H, VHr)
+
+
 def dictionary_oracle(X, W2, Y, rank, B2=None, alpha=1e-4, alpha_in=1e-3, rank_tol=.1, rng=None,
                       lasso="sklearn", ls="sklearn", ridge=0.0, log=None, refit="linear"):
     """Restatement of lib/decompose.py:386-634 (live path).

@@ -1,0 +1,42 @@
+"""TEST INFRASTRUCTURE -- golden vectors for VH_decompose / nonlinear_fc from the REAL reference
+(/root/reference/lib/decompose.py:85-146, 671-685), run here in the build container.
+    python oracle/gen_golden_vh.py      ->  tests/golden/v01_vh_svd.npz, v02_vh_refit.npz
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cp_oracle  # noqa: E402
+import ref_loader  # noqa: E402
+from gen_golden import versions  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+CASES = {
+    "v01_vh_svd": dict(layer_id=16, N=64, c=32, n=48, k=3, rank=40, with_x=False),
+    "v02_vh_refit": dict(layer_id=17, N=1500, c=24, n=40, k=3, rank=30, with_x=True),
+}
+
+
+def main():
+    D, _ = ref_loader.load()
+    for name, p in CASES.items():
+        X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+        t0 = time.perf_counter()
+        if p["with_x"]:
+            V, H, VHr, b = D.VH_decompose(W2.astype(np.float64), rank=p["rank"], X=X.astype(np.float64), Y=Y)
+        else:
+            V, H, VHr = D.VH_decompose(W2.astype(np.float64), rank=p["rank"])
+            b = np.zeros(0)
+        dt = time.perf_counter() - t0
+        np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), params=json.dumps(p), versions=json.dumps(versions()), V=V, H=H, VHr=VHr, b=b,
+                            ref_seconds=dt)
+        print("%-14s V%s H%s VHr%s  %.2fs" % (name, V.shape, H.shape, VHr.shape, dt))
+
+
+if __name__ == "__main__":
+    main()

@@ -483,3 +483,53 @@ def test_nonlinear_fc_rejects_rank_deficient_input(ctx):
     X = rs.randn(50, 80)          # N - 1 < p
     with pytest.raises(cpmi355.CpError):
         D.nonlinear_fc(X, rs.randn(50, 4))
+
+
+# ---------------------------------------------------------------------------------------------
+# VH_decompose (spatial decomposition, decompose.py:85-146): device SVD + nonlinear_fc refit
+# ---------------------------------------------------------------------------------------------
+def _align_signs(V, H, Vref):
+    """The reference's singular vectors carry LAPACK's signs, the device's Jacobi's: flip component k of both
+    factors where they disagree (V[k] and H[:, k] may be negated together without changing the model)."""
+    sgn = np.sign(np.sum(V.reshape(V.shape[0], -1) * Vref.reshape(Vref.shape[0], -1), axis=1))
+    sgn[sgn == 0] = 1.0
+    return V * sgn[:, None, None, None], H * sgn[None, :, None, None]
+
+
+def test_svd_rows_matches_numpy(ctx):
+    rs = np.random.RandomState(11)
+    for m, n, r in ((24, 40, 24), (96, 96, 48), (97, 130, 30)):
+        M = rs.randn(m, n) * (0.05 + rs.rand(m, 1))
+        s, Vt, SH = ctx.svd_rows(M, r)
+        U, S, Ht = np.linalg.svd(M, full_matrices=False)
+        assert np.abs(s - S[:r]).max() <= 1e-12 * S[0]
+        sgn = np.sign(np.sum(Vt * U[:, :r].T, axis=1))
+        assert np.abs(Vt * sgn[:, None] - U[:, :r].T).max() <= 1e-9
+        assert np.abs(SH * sgn[:, None] - S[:r, None] * Ht[:r]).max() <= 1e-9 * S[0]
+        assert np.abs(Vt @ Vt.T - np.eye(r)).max() <= 1e-12
+
+
+def test_vh_decompose_matches_reference_golden_svd(ctx):
+    import lib.decompose as D
+    g = np.load(os.path.join(GOLDEN_DIR, "v01_vh_svd.npz"))
+    p = json.loads(str(g["params"]))
+    import cp_oracle
+    _, W2, _, _ = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+    V, H, VHr = D.VH_decompose(W2.astype(np.float64), rank=p["rank"])
+    assert V.shape == g["V"].shape and H.shape == g["H"].shape and VHr.shape == g["VHr"].shape
+    V, H = _align_signs(V, H, g["V"])
+    assert relfro(VHr, g["VHr"]) <= 1e-10
+    assert relfro(V, g["V"]) <= 1e-7 and relfro(H, g["H"]) <= 1e-7
+
+
+def test_vh_decompose_matches_reference_golden_with_refit(ctx):
+    import cp_oracle
+    import lib.decompose as D
+    g = np.load(os.path.join(GOLDEN_DIR, "v02_vh_refit.npz"))
+    p = json.loads(str(g["params"]))
+    X, W2, Y, _ = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+    V, H, VHr, b = D.VH_decompose(W2.astype(np.float64), rank=p["rank"], X=X.astype(np.float64), Y=Y)
+    assert V.shape == g["V"].shape and H.shape == g["H"].shape and VHr.shape == g["VHr"].shape
+    V, H = _align_signs(V, H, g["V"])
+    assert relfro(VHr, g["VHr"]) <= REL_W and relfro(b, g["b"]) <= REL_W
+    assert relfro(V, g["V"]) <= 1e-7 and relfro(H, g["H"]) <= REL_W

@@ -207,3 +207,24 @@ def test_lstsq_min_norm_matches_scipy_gelsd():
         assert relfro(coef, ref.T) <= 1e-10
         assert relfro(b, Y.mean(0) - X.mean(0) @ ref) <= 1e-10
         assert np.abs(coef[:, 3]).max() <= 1e-13   # dead column: (numerically) zero weight
+
+
+# ---- VH_decompose (decompose.py:85-146) ---------------------------------------------------------------
+def _vh_case(name):
+    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    p = json.loads(str(g["params"]))
+    X, W2, Y, _ = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+    return g, p, X.astype(np.float64), W2.astype(np.float64), Y
+
+
+def test_vh_oracle_reproduces_reference_svd_truncation():
+    g, p, X, W2, Y = _vh_case("v01_vh_svd")
+    V, H, VHr = cp_oracle.vh_decompose_oracle(W2, rank=p["rank"])
+    assert np.array_equal(V, g["V"]) and np.array_equal(H, g["H"]) and np.array_equal(VHr, g["VHr"])
+
+
+def test_vh_oracle_reproduces_reference_refit():
+    g, p, X, W2, Y = _vh_case("v02_vh_refit")
+    V, H, VHr, b = cp_oracle.vh_decompose_oracle(W2, rank=p["rank"], X=X, Y=Y)
+    assert np.array_equal(V, g["V"])
+    assert relfro(H, g["H"]) <= 1e-12 and relfro(VHr, g["VHr"]) <= 1e-12 and relfro(b, g["b"]) <= 1e-12
