@@ -79,6 +79,7 @@ SIGNATURES = {
     "cp_svd_rows": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_c_int)]),
     "cp_vh_project": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "cp_matmul_tn": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
+    "cp_itq_iterate": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _vp]),
     "cp_prune_layer": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
                                 _c_dbl, _c_dbl, _c_dbl, _c_dbl, _vp, _c_int, _c_int, _c_dbl, _c_int, _c_dbl,
                                 _vp, _vp, _vp, ctypes.POINTER(PruneResult)]),
@@ -303,6 +304,25 @@ class Context:
             return self.to_host(Cd, (m, n), np.float64)
         finally:
             for bfr in (Ad, Bd, Cd):
+                bfr.free()
+
+    def itq_iterate(self, feature, gt_feature, rank, iters=(30, 20), lambdas=(0.1, 1.0), pinv_cond=1e-6):
+        """The alternations of ITQ_decompose on the device -> (T[n, n], Y_mean[n], U_mean[n]) as host arrays."""
+        F = np.ascontiguousarray(feature, dtype=np.float64)
+        Gt = np.ascontiguousarray(gt_feature, dtype=np.float64)
+        N, n = F.shape
+        it = np.ascontiguousarray(iters, dtype=np.int32)
+        lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+        Fd, Gd = self.to_device(F), self.to_device(Gt)
+        Td, yd, ud = self.empty(n * n * 8), self.empty(n * 8), self.empty(n * 8)
+        try:
+            self._check(self.lib.cp_itq_iterate(self.h, Fd.ptr, Gd.ptr, N, n, int(rank), it.ctypes.data, lam.ctypes.data,
+                                                int(it.shape[0]), float(pinv_cond), Td.ptr, yd.ptr, ud.ptr),
+                        "cp_itq_iterate")
+            return (self.to_host(Td, (n, n), np.float64), self.to_host(yd, (n,), np.float64),
+                    self.to_host(ud, (n,), np.float64))
+        finally:
+            for bfr in (Fd, Gd, Td, yd, ud):
                 bfr.free()
 
     def prune_layer(self, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, alpha_right0, rank, lbound, rbound,

@@ -101,3 +101,26 @@ int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const d
 int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
                         const double *Y, int n, double ridge, double *W_out, double *b_out, cp_refit_info *info,
                         bool host_out);
+
+// one-sided Jacobi SVD (svd_jacobi.hip) with caller-provided scratch -----------------------------------
+// Scratch of one decomposition (device): Wk [me, n], R [me, me], sig [me], rotated [16 ints], order [me ints]
+struct SvdScratch {
+    double *Wk, *R, *sig;
+    int *rotated, *order;
+    static size_t bytes(int m, int n) {
+        const size_t me = size_t(m + (m & 1));
+        return (me * n + me * me + me) * 8 + 64 + me * 4 + 1024;
+    }
+    bool take(cp_ctx *ctx, int m, int n) {
+        const size_t me = size_t(m + (m & 1));
+        Wk = cp_arena_take_t<double>(ctx, me * n);
+        R = cp_arena_take_t<double>(ctx, me * me);
+        sig = cp_arena_take_t<double>(ctx, me);
+        rotated = cp_arena_take_t<int>(ctx, 16);
+        order = cp_arena_take_t<int>(ctx, me);
+        return Wk && R && sig && rotated && order;
+    }
+};
+
+int cp_svd_rows_impl(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
+                     double *SH, int ldsh, SvdScratch &sc, int *sweeps_out);

@@ -927,6 +927,151 @@ extern "C" int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t 
     return CP_OK;
 }
 
+// ---- ITQ_decompose iterations (channel decomposition, lib/decompose.py:163-246) ----------------------------
+namespace {
+
+// G = Y - colmean(Y) (padded [Nr, n_pad]) from the partial column sums; also Z = relu(gt) and the means
+__global__ void __launch_bounds__(RT) k_itq_init(const double *__restrict__ Yf, const double *__restrict__ gt,
+                                                 const double *__restrict__ part, int nparts, int64_t N, int n,
+                                                 int n_pad, double inv_n, double *__restrict__ ymean,
+                                                 double *__restrict__ G, double *__restrict__ Z) {
+    const int64_t r = blockIdx.x;
+    for (int j = threadIdx.x; j < n_pad; j += RT) {
+        double m = 0.0;
+        if (j < n) {
+            for (int b = 0; b < nparts; ++b) m += part[size_t(b) * n_pad + j];
+            m *= inv_n;
+            if (r == 0) ymean[j] = m;
+        }
+        const bool live = r < N && j < n;
+        G[size_t(r) * n_pad + j] = live ? Yf[size_t(r) * n + j] - m : 0.0;
+        Z[size_t(r) * n_pad + j] = live ? fmax(gt[size_t(r) * n + j], 0.0) : 0.0;
+    }
+}
+
+// column sums of an unpadded [N, n] matrix into part[rb][col] (ld n_pad)
+__global__ void __launch_bounds__(RT) k_colsum_plain(const double *__restrict__ Y, int64_t N, int n, int n_pad,
+                                                     int rows_per_block, double *__restrict__ part) {
+    const int col = blockIdx.x * RT + threadIdx.x;
+    if (col >= n) return;
+    const int64_t r0 = int64_t(blockIdx.y) * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    double s = 0;
+    for (int64_t r = r0; r < r1; ++r) s += Y[size_t(r) * n + col];
+    part[size_t(blockIdx.y) * n_pad + col] = s;
+}
+
+// factors of pinv(PG) = sum_{sigma_k > cond sigma_0} v_k v_k^T / sigma_k:  A[k, :] = v_k / sigma_k, B[k, :] = v_k
+__global__ void __launch_bounds__(RT) k_pinv_factors(const double *__restrict__ sigma, const double *__restrict__ Vt, int n,
+                                                     int n_pad, double cond, double *__restrict__ A,
+                                                     double *__restrict__ B) {
+    const int k = blockIdx.x;  // < kp rows (zero beyond n)
+    const bool keep = k < n && sigma[k] > cond * sigma[0];
+    const double inv = keep ? 1.0 / sigma[k] : 0.0;
+    for (int j = threadIdx.x; j < n_pad; j += RT) {
+        const double v = (k < n && j < n) ? Vt[size_t(k) * n + j] : 0.0;
+        A[size_t(k) * n_pad + j] = v * inv;
+        B[size_t(k) * n_pad + j] = keep ? v : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(RT) k_pad_rows(const double *__restrict__ src, int rows, int cols, int ld_src,
+                                                 double *__restrict__ dst, int ld_dst) {
+    const int r = blockIdx.x;
+    for (int col = threadIdx.x; col < ld_dst; col += RT)
+        dst[size_t(r) * ld_dst + col] = (r < rows && col < cols) ? src[size_t(r) * ld_src + col] : 0.0;
+}
+
+}  // namespace
+
+// The 30 + 20 iterations of ITQ_decompose (decompose.py:163-246): feature / gt_feature DEVICE [N, n] f64.
+// Outputs DEVICE: T [n, n] (the last low-rank map, decompose.py:226), ymean [n] (Y_mean), umean [n] (the last U_mean).
+extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *gt_feature, int64_t N, int n, int rank,
+                              const int *iters, const double *lambdas, int n_stage, double pinv_cond, double *T_out,
+                              double *ymean_out, double *umean_out) {
+    if (!ctx || !feature || !gt_feature || !iters || !lambdas || !T_out || !ymean_out || !umean_out) return CP_ERR_ARG;
+    if (N <= 0 || n <= 0 || rank <= 0 || rank > n || n > N || n_stage <= 0)
+        return cp_set_error(ctx, CP_ERR_ARG, "itq: bad sizes (needs 0 < rank <= n <= N)");
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    const int np_ = int(cp_align_up(size_t(n), 128)), rp = int(cp_align_up(size_t(rank), 16));
+    const int kp = int(cp_align_up(size_t(n), 16));
+    const int64_t Nr = int64_t(cp_align_up(size_t(N), 128));
+    const int RB = 64, rows_per_block = int((N + RB - 1) / RB);
+    const size_t big = size_t(Nr) * np_, sq = size_t(np_) * np_;
+    size_t ws = cp_gemm_tn_workspace(ctx, np_, np_, int(Nr), CP_TRI_NONE);
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, int(Nr), np_, np_, CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, np_, int(Nr), np_, CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, int(Nr), np_, rp, CP_TRI_NONE));
+    const size_t need = (8 * big + 6 * sq + size_t(rp) * (np_ + size_t(Nr)) + size_t(RB) * np_ + 4 * size_t(np_) + 2 * size_t(n) * n) * 8 +
+                        SvdScratch::bytes(n, int(Nr)) + ws + (1 << 18);
+    CP_TRY(cp_arena_reserve(ctx, need));
+    double *G = cp_arena_take_t<double>(ctx, big), *GT = cp_arena_take_t<double>(ctx, big);
+    double *P1 = cp_arena_take_t<double>(ctx, big), *UU = cp_arena_take_t<double>(ctx, big);
+    double *Ub = cp_arena_take_t<double>(ctx, big), *Zb = cp_arena_take_t<double>(ctx, big);
+    double *XT = cp_arena_take_t<double>(ctx, big), *Tn = cp_arena_take_t<double>(ctx, big);  // XT [np_, Nr]; Tn / RU [Nr, np_]
+    double *PG = cp_arena_take_t<double>(ctx, sq), *PGi = cp_arena_take_t<double>(ctx, sq);
+    double *M1 = cp_arena_take_t<double>(ctx, sq), *T2 = cp_arena_take_t<double>(ctx, sq);
+    double *FA = cp_arena_take_t<double>(ctx, sq), *FB = cp_arena_take_t<double>(ctx, sq);
+    double *Vtp = cp_arena_take_t<double>(ctx, size_t(rp) * np_), *SHp = cp_arena_take_t<double>(ctx, size_t(rp) * Nr);
+    double *part = cp_arena_take_t<double>(ctx, size_t(RB) * np_);
+    double *ymean = cp_arena_take_t<double>(ctx, np_), *umean = cp_arena_take_t<double>(ctx, np_);
+    double *sigma = cp_arena_take_t<double>(ctx, np_), *Vt = cp_arena_take_t<double>(ctx, size_t(n) * n);
+    double *SHsq = cp_arena_take_t<double>(ctx, size_t(n) * n);
+    SvdScratch sc;
+    if (!G || !GT || !P1 || !UU || !Ub || !Zb || !XT || !Tn || !PG || !PGi || !M1 || !T2 || !FA || !FB || !Vtp || !SHp ||
+        !part || !ymean || !umean || !sigma || !Vt || !SHsq || !sc.take(ctx, n, int(Nr)))
+        return cp_set_error(ctx, CP_ERR_NOMEM, "itq: arena");
+    cp_stage_begin(ctx);
+    const int gy = (n + RT - 1) / RT;
+    // G = Y - Y_mean, Z = relu(gt); G^T; PG = pinv(G^T G); P1 = G PG (= PGGt^T)
+    k_colsum_plain<<<dim3(gy, RB), RT, 0, ctx->stream>>>(feature, N, n, np_, rows_per_block, part);
+    CP_LAUNCH_CHECK(ctx);
+    k_itq_init<<<unsigned(Nr), RT, 0, ctx->stream>>>(feature, gt_feature, part, RB, N, n, np_, 1.0 / double(N), ymean, G, Zb);
+    CP_LAUNCH_CHECK(ctx);
+    k_transpose_2d<<<dim3(unsigned(Nr / 32), np_ / 32), RT, 0, ctx->stream>>>(G, np_, GT, int(Nr));
+    CP_LAUNCH_CHECK(ctx);
+    CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, G, np_, G, np_, 0.0, PG, np_, CP_TRI_NONE));
+    int sweeps = 0;
+    CP_TRY(cp_svd_rows_impl(ctx, PG, np_, n, n, n, sigma, Vt, n, SHsq, n, sc, &sweeps));
+    CP_HIP(ctx, hipMemsetAsync(FA, 0, sq * 8, ctx->stream));
+    CP_HIP(ctx, hipMemsetAsync(FB, 0, sq * 8, ctx->stream));
+    k_pinv_factors<<<kp, RT, 0, ctx->stream>>>(sigma, Vt, n, np_, pinv_cond, FA, FB);
+    CP_LAUNCH_CHECK(ctx);
+    CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, kp, 1.0, FA, np_, FB, np_, 0.0, PGi, np_, CP_TRI_NONE));
+    CP_TRY(cp_gemm_tn_f64(ctx, int(Nr), np_, np_, 1.0, GT, int(Nr), PGi, np_, 0.0, P1, np_, CP_TRI_NONE));
+    // UU = G, U_mean = Y_mean
+    CP_HIP(ctx, hipMemcpyAsync(UU, G, big * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(umean, ymean, size_t(np_) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CP_HIP(ctx, hipMemsetAsync(SHp, 0, size_t(rp) * Nr * 8, ctx->stream));
+    cp_stage_mark(ctx, "itq_setup");
+    for (int st = 0; st < n_stage; ++st)
+        for (int it = 0; it < iters[st]; ++it) {
+            // X = G (PGGt UU), kept as X^T [n, Nr]
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, P1, np_, UU, np_, 0.0, M1, np_, CP_TRI_NONE));
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, int(Nr), np_, 1.0, M1, np_, GT, int(Nr), 0.0, XT, int(Nr), CP_TRI_NONE));
+            // L, sigma, R = svd(X); T = L_r diag(sigma_r) R_r  (rows of X^T: Vt = R_r, SH = sigma_r L_r^T)
+            CP_TRY(cp_svd_rows_impl(ctx, XT, int(Nr), n, int(Nr), rank, sigma, Vt, n, SHp, int(Nr), sc, &sweeps));
+            k_pad_rows<<<rp, RT, 0, ctx->stream>>>(Vt, rank, n, n, Vtp, np_);
+            CP_LAUNCH_CHECK(ctx);
+            CP_TRY(cp_gemm_tn_f64(ctx, int(Nr), np_, rp, 1.0, SHp, int(Nr), Vtp, np_, 0.0, Tn, np_, CP_TRI_NONE));
+            // T = PGGt T (n x n); RU = G T + U_mean; U = solve_relu(RU, Z, lambda); U_mean = mean(U); UU = U - U_mean
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, P1, np_, Tn, np_, 0.0, T2, np_, CP_TRI_NONE));
+            CP_TRY(cp_gemm_tn_f64(ctx, int(Nr), np_, np_, 1.0, GT, int(Nr), T2, np_, 0.0, Tn, np_, CP_TRI_NONE));
+            k_solve_relu<<<unsigned(Nr), RT, 0, ctx->stream>>>(Tn, umean, Zb, lambdas[st], N, n, np_, Ub);
+            CP_LAUNCH_CHECK(ctx);
+            k_colsum_u<<<dim3(gy, RB), RT, 0, ctx->stream>>>(Ub, N, n, np_, rows_per_block, part);
+            CP_LAUNCH_CHECK(ctx);
+            k_center_u<<<unsigned(Nr), RT, 0, ctx->stream>>>(Ub, part, RB, N, n, np_, 1.0 / double(N), umean, UU);
+            CP_LAUNCH_CHECK(ctx);
+        }
+    cp_stage_mark(ctx, "itq_iterations");
+    CP_HIP(ctx, hipMemcpy2DAsync(T_out, size_t(n) * 8, T2, size_t(np_) * 8, size_t(n) * 8, size_t(n), hipMemcpyDeviceToDevice,
+                                 ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(ymean_out, ymean, size_t(n) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(umean_out, umean, size_t(n) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    return CP_OK;
+}
+
 extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
                               const double *Y, int n, double ridge, double *W_out, double *b_out,
                               cp_refit_info *info) {

@@ -105,24 +105,17 @@ __global__ void __launch_bounds__(JT) k_row_norms(const double *__restrict__ Wk,
 
 }  // namespace
 
-// M DEVICE [m, n] row-major f64 (m <= n, untouched).  Outputs DEVICE: sigma [r] descending, Vt [r, m] (row k =
-// k-th left singular vector, i.e. V[:, k]), SH [r, n] = diag(sigma) H[:r] (k-th right singular vector scaled by
-// sigma_k).  r <= m.  sweeps_out HOST (may be NULL).
-extern "C" int cp_svd_rows(cp_ctx *ctx, const double *M, int m, int n, int r, double *sigma, double *Vt, double *SH,
-                           int *sweeps_out) {
-    if (!ctx || !M || !sigma || !Vt || !SH || m <= 0 || n < m || r <= 0 || r > m)
-        return ctx ? cp_set_error(ctx, CP_ERR_ARG, "svd_rows: bad arguments (needs 0 < r <= m <= n)") : CP_ERR_ARG;
-    CP_HIP(ctx, hipSetDevice(ctx->device));
+// M DEVICE [m, n] with row stride ldm (m <= n, untouched) -> sigma [r], Vt [r, m] (row stride ldv), SH [r, n] (row
+// stride ldsh); scratch from the caller (the arena is NOT re-reserved here).
+int cp_svd_rows_impl(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
+                     double *SH, int ldsh, SvdScratch &sc, int *sweeps_out) {
     const int me = m + (m & 1);  // even number of players: an all-zero row plays along if m is odd
-    CP_TRY(cp_arena_reserve(ctx, (size_t(me) * n + size_t(me) * me + size_t(me)) * 8 + size_t(me) * 4 + (1 << 16)));
-    double *Wk = cp_arena_take_t<double>(ctx, size_t(me) * n);
-    double *R = cp_arena_take_t<double>(ctx, size_t(me) * me);
-    double *sig = cp_arena_take_t<double>(ctx, me);
-    int *rotated = cp_arena_take_t<int>(ctx, 16);
-    if (!Wk || !R || !sig || !rotated) return cp_set_error(ctx, CP_ERR_NOMEM, "svd_rows: arena");
+    double *Wk = sc.Wk, *R = sc.R, *sig = sc.sig;
+    int *rotated = sc.rotated;
     CP_TRY(cp_pinned_reserve(ctx, 4096));
     CP_HIP(ctx, hipMemsetAsync(Wk, 0, size_t(me) * n * 8, ctx->stream));
-    CP_HIP(ctx, hipMemcpyAsync(Wk, M, size_t(m) * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CP_HIP(ctx, hipMemcpy2DAsync(Wk, size_t(n) * 8, M, size_t(ldm) * 8, size_t(n) * 8, size_t(m), hipMemcpyDeviceToDevice,
+                                 ctx->stream));
     k_identity<<<me, JT, 0, ctx->stream>>>(R, me);
     CP_LAUNCH_CHECK(ctx);
     int sweeps = 0;
@@ -152,16 +145,28 @@ extern "C" int cp_svd_rows(cp_ctx *ctx, const double *M, int m, int n, int r, do
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hs[x] > hs[y]; });
     std::vector<double> hsorted(r);
     for (int k = 0; k < r; ++k) hsorted[k] = hs[order[k]];
-    int *dorder = reinterpret_cast<int *>(cp_arena_take(ctx, size_t(me) * sizeof(int)));
-    if (!dorder) return cp_set_error(ctx, CP_ERR_NOMEM, "svd_rows: arena");
-    CP_HIP(ctx, hipMemcpyAsync(dorder, order.data(), size_t(r) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    k_take_rows<<<r, JT, 0, ctx->stream>>>(R, me, dorder, m, Vt, m);
+    CP_HIP(ctx, hipMemcpyAsync(sc.order, order.data(), size_t(r) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    k_take_rows<<<r, JT, 0, ctx->stream>>>(R, me, sc.order, m, Vt, ldv);
     CP_LAUNCH_CHECK(ctx);
-    k_take_rows<<<r, JT, 0, ctx->stream>>>(Wk, n, dorder, n, SH, n);
+    k_take_rows<<<r, JT, 0, ctx->stream>>>(Wk, n, sc.order, n, SH, ldsh);
     CP_LAUNCH_CHECK(ctx);
     CP_HIP(ctx, hipMemcpyAsync(sigma, hsorted.data(), size_t(r) * 8, hipMemcpyHostToDevice, ctx->stream));
     CP_HIP(ctx, cp_stream_wait(ctx));
     return CP_OK;
+}
+
+// M DEVICE [m, n] row-major f64 (m <= n, untouched).  Outputs DEVICE: sigma [r] descending, Vt [r, m] (row k =
+// k-th left singular vector, i.e. V[:, k]), SH [r, n] = diag(sigma) H[:r] (k-th right singular vector scaled by
+// sigma_k).  r <= m.  sweeps_out HOST (may be NULL).
+extern "C" int cp_svd_rows(cp_ctx *ctx, const double *M, int m, int n, int r, double *sigma, double *Vt, double *SH,
+                           int *sweeps_out) {
+    if (!ctx || !M || !sigma || !Vt || !SH || m <= 0 || n < m || r <= 0 || r > m)
+        return ctx ? cp_set_error(ctx, CP_ERR_ARG, "svd_rows: bad arguments (needs 0 < r <= m <= n)") : CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    CP_TRY(cp_arena_reserve(ctx, SvdScratch::bytes(m, n) + (1 << 16)));
+    SvdScratch sc;
+    if (!sc.take(ctx, m, n)) return cp_set_error(ctx, CP_ERR_NOMEM, "svd_rows: arena");
+    return cp_svd_rows_impl(ctx, M, n, m, n, r, sigma, Vt, m, SH, n, sc, sweeps_out);
 }
 
 // ---- VH_decompose helpers (lib/decompose.py:85-146) ------------------------------------------------------

@@ -154,6 +154,53 @@ def VH_decompose(weights, rank=None, DEBUG=0, X=None, Y=None):
     return V, H, VHr
 
 
+def ITQ_decompose(feature, gt_feature, weight, rank, bias=None, DEBUG=False, Wr=None):
+    """Channel decomposition of a convolution into rank filters followed by a 1 x 1 (decompose.py:163-319):
+
+        feature, gt_feature [N, n]; weight [n, c, h, w] -> W1 [rank, c, h, w], W2 [n, rank, 1, 1], B [n], W12 [n, c, h, w]
+
+    The 50 alternations (projection, rank-truncated SVD, ReLU-aware update) and the final SVD run on the device
+    (cp_itq_iterate, cp_svd_rows); the weight products go through cp_matmul_tn."""
+    feature = np.asarray(feature)
+    gt_feature = np.asarray(gt_feature)
+    n_ins = feature.shape[0]
+    n_filter_channels = feature.shape[1]
+    assert gt_feature.shape[0] == n_ins
+    assert gt_feature.shape[1] == n_filter_channels
+    ctx = default_context()
+    T, Y_mean, U_mean = ctx.itq_iterate(feature, gt_feature, rank)        # decompose.py:170-246
+    _, Lt, R = ctx.svd_rows(T, rank)                                      # decompose.py:249-252: L = Lt.T, R = diag(s) R
+    L = np.ascontiguousarray(Lt.T)
+    weight = np.asarray(weight)
+    dim = weight.shape
+    assert len(dim) == 4
+    if dim[3] == n_filter_channels:
+        assert False                                                      # decompose.py:286 (dead branch there too)
+    assert dim[0] == n_filter_channels
+    # right = 1 (decompose.py:258): W1 = weight^T-reshaped . L, i.e. (weight as [n, chw])^T L
+    wt_shape = (dim[1], dim[2], dim[3])
+    W1 = ctx.matmul_tn(np.ascontiguousarray(weight, dtype=np.float64).reshape(n_filter_channels, -1), L)   # [chw, rank]
+    if Wr is not None:
+        Wr = np.asarray(Wr)
+        W12 = ctx.matmul_tn(np.ascontiguousarray(Wr, dtype=np.float64).reshape(n_filter_channels, -1), L)
+        w12_shape = (Wr.shape[1], Wr.shape[2], Wr.shape[3])
+    else:
+        W12 = W1
+        w12_shape = wt_shape
+    W1 = np.transpose(W1.reshape(wt_shape + (rank,)), [3, 0, 1, 2])       # decompose.py:278-279
+    W2 = R
+    W12 = ctx.matmul_tn(np.ascontiguousarray(W12.T), W2)                  # decompose.py:293  [chw, n]
+    W2 = W2.T.reshape([n_filter_channels, rank, 1, 1])                    # decompose.py:296-297
+    W12 = np.transpose(W12.reshape(w12_shape + (n_filter_channels,)), [3, 0, 1, 2])
+    B = -ctx.matmul_tn(Y_mean.reshape(-1, 1), T).reshape(-1) + U_mean      # decompose.py:305
+    B = B.T + bias if bias is not None else B.T
+    for arr in (W1, W2, B, W12):
+        epscheck(arr, 2)
+    for arr in (W1, W2, B, W12):
+        epscheck(arr, 4)
+    return W1, W2, B, W12
+
+
 def nonlinear_fc(X, Y, copy_X=True, W=None, B=None):
     """ReLU-aware reconstruction (decompose.py:671-685): 30 + 20 alternations of fc_kernel and solve_relu with
     X[N,p] constant; returns (coef_[n, p], intercept_[n]) of the last regression."""

@@ -170,6 +170,16 @@ int cp_vh_project(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int
  * reconstructions V.dot(H) of decompose.py:114, 139. */
 int cp_matmul_tn(cp_ctx *ctx, const double *A, const double *B, int m, int n, int k, double *C);
 
+/* ---- f2: ITQ_decompose (channel decomposition, lib/decompose.py:163-319) ---------------------------- */
+/* The 30 + 20 alternations of decompose.py:163-246 on the device: G = Y - mean, PGGt = pinv(G^T G, cond) G^T,
+ * then per iteration  X = G (PGGt UU);  T = rank-truncated SVD of X (cp_svd_rows on X^T);  T = PGGt T;
+ * U = solve_relu(G T + U_mean, relu(gt), lambda);  U_mean = mean(U), UU = U - U_mean.  feature / gt_feature
+ * DEVICE [N, n] f64; outputs DEVICE: T [n, n] (decompose.py:226), ymean [n], umean [n] (last U_mean).
+ * pinv_cond = 1e-6 in the reference (scipy.linalg.pinv(x, 1e-6), decompose.py:148-151). */
+int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *gt_feature, int64_t N, int n, int rank,
+                   const int *iters, const double *lambdas, int n_stage, double pinv_cond, double *T_out,
+                   double *ymean_out, double *umean_out);
+
 /* ---- a3: one whole dictionary() call -------------------------------------------- */
 #define CP_MAX_FITS 64
 typedef struct cp_prune_result {

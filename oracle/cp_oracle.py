@@ -324,6 +324,59 @@ def vh_decompose_oracle(weights, rank=None, X=None, Y=None, engine="sklearn"):
     return (V, H, VHr, b) if X is not None else (V, H, VHr)
 
 
+def itq_decompose_oracle(feature, gt_feature, weight, rank, bias=None, Wr=None):
+    """decompose.py:163-319 restated (scipy gesvd, pinv with the 1e-6 relative cut-off): W1, W2, B, W12."""
+    import scipy.linalg
+    svd = lambda x: scipy.linalg.svd(x, full_matrices=False, lapack_driver='gesvd')  # noqa: E731
+    n = feature.shape[1]
+    Y = feature.copy()
+    Z = np.maximum(gt_feature, 0.)
+    Zsq = Z ** 2
+    Y_mean = Y.mean(0)
+    G = Y - Y_mean
+    PG = scipy.linalg.pinv((G.T).dot(G), rtol=1e-6)
+    PGGt = PG.dot(G.T)
+    UU = G.copy()
+    U_mean = Y_mean.copy()
+    T = None
+    for Lambda, its in zip([0.1, 1], [30, 20]):
+        for _ in range(its):
+            X = G.dot(PGGt.dot(UU))
+            L, sigma, R = svd(X)
+            T = L[:, :rank].dot(np.diag(sigma[:rank])).dot(R[:rank, :])
+            T = PGGt.dot(T)
+            RU = G.dot(T)
+            RU += U_mean
+            U0 = np.minimum(RU, 0.)
+            Cost0 = Zsq + Lambda * (U0 - RU) ** 2
+            U1 = np.maximum((Lambda * RU + Z) / (Lambda + 1.), 0.)
+            Cost1 = (U1 - Z) ** 2 + Lambda * (U1 - RU) ** 2
+            U = (Cost0 <= Cost1) * U0 + (Cost0 > Cost1) * U1
+            U_mean = U.mean(0)
+            UU = U - U_mean
+    L, sigma, R = svd(T)
+    L = L[:, :rank]
+    R = np.diag(sigma[:rank]).dot(R[:rank, :])
+    assert weight.shape[0] == n and weight.shape[3] != n
+    wt = np.transpose(weight, [1, 2, 3, 0])
+    W1 = wt.reshape([-1, n]).dot(L)
+    if Wr is not None:
+        Wrt = np.transpose(Wr, [1, 2, 3, 0])
+        W12 = Wrt.reshape([-1, n]).dot(L)
+        shp12 = Wrt.shape[:3]
+    else:
+        W12 = W1
+        shp12 = wt.shape[:3]
+    W1 = np.transpose(W1.reshape(wt.shape[:3] + (rank,)), [3, 0, 1, 2])
+    W2 = R
+    W12 = W12.dot(W2)
+    W2 = W2.T.reshape([n, rank, 1, 1])
+    W12 = np.transpose(W12.reshape(shp12 + (n,)), [3, 0, 1, 2])
+    B = -Y_mean.dot(T) + U_mean
+    B = B.T + bias if bias is not None else B.T
+    return W1, W2, B, W12
+
+
 def dictionary_oracle(X, W2, Y, rank, B2=None, alpha=1e-4, alpha_in=1e-3, rank_tol=.1, rng=None,
                       lasso="sklearn", ls="sklearn", ridge=0.0, log=None, refit="linear"):
     """Restatement of lib/decompose.py:386-634 (live path).

@@ -16,6 +16,9 @@ import ref_loader  # noqa: E402
 from gen_golden import versions  # noqa: E402
 
 GOLDEN_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+ITQ_CASES = {
+    "i01_itq": dict(layer_id=18, N=1500, c=24, n=40, k=3, rank=20, noise=0.05),
+}
 CASES = {
     "v01_vh_svd": dict(layer_id=16, N=64, c=32, n=48, k=3, rank=40, with_x=False),
     "v02_vh_refit": dict(layer_id=17, N=1500, c=24, n=40, k=3, rank=30, with_x=True),
@@ -36,6 +39,15 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), params=json.dumps(p), versions=json.dumps(versions()), V=V, H=H, VHr=VHr, b=b,
                             ref_seconds=dt)
         print("%-14s V%s H%s VHr%s  %.2fs" % (name, V.shape, H.shape, VHr.shape, dt))
+    for name, p in ITQ_CASES.items():
+        X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+        feature = Y + p["noise"] * np.random.RandomState(p["layer_id"]).randn(*Y.shape)   # the approximated layer's output
+        t0 = time.perf_counter()
+        W1, Wo2, B, W12 = D.ITQ_decompose(feature, Y, W2.astype(np.float64), p["rank"], bias=B2.astype(np.float64))
+        dt = time.perf_counter() - t0
+        np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), params=json.dumps(p), versions=json.dumps(versions()),
+                            W1=W1, W2=Wo2, B=B, W12=W12, ref_seconds=dt)
+        print("%-14s W1%s W2%s B%s W12%s  %.2fs" % (name, W1.shape, Wo2.shape, B.shape, W12.shape, dt))
 
 
 if __name__ == "__main__":

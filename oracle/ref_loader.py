@@ -53,6 +53,19 @@ def _install_stubs():
         m = types.ModuleType("termcolor")
         m.colored = lambda s, *a, **k: s
         sys.modules["termcolor"] = m
+    # The reference calls scipy.linalg.pinv(x, 1e-6) (decompose.py:151) -- the second positional argument was
+    # `cond` (singular values below cond * largest are dropped) in the SciPy it was written for and is gone from the
+    # installed one; `rtol` has exactly that meaning.  Only ITQ_decompose uses it.
+    import scipy.linalg as sl
+    if not getattr(sl.pinv, "_cp_shim", False):
+        _orig_pinv = sl.pinv
+
+        def pinv(a, cond=None, rcond=None, **kw):
+            c = cond if cond is not None else rcond
+            return _orig_pinv(a, rtol=c, **kw) if c is not None else _orig_pinv(a, **kw)
+
+        pinv._cp_shim = True
+        sl.pinv = pinv
     import sklearn.linear_model as lm
 
     if not hasattr(lm, "RandomizedLasso"):

@@ -533,3 +533,23 @@ def test_vh_decompose_matches_reference_golden_with_refit(ctx):
     V, H = _align_signs(V, H, g["V"])
     assert relfro(VHr, g["VHr"]) <= REL_W and relfro(b, g["b"]) <= REL_W
     assert relfro(V, g["V"]) <= 1e-7 and relfro(H, g["H"]) <= REL_W
+
+
+# ---------------------------------------------------------------------------------------------
+# ITQ_decompose (channel decomposition, decompose.py:163-319)
+# ---------------------------------------------------------------------------------------------
+def test_itq_decompose_matches_reference_golden(ctx):
+    import cp_oracle
+    import lib.decompose as D
+    g = np.load(os.path.join(GOLDEN_DIR, "i01_itq.npz"))
+    p = json.loads(str(g["params"]))
+    X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+    feature = Y + p["noise"] * np.random.RandomState(p["layer_id"]).randn(*Y.shape)
+    W1, Wo2, B, W12 = D.ITQ_decompose(feature, Y, W2.astype(np.float64), p["rank"], bias=B2.astype(np.float64))
+    assert W1.shape == g["W1"].shape and Wo2.shape == g["W2"].shape and W12.shape == g["W12"].shape
+    # the two factors share LAPACK's / Jacobi's arbitrary sign per component; their product and the bias do not
+    sgn = np.sign(np.sum(W1.reshape(W1.shape[0], -1) * g["W1"].reshape(W1.shape[0], -1), axis=1))
+    sgn[sgn == 0] = 1.0
+    assert relfro(W12, g["W12"]) <= REL_W and relfro(B, g["B"]) <= REL_W
+    assert relfro(W1 * sgn[:, None, None, None], g["W1"]) <= REL_W
+    assert relfro(Wo2 * sgn[None, :, None, None], g["W2"]) <= REL_W

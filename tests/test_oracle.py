@@ -228,3 +228,14 @@ def test_vh_oracle_reproduces_reference_refit():
     V, H, VHr, b = cp_oracle.vh_decompose_oracle(W2, rank=p["rank"], X=X, Y=Y)
     assert np.array_equal(V, g["V"])
     assert relfro(H, g["H"]) <= 1e-12 and relfro(VHr, g["VHr"]) <= 1e-12 and relfro(b, g["b"]) <= 1e-12
+
+
+def test_itq_oracle_reproduces_reference():
+    g = np.load(os.path.join(GOLDEN_DIR, "i01_itq.npz"))
+    p = json.loads(str(g["params"]))
+    X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+    feature = Y + p["noise"] * np.random.RandomState(p["layer_id"]).randn(*Y.shape)
+    W1, Wo2, B, W12 = cp_oracle.itq_decompose_oracle(feature, Y, W2.astype(np.float64), p["rank"],
+                                                     bias=B2.astype(np.float64))
+    for a, name in ((W1, "W1"), (Wo2, "W2"), (B, "B"), (W12, "W12")):
+        assert a.shape == g[name].shape and relfro(a, g[name]) <= 1e-10, name
