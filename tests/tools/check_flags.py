@@ -1,6 +1,6 @@
 """Run every golden case through the drop-in dictionary() with a given CD flag set; report mask/fit-log parity."""
 import glob, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import cp_oracle, cpmi355

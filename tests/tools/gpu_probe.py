@@ -1,6 +1,6 @@
 """Quick on-GPU probe: MFMA f64 / HBM copy ceilings, CD step latency, per-stage times."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import cpmi355, cp_oracle

@@ -1,6 +1,6 @@
 """Wall-clock split of one resident prune_layer() call (host view) next to the device stage times."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, cpmi355, cp_oracle
 ctx = cpmi355.Context(0)

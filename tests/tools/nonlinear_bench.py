@@ -1,6 +1,6 @@
 """nonlinear_fc at BASELINE size (N=5000, 131 kept channels x 9, n=256): device time vs the numpy restatement."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, cpmi355, cp_oracle
 ctx = cpmi355.Context(0)

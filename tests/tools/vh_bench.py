@@ -1,7 +1,7 @@
 """VH_decompose at VGG conv3 size (weights 256x256x3x3, rank 128, N=5000 sampled patches): device path vs the
 numpy/scipy restatement of the reference on this box's host."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, cp_oracle
 import lib.decompose as D
