@@ -51,6 +51,9 @@ CASES = {
     # refit variants of dictionary(): ReLU-aware nonlinear_fc (decompose.py:615-617, 671-685) and nofc (618-620)
     "s14_nonlinear_fc": dict(layer_id=14, N=1200, c=24, n=20, k=3, rank=12, nonlinear_fc=1),
     "s15_nofc": dict(layer_id=15, N=400, c=32, n=24, k=3, rank=16, nofc=1),
+    # larger kernels (k*k = 25 and 49 taps per channel)
+    "s16_k5": dict(layer_id=19, N=900, c=16, n=12, k=5, rank=8),
+    "s17_k7": dict(layer_id=20, N=1200, c=12, n=10, k=7, rank=6),
     "L01_conv2_2_conv3_1": dict(layer_id=31, N=5000, c=128, n=256, k=3, rank=64, large=True),
     "L02_conv3_1_conv3_2": dict(layer_id=32, N=5000, c=256, n=256, k=3, rank=128, large=True),
     "L03_conv3_2_conv3_3": dict(layer_id=33, N=5000, c=256, n=256, k=3, rank=128, large=True),
