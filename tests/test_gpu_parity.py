@@ -317,17 +317,18 @@ def test_dictionary_matches_reference_golden_full_size(ctx, name):
 
 
 def test_f32_and_f64_storage_agree(ctx):
-    """X handed over as float32 (exactly representable) or float64 gives the same result."""
+    """X / W2 handed over as float32 (exactly representable) or float64 give bit-identical results."""
     import cp_oracle
     from cpmi355 import LayerProblem, prune_layer
     X, W2, Y, B2 = cp_oracle.synth_layer(2, 600, 64, 48, 3)
     outs = []
-    for dt in (np.float32, np.float64):
-        prob = LayerProblem(ctx, X.astype(dt), W2, Y)
+    for dt, wdt in ((np.float32, np.float32), (np.float64, np.float32), (np.float32, np.float64), (np.float64, np.float64)):
+        prob = LayerProblem(ctx, X.astype(dt), W2.astype(wdt), Y)
         outs.append(prune_layer(prob, 32, 1e-3, rng=np.random.RandomState(99)))
         prob.free()
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0])
+        assert np.array_equal(outs[0][1], o[1]) and np.array_equal(outs[0][2], o[2])
 
 
 def test_run_to_run_reproducible(ctx):
