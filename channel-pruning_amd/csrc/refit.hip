@@ -146,7 +146,10 @@ typedef double v4f64c __attribute__((ext_vector_type(4)));
 constexpr int PNB = 16, NPAN = NB / PNB, DLD = 136;
 constexpr int PT = 512;  // threads of the diagonal-block kernel (8 waves)
 
-__device__ unsigned long long g_potrf_debug[8];  // phase cycle counters of the last diagonal-block kernel
+#ifndef CP_POTRF_TIMERS
+#define CP_POTRF_TIMERS 0
+#endif
+__device__ unsigned long long g_potrf_debug[8];  // phase cycle counters of the last diagonal-block kernel (timers on)
 
 __device__ __forceinline__ double read_lane_c(double v, int lane) {  // lane: compile-time constant after unrolling
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -249,9 +252,15 @@ __global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout
     }
     if (tid < NB) dref[tid] = dg0[blk * NB + tid];
     __syncthreads();
+    // phase timers (tests/tools/potrf_phases.py): compiled in only with -DCP_POTRF_TIMERS=1 -- every s_memtime
+    // drains the wave's outstanding LDS / scalar traffic first
+#if CP_POTRF_TIMERS
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
 #define CP_PH(i) { const unsigned long long tn_ = __builtin_readcyclecounter(); tph[i] += tn_ - tlast; tlast = tn_; }
+#else
+#define CP_PH(i)
+#endif
     CP_PH(0)
 
     for (int p = 0; p < NPAN; ++p) {
@@ -400,7 +409,9 @@ __global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // TI_b is complete
+#if CP_POTRF_TIMERS
         for (int i = 0; i < 8; ++i) g_potrf_debug[i] = tph[i];
+#endif
     }
 }
 
