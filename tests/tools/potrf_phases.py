@@ -1,5 +1,5 @@
 """Phase cycle counters of the Cholesky diagonal-block kernel.  Needs a library built with the timers compiled in:
-   make -C channel-pruning_amd/csrc clean all CXXFLAGS+=-DCP_POTRF_TIMERS=1   (they are off by default)"""
+   touch channel-pruning_amd/csrc/refit.hip; make -C channel-pruning_amd/csrc FLAGS_refit=-DCP_POTRF_TIMERS=1   (off by default)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
