@@ -40,3 +40,28 @@ def test_missing_gpu_fails_loudly():
         pytest.skip("a GPU is visible here")
     with pytest.raises(capi.CpError):
         capi.Context(0)
+
+
+def test_header_is_valid_c99_and_links_from_plain_c(tmp_path):
+    """include/cpmi355.h compiles as C99 and a plain C program links against libcpmi355.so and calls the
+    entry points that need no GPU (what a cgo / JNI style binding would do)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "channel-pruning_amd", "cpmi355")
+    if not os.path.isfile(os.path.join(lib_dir, "libcpmi355.so")):
+        pytest.skip("library not built")
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "cpmi355.h"\n'
+                   'int main(void) {\n'
+                   '  if (cp_version() != CP_VERSION) return 1;\n'
+                   '  if (strlen(cp_strerror(CP_ERR_NODEVICE)) == 0) return 2;\n'
+                   '  if (cp_ctx_destroy(0) != CP_OK) return 3;\n'
+                   '  printf("ok %d\\n", cp_version());\n  return 0;\n}\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                           "-L", lib_dir, "-lcpmi355", "-Wl,-rpath," + lib_dir, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
