@@ -3,6 +3,8 @@
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
