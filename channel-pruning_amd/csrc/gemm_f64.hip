@@ -78,8 +78,9 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     constexpr int WROWS = NTH / 128;        // wave rows (2 or 4)
     constexpr int WTM = TM / WROWS;         // wave tile rows
     constexpr int FRM = WTM / 16, FRN = WT / 16;  // MFMA tiles per wave (rows, cols)
-    __shared__ __attribute__((aligned(16))) double As[BK * TLD];
-    __shared__ __attribute__((aligned(16))) double Bs[BK * TLD];
+    // two LDS stages: stage kt+1 is written while stage kt is being read, one barrier per k-stage
+    __shared__ __attribute__((aligned(16))) double As2[2][BK * TLD];
+    __shared__ __attribute__((aligned(16))) double Bs2[2][BK * TLD];
 
     const int tid = threadIdx.x;
     int tile, z;
@@ -124,14 +125,20 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
 #pragma unroll
         for (int j = 0; j < FRN; ++j) acc[i][j] = v4f64{0., 0., 0., 0.};
 
-    if (nk > 0) load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    auto stage_write = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            *reinterpret_cast<double2 *>(&As[(lrow + RPP * i) * TLD + lcol]) = ar[i];
-            *reinterpret_cast<double2 *>(&Bs[(lrow + RPP * i) * TLD + lcol]) = br[i];
+            *reinterpret_cast<double2 *>(&As2[buf][(lrow + RPP * i) * TLD + lcol]) = ar[i];
+            *reinterpret_cast<double2 *>(&Bs2[buf][(lrow + RPP * i) * TLD + lcol]) = br[i];
         }
-        __syncthreads();
+    };
+    if (nk > 0) {
+        load_tile(0);
+        stage_write(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const double *As = As2[kt & 1], *Bs = Bs2[kt & 1];
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
@@ -146,6 +153,7 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
                 for (int j = 0; j < FRN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (kt + 1 < nk) stage_write((kt + 1) & 1);  // the other buffer: its readers passed the previous barrier
         __syncthreads();
     }
 
