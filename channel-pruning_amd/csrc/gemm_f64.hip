@@ -104,14 +104,17 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     const int lrow = tid / TPR, lcol = (tid % TPR) * 2;
     const double *Ag = A + size_t(k0 + lrow) * lda + m0 + lcol;
     const double *Bg = B + size_t(k0 + lrow) * ldb + n0 + lcol;
-    double2 ar[NPASS], br[NPASS];
+    // native 2-vectors (HIP's double2 is a struct with unions: the staging arrays then stay in scratch memory and every
+    // prefetched tile makes a round trip through it, with the global-load latency exposed in every k-stage)
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    v2f64 ar[NPASS], br[NPASS];
     auto load_tile = [&](int kt) {
         const double *a = Ag + size_t(kt) * BK * lda;
         const double *b = Bg + size_t(kt) * BK * ldb;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            ar[i] = *reinterpret_cast<const double2 *>(a + size_t(RPP * i) * lda);
-            br[i] = *reinterpret_cast<const double2 *>(b + size_t(RPP * i) * ldb);
+            ar[i] = *reinterpret_cast<const v2f64 *>(a + size_t(RPP * i) * lda);
+            br[i] = *reinterpret_cast<const v2f64 *>(b + size_t(RPP * i) * ldb);
         }
     };
 
@@ -128,8 +131,8 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     auto stage_write = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            *reinterpret_cast<double2 *>(&As2[buf][(lrow + RPP * i) * TLD + lcol]) = ar[i];
-            *reinterpret_cast<double2 *>(&Bs2[buf][(lrow + RPP * i) * TLD + lcol]) = br[i];
+            *reinterpret_cast<v2f64 *>(&As2[buf][(lrow + RPP * i) * TLD + lcol]) = ar[i];
+            *reinterpret_cast<v2f64 *>(&Bs2[buf][(lrow + RPP * i) * TLD + lcol]) = br[i];
         }
     };
     if (nk > 0) {
