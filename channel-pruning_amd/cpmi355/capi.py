@@ -74,6 +74,11 @@ SIGNATURES = {
                                        ctypes.POINTER(_c_dbl), _vp, _vp]),
     "cp_lstsq_refit": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _c_dbl, _vp, _vp,
                                 ctypes.POINTER(RefitInfo)]),
+    "cp_refit_shard_layout": (_c_int, [_c_int, _c_int, _c_int, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
+    "cp_refit_shard_sums": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _vp]),
+    "cp_refit_shard_gram": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _c_i64, _vp, _vp]),
+    "cp_refit_shard_solve": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_i64, _c_dbl, _vp, _vp, _vp, _vp,
+                                      ctypes.POINTER(RefitInfo)]),
     "cp_nonlinear_fc": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp, _vp,
                                  ctypes.POINTER(RefitInfo)]),
     "cp_svd_rows": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_c_int)]),
@@ -104,6 +109,12 @@ def load():
         # queues several streams share one, and a multi-millisecond single-wave CD kernel then holds up
         # every kernel queued behind it; has to be in the environment before the HIP runtime starts.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+        # torch ships its own libamdhip64 / libhsa-runtime64.  Whichever HIP runtime enters the process first serves
+        # both; torch cannot initialise on the system one ("No HIP GPUs are available"), this library runs equally
+        # fast on either (measured).  So a process that also uses torch.cuda (cpmi355.shard's row-sharded path,
+        # bench.py --gpus > 1) has to import torch BEFORE the first Context; CP_PRELOAD_TORCH=1 does it here.
+        if os.environ.get("CP_PRELOAD_TORCH", "") == "1":
+            import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
@@ -261,6 +272,31 @@ class Context:
         self._check(self.lib.cp_lstsq_refit(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), mask.ctypes.data,
                                             _ptr(Y), int(n), float(ridge), _ptr(W_out), _ptr(b_out),
                                             ctypes.byref(info)), "cp_lstsq_refit")
+        return info
+
+    # -- sample-sharded refit: three calls, the caller all-reduces `sums` and `gram` in between ---------
+    def refit_shard_layout(self, kept, kk, n):
+        a, b = _c_i64(), _c_i64()
+        self._check(self.lib.cp_refit_shard_layout(int(kept), int(kk), int(n), ctypes.byref(a), ctypes.byref(b)),
+                    "cp_refit_shard_layout")
+        return a.value, b.value
+
+    def refit_shard_sums(self, X, x_dtype, N_local, c, kk, mask, Y, n, sums):
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self.lib.cp_refit_shard_sums(self.h, _ptr(X), x_dtype, int(N_local), int(c), int(kk),
+                                                 mask.ctypes.data, _ptr(Y), int(n), _ptr(sums)), "cp_refit_shard_sums")
+
+    def refit_shard_gram(self, X, x_dtype, N_local, c, kk, mask, Y, n, N_total, sums, gram):
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self.lib.cp_refit_shard_gram(self.h, _ptr(X), x_dtype, int(N_local), int(c), int(kk),
+                                                 mask.ctypes.data, _ptr(Y), int(n), int(N_total), _ptr(sums),
+                                                 _ptr(gram)), "cp_refit_shard_gram")
+
+    def refit_shard_solve(self, kept, kk, n, N_total, ridge, sums, gram, W_out, b_out):
+        info = RefitInfo()
+        self._check(self.lib.cp_refit_shard_solve(self.h, int(kept), int(kk), int(n), int(N_total), float(ridge),
+                                                  _ptr(sums), _ptr(gram), _ptr(W_out), _ptr(b_out),
+                                                  ctypes.byref(info)), "cp_refit_shard_solve")
         return info
 
     def nonlinear_fc(self, X, x_dtype, N, c, kk, mask, Y, n, W_out, b_out, iters=(30, 20), lambdas=(0.1, 1.0)):

@@ -9,6 +9,14 @@ hundred bytes each, plus the reconstructed weights) over torch.distributed -- ba
     assign_layers(costs, world)        longest-processing-time-first assignment
     layer_cost(N, c, n, k, rank)       FLOP model of SURVEY.md section 8d (plus the serial CD term)
     prune_sharded(specs, compute_fn)   run this rank's share, all-gather every result
+
+For the layers that dominate (conv4/conv5 sizes) the ROWS of one layer can be spread over the ranks instead
+("secondary"):
+
+    row_range(N, world, rank)          contiguous balanced row slice of a rank
+    prune_layer_rows(...)              dictionary() with X / Y row-sharded: the S sampled rows are exchanged once
+                                       (a few MB), every rank runs the identical alpha search, the refit's column
+                                       sums and Gram are summed with two all-reduces (RCCL), every rank solves
 """
 import numpy as np
 
@@ -74,3 +82,174 @@ def prune_sharded(specs, compute_fn, dist=None, device=None):
         dist.broadcast(b, src=owner[i])
         results[i] = (masks[i], W.cpu().numpy(), b.cpu().numpy())
     return results
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one layer, rows sharded over the ranks
+# ---------------------------------------------------------------------------------------------------------
+def row_range(N, world, rank):
+    """[lo, hi) of `rank` when N rows are split into `world` contiguous, balanced slices."""
+    base, extra = divmod(int(N), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allreduce_sum(dist, t):
+    """In-place sum over the ranks of a torch tensor.  RCCL ("nccl") reduces device tensors in place over xGMI;
+    with "gloo" (CPU tests, or several ranks on one GPU) a device tensor is staged through the host."""
+    if dist is None or dist.get_world_size() == 1:
+        return t
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    elif not t.is_cuda and dist.get_backend() == "nccl":
+        import torch
+        d = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(d)
+        t.copy_(d.cpu())
+    else:
+        dist.all_reduce(t)
+    if t.is_cuda:
+        import torch
+        torch.cuda.synchronize(t.device)   # the library runs on its own stream
+    return t
+
+
+class RowShardEngine:
+    """The per-rank arithmetic of prune_layer_rows on the GPU (libcpmi355 through capi.Context).
+    tests/test_host_logic.py swaps in a NumPy stand-in with the same methods to exercise the exchange on CPU."""
+
+    def __init__(self, ctx, flags=0):
+        import torch
+        self.ctx, self.flags = ctx, flags
+        self.device = torch.device("cuda", ctx.device)
+        self.fits = []
+        try:
+            torch.cuda.init()
+        except RuntimeError as e:   # the system HIP runtime got into the process first (see capi.load)
+            raise RuntimeError("torch.cuda cannot initialise after libcpmi355 loaded the system HIP runtime: import torch "
+                               "(or set CP_PRELOAD_TORCH=1) before creating the first cpmi355 Context") from e
+
+    def buffer(self, elems):
+        import torch
+        return torch.zeros(int(elems), dtype=torch.float64, device=self.device)
+
+    def select(self, Xs, W2, Ys, rank, alpha_in, rank_tol, rng):
+        """alpha search on the S exchanged rows (identical on every rank) -> (idxs, alpha)"""
+        from .pruner import LayerProblem
+        prob = LayerProblem(self.ctx, Xs, W2, Ys, flags=self.flags)
+        try:
+            prob.lasso_gram(np.arange(Xs.shape[0], dtype=np.int64))
+            alpha = prob.alpha_search(rank, alpha_in, rank_tol, rng, mode="device")
+            self.fits = list(prob.fits)
+            return prob.mask(), alpha
+        finally:
+            prob.free()
+
+    def load_rows(self, X_local, Y_local):
+        from .pruner import _np_dtype_code
+        X_local = np.ascontiguousarray(X_local)
+        if X_local.dtype not in (np.float32, np.float64):
+            X_local = X_local.astype(np.float64)
+        self.x_dtype = _np_dtype_code(X_local)
+        self.N_local, self.c = int(X_local.shape[0]), int(X_local.shape[1])
+        self.kk = int(np.prod(X_local.shape[2:]))
+        self.n = int(Y_local.shape[1])
+        self.Xd = self.ctx.to_device(X_local)
+        self.Yd = self.ctx.to_device(np.ascontiguousarray(Y_local, dtype=np.float64))
+
+    def layout(self, kept):
+        return self.ctx.refit_shard_layout(kept, self.kk, self.n)
+
+    def sums(self, mask, sums):
+        self.ctx.refit_shard_sums(self.Xd, self.x_dtype, self.N_local, self.c, self.kk, mask, self.Yd, self.n, sums)
+
+    def gram(self, mask, N_total, sums, gram):
+        self.ctx.refit_shard_gram(self.Xd, self.x_dtype, self.N_local, self.c, self.kk, mask, self.Yd, self.n, N_total,
+                                  sums, gram)
+
+    def solve(self, kept, N_total, ridge, sums, gram):
+        p = kept * self.kk
+        Wd, bd = self.ctx.empty(self.n * p * 8), self.ctx.empty(self.n * 8)
+        try:
+            self.refit_info = self.ctx.refit_shard_solve(kept, self.kk, self.n, N_total, ridge, sums, gram, Wd, bd)
+            return self.ctx.to_host(Wd, (self.n, p), np.float64), self.ctx.to_host(bd, (self.n,), np.float64)
+        finally:
+            Wd.free()
+            bd.free()
+
+    def free(self):
+        for name in ("Xd", "Yd"):
+            buf = getattr(self, name, None)
+            if buf is not None:
+                buf.free()
+                setattr(self, name, None)
+
+
+def prune_layer_rows(engine, X_local, W2, Y_local, row0, N_total, rank, alpha_in, dist=None, rank_tol=.1, rng=None,
+                     ridge=0.0, alpha_arg=1e-4, timings=None):
+    """dictionary() (lib/decompose.py:386-634) on a layer whose N_total rows are spread over the ranks; this rank
+    holds rows [row0, row0 + len(X_local)).  Every rank must enter with the same RNG state (the reference's draws
+    -- the sample subset, one seed per fit -- are then identical everywhere) and gets the same
+    (idxs, newW2[n, nnz, k, k], newB2, alpha_out) back.
+
+    Exchanges: the S = min(400, N_total // 20) sampled rows of X and Y (each owned by exactly one rank; a sum
+    all-reduce of zero-filled buffers is exact), then the two all-reduces of the refit (column sums, Gram).
+    An engine whose rows are already resident (engine.load_rows called by the caller) is used as it is and not
+    freed.  timings: optional dict, filled with seconds per phase."""
+    import time
+
+    import torch
+    rng = np.random if rng is None else rng
+    X_local = np.asarray(X_local)
+    Y_local = np.asarray(Y_local, dtype=np.float64)
+    W2 = np.asarray(W2)
+    N_local, c = X_local.shape[0], X_local.shape[1]
+    k = X_local.shape[2] if X_local.ndim > 2 else 1
+    n = W2.shape[0]
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + now - t_last[0]
+            t_last[0] = now
+
+    samples = rng.randint(0, N_total, min(400, N_total // 20))               # decompose.py:425
+    if rank == c:                                                             # decompose.py:487-488
+        idxs, alpha = np.array([True] * rank), alpha_arg
+    else:
+        own = (samples >= row0) & (samples < row0 + N_local)
+        Xs = np.zeros((samples.shape[0],) + X_local.shape[1:], dtype=X_local.dtype)
+        Ys = np.zeros((samples.shape[0], n), dtype=np.float64)
+        Xs[own] = X_local[samples[own] - row0]
+        Ys[own] = Y_local[samples[own] - row0]
+        Xs = allreduce_sum(dist, torch.from_numpy(Xs)).numpy()
+        Ys = allreduce_sum(dist, torch.from_numpy(Ys)).numpy()
+        lap("exchange_sampled_rows")
+        idxs, alpha = engine.select(Xs, W2, Ys, rank, alpha_in, rank_tol, rng)
+        lap("alpha_search")
+    kept = int(idxs.sum())
+    mask = idxs.astype(np.uint8)
+    own_rows = getattr(engine, "Xd", None) is None
+    if own_rows:
+        engine.load_rows(X_local, Y_local)
+        lap("upload_rows")
+    try:
+        sums_elems, gram_elems = engine.layout(kept)
+        sums, gram = engine.buffer(sums_elems), engine.buffer(gram_elems)
+        engine.sums(mask, sums)
+        lap("refit_sums")
+        allreduce_sum(dist, sums)
+        lap("allreduce_sums")
+        engine.gram(mask, N_total, sums, gram)
+        lap("refit_gram")
+        allreduce_sum(dist, gram)
+        lap("allreduce_gram")
+        W, b = engine.solve(kept, N_total, ridge, sums, gram)
+        lap("refit_solve")
+    finally:
+        if own_rows:
+            engine.free()
+    return idxs, W.reshape((n, kept, k, k)), b, alpha

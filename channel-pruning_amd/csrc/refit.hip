@@ -599,6 +599,94 @@ extern "C" int cp_debug_potrf_cycles(cp_ctx *ctx, unsigned long long *out8) {
     return CP_OK;
 }
 
+namespace {
+
+// Everything after the normal equations exist: factor, substitute, lay out (W, b); shared by the single-GPU refit
+// and by the sample-sharded one (whose Gram arrives from an all-reduce instead of from this rank's GEMM).
+struct RefitSolve {
+    double *G, *G0, *Lt, *Uf, *Yt, *Rm, *R2, *TI, *TIT, *xmean, *ymean, *dg0, *gmax;
+    int *dinfo;
+    int p, p_pad, n, n_pad, nblk;
+    int64_t N;  // rows behind the Gram (all ranks)
+    double ridge;
+    double *W_out, *b_out;
+    int *info_host;
+    double *b_host, *W_host;
+};
+
+template <class NormalEquations>
+int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal_equations, cp_refit_info *info) {
+    double *const G = rs.G, *const G0 = rs.G0, *const Lt = rs.Lt, *const Uf = rs.Uf, *const Yt = rs.Yt, *const Rm = rs.Rm,
+                 *const R2 = rs.R2, *const TI = rs.TI, *const TIT = rs.TIT, *const xmean = rs.xmean, *const ymean = rs.ymean,
+                 *const dg0 = rs.dg0, *const gmax = rs.gmax, *const W_out = rs.W_out, *const b_out = rs.b_out,
+                 *const b_host = rs.b_host, *const W_host = rs.W_host;
+    int *const dinfo = rs.dinfo, *const info_host = rs.info_host;
+    const int p = rs.p, p_pad = rs.p_pad, n = rs.n, n_pad = rs.n_pad, nblk = rs.nblk;
+    const int64_t N = rs.N;
+    const double ridge = rs.ridge;
+    const size_t g_b = size_t(p_pad) * p_pad * 8, r_b = size_t(p_pad) * n_pad * 8;
+    Chol ch{G, Uf, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
+    int hinfo = 0;
+    bool fallback = (ridge == 0.0) && (N - 1 < p);  // centred X has rank <= N-1
+    auto finalize = [&]() -> int {
+        k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo,
+                                              info_host);
+        CP_LAUNCH_CHECK(ctx);
+        cp_stage_mark(ctx, "refit_finalize");
+        CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
+        hinfo = *info_host;
+        return CP_OK;
+    };
+    if (!fallback) {
+        CP_TRY(normal_equations(G, Rm, true));
+        CP_TRY(chol_factor(ctx, ch, 1e-10));
+        cp_stage_mark(ctx, "refit_cholesky");
+        StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
+        CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin));  // substitutions + coefficient lay-out + intercept in one launch
+        cp_stage_mark(ctx, "refit_solve");
+        CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
+        hinfo = *info_host;                // outputs are overwritten below if a pivot failed
+        if (hinfo != 0) fallback = true;
+    }
+    int rank = p;
+    if (fallback) {
+        // iterated Tikhonov on an untouched Gram G0 and right-hand side R2 (recomputed: this path is rare)
+        double *Wacc = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
+        if (!Wacc) return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena (fallback)");
+        CP_TRY(normal_equations(G0, R2, false));
+        CP_HIP(ctx, hipMemcpyAsync(G, G0, g_b, hipMemcpyDeviceToDevice, ctx->stream));
+        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0, dinfo, nblk + 1);
+        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(chol_factor(ctx, ch, 0.0));
+        CP_HIP(ctx, hipMemsetAsync(Wacc, 0, r_b, ctx->stream));
+        const size_t cnt = size_t(p_pad) * n_pad;
+        const int ab = int(std::min<size_t>((cnt + RT - 1) / RT, size_t(ctx->cu_count) * 8));
+        for (int sweep = 0; sweep < 5; ++sweep) {
+            CP_HIP(ctx, hipMemcpyAsync(Rm, R2, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+            if (sweep > 0)  // Rm = R - G0 W   (G0 symmetric: G0^T W)
+                CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, p_pad, -1.0, G0, p_pad, Wacc, n_pad, 1.0, Rm, n_pad,
+                                      CP_TRI_NONE));
+            CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad));
+            k_axpy<<<ab, RT, 0, ctx->stream>>>(Wacc, Rm, cnt);
+            CP_LAUNCH_CHECK(ctx);
+        }
+        CP_HIP(ctx, hipMemcpyAsync(Rm, Wacc, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+        cp_stage_mark(ctx, "refit_minnorm_fallback");
+        CP_TRY(finalize());
+        if (hinfo != 0)
+            return cp_set_error(ctx, CP_ERR_NUMERIC, "refit: regularised factorisation broke down at column %d",
+                                hinfo - 1);
+        rank = -1;  // not determined on this path
+    }
+    info->p = p;
+    info->rank = rank;
+    info->fallback = fallback ? 1 : 0;
+    info->reserved = 0;
+    return CP_OK;
+}
+
+}  // namespace
+
 // host_out: also leave b (n) and W (n x p) in the context's pinned block at offset 64 (cp_prune_layer)
 int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
                         const double *Y, int n, double ridge, double *W_out, double *b_out, cp_refit_info *info,
@@ -698,64 +786,9 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         return CP_OK;
     };
 
-    Chol ch{G, Uf, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
-    int hinfo = 0;
-    bool fallback = (ridge == 0.0) && (N - 1 < p);  // centred X has rank <= N-1
-    auto finalize = [&]() -> int {
-        k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo,
-                                              info_host);
-        CP_LAUNCH_CHECK(ctx);
-        cp_stage_mark(ctx, "refit_finalize");
-        CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
-        hinfo = *info_host;
-        return CP_OK;
-    };
-    if (!fallback) {
-        CP_TRY(normal_equations(G, Rm, true));
-        CP_TRY(chol_factor(ctx, ch, 1e-10));
-        cp_stage_mark(ctx, "refit_cholesky");
-        StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
-        CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin));  // substitutions + coefficient lay-out + intercept in one launch
-        cp_stage_mark(ctx, "refit_solve");
-        CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
-        hinfo = *info_host;                // outputs are overwritten below if a pivot failed
-        if (hinfo != 0) fallback = true;
-    }
-    int rank = p;
-    if (fallback) {
-        // iterated Tikhonov on an untouched Gram G0 and right-hand side R2 (recomputed: this path is rare)
-        double *Wacc = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
-        if (!Wacc) return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena (fallback)");
-        CP_TRY(normal_equations(G0, R2, false));
-        CP_HIP(ctx, hipMemcpyAsync(G, G0, g_b, hipMemcpyDeviceToDevice, ctx->stream));
-        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0, dinfo, nblk + 1);
-        CP_LAUNCH_CHECK(ctx);
-        CP_TRY(chol_factor(ctx, ch, 0.0));
-        CP_HIP(ctx, hipMemsetAsync(Wacc, 0, r_b, ctx->stream));
-        const size_t cnt = size_t(p_pad) * n_pad;
-        const int ab = int(std::min<size_t>((cnt + RT - 1) / RT, size_t(ctx->cu_count) * 8));
-        for (int sweep = 0; sweep < 5; ++sweep) {
-            CP_HIP(ctx, hipMemcpyAsync(Rm, R2, r_b, hipMemcpyDeviceToDevice, ctx->stream));
-            if (sweep > 0)  // Rm = R - G0 W   (G0 symmetric: G0^T W)
-                CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, p_pad, -1.0, G0, p_pad, Wacc, n_pad, 1.0, Rm, n_pad,
-                                      CP_TRI_NONE));
-            CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad));
-            k_axpy<<<ab, RT, 0, ctx->stream>>>(Wacc, Rm, cnt);
-            CP_LAUNCH_CHECK(ctx);
-        }
-        CP_HIP(ctx, hipMemcpyAsync(Rm, Wacc, r_b, hipMemcpyDeviceToDevice, ctx->stream));
-        cp_stage_mark(ctx, "refit_minnorm_fallback");
-        CP_TRY(finalize());
-        if (hinfo != 0)
-            return cp_set_error(ctx, CP_ERR_NUMERIC, "refit: regularised factorisation broke down at column %d",
-                                hinfo - 1);
-        rank = -1;  // not determined on this path
-    }
-    info->p = p;
-    info->rank = rank;
-    info->fallback = fallback ? 1 : 0;
-    info->reserved = 0;
-    return CP_OK;
+    RefitSolve rs{G, G0, Lt, Uf, Yt, Rm, R2, TI, TIT, xmean, ymean, dg0, gmax, dinfo, p, p_pad, n, n_pad, nblk, N, ridge,
+                  W_out, b_out, info_host, b_host, W_host};
+    return refit_solve_tail(ctx, rs, normal_equations, info);
 }
 
 // ---- nonlinear_fc: ReLU-aware reconstruction (lib/decompose.py:671-685, 51-59) -------------------------------
@@ -1087,4 +1120,170 @@ extern "C" int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
                               const double *Y, int n, double ridge, double *W_out, double *b_out,
                               cp_refit_info *info) {
     return cp_lstsq_refit_impl(ctx, X, x_dtype, N, c, kk, mask, Y, n, ridge, W_out, b_out, info, false);
+}
+
+// ---- sample-sharded refit ("secondary"): rows of X / Y live on several ranks ----------------
+// Three calls with one all-reduce between each pair; the caller owns the exchange buffers (cp_refit_shard_layout)
+// and runs the collectives (torch.distributed / RCCL) on them:
+//   cp_refit_shard_sums   column sums of this rank's rows            -> all-reduce(sum) of sums[p_pad + n_pad]
+//   cp_refit_shard_gram   centre with the GLOBAL means, Xs^T Xs and Xs^T Yc of this rank's rows
+//                                                                    -> all-reduce(sum) of gram[p_pad (p_pad + n_pad)]
+//   cp_refit_shard_solve  the same factor / substitute / lay-out tail as cp_lstsq_refit, on every rank (identical
+//                         inputs after the all-reduce => identical outputs, nothing else to exchange)
+namespace {
+
+__global__ void __launch_bounds__(RT) k_scale_vec(const double *__restrict__ src, double scale, int count,
+                                                  double *__restrict__ dst) {
+    const int i = blockIdx.x * RT + threadIdx.x;
+    if (i < count) dst[i] = src[i] * scale;
+}
+
+struct ShardDims {
+    int kept, p, p_pad, n_pad, nblk;
+    std::vector<int> chan;
+};
+
+int shard_dims(cp_ctx *ctx, int c, int kk, const uint8_t *mask, int n, ShardDims &d) {
+    d.chan.clear();
+    for (int i = 0; i < c; ++i)
+        if (mask[i]) d.chan.push_back(i);
+    d.kept = int(d.chan.size());
+    if (d.kept == 0) return cp_set_error(ctx, CP_ERR_ARG, "refit: empty mask");
+    d.p = d.kept * kk;
+    d.p_pad = int(cp_align_up(size_t(d.p), NB));
+    d.n_pad = int(cp_align_up(size_t(n), 128));
+    d.nblk = d.p_pad / NB;
+    return CP_OK;
+}
+
+}  // namespace
+
+extern "C" int cp_refit_shard_layout(int kept, int kk, int n, int64_t *sums_elems, int64_t *gram_elems) {
+    if (kept <= 0 || kk <= 0 || n <= 0 || !sums_elems || !gram_elems) return CP_ERR_ARG;
+    const int64_t p_pad = int64_t(cp_align_up(size_t(kept) * kk, NB)), n_pad = int64_t(cp_align_up(size_t(n), 128));
+    *sums_elems = p_pad + n_pad;
+    *gram_elems = p_pad * (p_pad + n_pad);
+    return CP_OK;
+}
+
+extern "C" int cp_refit_shard_sums(cp_ctx *ctx, const void *X, int x_dtype, int64_t N_local, int c, int kk,
+                                   const uint8_t *mask, const double *Y, int n, double *sums) {
+    if (!ctx || !X || !mask || !Y || !sums) return CP_ERR_ARG;
+    if (N_local <= 0 || c <= 0 || kk <= 0 || n <= 0) return cp_set_error(ctx, CP_ERR_ARG, "refit shard: bad sizes");
+    if (x_dtype != CP_F32 && x_dtype != CP_F64) return cp_set_error(ctx, CP_ERR_ARG, "refit shard: bad dtype");
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    ShardDims d;
+    CP_TRY(shard_dims(ctx, c, kk, mask, n, d));
+    const int RB = 64;
+    const int rows_per_block = int((N_local + RB - 1) / RB);
+    CP_TRY(cp_arena_reserve(ctx, size_t(RB) * size_t(d.p_pad + d.n_pad) * 8 + size_t(d.kept) * 4 + (1 << 16)));
+    double *part_x = cp_arena_take_t<double>(ctx, size_t(RB) * d.p_pad);
+    double *part_y = cp_arena_take_t<double>(ctx, size_t(RB) * d.n_pad);
+    int *dchan = cp_arena_take_t<int>(ctx, d.kept);
+    if (!part_x || !part_y || !dchan) return cp_set_error(ctx, CP_ERR_NOMEM, "refit shard: arena");
+    CP_HIP(ctx, hipMemcpyAsync(dchan, d.chan.data(), size_t(d.kept) * 4, hipMemcpyHostToDevice, ctx->stream));
+    CP_HIP(ctx, hipMemsetAsync(sums, 0, size_t(d.p_pad + d.n_pad) * 8, ctx->stream));
+    const int gx = (d.p + RT - 1) / RT, gy = (n + RT - 1) / RT;
+    dim3 gs(gx + gy, RB);
+    if (x_dtype == CP_F32)
+        k_colsum_xy<float><<<gs, RT, 0, ctx->stream>>>(static_cast<const float *>(X), Y, N_local, c, kk, n, dchan, d.p, gx,
+                                                       rows_per_block, part_x, d.p_pad, part_y, d.n_pad);
+    else
+        k_colsum_xy<double><<<gs, RT, 0, ctx->stream>>>(static_cast<const double *>(X), Y, N_local, c, kk, n, dchan, d.p,
+                                                        gx, rows_per_block, part_x, d.p_pad, part_y, d.n_pad);
+    CP_LAUNCH_CHECK(ctx);
+    k_mean_finish_xy<<<gx + gy, RT, 0, ctx->stream>>>(part_x, d.p_pad, d.p, part_y, d.n_pad, n, gx, RB, 1.0, sums,
+                                                      sums + d.p_pad);
+    CP_LAUNCH_CHECK(ctx);
+    CP_HIP(ctx, cp_stream_wait(ctx));  // the caller's collective runs on another stream
+    return CP_OK;
+}
+
+extern "C" int cp_refit_shard_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N_local, int c, int kk,
+                                   const uint8_t *mask, const double *Y, int n, int64_t N_total, const double *sums,
+                                   double *gram) {
+    if (!ctx || !X || !mask || !Y || !sums || !gram) return CP_ERR_ARG;
+    if (N_local <= 0 || N_total < N_local || c <= 0 || kk <= 0 || n <= 0)
+        return cp_set_error(ctx, CP_ERR_ARG, "refit shard: bad sizes");
+    if (x_dtype != CP_F32 && x_dtype != CP_F64) return cp_set_error(ctx, CP_ERR_ARG, "refit shard: bad dtype");
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    ShardDims d;
+    CP_TRY(shard_dims(ctx, c, kk, mask, n, d));
+    const int p_pad = d.p_pad, n_pad = d.n_pad;
+    const int64_t N_pad = int64_t(cp_align_up(size_t(N_local), 16));
+    const size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
+                               cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
+    CP_TRY(cp_arena_reserve(ctx, size_t(N_pad) * size_t(p_pad + n_pad) * 8 + size_t(p_pad + n_pad) * 8 +
+                                     size_t(d.kept) * 4 + ws + (1 << 16)));
+    double *Xs = cp_arena_take_t<double>(ctx, size_t(N_pad) * p_pad);
+    double *Yc = cp_arena_take_t<double>(ctx, size_t(N_pad) * n_pad);
+    double *means = cp_arena_take_t<double>(ctx, size_t(p_pad + n_pad));
+    int *dchan = cp_arena_take_t<int>(ctx, d.kept);
+    if (!Xs || !Yc || !means || !dchan) return cp_set_error(ctx, CP_ERR_NOMEM, "refit shard: arena");
+    CP_HIP(ctx, hipMemcpyAsync(dchan, d.chan.data(), size_t(d.kept) * 4, hipMemcpyHostToDevice, ctx->stream));
+    k_scale_vec<<<(p_pad + n_pad + RT - 1) / RT, RT, 0, ctx->stream>>>(sums, 1.0 / double(N_total), p_pad + n_pad, means);
+    CP_LAUNCH_CHECK(ctx);
+    if (x_dtype == CP_F32)
+        k_gather_center_xy<float><<<unsigned(N_pad), RT, 0, ctx->stream>>>(static_cast<const float *>(X), Y, N_local, c, kk,
+                                                                           n, dchan, d.p, p_pad, n_pad, means,
+                                                                           means + p_pad, Xs, Yc);
+    else
+        k_gather_center_xy<double><<<unsigned(N_pad), RT, 0, ctx->stream>>>(static_cast<const double *>(X), Y, N_local, c,
+                                                                            kk, n, dchan, d.p, p_pad, n_pad, means,
+                                                                            means + p_pad, Xs, Yc);
+    CP_LAUNCH_CHECK(ctx);
+    double *Gd = gram, *Rd = gram + size_t(p_pad) * p_pad;
+    ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
+    ctx->gemm_mark = nullptr;
+    CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad, CP_TRI_LOWER_MIRROR));
+    ctx->gemm_tag = CP_GEMM_REFIT_XTY;
+    CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    return CP_OK;
+}
+
+extern "C" int cp_refit_shard_solve(cp_ctx *ctx, int kept, int kk, int n, int64_t N_total, double ridge,
+                                    const double *sums, const double *gram, double *W_out, double *b_out,
+                                    cp_refit_info *info) {
+    if (!ctx || !sums || !gram || !W_out || !b_out || !info) return CP_ERR_ARG;
+    if (kept <= 0 || kk <= 0 || n <= 0 || N_total <= 0 || ridge < 0)
+        return cp_set_error(ctx, CP_ERR_ARG, "refit shard: bad sizes");
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    const int p = kept * kk;
+    const int p_pad = int(cp_align_up(size_t(p), NB)), n_pad = int(cp_align_up(size_t(n), 128));
+    const int nblk = p_pad / NB;
+    const size_t g_b = size_t(p_pad) * p_pad * 8, r_b = size_t(p_pad) * n_pad * 8, ti_b = size_t(nblk) * NB * NB * 8;
+    const size_t ws = cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE);
+    CP_TRY(cp_arena_reserve(ctx, 4 * g_b + 4 * r_b + 2 * ti_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 + ws + (1 << 16)));
+    double *G = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
+    double *G0 = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
+    double *Lt = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
+    double *Uf = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
+    double *Yt = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
+    double *Rm = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
+    double *R2 = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
+    double *TI = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB);
+    double *TIT = cp_arena_take_t<double>(ctx, size_t(nblk) * NB * NB);
+    double *means = cp_arena_take_t<double>(ctx, size_t(p_pad + n_pad));
+    double *dg0 = cp_arena_take_t<double>(ctx, p_pad);
+    double *gmax = cp_arena_take_t<double>(ctx, 8);
+    int *dinfo = cp_arena_take_t<int>(ctx, nblk + 16);
+    if (!G || !G0 || !Lt || !Uf || !Yt || !Rm || !R2 || !TI || !TIT || !means || !dg0 || !gmax || !dinfo)
+        return cp_set_error(ctx, CP_ERR_NOMEM, "refit shard: arena");
+    CP_TRY(cp_pinned_reserve(ctx, 64));
+    int *info_host = reinterpret_cast<int *>(ctx->pinned);
+    cp_stage_begin(ctx);
+    k_scale_vec<<<(p_pad + n_pad + RT - 1) / RT, RT, 0, ctx->stream>>>(sums, 1.0 / double(N_total), p_pad + n_pad, means);
+    CP_LAUNCH_CHECK(ctx);
+    // the "normal equations" of this path: the all-reduced Gram and right-hand side, diagonal prepared as usual
+    auto normal_equations = [&](double *Gd, double *Rd, bool) -> int {
+        CP_HIP(ctx, hipMemcpyAsync(Gd, gram, g_b, hipMemcpyDeviceToDevice, ctx->stream));
+        CP_HIP(ctx, hipMemcpyAsync(Rd, gram + size_t(p_pad) * p_pad, r_b, hipMemcpyDeviceToDevice, ctx->stream));
+        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, nblk + 1);
+        CP_LAUNCH_CHECK(ctx);
+        return CP_OK;
+    };
+    RefitSolve rs{G,  G0, Lt, Uf, Yt, Rm, R2, TI, TIT, means, means + p_pad, dg0, gmax, dinfo, p, p_pad, n, n_pad, nblk,
+                  N_total, ridge, W_out, b_out, info_host, nullptr, nullptr};
+    return refit_solve_tail(ctx, rs, normal_equations, info);
 }

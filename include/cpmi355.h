@@ -144,6 +144,31 @@ int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, in
                    const uint8_t *mask, const double *Y, int n, double ridge, double *W_out,
                    double *b_out, cp_refit_info *info);
 
+/* fc_kernel (lib/decompose.py:636-669) with the ROWS of X / Y spread over several ranks (one process per GPU;
+ * SURVEY.md section 8e "shard N across GPUs for the Gram builds, one all-reduce each").  The library does the
+ * per-rank arithmetic, the caller runs the two sum all-reduces (RCCL via torch.distributed) on buffers it owns:
+ *
+ *   cp_refit_shard_layout(kept, kk, n, &sums_elems, &gram_elems)      sizes (f64 elements) of the two buffers
+ *   cp_refit_shard_sums (.., X_local, N_local, .., sums)              column sums of this rank's rows
+ *       all-reduce(sum) sums[sums_elems]
+ *   cp_refit_shard_gram (.., X_local, N_local, .., N_total, sums, gram)
+ *       centres this rank's rows with the GLOBAL means (what LinearRegression's _preprocess_data does,
+ *       sklearn/linear_model/_base.py:108-205) and writes Xs^T Xs | Xs^T Yc of them
+ *       all-reduce(sum) gram[gram_elems]
+ *   cp_refit_shard_solve(.., N_total, ridge, sums, gram, W_out, b_out, info)
+ *       the factor / substitute / intercept tail of cp_lstsq_refit, run on every rank on identical inputs.
+ *
+ * X_local DEVICE [N_local, c, kk] (x_dtype), Y_local DEVICE [N_local, n] f64, mask HOST uint8[c], sums / gram DEVICE
+ * f64 (written by _sums / _gram, read-only afterwards), W_out / b_out DEVICE as cp_lstsq_refit.  Every call returns
+ * with its stream drained, so the collective may run on any other stream. */
+int cp_refit_shard_layout(int kept, int kk, int n, int64_t *sums_elems, int64_t *gram_elems);
+int cp_refit_shard_sums(cp_ctx *ctx, const void *X, int x_dtype, int64_t N_local, int c, int kk, const uint8_t *mask,
+                        const double *Y, int n, double *sums);
+int cp_refit_shard_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N_local, int c, int kk, const uint8_t *mask,
+                        const double *Y, int n, int64_t N_total, const double *sums, double *gram);
+int cp_refit_shard_solve(cp_ctx *ctx, int kept, int kk, int n, int64_t N_total, double ridge, const double *sums,
+                         const double *gram, double *W_out, double *b_out, cp_refit_info *info);
+
 /* Replaces nonlinear_fc(X[:, idxs].reshape(N, -1), Y) (lib/decompose.py:671-685; the dcfgs.nonlinear_fc
  * branch of dictionary(), decompose.py:615-617): Z = relu(Y), U = Y, then for every stage s (reference: iters =
  * {30, 20}, lambdas = {0.1, 1}) iters[s] times  reg = fc_kernel(X, U);  U = solve_relu(reg.predict(X), Z, lambdas[s])

@@ -149,6 +149,117 @@ def test_sharded_pruning_world_size_2_gloo():
         assert m == r[0].tolist() and abs(sw - np.abs(r[1]).sum()) <= 1e-9 * sw and abs(sb - np.abs(r[2]).sum()) <= 1e-9
 
 
+class _NumpyRowEngine:
+    """CPU stand-in for cpmi355.shard.RowShardEngine (same methods, NumPy/oracle arithmetic, unpadded buffers):
+    lets the world-size-2 gloo test drive the real exchange logic of prune_layer_rows without a GPU."""
+
+    def buffer(self, elems):
+        import torch
+        return torch.zeros(int(elems), dtype=torch.float64)
+
+    def select(self, Xs, W2, Ys, rank, alpha_in, rank_tol, rng):
+        import cp_oracle
+
+        class FirstDrawIsIdentity:      # dictionary_oracle draws its sample subset first: hand it every row
+            def __init__(self):
+                self.first = True
+
+            def randint(self, lo, hi, size=None):
+                if self.first:
+                    self.first = False
+                    return np.arange(Xs.shape[0])
+                return rng.randint(lo, hi, size)
+
+        out = cp_oracle.dictionary_oracle(Xs.astype(np.float64), W2, Ys, rank, alpha_in=alpha_in, rank_tol=rank_tol,
+                                          rng=FirstDrawIsIdentity(), lasso="c_gram", refit="none")
+        return out[0], out[3]
+
+    def load_rows(self, X_local, Y_local):
+        self.X = X_local.reshape(X_local.shape[0], X_local.shape[1], -1).astype(np.float64)
+        self.Y = Y_local
+        self.kk, self.n = self.X.shape[2], Y_local.shape[1]
+
+    def layout(self, kept):
+        p = kept * self.kk
+        return p + self.n, p * (p + self.n)
+
+    def _cols(self, mask):
+        return self.X[:, mask.astype(bool)].reshape(self.X.shape[0], -1)
+
+    def sums(self, mask, sums):
+        sums[:] = __import__("torch").from_numpy(np.concatenate([self._cols(mask).sum(0), self.Y.sum(0)]))
+
+    def gram(self, mask, N_total, sums, gram):
+        import torch
+        Xk = self._cols(mask)
+        p = Xk.shape[1]
+        m = sums.numpy() / N_total
+        Xc, Yc = Xk - m[:p], self.Y - m[p:]
+        gram[:] = torch.from_numpy(np.concatenate([(Xc.T @ Xc).ravel(), (Xc.T @ Yc).ravel()]))
+
+    def solve(self, kept, N_total, ridge, sums, gram):
+        p = kept * self.kk
+        g, m = gram.numpy(), sums.numpy() / N_total
+        G, R = g[:p * p].reshape(p, p), g[p * p:].reshape(p, self.n)
+        W = np.linalg.lstsq(G + ridge * np.eye(p), R, rcond=None)[0].T
+        return W, m[p:] - W @ m[:p]
+
+    def free(self):
+        pass
+
+
+def _row_shard_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cp_oracle
+    from cpmi355.shard import prune_layer_rows, row_range
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    for lid, (N, c, n, k, r) in enumerate([(600, 16, 12, 3, 8), (500, 24, 16, 1, 10), (400, 12, 12, 3, 12)], start=1):
+        X, W2, Y, B2 = cp_oracle.synth_layer(lid, N, c, n, k)
+        lo, hi = row_range(N, world, rank)
+        rng = np.random.RandomState(1234 + lid)
+        idxs, W, b, alpha = prune_layer_rows(_NumpyRowEngine(), X[lo:hi], W2, Y[lo:hi], lo, N, r, 1e-3, dist=dist,
+                                             rng=rng)
+        out.append((idxs.tolist(), W, b, alpha, int(rng.randint(0, 2147483647))))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_row_sharded_layer_world_size_2_gloo():
+    """prune_layer_rows with the rows of each layer split over two ranks: the sampled-row exchange and the two
+    all-reduces reproduce the single-process result (mask, alpha and RNG stream exactly; W, b to 1e-9) on both
+    ranks.  The arithmetic is the NumPy stand-in; the GPU engine is covered by tests/test_gpu_rowshard.py."""
+    import multiprocessing as mp
+    import cp_oracle
+    from cpmi355.shard import row_range
+    assert [row_range(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_row_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for lid, (N, c, n, k, r) in enumerate([(600, 16, 12, 3, 8), (500, 24, 16, 1, 10), (400, 12, 12, 3, 12)], start=1):
+        X, W2, Y, B2 = cp_oracle.synth_layer(lid, N, c, n, k)
+        rng = np.random.RandomState(1234 + lid)
+        ref = cp_oracle.dictionary_oracle(X.astype(np.float64), W2, Y, r, B2, rng=rng, lasso="c_gram", ls="numpy")
+        nxt = int(rng.randint(0, 2147483647))
+        for rank in range(2):
+            idxs, W, b, alpha, rng_next = got[rank][lid - 1]
+            assert idxs == ref[0].tolist() and rng_next == nxt
+            assert r == c or alpha == ref[3]
+            assert np.linalg.norm(W - ref[1]) <= 1e-9 * np.linalg.norm(ref[1])
+            assert np.linalg.norm(b - ref[2]) <= 1e-9 * max(1.0, np.linalg.norm(ref[2]))
+
+
 def test_alpha_search_rng_rewind_matches_reference_consumption():
     """The device-mode search pre-draws seeds, then rewinds and re-draws exactly F of them: the
     stream position afterwards must equal 1 + F draws (what the reference consumes)."""
