@@ -13,11 +13,16 @@ names, argument meaning and return contracts:
     Net.R3()                           the VGG "3C" driver loop, pruning step  net.py:1292-1471
     Net.pruning_kernel / param accessors used by the above
 
-The spatial (VH) and channel (ITQ) decompositions that the reference's R3 interleaves with the
-pruning step (net.py:1351-1404) are "next" rows of the scope table and are not performed here:
-R3 runs the pruning step of every (producer, consumer) pair the reference prunes, in the same
-order, with the same kept-channel request d_c = max(int(c / 1.15), rank) (net.py:1327,1346-1349).
+``Net.R3()`` runs the whole "3C" loop of the reference (net.py:1292-1471) -- spatial decomposition (VH_decompose),
+channel decomposition (ITQ_decompose), channel pruning (dictionary) per conv, in that order -- when the provider is
+LIVE, i.e. takes ``(batch, net)`` and computes the blobs from the net's CURRENT weights (the reference re-runs the
+Caffe forward on the modified net between the steps).  With a one-argument provider (activations of the original
+network only) it runs the pruning step of every (producer, consumer) pair the reference prunes, in the same order,
+with the same kept-channel request d_c = max(int(c / 1.15), rank) (net.py:1327,1346-1349).  The prototxt surgery
+(insert / set_conv / save_pt) is replaced by ``Net.emit_layers()``: the decomposed network as an ordered list of
+plain layer descriptions.
 """
+import inspect
 import pickle
 from collections import OrderedDict
 
@@ -29,7 +34,7 @@ from cpmi355 import capi as _capi
 from . import cfgs
 from . import decompose as _decompose
 from .cfgs import c as dcfgs
-from .decompose import rel_error
+from .decompose import ITQ_decompose, VH_decompose, rel_error
 from .utils import Timer, underline
 
 
@@ -68,6 +73,11 @@ class Net(object):
         self.selection = dict()
         self.bottom_names = dict((n, [cv.bottom]) for n, cv in self.layers.items())
         self._blob_cache = (None, None)
+        try:    # provider(batch, net): blobs follow the net's current weights (needed by the full 3C loop)
+            self._live = len([p for p in inspect.signature(provider).parameters.values()
+                              if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]) >= 2
+        except (TypeError, ValueError):
+            self._live = False
 
     # ---- accessors with the reference's names (net.py:46-349) --------------------------------
     def ctx(self):
@@ -84,9 +94,11 @@ class Net(object):
 
     def set_param_data(self, name, data):
         self.layers[name].W = np.ascontiguousarray(data, dtype=np.float32)
+        self._blob_cache = (None, None)
 
     def set_param_b(self, name, data):
         self.layers[name].b = np.ascontiguousarray(data, dtype=np.float32)
+        self._blob_cache = (None, None)
 
     def conv_param_pad(self, name):
         return self.layers[name].pad
@@ -100,7 +112,7 @@ class Net(object):
     def forward(self, batch):
         """One provider call per batch (cached: extract_features and extract_XY share it)."""
         if self._blob_cache[0] != batch:
-            self._blob_cache = (batch, self.provider(batch))
+            self._blob_cache = (batch, self.provider(batch, self) if self._live else self.provider(batch))
         return self._blob_cache[1]
 
     # ---- feature sampling (net.py:368-532) -----------------------------------------------------
@@ -247,19 +259,34 @@ class Net(object):
         return idxs, W2[:, idxs], self.param_b_data(Y_name)
 
     # ---- driver (net.py:1292-1471) ------------------------------------------------------------------
-    def R3(self, alldic=None, pooldic=None, rankdic=None):
-        """The channel-pruning step of the reference's "3C" loop over VGG-16.
+    def R3(self, alldic=None, pooldic=None, rankdic=None, decompose=None):
+        """The reference's "3C" loop over VGG-16 (net.py:1292-1471).
 
-        Returns (WPQ, new_pt): WPQ maps (layer, 0) / (layer, 1) to the layer's final compact weights /
-        bias (input channels pruned when it was the consumer, filters pruned when it was the
-        producer); new_pt is the prefix string the
-        reference derives its output prototxt name from ('3C4x' for dic.keep = 3, net.py:1293-1300)."""
+        decompose (default: True with a live provider, else False):
+          True   per conv (from the second on): spatial decomposition (VH_decompose with the ReLU-aware refit of H on
+                 sampled patches), channel decomposition (ITQ_decompose on the features of the modified net), then
+                 channel pruning of its outputs against the next conv -- exactly the reference's order; WPQ gets the
+                 reference's keys: conv_V -> V[rank, c, k, 1]; (conv_H, 0/1) -> W'[d', rank, 1, k], zeros(d');
+                 (conv_P, 0/1) -> P[n, d', 1, 1], B (rows [idxs] once the conv was pruned as a producer).
+          False  the pruning step alone: WPQ maps (layer, 0) / (layer, 1) to the layer's compact weights / bias
+                 (input channels pruned when it was the consumer, filters pruned when it was the producer).
+        Returns (WPQ, new_pt); new_pt is the prefix string the reference derives its output prototxt name from
+        ('3C4x' for dic.keep = 3, net.py:1293-1300)."""
         speed_ratio = dcfgs.dic.keep
         prefix = ('3C' if dcfgs.dic.vh else '2C') + str(int(speed_ratio) + 1) + 'x'
         convs = self.convs
+        if decompose is None:
+            decompose = self._live
+        if decompose and not self._live:
+            raise ValueError("the decomposition steps re-extract features from the MODIFIED network: the provider "
+                             "has to be live, provider(batch, net)")
         self.WPQ = dict()
         self.selection = dict()
+        self._decomposed = bool(decompose)
         self._mem = bool(self._feats_dict)
+        if decompose and not self._mem:
+            raise ValueError("R3 needs the frozen features of the original network: call freeze_images() first "
+                             "(the reference asserts the same through self._mem = True, net.py:1305)")
         end = 5
         if alldic is None:
             alldic = ['conv%d_1' % i for i in range(1, end)] + ['conv%d_2' % i for i in range(3, end)]
@@ -275,13 +302,58 @@ class Net(object):
                     continue
                 rankdic[i] = int(rankdic[i] * 4. / speed_ratio)
         c_ratio = 1.15
+
+        def getX(name):                                                        # net.py:1329-1331
+            x = self.extract_XY(self.bottom_names[name][0], name)
+            k = self.conv_param_kernel_size(name)
+            return np.rollaxis(x.reshape((-1, k, k, x.shape[1])), 3, 1).copy()
+
+        def setConv(c, d):                                                     # net.py:1333-1337
+            if c in self.selection:
+                Wc = self.param_data(c).copy()
+                Wc[:, self.selection[c], :, :] = d
+                self.set_param_data(c, Wc)
+            else:
+                self.set_param_data(c, d)
+
         t = Timer()
         for conv, convnext in zip(convs[1:], convs[2:] + ['pool5']):
+            conv_V, conv_H, conv_P = underline(conv, 'V'), underline(conv, 'H'), underline(conv, 'P')
             W_shape = self.param_shape(conv)
             d_c = int(W_shape[0] / c_ratio)
             rank = rankdic.get(conv, d_c)
+            d_prime = rank
             if d_c < rank:
                 d_c = rank
+            if decompose:
+                # ---- spatial decomposition (net.py:1351-1379) ----
+                t.tic()
+                weights = self.param_data(conv)
+                if conv in self.selection:
+                    weights = weights[:, self.selection[conv], :, :]
+                Y = self._feats_dict[conv] - self.param_b_data(conv)
+                X = getX(conv)
+                if conv in self.selection:
+                    X = X[:, self.selection[conv], :, :]
+                V, H, VHr, b = VH_decompose(weights, rank=rank, DEBUG=True, X=X, Y=Y)
+                self.set_param_b(conv, b)
+                self.WPQ[conv_V] = V
+                setConv(conv, VHr)                        # the net keeps computing with the low-rank k x k weights
+                self.WPQ[(conv_H, 0)] = H
+                self.WPQ[(conv_H, 1)] = self.param_b_data(conv)
+                t.toc('spatial_decomposition')
+                # ---- channel decomposition (net.py:1383-1404) ----
+                t.tic()
+                feats_dict, _ = self.extract_features(names=conv, points_dict=self._points_dict, save=1)
+                W1, W2, B, W12 = ITQ_decompose(feats_dict[conv], self._feats_dict[conv], H, d_prime,
+                                               bias=self.param_b_data(conv), DEBUG=0, Wr=VHr)
+                setConv(conv, W12.copy())
+                self.set_param_b(conv, B.copy())
+                self.WPQ[(conv_H, 0)] = W1.reshape([d_prime, H.shape[1], H.shape[2], H.shape[3]])
+                self.WPQ[(conv_H, 1)] = np.zeros(d_prime)
+                self.WPQ[(conv_P, 0)] = W2.reshape([W2.shape[0], W2.shape[1], 1, 1])
+                self.WPQ[(conv_P, 1)] = B
+                t.toc('channel_decomposition')
             if dcfgs.dic.vh and (conv in alldic or conv in pooldic) and (convnext in self.convs):
                 t.tic()
                 X_name = self.bottom_names[convnext][0] if conv in pooldic else conv
@@ -292,17 +364,61 @@ class Net(object):
                 Wn[:, idxs, ...] = W2
                 self.set_param_data(convnext, Wn)
                 self.set_param_b(convnext, B2)
-                # compact weights: the consumer keeps only the selected input channels ...
-                self.WPQ[(convnext, 0)] = W2.astype(np.float32)
-                self.WPQ[(convnext, 1)] = np.asarray(B2, dtype=np.float32)
-                # ... and the producer only the filters that feed them (net.py:1455-1457); a layer
-                # that was a consumer one iteration earlier is already compact on its input axis
-                Wc = self.WPQ.get((conv, 0), self.param_data(conv))
-                bc = self.WPQ.get((conv, 1), self.param_b_data(conv))
-                self.WPQ[(conv, 0)] = Wc[idxs]
-                self.WPQ[(conv, 1)] = bc[idxs]
+                if decompose:                                                     # net.py:1451-1457
+                    key = conv_P if (conv_P, 0) in self.WPQ else conv_H
+                    self.WPQ[(key, 0)] = self.WPQ[(key, 0)][idxs]
+                    self.WPQ[(key, 1)] = self.WPQ[(key, 1)][idxs]
+                else:
+                    # compact weights: the consumer keeps only the selected input channels ...
+                    self.WPQ[(convnext, 0)] = W2.astype(np.float32)
+                    self.WPQ[(convnext, 1)] = np.asarray(B2, dtype=np.float32)
+                    # ... and the producer only the filters that feed them (net.py:1455-1457); a layer
+                    # that was a consumer one iteration earlier is already compact on its input axis
+                    Wc = self.WPQ.get((conv, 0), self.param_data(conv))
+                    bc = self.WPQ.get((conv, 1), self.param_b_data(conv))
+                    self.WPQ[(conv, 0)] = Wc[idxs]
+                    self.WPQ[(conv, 1)] = bc[idxs]
                 t.toc('channel_pruning')
         return self.WPQ, underline(prefix, 'pruned')
+
+    # ---- what the reference writes into the new prototxt/caffemodel (net.py:1459-1470, 884-911, 967-988) -------
+    def emit_layers(self):
+        """The network after R3 as an ordered list of dicts
+            {name, top, bottom, W float32[n, c, kh, kw], b float32[n] or None, pad (ph, pw), stride (sh, sw)}.
+        A decomposed conv becomes conv_V (k x 1, no bias) -> conv_H (1 x k) -> conv_P (1 x 1) exactly as the reference
+        inserts them (pad / kernel inferred from the weight shape, infer_pad_kernel; the stride of a strided conv goes
+        to the axis the kernel extends along).  The last layer of each chain writes the ORIGINAL blob name (`top`), so
+        ReLU / pooling / the consumers' bottoms stay as they were.  Undecomposed layers are emitted with their
+        compact weights."""
+        out = []
+        decomposed = getattr(self, "_decomposed", False)
+        for name in self.convs:
+            cv = self.layers[name]
+            conv_V, conv_H, conv_P = underline(name, 'V'), underline(name, 'H'), underline(name, 'P')
+            if decomposed and conv_V in self.WPQ:
+                def geom(W):
+                    kh, kw = W.shape[2], W.shape[3]
+                    return ((cv.pad if kh > 1 else 0, cv.pad if kw > 1 else 0),
+                            (cv.stride if kh > 1 else 1, cv.stride if kw > 1 else 1))
+                V = np.asarray(self.WPQ[conv_V], dtype=np.float32)
+                Hw = np.asarray(self.WPQ[(conv_H, 0)], dtype=np.float32)
+                Hb = np.asarray(self.WPQ[(conv_H, 1)], dtype=np.float32)
+                chain = [(conv_V, V, None), (conv_H, Hw, Hb)]
+                if (conv_P, 0) in self.WPQ:
+                    chain.append((conv_P, np.asarray(self.WPQ[(conv_P, 0)], dtype=np.float32),
+                                  np.asarray(self.WPQ[(conv_P, 1)], dtype=np.float32)))
+                bottom = cv.bottom
+                for i, (lname, W, b) in enumerate(chain):
+                    pad, stride = geom(W)
+                    top = name if i == len(chain) - 1 else lname
+                    out.append(dict(name=lname, top=top, bottom=bottom, W=W, b=b, pad=pad, stride=stride))
+                    bottom = top
+            else:
+                W = np.asarray(self.WPQ.get((name, 0), cv.W), dtype=np.float32)
+                b = np.asarray(self.WPQ.get((name, 1), cv.b), dtype=np.float32)
+                out.append(dict(name=name, top=name, bottom=cv.bottom, W=W, b=b, pad=(cv.pad, cv.pad),
+                                stride=(cv.stride, cv.stride)))
+        return out
 
 
 __all__ = ["Net", "ConvSpec", "rel_error"]
