@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, 
                                                         const double *__restrict__ gmax, double rel,
                                                         double *__restrict__ dg0, int *__restrict__ info, int n_info) {
     const int i = blockIdx.x * RT + threadIdx.x;
-    if (i < n_info) info[i] = 0;  // n_info <= p: one entry per 128-column block + 1
+    for (int e = i; e < n_info; e += int(gridDim.x) * RT) info[e] = 0;
     if (i >= p) return;
     const double d = G[size_t(i) * ld + i] + rel * gmax[0];
     G[size_t(i) * ld + i] = d;
@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, 
 // <= piv_tol * original diagonal (also NaN).
 typedef double v4f64c __attribute__((ext_vector_type(4)));
 constexpr int PNB = 16, NPAN = NB / PNB, DLD = 136;
-constexpr int PT = 512;  // threads of the diagonal-block kernel (8 waves)
+constexpr int PT = 512;  // threads of the factorisation kernel (8 waves)
+// info[0] first failed pivot, info[1 + b] diagonal block b done, then one flag per tile (row-major nblk x nblk)
+constexpr int chol_info_count(int nblk) { return 1 + nblk + nblk * nblk; }
 
 #ifndef CP_POTRF_TIMERS
 #define CP_POTRF_TIMERS 0
@@ -193,50 +195,144 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 
-// Workgroups 1.. of the same launch are the panel of this block step: workgroup j waits for the
-// diagonal workgroup's flag (info[1 + blk]; workgroup 0 is dispatched first, so it is never starved by
-// the waiters) and computes U[blk, blk + j] = U_bb^-T G[blk, blk + j] on MFMA (wave w: 16 rows x 128
-// columns).  One launch per block step instead of two: with many layers in flight every launch in
-// the chain costs tens of microseconds of dispatch latency.
-__global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout, double *Lt, int ld, int blk,
-                                                   const double *__restrict__ dg0, double piv_tol, double *TI,
-                                                   double *TIT, int *info) {
+// The whole factorisation in ONE launch (left-looking, one workgroup per upper 128 x 128 tile, row-major task
+// order).  Workgroup (i, j), i <= j:
+//   S = G[i,j] - sum_{b<i} U[b,i]^T U[b,j]      accumulated on MFMA as the rows b complete (tile flags), so that only
+//                                                the last k-block is left when row i - 1 finishes;
+//   i == j:  S -> LDS, the in-LDS factorisation below (U_ii, TI_i = U_ii^-1, TIT_i), diagonal flag info[1 + i];
+//   i <  j:  wait for the diagonal flag, U[i,j] = TI_i^T S (S through LDS), also stored transposed into Lt[j,i],
+//            tile flag info[1 + nblk + i nblk + j].
+// A workgroup waits only for workgroups with a smaller index of the same launch, which the dispatcher starts
+// first, so it can never be starved by its own waiters.  With many layers in flight every launch in a dependent chain
+// costs tens of microseconds of dispatch latency: the 2 launches per block step this replaces were 3 ms of a
+// 4 ms layer there.
+__device__ __forceinline__ void flag_wait(const int *flag, int *info) {
+    for (int spin = 0; spin < (1 << 26); ++spin) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    atomicCAS(info, 0, 0x7fffffff);  // never observed; the caller then reports a failed factorisation instead of hanging
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, double *Lt, int ld, int blk_or_nblk,
+                                              const double *__restrict__ dg0, double piv_tol, double *TI, double *TIT,
+                                              int *info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (blockIdx.x > 0) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
-        int *flag = info + 1 + blk;
-        if (tid == 0) {
-            for (int spin = 0; spin < (1 << 24); ++spin) {
-                if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                __builtin_amdgcn_s_sleep(8);
+    int blk = blk_or_nblk;
+    if constexpr (FUSED) {
+        const int nblk = blk_or_nblk;
+        blk = 0;
+        int jcol;
+        {   // task -> (blk, jcol): row blk holds nblk - blk tiles
+            int t = int(blockIdx.x);
+            while (t >= nblk - blk) {
+                t -= nblk - blk;
+                ++blk;
             }
+            jcol = blk + t;
         }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int j = blk + int(blockIdx.x);
-        const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
-        const double *Gbj = G + size_t(blk) * NB * ld + size_t(j) * NB + fi;
-        double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
-        v4f64c acc[NB / 16];
-#pragma unroll
-        for (int t = 0; t < NB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
-#pragma unroll 2
-        for (int q = 0; q < NB / 4; ++q) {
-            const double av = TIb[size_t(4 * q + fk) * NB];
-#pragma unroll
+        int *tile_flag = info + 1 + nblk;
+        {
+            const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
+            v4f64c acc[NB / 16];
+            {
+                const double *Gij = G + (size_t(blk) * NB + wave * 16 + fk) * ld + size_t(jcol) * NB + fi;
+    #pragma unroll
+                for (int t = 0; t < NB / 16; ++t)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][r] = Gij[size_t(4 * r) * ld + 16 * t];
+            }
+            for (int b = 0; b < blk; ++b) {
+                if (tid == 0) {
+                    flag_wait(tile_flag + b * nblk + blk, info);
+                    if (jcol != blk) flag_wait(tile_flag + b * nblk + jcol, info);
+                }
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const double *Ubi = Uout + size_t(b) * NB * ld + size_t(blk) * NB + wave * 16 + fi;
+                const double *Ubj = Uout + size_t(b) * NB * ld + size_t(jcol) * NB + fi;
+    #pragma unroll 2
+                for (int q = 0; q < NB / 4; ++q) {
+                    const double av = -Ubi[size_t(4 * q + fk) * ld];
+    #pragma unroll
+                    for (int t = 0; t < NB / 16; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ubj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
+                }
+            }
+            // S -> LDS (the diagonal path factors it there; the panel path needs every row of it in every wave)
+    #pragma unroll
             for (int t = 0; t < NB / 16; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Gbj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
-        }
-        // U[blk, j] and its transpose Lt[j, blk] (what the backward substitution reads; no separate transpose pass)
-        double *Ltj = Lt + size_t(j) * NB * ld + size_t(blk) * NB + wave * 16;
-#pragma unroll
-        for (int t = 0; t < NB / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
-                Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) sm[(wave * 16 + fk + 4 * r) * DLD + 16 * t + fi] = acc[t][r];
+            if (jcol != blk) {
+                if (tid == 0) flag_wait(info + 1 + blk, info);
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int j = jcol;
+                const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
+                const double *Sb = sm + fi;
+                double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
+    #pragma unroll
+                for (int t = 0; t < NB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
+    #pragma unroll 2
+                for (int q = 0; q < NB / 4; ++q) {
+                    const double av = TIb[size_t(4 * q + fk) * NB];
+    #pragma unroll
+                    for (int t = 0; t < NB / 16; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Sb[(4 * q + fk) * DLD + 16 * t], acc[t], 0, 0, 0);
+                }
+                // U[blk, j] and its transpose Lt[j, blk] (what the backward substitution reads; no separate transpose pass)
+                double *Ltj = Lt + size_t(j) * NB * ld + size_t(blk) * NB + wave * 16;
+    #pragma unroll
+                for (int t = 0; t < NB / 16; ++t)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
+                        Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
+                    }
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(tile_flag + blk * nblk + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                return;
             }
-        return;
+        }
+    } else {
+        if (blockIdx.x > 0) {
+            const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
+            int *flag = info + 1 + blk;
+            if (tid == 0) {
+                for (int spin = 0; spin < (1 << 24); ++spin) {
+                    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int j = blk + int(blockIdx.x);
+            const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
+            const double *Gbj = G + size_t(blk) * NB * ld + size_t(j) * NB + fi;
+            double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
+            v4f64c acc[NB / 16];
+    #pragma unroll
+            for (int t = 0; t < NB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
+    #pragma unroll 2
+            for (int q = 0; q < NB / 4; ++q) {
+                const double av = TIb[size_t(4 * q + fk) * NB];
+    #pragma unroll
+                for (int t = 0; t < NB / 16; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Gbj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
+            }
+            // U[blk, j] and its transpose Lt[j, blk] (what the backward substitution reads; no separate transpose pass)
+            double *Ltj = Lt + size_t(j) * NB * ld + size_t(blk) * NB + wave * 16;
+    #pragma unroll
+            for (int t = 0; t < NB / 16; ++t)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
+                    Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
+                }
+            return;
+        }
     }
     double *A = sm;                        // NB x DLD
     double *Tl = sm + NB * DLD;            // NPAN x 16 x 16 : inverses of the diagonal sub-blocks
@@ -244,11 +340,13 @@ __global__ void __launch_bounds__(PT) k_potrf_diag(const double *G, double *Uout
     double *dref = dinv + NB;              // NB : original diagonal (pivot reference)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fk = lane >> 4, fi = lane & 15;
-    const double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
     double *Ub = Uout + size_t(blk) * NB * ld + size_t(blk) * NB;
-    for (int e = tid; e < NB * NB / 2; e += PT) {
-        const int r = e / (NB / 2), cc = (e % (NB / 2)) * 2;
-        *reinterpret_cast<double2 *>(&A[r * DLD + cc]) = *reinterpret_cast<const double2 *>(&Gb[size_t(r) * ld + cc]);
+    if constexpr (!FUSED) {
+        const double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
+        for (int e = tid; e < NB * NB / 2; e += PT) {
+            const int r = e / (NB / 2), cc = (e % (NB / 2)) * 2;
+            *reinterpret_cast<double2 *>(&A[r * DLD + cc]) = *reinterpret_cast<const double2 *>(&Gb[size_t(r) * ld + cc]);
+        }
     }
     if (tid < NB) dref[tid] = dg0[blk * NB + tid];
     __syncthreads();
@@ -468,14 +566,26 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     const int ld = ch.p_pad;
     const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
     if (!ctx->potrf_lds_opt_in) {  // > 64 KB of dynamic LDS needs an explicit opt-in (per device; idempotent)
-        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_diag),
+        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         ctx->potrf_lds_opt_in = true;
     }
+    static const bool fused = [] {  // CP_CHOL_FUSED=0: the one-launch-pair-per-block-step path (A/B measurements)
+        const char *e = getenv("CP_CHOL_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (fused) {  // one launch, left-looking, a workgroup per tile
+        k_potrf<true><<<ch.nblk * (ch.nblk + 1) / 2, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, ch.nblk, ch.dg0, piv_tol,
+                                                                             ch.TI, ch.TIT, ch.info);
+        CP_LAUNCH_CHECK(ctx);
+        return CP_OK;
+    }
     for (int b = 0; b < ch.nblk; ++b) {
         // diagonal block + its panel U12 = U11^-T G12 (workgroups 1..)
-        k_potrf_diag<<<ch.nblk - b, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT,
-                                                            ch.info);
+        k_potrf<false><<<ch.nblk - b, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT,
+                                                              ch.info);
         CP_LAUNCH_CHECK(ctx);
         const int rest = (ch.nblk - b - 1) * NB;
         if (rest > 0) {
@@ -655,7 +765,7 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
         if (!Wacc) return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena (fallback)");
         CP_TRY(normal_equations(G0, R2, false));
         CP_HIP(ctx, hipMemcpyAsync(G, G0, g_b, hipMemcpyDeviceToDevice, ctx->stream));
-        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0, dinfo, nblk + 1);
+        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(G, p_pad, p, gmax, 1e-9, dg0, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
         CP_TRY(chol_factor(ctx, ch, 0.0));
         CP_HIP(ctx, hipMemsetAsync(Wacc, 0, r_b, ctx->stream));
@@ -714,7 +824,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
                          cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE));
     const size_t need = xs_b + yc_b + 4 * g_b + 4 * r_b + 2 * ti_b + part_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 +
-                        size_t(kept) * 4 + ws + (1 << 16);
+                        size_t(kept) * 4 + size_t(chol_info_count(nblk)) * 4 + ws + (1 << 16);
     CP_TRY(cp_arena_reserve(ctx, need));
     double *Xs = cp_arena_take_t<double>(ctx, size_t(N_pad) * p_pad);
     double *Yc = cp_arena_take_t<double>(ctx, size_t(N_pad) * n_pad);
@@ -734,7 +844,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     double *gmax = cp_arena_take_t<double>(ctx, 8);
     double *ymean = cp_arena_take_t<double>(ctx, n_pad);
     int *dchan = cp_arena_take_t<int>(ctx, kept);
-    int *dinfo = cp_arena_take_t<int>(ctx, nblk + 16);
+    int *dinfo = cp_arena_take_t<int>(ctx, chol_info_count(nblk) + 16);
     if (!Xs || !Yc || !G || !G0 || !Lt || !Uf || !Yt || !Rm || !R2 || !TI || !TIT || !part_x || !part_y || !xmean || !dg0 ||
         !gmax || !ymean || !dchan || !dinfo)
         return cp_set_error(ctx, CP_ERR_NOMEM, "refit: arena");
@@ -781,7 +891,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
         CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
         if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
-        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, nblk + 1);
+        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;
     };
@@ -887,7 +997,7 @@ extern "C" int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t 
                          cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(Nr), CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, int(Nr), n_pad, p_pad, CP_TRI_NONE));
     const size_t need = (2 * xs_c + 4 * u_c + 3 * g_c + r_c + 2 * size_t(nblk) * NB * NB + size_t(RB) * (p_pad + n_pad) +
-                         3 * size_t(p_pad) + 2 * size_t(n_pad) + 64) * 8 + size_t(kept) * 4 + size_t(nblk + 16) * 4 + ws +
+                         3 * size_t(p_pad) + 2 * size_t(n_pad) + 64) * 8 + size_t(kept) * 4 + size_t(chol_info_count(nblk) + 16) * 4 + ws +
                         (1 << 16);
     CP_TRY(cp_arena_reserve(ctx, need));
     double *Xs = cp_arena_take_t<double>(ctx, xs_c), *XsT = cp_arena_take_t<double>(ctx, xs_c);
@@ -900,7 +1010,7 @@ extern "C" int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t 
     double *xmean = cp_arena_take_t<double>(ctx, p_pad), *dg0 = cp_arena_take_t<double>(ctx, p_pad);
     double *gmax = cp_arena_take_t<double>(ctx, 8), *umean = cp_arena_take_t<double>(ctx, n_pad);
     double *ydummy = cp_arena_take_t<double>(ctx, n_pad);
-    int *dchan = cp_arena_take_t<int>(ctx, kept), *dinfo = cp_arena_take_t<int>(ctx, nblk + 16);
+    int *dchan = cp_arena_take_t<int>(ctx, kept), *dinfo = cp_arena_take_t<int>(ctx, chol_info_count(nblk) + 16);
     if (!Xs || !XsT || !Ub || !Zb || !Uc || !RU || !G || !Uf || !Lt || !Rm || !TI || !TIT || !part_x || !part_y || !xmean ||
         !dg0 || !gmax || !umean || !ydummy || !dchan || !dinfo)
         return cp_set_error(ctx, CP_ERR_NOMEM, "nonlinear_fc: arena");
@@ -933,7 +1043,7 @@ extern "C" int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t 
         k_transpose_2d<<<dim3(unsigned(Nr / 32), p_pad / 32), RT, 0, ctx->stream>>>(Xs, p_pad, XsT, int(Nr));
         CP_LAUNCH_CHECK(ctx);
         CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(Nr), 1.0, Xs, p_pad, Xs, p_pad, 0.0, G, p_pad, CP_TRI_LOWER_MIRROR));
-        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(G, p_pad, p, p_pad, 0.0, dg0, gmax, dinfo, nblk + 1);
+        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(G, p_pad, p, p_pad, 0.0, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
     }
     Chol ch{G, Uf, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
@@ -1254,7 +1364,8 @@ extern "C" int cp_refit_shard_solve(cp_ctx *ctx, int kept, int kk, int n, int64_
     const int nblk = p_pad / NB;
     const size_t g_b = size_t(p_pad) * p_pad * 8, r_b = size_t(p_pad) * n_pad * 8, ti_b = size_t(nblk) * NB * NB * 8;
     const size_t ws = cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE);
-    CP_TRY(cp_arena_reserve(ctx, 4 * g_b + 4 * r_b + 2 * ti_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 + ws + (1 << 16)));
+    CP_TRY(cp_arena_reserve(ctx, 4 * g_b + 4 * r_b + 2 * ti_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 + ws +
+                                     size_t(chol_info_count(nblk)) * 4 + (1 << 16)));
     double *G = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
     double *G0 = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
     double *Lt = cp_arena_take_t<double>(ctx, size_t(p_pad) * p_pad);
@@ -1267,7 +1378,7 @@ extern "C" int cp_refit_shard_solve(cp_ctx *ctx, int kept, int kk, int n, int64_
     double *means = cp_arena_take_t<double>(ctx, size_t(p_pad + n_pad));
     double *dg0 = cp_arena_take_t<double>(ctx, p_pad);
     double *gmax = cp_arena_take_t<double>(ctx, 8);
-    int *dinfo = cp_arena_take_t<int>(ctx, nblk + 16);
+    int *dinfo = cp_arena_take_t<int>(ctx, chol_info_count(nblk) + 16);
     if (!G || !G0 || !Lt || !Uf || !Yt || !Rm || !R2 || !TI || !TIT || !means || !dg0 || !gmax || !dinfo)
         return cp_set_error(ctx, CP_ERR_NOMEM, "refit shard: arena");
     CP_TRY(cp_pinned_reserve(ctx, 64));
@@ -1279,7 +1390,7 @@ extern "C" int cp_refit_shard_solve(cp_ctx *ctx, int kept, int kk, int n, int64_
     auto normal_equations = [&](double *Gd, double *Rd, bool) -> int {
         CP_HIP(ctx, hipMemcpyAsync(Gd, gram, g_b, hipMemcpyDeviceToDevice, ctx->stream));
         CP_HIP(ctx, hipMemcpyAsync(Rd, gram + size_t(p_pad) * p_pad, r_b, hipMemcpyDeviceToDevice, ctx->stream));
-        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, nblk + 1);
+        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;
     };
