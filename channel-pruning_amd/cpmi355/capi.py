@@ -40,6 +40,16 @@ class PruneResult(ctypes.Structure):
                 ("fit_alpha", ctypes.c_double * CP_MAX_FITS)]
 
 
+class PruneJob(ctypes.Structure):
+    """cp_prune_job: the argument list of cp_prune_layer as one record (cp_prune_layers takes an array of them)."""
+    _fields_ = [("X", _vp), ("x_dtype", ctypes.c_int32), ("c", ctypes.c_int32), ("N", ctypes.c_int64),
+                ("kk", ctypes.c_int32), ("w_dtype", ctypes.c_int32), ("W2", _vp), ("n", ctypes.c_int32),
+                ("S", ctypes.c_int32), ("Y", _vp), ("samples", _vp), ("alpha_right0", _c_dbl), ("rank", _c_dbl),
+                ("lbound", _c_dbl), ("rbound", _c_dbl), ("seeds", _vp), ("max_fits", ctypes.c_int32),
+                ("max_iter", ctypes.c_int32), ("tol", _c_dbl), ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("ridge", _c_dbl), ("mask_out", _vp), ("W_out", _vp), ("b_out", _vp)]
+
+
 class CpError(RuntimeError):
     def __init__(self, code, what, detail=""):
         self.code = code
@@ -55,6 +65,7 @@ SIGNATURES = {
     "cp_device_count": (_c_int, [ctypes.POINTER(_c_int)]),
     "cp_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_vp)]),
     "cp_ctx_destroy": (_c_int, [_vp]),
+    "cp_ctx_create_sibling": (_c_int, [_vp, ctypes.POINTER(_vp)]),
     "cp_ctx_set_stream": (_c_int, [_vp, _vp]),
     "cp_sync": (_c_int, [_vp]),
     "cp_malloc": (_c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
@@ -88,6 +99,7 @@ SIGNATURES = {
     "cp_prune_layer": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
                                 _c_dbl, _c_dbl, _c_dbl, _c_dbl, _vp, _c_int, _c_int, _c_dbl, _c_int, _c_dbl,
                                 _vp, _vp, _vp, ctypes.POINTER(PruneResult)]),
+    "cp_prune_layers": (_c_int, [_c_int, ctypes.POINTER(_vp), _vp, _vp]),
     "cp_probe_mfma_f64": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
     "cp_probe_hbm_copy": (_c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_c_dbl)]),
     "cp_last_stage_times": (_c_int, [_vp, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_float)]),
@@ -179,6 +191,15 @@ class Context:
         self.h = h.value
         self.device = int(device)
         self.pid = os.getpid()
+
+    def sibling(self):
+        """A context with its own workspace on THIS context's stream (for cp_prune_layers batches); close it first."""
+        other = Context.__new__(Context)
+        other.lib = self.lib
+        h = _vp()
+        self._check(self.lib.cp_ctx_create_sibling(self.h, ctypes.byref(h)), "cp_ctx_create_sibling")
+        other.h, other.device, other.pid = h.value, self.device, self.pid
+        return other
 
     def close(self):
         if getattr(self, "h", None) and self.pid == os.getpid():
@@ -380,6 +401,44 @@ class Context:
         if res.fits_used < 0:
             return res, None, None, None
         return res, mask.astype(bool), W[:int(n) * int(res.p)].reshape(int(n), int(res.p)), b
+
+    @staticmethod
+    def prune_layers(jobs):
+        """cp_prune_layers.  jobs: list of dicts with the keyword arguments of prune_layer plus "ctx" (distinct
+        contexts on one stream: a Context and its sibling()s).  -> list of (PruneResult, mask, W, b) like prune_layer."""
+        B = len(jobs)
+        arr = (PruneJob * B)()
+        ctxs = (_vp * B)()
+        keep = []
+        for i, j in enumerate(jobs):
+            samples = np.ascontiguousarray(j["samples"], dtype=np.int64)
+            seeds = np.ascontiguousarray(j["seeds"], dtype=np.uint32)
+            c, n, kk = int(j["c"]), int(j["n"]), int(j["kk"])
+            mask = np.zeros(c, dtype=np.uint8)
+            W = np.empty(n * c * kk, dtype=np.float64)
+            b = np.empty(n, dtype=np.float64)
+            keep.append((samples, seeds, mask, W, b))
+            a = arr[i]
+            a.X, a.x_dtype, a.c, a.N, a.kk = _ptr(j["X"]), j["x_dtype"], c, int(j["N"]), kk
+            a.w_dtype, a.W2, a.n, a.S, a.Y = j["w_dtype"], _ptr(j["W2"]), n, samples.shape[0], _ptr(j["Y"])
+            a.samples, a.alpha_right0, a.rank = samples.ctypes.data, float(j["alpha_right0"]), float(j["rank"])
+            a.lbound, a.rbound, a.seeds = float(j["lbound"]), float(j["rbound"]), seeds.ctypes.data
+            a.max_fits, a.max_iter, a.tol = seeds.shape[0], int(j.get("max_iter", 1000)), float(j.get("tol", 1e-4))
+            a.flags, a.ridge = int(j.get("flags", 0)), float(j.get("ridge", 0.0))
+            a.mask_out, a.W_out, a.b_out = mask.ctypes.data, W.ctypes.data, b.ctypes.data
+            ctxs[i] = j["ctx"].h
+        res = (PruneResult * B)()
+        ctx0 = jobs[0]["ctx"]
+        ctx0._check(ctx0.lib.cp_prune_layers(B, ctxs, ctypes.cast(arr, _vp), ctypes.cast(res, _vp)), "cp_prune_layers")
+        out = []
+        for i, (samples, seeds, mask, W, b) in enumerate(keep):
+            r = res[i]
+            if r.fits_used < 0:
+                out.append((r, None, None, None))
+            else:
+                n, p = int(jobs[i]["n"]), int(r.p)
+                out.append((r, mask.astype(bool), W[:n * p].reshape(n, p), b))
+        return out
 
     # -- measurement ------------------------------------------------------------------
     def probe_mfma_f64(self):

@@ -1365,8 +1365,8 @@ __global__ void __launch_bounds__(WAVE) k_cd_fit(const double *__restrict__ Q, i
 
 // Whole alpha search of lib/decompose.py:490-525 on the device.
 template <int R>
-__global__ void __launch_bounds__(WAVE)
-k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
+__device__ __forceinline__ void
+cd_search_body(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
             int c, double M, double right0, double rank, double lbound, double rbound,
             const uint32_t *__restrict__ seeds, int max_fits, int max_iter, double tol, int flags,
             double *__restrict__ w, double *__restrict__ w_host, DevResult *__restrict__ log,
@@ -1483,8 +1483,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_cd_fit_duo(const double *__restric
 }
 
 template <int R>
-__global__ void __launch_bounds__(2 * WAVE)
-k_cd_search_duo(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
+__device__ __forceinline__ void
+cd_search_duo_body(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
                 int c, double M, double right0, double rank, double lbound, double rbound,
                 const uint32_t *__restrict__ seeds, int max_fits, int max_iter, double tol, int flags,
                 double *__restrict__ w, double *__restrict__ w_host, DevResult *__restrict__ log,
@@ -1535,6 +1535,59 @@ k_cd_search_duo(const double *__restrict__ Q, int ldq, const double *__restrict_
         *fits_used = ok ? fit : -fit;  // negative: ran out of pre-drawn seeds
         *alpha_out = alpha;
     }
+}
+
+// One alpha search per workgroup.  k_cd_search / k_cd_search_duo: one layer per launch; the _batch forms take up
+// to CP_CD_MAX_BATCH layers of the same width (blockIdx.x picks the argument block): independent layers that share a
+// stream then run their searches side by side instead of one after the other.
+struct CdSearchArgs {
+    const double *Q;
+    int ldq;
+    const double *q, *stats;
+    int c;
+    double M, right0, rank, lbound, rbound;
+    const uint32_t *seeds;
+    int max_fits, max_iter;
+    double tol;
+    int flags;
+    double *w, *w_host;
+    DevResult *log;
+    double *log_alpha;
+    int *fits_used;
+    double *alpha_out;
+};
+constexpr int CP_CD_MAX_BATCH = 8;
+struct CdSearchBatch {
+    CdSearchArgs a[CP_CD_MAX_BATCH];
+};
+
+template <int R>
+__global__ void __launch_bounds__(WAVE)
+k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
+            int c, double M, double right0, double rank, double lbound, double rbound,
+            const uint32_t *__restrict__ seeds, int max_fits, int max_iter, double tol, int flags,
+            double *__restrict__ w, double *__restrict__ w_host, DevResult *__restrict__ log,
+            double *__restrict__ log_alpha, int *__restrict__ fits_used, double *__restrict__ alpha_out) {
+    cd_search_body<R>(Q, ldq, q, stats, c, M, right0, rank, lbound, rbound, seeds, max_fits, max_iter, tol, flags, w, w_host, log, log_alpha, fits_used, alpha_out);
+}
+template <int R>
+__global__ void __launch_bounds__(2 * WAVE)
+k_cd_search_duo(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
+            int c, double M, double right0, double rank, double lbound, double rbound,
+            const uint32_t *__restrict__ seeds, int max_fits, int max_iter, double tol, int flags,
+            double *__restrict__ w, double *__restrict__ w_host, DevResult *__restrict__ log,
+            double *__restrict__ log_alpha, int *__restrict__ fits_used, double *__restrict__ alpha_out) {
+    cd_search_duo_body<R>(Q, ldq, q, stats, c, M, right0, rank, lbound, rbound, seeds, max_fits, max_iter, tol, flags, w, w_host, log, log_alpha, fits_used, alpha_out);
+}
+template <int R>
+__global__ void __launch_bounds__(WAVE) k_cd_search_batch(CdSearchBatch b) {
+    const CdSearchArgs &a = b.a[blockIdx.x];
+    cd_search_body<R>(a.Q, a.ldq, a.q, a.stats, a.c, a.M, a.right0, a.rank, a.lbound, a.rbound, a.seeds, a.max_fits, a.max_iter, a.tol, a.flags, a.w, a.w_host, a.log, a.log_alpha, a.fits_used, a.alpha_out);
+}
+template <int R>
+__global__ void __launch_bounds__(2 * WAVE) k_cd_search_duo_batch(CdSearchBatch b) {
+    const CdSearchArgs &a = b.a[blockIdx.x];
+    cd_search_duo_body<R>(a.Q, a.ldq, a.q, a.stats, a.c, a.M, a.right0, a.rank, a.lbound, a.rbound, a.seeds, a.max_fits, a.max_iter, a.tol, a.flags, a.w, a.w_host, a.log, a.log_alpha, a.fits_used, a.alpha_out);
 }
 
 }  // namespace
@@ -1654,5 +1707,89 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     if (fit_alpha) memcpy(fit_alpha, h + off_al, al_bytes);
     if (*fits_used < 0)
         return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search did not terminate within %d fits", max_fits);
+    return CP_OK;
+}
+
+// ---- batched alpha search: several layers of the same width, one launch, one workgroup each ---------------------
+namespace {
+struct SearchPinned {  // lay-out of the pinned block the search kernel reads its seeds from and reports into
+    size_t off_log, off_al, off_seed, off_w, total;
+    SearchPinned(int max_fits, int c) {
+        const size_t log_bytes = size_t(max_fits) * sizeof(DevResult), al_bytes = size_t(max_fits) * sizeof(double),
+                     seed_bytes = cp_align_up(size_t(max_fits) * sizeof(uint32_t), 64);
+        off_log = 128;
+        off_al = off_log + log_bytes;
+        off_seed = off_al + al_bytes;
+        off_w = off_seed + seed_bytes;
+        total = off_w + size_t(c) * sizeof(double);
+    }
+};
+}  // namespace
+
+int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_search_job *jobs) {
+    if (!ctxs || !jobs || n_jobs <= 0 || n_jobs > CP_CD_MAX_BATCH) return CP_ERR_ARG;
+    cp_ctx *ctx = ctxs[0];
+    const int c = jobs[0].c;
+    if (c <= 0 || c > 32 * WAVE) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d", c);
+    CdSearchBatch batch;
+    memset(&batch, 0, sizeof(batch));
+    for (int l = 0; l < n_jobs; ++l) {
+        const cp_search_job &j = jobs[l];
+        if (j.c != c || j.ldq < c || j.max_fits <= 0 || j.max_fits > 4096 || j.max_iter <= 0 || !j.Q || !j.q || !j.stats ||
+            !j.w || !j.seeds)
+            return cp_set_error(ctx, CP_ERR_ARG, "alpha search batch: job %d does not match the batch (c=%d vs %d)", l, j.c, c);
+        cp_ctx *cl = ctxs[l];
+        const SearchPinned lay(j.max_fits, c);
+        CP_TRY(cp_pinned_reserve(cl, lay.total));
+        char *h = cl->pinned;
+        *reinterpret_cast<int *>(h) = 0;
+        memcpy(h + lay.off_seed, j.seeds, size_t(j.max_fits) * sizeof(uint32_t));
+        cl->pinned_w = reinterpret_cast<const double *>(h + lay.off_w);
+        CdSearchArgs &a = batch.a[l];
+        a.Q = j.Q; a.ldq = j.ldq; a.q = j.q; a.stats = j.stats; a.c = c; a.M = j.M; a.right0 = j.alpha_right0;
+        a.rank = j.rank; a.lbound = j.lbound; a.rbound = j.rbound;
+        a.seeds = reinterpret_cast<const uint32_t *>(h + lay.off_seed);
+        a.max_fits = j.max_fits; a.max_iter = j.max_iter; a.tol = j.tol; a.flags = j.flags; a.w = j.w;
+        a.w_host = reinterpret_cast<double *>(h + lay.off_w);
+        a.log = reinterpret_cast<DevResult *>(h + lay.off_log);
+        a.log_alpha = reinterpret_cast<double *>(h + lay.off_al);
+        a.fits_used = reinterpret_cast<int *>(h);
+        a.alpha_out = reinterpret_cast<double *>(h + 64);
+    }
+    const bool duo = use_duo(c);
+    const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
+    const int R = pick_R(c);
+    cp_stage_begin(ctx);
+    if (duo) {
+        switch (R) {
+            case 1: k_cd_search_duo_batch<1><<<n_jobs, 2 * WAVE, lds, ctx->stream>>>(batch); break;
+            case 2: k_cd_search_duo_batch<2><<<n_jobs, 2 * WAVE, lds, ctx->stream>>>(batch); break;
+            case 4: k_cd_search_duo_batch<4><<<n_jobs, 2 * WAVE, lds, ctx->stream>>>(batch); break;
+            default: k_cd_search_duo_batch<8><<<n_jobs, 2 * WAVE, lds, ctx->stream>>>(batch); break;
+        }
+    } else {
+        switch (R) {
+            case 1: k_cd_search_batch<1><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
+            case 2: k_cd_search_batch<2><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
+            case 4: k_cd_search_batch<4><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
+            case 8: k_cd_search_batch<8><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
+            case 16: k_cd_search_batch<16><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
+            default: k_cd_search_batch<32><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
+        }
+    }
+    CP_LAUNCH_CHECK(ctx);
+    cp_stage_mark(ctx, "cd_alpha_search");
+    return CP_OK;
+}
+
+int cp_alpha_search_collect(cp_ctx *ctx, int c, int max_fits, int *fits_used, double *alpha_out, cp_cd_result *fit_log,
+                            double *fit_alpha) {
+    const SearchPinned lay(max_fits, c);
+    const char *h = ctx->pinned;
+    memcpy(fits_used, h, sizeof(int));
+    memcpy(alpha_out, h + 64, sizeof(double));
+    if (fit_log) memcpy(fit_log, h + lay.off_log, size_t(max_fits) * sizeof(DevResult));
+    if (fit_alpha) memcpy(fit_alpha, h + lay.off_al, size_t(max_fits) * sizeof(double));
+    if (*fits_used < 0) return CP_ERR_NUMERIC;
     return CP_OK;
 }

@@ -11,6 +11,17 @@
 
 #include "cpmi355.h"
 
+// what a deferred refit (cp_prune_layers) leaves behind: everything its factorisation and substitution launches need,
+// so that the batch can run them as ONE launch each for all of its layers
+struct cp_refit_deferred {
+    double *G, *U, *Lt, *TI, *TIT, *dg0, *gmax, *Rm;
+    int *info;
+    int p, p_pad, nblk, n, n_pad;
+    const double *xmean, *ymean;
+    double *W_out, *b_out, *W_host, *b_host;
+    int *info_host;
+};
+
 struct cp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -42,6 +53,9 @@ struct cp_ctx {
     const char *gemm_mark = nullptr;  // if set, cp_gemm_tn_f64 marks this stage right after its main kernel
     int gemm_tag = 0;                 // selects a distinctly named instantiation of the GEMM kernel
     int cu_count = 256;
+    bool defer_refit_wait = false;    // cp_prune_layers: enqueue the refit, the caller waits once for the whole batch
+    bool refit_pending = false;       // set by a deferred refit: factor + solve still to be launched by the batch
+    cp_refit_deferred deferred = {};
     bool potrf_lds_opt_in = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
 
@@ -98,6 +112,25 @@ int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const d
                         int K2, const double *A2, const double *B2, double *C2, int lda, int ldb, int ldc, int tri);
 
 // cp_lstsq_refit with optional host-visible outputs: b (n doubles) then W (n x p) at ctx->pinned + 64
+// batched alpha search (cd_gram.hip): one launch on ctxs[0]->stream, one workgroup per job; results land in each
+// context's pinned block and are read by cp_alpha_search_collect after the stream has been waited on
+struct cp_search_job {
+    const double *Q;
+    int ldq;
+    const double *q, *stats;
+    int c;
+    double M, alpha_right0, rank, lbound, rbound;
+    const uint32_t *seeds;
+    int max_fits, max_iter;
+    double tol;
+    int flags;
+    double *w;
+};
+int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_search_job *jobs);
+int cp_alpha_search_collect(cp_ctx *ctx, int c, int max_fits, int *fits_used, double *alpha_out, cp_cd_result *fit_log,
+                            double *fit_alpha);
+// factor + substitute every pending deferred refit of the batch: two launches on ctxs[0]->stream (refit.hip)
+int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx);
 int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
                         const double *Y, int n, double ridge, double *W_out, double *b_out, cp_refit_info *info,
                         bool host_out);

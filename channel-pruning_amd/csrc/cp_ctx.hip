@@ -73,6 +73,23 @@ extern "C" int cp_ctx_create(int device, cp_ctx **out) {
     return CP_OK;
 }
 
+// A context that runs on `of`'s stream and owns no stream of its own (every HIP stream claims a hardware queue, and
+// dispatch gets slow for everybody once ~20 of them exist): the per-job contexts of cp_prune_layers.  Destroy it
+// before `of`.
+extern "C" int cp_ctx_create_sibling(cp_ctx *of, cp_ctx **out) {
+    if (!of || !out) return CP_ERR_ARG;
+    *out = nullptr;
+    if (hipSetDevice(of->device) != hipSuccess) return CP_ERR_HIP;
+    cp_ctx *ctx = new cp_ctx();
+    ctx->device = of->device;
+    ctx->cu_count = of->cu_count;
+    ctx->own_stream = nullptr;
+    ctx->stream = of->stream;
+    for (int i = 0; i < 2 * CP_MAX_STAGES; ++i) hipEventCreate(&ctx->ev[i]);
+    *out = ctx;
+    return CP_OK;
+}
+
 extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     if (!ctx) return CP_OK;
     hipSetDevice(ctx->device);

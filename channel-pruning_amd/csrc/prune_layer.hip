@@ -105,3 +105,129 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     ctx->host_ms[3] = now_ms() - t3;  // copies back + last wait
     return CP_OK;
 }
+
+
+// cp_prune_layers: the same work for several independent layers of the same width that share ONE stream.  A stream
+// runs one kernel at a time and a layer is mostly its single-workgroup alpha search, so the searches of the batch
+// are the workgroups of one launch; LASSO operands and refits are enqueued layer after layer around it.  Two host
+// waits per batch (after the searches, after the refits).  Contexts: one per job (own arena / pinned block), all
+// bound to the same stream (cp_ctx_set_stream), distinct from each other.
+extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_job *jobs, cp_prune_result *results) {
+    if (!ctxs || !jobs || !results || n_jobs <= 0 || !ctxs[0]) return CP_ERR_ARG;
+    cp_ctx *ctx0 = ctxs[0];
+    if (n_jobs > 8) return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: at most 8 jobs per call (got %d)", n_jobs);
+    for (int l = 0; l < n_jobs; ++l) {
+        const cp_prune_job &j = jobs[l];
+        if (!ctxs[l] || !j.X || !j.W2 || !j.Y || !j.mask_out || !j.W_out || !j.b_out)
+            return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: null argument in job %d", l);
+        if (ctxs[l]->stream != ctx0->stream || ctxs[l]->device != ctx0->device)
+            return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: the contexts of a batch must share one stream "
+                                                  "(cp_ctx_set_stream) and device (job %d)", l);
+        for (int m = 0; m < l; ++m)
+            if (ctxs[m] == ctxs[l]) return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: context used twice");
+        if (j.c != jobs[0].c || j.c <= 0 || j.n <= 0 || j.kk <= 0 || j.N <= 0 || j.max_fits < 0 || j.max_fits > CP_MAX_FITS)
+            return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: job %d: bad size or channel count differs from job 0", l);
+    }
+    CP_HIP(ctx0, hipSetDevice(ctx0->device));
+    for (int l = 0; l < n_jobs; ++l) ctxs[l]->refit_pending = false;  // nothing left over from a call that failed midway
+    const int c = jobs[0].c;
+    const size_t cc = size_t(c);
+    struct Ws {
+        double *Q, *q, *stats, *w, *Wd, *bd;
+    } ws[8];
+    cp_search_job sj[8];
+    cp_ctx *sctx[8];
+    int smap[8], n_search = 0;
+    for (int l = 0; l < n_jobs; ++l) {
+        const cp_prune_job &j = jobs[l];
+        cp_ctx *ctx = ctxs[l];
+        memset(&results[l], 0, sizeof(cp_prune_result));
+        const size_t n_q = cp_align_up(cc * cc, 32), n_v = cp_align_up(cc, 32),
+                     n_w = cp_align_up(size_t(j.n) * cc * j.kk, 32), n_b = cp_align_up(size_t(j.n), 32);
+        CP_TRY(layer_ws_reserve(ctx, (n_q + 3 * n_v + n_w + n_b) * sizeof(double)));
+        Ws &w = ws[l];
+        w.Q = reinterpret_cast<double *>(ctx->layer_ws);
+        w.q = w.Q + n_q;
+        w.stats = w.q + n_v;
+        w.w = w.stats + n_v;
+        w.Wd = w.w + n_v;
+        w.bd = w.Wd + n_w;
+        if (j.rank >= double(c)) {  // decompose.py:487-488: nothing to select
+            for (size_t i = 0; i < cc; ++i) j.mask_out[i] = 1;
+            continue;
+        }
+        if (!j.samples || j.S <= 0 || !j.seeds || j.max_fits == 0)
+            return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: samples / seeds missing in job %d", l);
+        CP_TRY(cp_lasso_gram(ctx, j.X, j.x_dtype, j.N, c, j.kk, j.W2, j.w_dtype, j.n, j.Y, j.samples, j.S, w.Q, w.q, w.stats));
+        cp_search_job &s = sj[n_search];
+        s.Q = w.Q; s.ldq = c; s.q = w.q; s.stats = w.stats; s.c = c; s.M = double(j.S) * double(j.n);
+        s.alpha_right0 = j.alpha_right0; s.rank = j.rank; s.lbound = j.lbound; s.rbound = j.rbound; s.seeds = j.seeds;
+        s.max_fits = j.max_fits; s.max_iter = j.max_iter; s.tol = j.tol; s.flags = j.flags; s.w = w.w;
+        sctx[n_search] = ctx;
+        smap[n_search++] = l;
+    }
+    if (n_search > 0) {
+        CP_TRY(cp_alpha_search_enqueue_batch(sctx, n_search, sj));
+        CP_HIP(ctx0, cp_stream_wait(sctx[0]));   // one wait for every search of the batch
+        for (int k = 0; k < n_search; ++k) {
+            const int l = smap[k];
+            const cp_prune_job &j = jobs[l];
+            int fits_used = 0;
+            double alpha = 0.0;
+            const int rc = cp_alpha_search_collect(sctx[k], c, j.max_fits, &fits_used, &alpha, results[l].fit_log,
+                                                   results[l].fit_alpha);
+            if (rc == CP_ERR_NUMERIC) {  // did not settle within max_fits: the caller replays this layer fit by fit
+                results[l].fits_used = -1;
+                continue;
+            }
+            results[l].fits_used = fits_used;
+            results[l].alpha = alpha;
+            const double *wh = sctx[k]->pinned_w;
+            for (size_t i = 0; i < cc; ++i) j.mask_out[i] = wh[i] != 0.0 ? 1 : 0;  // decompose.py:463
+        }
+    }
+    // refits: every layer's front (means, centring, Gram, X^T Y) is enqueued, then the batch factors and substitutes
+    cp_refit_info info[8];
+    for (int l = 0; l < n_jobs; ++l) {
+        if (results[l].fits_used < 0) continue;
+        const cp_prune_job &j = jobs[l];
+        cp_ctx *ctx = ctxs[l];
+        int nnz = 0;
+        for (size_t i = 0; i < cc; ++i) nnz += j.mask_out[i];
+        results[l].nnz = nnz;
+        ctx->defer_refit_wait = true;
+        ctx->refit_pending = false;
+        const int rc = cp_lstsq_refit_impl(ctx, j.X, j.x_dtype, j.N, c, j.kk, j.mask_out, j.Y, j.n, j.ridge, ws[l].Wd, ws[l].bd,
+                                           &info[l], true);
+        ctx->defer_refit_wait = false;
+        if (rc != CP_OK) {
+            if (ctx != ctx0) cp_set_error(ctx0, rc, "cp_prune_layers: job %d: %s", l, ctx->err);
+            return rc;
+        }
+    }
+    CP_TRY(cp_refit_batch_factor_solve(ctxs, n_jobs));  // every pending factorisation in one launch, every substitution in another
+    CP_HIP(ctx0, cp_stream_wait(ctx0));
+    for (int l = 0; l < n_jobs; ++l) {
+        if (results[l].fits_used < 0) continue;
+        const cp_prune_job &j = jobs[l];
+        cp_ctx *ctx = ctxs[l];
+        if (ctx->refit_pending) {
+            ctx->refit_pending = false;
+            if (*reinterpret_cast<const int *>(ctx->pinned) != 0) {  // a pivot failed: the rank-deficient branch, synchronously
+                const int rc = cp_lstsq_refit_impl(ctx, j.X, j.x_dtype, j.N, c, j.kk, j.mask_out, j.Y, j.n, j.ridge, ws[l].Wd,
+                                                   ws[l].bd, &info[l], true);
+                if (rc != CP_OK) {
+                    if (ctx != ctx0) cp_set_error(ctx0, rc, "cp_prune_layers: job %d: %s", l, ctx->err);
+                    return rc;
+                }
+            }
+        }
+        results[l].p = info[l].p;
+        results[l].refit_rank = info[l].rank;
+        results[l].fallback = info[l].fallback;
+        const double *b_host = reinterpret_cast<const double *>(ctx->pinned + 64);
+        memcpy(j.b_out, b_host, size_t(j.n) * sizeof(double));
+        memcpy(j.W_out, b_host + j.n, size_t(j.n) * size_t(info[l].p) * sizeof(double));
+    }
+    return CP_OK;
+}

@@ -215,9 +215,9 @@ __device__ __forceinline__ void flag_wait(const int *flag, int *info) {
 }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, double *Lt, int ld, int blk_or_nblk,
-                                              const double *__restrict__ dg0, double piv_tol, double *TI, double *TIT,
-                                              int *info) {
+__device__ __forceinline__ void potrf_body(const double *G, double *Uout, double *Lt, int ld, int blk_or_nblk,
+                                           const double *__restrict__ dg0, double piv_tol, double *TI, double *TIT,
+                                           int *info, int task) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     int blk = blk_or_nblk;
     if constexpr (FUSED) {
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, dou
         blk = 0;
         int jcol;
         {   // task -> (blk, jcol): row blk holds nblk - blk tiles
-            int t = int(blockIdx.x);
+            int t = task;
             while (t >= nblk - blk) {
                 t -= nblk - blk;
                 ++blk;
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, dou
             }
         }
     } else {
-        if (blockIdx.x > 0) {
+        if (task > 0) {
             const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
             int *flag = info + 1 + blk;
             if (tid == 0) {
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, dou
             }
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const int j = blk + int(blockIdx.x);
+            const int j = blk + task;
             const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
             const double *Gbj = G + size_t(blk) * NB * ld + size_t(j) * NB + fi;
             double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
@@ -513,6 +513,34 @@ __global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, dou
     }
 }
 
+template <bool FUSED>
+__global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, double *Lt, int ld, int blk_or_nblk,
+                                              const double *__restrict__ dg0, double piv_tol, double *TI, double *TIT,
+                                              int *info) {
+    potrf_body<FUSED>(G, Uout, Lt, ld, blk_or_nblk, dg0, piv_tol, TI, TIT, info, int(blockIdx.x));
+}
+
+// several factorisations in one launch (cp_prune_layers): blockIdx.y = job, blockIdx.x = its tile task.  Workgroups
+// are dispatched x-fastest, so a job's tasks still start in task order.
+struct PotrfJob {
+    const double *G;
+    double *U, *Lt;
+    int ld, nblk;
+    const double *dg0;
+    double piv_tol;
+    double *TI, *TIT;
+    int *info;
+};
+constexpr int CP_REFIT_MAX_BATCH = 8;
+struct PotrfBatch {
+    PotrfJob j[CP_REFIT_MAX_BATCH];
+};
+__global__ void __launch_bounds__(PT) k_potrf_batch(PotrfBatch b) {
+    const PotrfJob &a = b.j[blockIdx.y];
+    if (int(blockIdx.x) >= a.nblk * (a.nblk + 1) / 2) return;
+    potrf_body<true>(a.G, a.U, a.Lt, a.ld, a.nblk, a.dg0, a.piv_tol, a.TI, a.TIT, a.info, int(blockIdx.x));
+}
+
 __global__ void __launch_bounds__(RT) k_axpy(double *__restrict__ y, const double *__restrict__ x, size_t count) {
     size_t i = blockIdx.x * size_t(RT) + threadIdx.x;
     const size_t step = size_t(gridDim.x) * RT;
@@ -561,6 +589,14 @@ struct Chol {
     int p, p_pad, nblk;
 };
 
+bool chol_fused_requested() {
+    static const bool on = [] {
+        const char *e = getenv("CP_CHOL_FUSED");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 // G = U^T U (upper, into ch.U), TI/TIT per diagonal block, and the off-diagonal blocks of Lt = U^T.
 int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     const int ld = ch.p_pad;
@@ -572,10 +608,13 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         ctx->potrf_lds_opt_in = true;
     }
-    static const bool fused = [] {  // CP_CHOL_FUSED=0: the one-launch-pair-per-block-step path (A/B measurements)
-        const char *e = getenv("CP_CHOL_FUSED");
-        return !(e && e[0] == '0');
-    }();
+    // CP_CHOL_FUSED=1 selects the one-launch factorisation.  It is NOT the default: its workgroups wait for each other
+    // for up to a millisecond while holding a whole CU's LDS, and workgroups of one launch are only dispatched in order
+    // PER XCD -- with enough factorisations in flight to oversubscribe the CUs (measured: 18 streams x batches of 8)
+    // two launches can hold the slots each other's next workgroups need, and only the bounded spins get them out.
+    // The default (diagonal block + panel in one launch, trailing update as a GEMM) has no such cycle: a panel
+    // workgroup waits only for workgroup 0 of its own launch, which an XCD always dispatches before its later ones.
+    static const bool fused = chol_fused_requested();
     if (fused) {  // one launch, left-looking, a workgroup per tile
         k_potrf<true><<<ch.nblk * (ch.nblk + 1) / 2, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, ch.nblk, ch.dg0, piv_tol,
                                                                              ch.TI, ch.TIT, ch.info);
@@ -615,9 +654,9 @@ struct StripFinal {  // optional tail of k_solve_strips: what k_finalize does, f
     int *info_host;
 };
 
-__global__ void __launch_bounds__(512) k_solve_strips(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
-                                                      const double *__restrict__ TI, const double *__restrict__ TIT,
-                                                      int nblk, double *R, int n_pad, StripFinal fin) {
+__device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
+                                                  const double *__restrict__ TI, const double *__restrict__ TIT,
+                                                  int nblk, double *R, int n_pad, const StripFinal &fin) {
     __shared__ double S[NB][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fk = lane >> 4, fi = lane & 15;
@@ -694,6 +733,30 @@ __global__ void __launch_bounds__(512) k_solve_strips(const double *__restrict__
     }
 }
 
+__global__ void __launch_bounds__(512) k_solve_strips(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
+                                                      const double *__restrict__ TI, const double *__restrict__ TIT,
+                                                      int nblk, double *R, int n_pad, StripFinal fin) {
+    solve_strips_body(U, Lt, ld, TI, TIT, nblk, R, n_pad, fin);
+}
+
+struct StripJob {
+    const double *U, *Lt;
+    int ld;
+    const double *TI, *TIT;
+    int nblk;
+    double *R;
+    int n_pad;
+    StripFinal fin;
+};
+struct StripBatch {
+    StripJob j[CP_REFIT_MAX_BATCH];
+};
+__global__ void __launch_bounds__(512) k_solve_strips_batch(StripBatch b) {  // blockIdx.y = job
+    const StripJob &a = b.j[blockIdx.y];
+    if (int(blockIdx.x) * 16 >= a.n_pad) return;
+    solve_strips_body(a.U, a.Lt, a.ld, a.TI, a.TIT, a.nblk, a.R, a.n_pad, a.fin);
+}
+
 int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad, const StripFinal &fin = StripFinal{}) {
     k_solve_strips<<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad, fin);
     CP_LAUNCH_CHECK(ctx);
@@ -749,6 +812,16 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
     };
     if (!fallback) {
         CP_TRY(normal_equations(G, Rm, true));
+        if (ctx->defer_refit_wait) {  // cp_prune_layers factors and substitutes all its layers with one launch each
+            ctx->deferred = cp_refit_deferred{G, Uf, Lt, TI, TIT, dg0, gmax, Rm, dinfo, p, p_pad, nblk, n, n_pad, xmean, ymean,
+                                              W_out, b_out, W_host, b_host, info_host};
+            ctx->refit_pending = true;
+            info->p = p;
+            info->rank = p;
+            info->fallback = 0;
+            info->reserved = 0;
+            return CP_OK;
+        }
         CP_TRY(chol_factor(ctx, ch, 1e-10));
         cp_stage_mark(ctx, "refit_cholesky");
         StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
@@ -796,6 +869,53 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
 }
 
 }  // namespace
+
+int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
+    if (!ctxs || n_ctx <= 0 || n_ctx > CP_REFIT_MAX_BATCH) return CP_ERR_ARG;
+    PotrfBatch pb;
+    StripBatch sb;
+    memset(&pb, 0, sizeof(pb));
+    memset(&sb, 0, sizeof(sb));
+    int nj = 0, max_tasks = 0, max_strips = 0;
+    cp_ctx *ctx0 = nullptr;
+    for (int l = 0; l < n_ctx; ++l) {
+        cp_ctx *c = ctxs[l];
+        if (!c || !c->refit_pending) continue;
+        if (!ctx0) ctx0 = c;
+        const cp_refit_deferred &d = c->deferred;
+        pb.j[nj] = PotrfJob{d.G, d.U, d.Lt, d.p_pad, d.nblk, d.dg0, 1e-10, d.TI, d.TIT, d.info};
+        sb.j[nj] = StripJob{d.U, d.Lt, d.p_pad, d.TI, d.TIT, d.nblk, d.Rm, d.n_pad,
+                            StripFinal{d.p, d.n, d.xmean, d.ymean, d.W_out, d.b_out, d.W_host, d.b_host, d.info, d.info_host}};
+        max_tasks = std::max(max_tasks, d.nblk * (d.nblk + 1) / 2);
+        max_strips = std::max(max_strips, d.n_pad / 16);
+        ++nj;
+    }
+    if (nj == 0) return CP_OK;
+    cp_ctx *ctx = ctx0;
+    if (chol_fused_requested()) {  // all factorisations as one launch (see chol_factor for why this is opt-in)
+        const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
+        static bool opt_in = false;  // > 64 KB of dynamic LDS needs an explicit opt-in (idempotent)
+        if (!opt_in) {
+            CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_batch),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            opt_in = true;
+        }
+        k_potrf_batch<<<dim3(max_tasks, nj), PT, lds, ctx->stream>>>(pb);
+        CP_LAUNCH_CHECK(ctx);
+    } else {
+        for (int l = 0; l < n_ctx; ++l) {
+            cp_ctx *c = ctxs[l];
+            if (!c || !c->refit_pending) continue;
+            const cp_refit_deferred &d = c->deferred;
+            Chol ch{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
+            CP_TRY(chol_factor(c, ch, 1e-10));
+        }
+    }
+    // the substitutions of every layer of the batch: one launch (no workgroup waits for another one)
+    k_solve_strips_batch<<<dim3(max_strips, nj), 512, 0, ctx->stream>>>(sb);
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}
 
 // host_out: also leave b (n) and W (n x p) in the context's pinned block at offset 64 (cp_prune_layer)
 int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,

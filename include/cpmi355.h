@@ -52,6 +52,9 @@ const char *cp_last_error(const cp_ctx *ctx);
 int cp_device_count(int *count);
 int cp_ctx_create(int device, cp_ctx **out);
 int cp_ctx_destroy(cp_ctx *ctx);
+/* a context with its own workspace that runs on `of`'s stream (no stream / hardware queue of its own): the per-job
+ * contexts of cp_prune_layers.  Destroy it before `of`. */
+int cp_ctx_create_sibling(cp_ctx *of, cp_ctx **out);
 /* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
  * NULL restores the ctx's own stream. */
 int cp_ctx_set_stream(cp_ctx *ctx, void *hip_stream);
@@ -233,6 +236,38 @@ int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, in
                    const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
                    double ridge, uint8_t *mask_out, double *W_out, double *b_out,
                    cp_prune_result *res);
+
+/* The same for several independent layers at once (e.g. the equal-shaped layers of a ResNet stage, or one layer of
+ * several networks): jobs[i] is exactly the argument list of cp_prune_layer.  All jobs must have the same channel
+ * count c; ctxs[i] are DISTINCT contexts bound to ONE stream (cp_ctx_set_stream) on one device -- each keeps its own
+ * workspace and pinned result block.  A stream runs one kernel at a time and most of a layer's time is its
+ * single-workgroup alpha search, so the searches of the batch are the workgroups of one launch; the host waits twice
+ * per call.  results[i] as cp_prune_layer's (fits_used == -1: that layer's search did not settle, nothing else of
+ * results[i] / its outputs is valid).  At most 8 jobs per call. */
+typedef struct cp_prune_job {
+    const void *X;
+    int32_t x_dtype;
+    int32_t c;
+    int64_t N;
+    int32_t kk;
+    int32_t w_dtype;
+    const void *W2;
+    int32_t n;
+    int32_t S;
+    const double *Y;
+    const int64_t *samples;
+    double alpha_right0, rank, lbound, rbound;
+    const uint32_t *seeds;
+    int32_t max_fits, max_iter;
+    double tol;
+    int32_t flags;
+    int32_t reserved;
+    double ridge;
+    uint8_t *mask_out;
+    double *W_out;
+    double *b_out;
+} cp_prune_job;
+int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_job *jobs, cp_prune_result *results);
 
 /* ---- micro-benchmarks used by bench.py for roofline denominators ---------------- */
 /* Sustained v_mfma_f64_16x16x4_f64 rate (TFLOP/s) and float4-copy HBM bandwidth (GB/s). */

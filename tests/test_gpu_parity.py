@@ -554,3 +554,70 @@ def test_itq_decompose_matches_reference_golden(ctx):
     assert relfro(W12, g["W12"]) <= REL_W and relfro(B, g["B"]) <= REL_W
     assert relfro(W1 * sgn[:, None, None, None], g["W1"]) <= REL_W
     assert relfro(Wo2 * sgn[None, :, None, None], g["W2"]) <= REL_W
+
+
+# ---------------------------------------------------------------------------------------------
+# cp_prune_layers: several layers of one width on ONE stream, their alpha searches in one launch
+# ---------------------------------------------------------------------------------------------
+def _batched(ctx, names, flags=3):
+    from cpmi355 import LayerProblem, prune_layers_batched
+    ctxs = [ctx] + [ctx.sibling() for _ in names[1:]]
+    cases = [load_case(nm) for nm in names]
+    probs = [LayerProblem(cx, X.astype(np.float64), W2, Y, flags=flags) for cx, (g, p, X, W2, Y, B2) in zip(ctxs, cases)]
+    rngs = []
+    for g, p, *_ in cases:
+        r = np.random.RandomState(0)
+        r.seed(1234 + p["layer_id"])
+        rngs.append(r)
+    try:
+        out = prune_layers_batched(probs, [p["rank"] for _, p, *_ in cases], [p.get("alpha_in", 1e-3) for _, p, *_ in cases],
+                                   rngs, rank_tol=cases[0][1].get("rank_tol", .1))
+        infos = [dict(fits=list(pr.fits), samples=pr.samples) for pr in probs]
+    finally:
+        for pr in probs:
+            pr.free()
+        for cx in ctxs[1:]:
+            cx.close()
+    return cases, out, infos, rngs
+
+
+@pytest.mark.parametrize("names", [["s01_c32_k3", "s06_dead", "s10_alpha_carry", "s15_nofc"],
+                                   ["L02_conv3_1_conv3_2", "L03_conv3_2_conv3_3", "L04_conv3_1_dc222"],
+                                   ["s05_rank_eq_c", "s11_rank_eq_c_dead"], ["L05_conv4_1_conv4_2"]])
+def test_prune_layers_batch_matches_reference_golden(ctx, names):
+    """Every layer of a batch equals its reference golden exactly as through cp_prune_layer: mask, per-fit log, alpha,
+    RNG stream; weights <= 1e-5.  Covers the one-wave (c = 32), assist (c = 256) and two-wave (c = 512) search
+    kernels, a dead-channel layer (its refit falls back after the batch's wait) and rank == c (no search)."""
+    cases, out, infos, rngs = _batched(ctx, names)
+    for (g, p, X, W2, Y, B2), (idxs, newW2, newB2, alpha), info, rng, nm in zip(cases, out, infos, rngs, names):
+        assert np.array_equal(idxs, g["idxs"]), nm
+        if p["rank"] != p["c"]:
+            fits = np.array(info["fits"], dtype=np.float64).reshape(-1, 3)
+            assert np.array_equal(fits, g["fits"]), nm
+            assert alpha == float(g["alpha_out"]), nm
+        assert np.array_equal(info["samples"], g["samples"])
+        assert int(rng.randint(0, 2147483647)) == int(g["rng_next"]), nm
+        if not p.get("nofc"):
+            assert newW2.shape == g["newW2"].shape
+            assert relfro(newW2, g["newW2"]) <= REL_W and relfro(newB2, g["newB2"]) <= REL_W, nm
+
+
+def test_prune_layers_rejects_mixed_widths_and_foreign_streams(ctx):
+    import cpmi355
+    from cpmi355 import LayerProblem, prune_layers_batched
+    cases = [load_case("s01_c32_k3"), load_case("s02_c64_k3")]
+    sib = ctx.sibling()
+    other = cpmi355.Context(0)            # own stream: not part of the batch's stream
+    try:
+        probs = [LayerProblem(cx, X.astype(np.float64), W2, Y) for cx, (g, p, X, W2, Y, B2) in zip([ctx, sib], cases)]
+        with pytest.raises(cpmi355.CpError, match="channel count"):
+            prune_layers_batched(probs, [16, 32], [1e-3, 1e-3], [np.random.RandomState(1), np.random.RandomState(2)])
+        g, p, X, W2, Y, B2 = cases[0]
+        probs2 = [LayerProblem(cx, X.astype(np.float64), W2, Y) for cx in (ctx, other)]
+        with pytest.raises(cpmi355.CpError, match="share one stream"):
+            prune_layers_batched(probs2, [16, 16], [1e-3, 1e-3], [np.random.RandomState(1), np.random.RandomState(2)])
+        for pr in probs + probs2:
+            pr.free()
+    finally:
+        sib.close()
+        other.close()

@@ -285,3 +285,49 @@ def test_alpha_search_rng_rewind_matches_reference_consumption():
     for _ in range(5):
         ref.randint(0, pruner.RAND_R_MAX)
     assert after == ref.randint(0, 2147483647)
+
+
+def test_cheap_rng_bookkeeping_equals_numpy_semantics():
+    """draw_seeds (one vectorised randint) leaves the values and the generator state that the same number of scalar
+    rng.randint(0, 2147483647) calls leave -- the reference draws them one per Lasso.fit (_cd_fast.pyx:164) -- and
+    rng_mark / rng_rewind restore a legacy generator exactly (also across a Mersenne-Twister block boundary), for
+    RandomState objects and for the np.random module itself."""
+    from cpmi355 import pruner
+    for seed in (0, 7, 1234, 987654):
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        a.randint(0, 10, size=590)
+        b.randint(0, 10, size=590)                              # 64 more draws cross the 624-word block
+        ref = np.array([a.randint(0, pruner.RAND_R_MAX) for _ in range(64)], dtype=np.uint32)
+        mark = pruner.rng_mark(b)
+        got = pruner.draw_seeds(b, 64)
+        assert got.dtype == np.uint32 and np.array_equal(got, ref)
+        assert a.randint(0, 1 << 30) == b.randint(0, 1 << 30)
+        pruner.rng_rewind(b, mark)
+        assert np.array_equal(pruner.draw_seeds(b, 64), ref)
+        pruner.rng_rewind(b, mark)
+        pruner.draw_seeds(b, 9)
+        a2 = np.random.RandomState(seed)
+        a2.randint(0, 10, size=590)
+        for _ in range(9):
+            a2.randint(0, pruner.RAND_R_MAX)
+        assert a2.randint(0, 1 << 30) == b.randint(0, 1 << 30)
+    np.random.seed(42)
+    mark = pruner.rng_mark(np.random)
+    x = np.random.randint(0, 1000, size=10)
+    pruner.rng_rewind(np.random, mark)
+    assert np.array_equal(np.random.randint(0, 1000, size=10), x)
+
+    class Other:                                                 # not a Mersenne Twister: falls back to get/set_state
+        def __init__(self):
+            self.s = 0
+
+        def get_state(self):
+            return self.s
+
+        def set_state(self, s):
+            self.s = s
+    o = Other()
+    m = pruner.rng_mark(o)
+    o.s = 5
+    pruner.rng_rewind(o, m)
+    assert o.s == 0
