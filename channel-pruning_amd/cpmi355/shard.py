@@ -9,6 +9,7 @@ hundred bytes each, plus the reconstructed weights) over torch.distributed -- ba
     assign_layers(costs, world)        longest-processing-time-first assignment
     layer_cost(N, c, n, k, rank)       FLOP model of SURVEY.md section 8d (plus the serial CD term)
     prune_sharded(specs, compute_fn)   run this rank's share, all-gather every result
+    GpuLayerBatches(ctx, operands)     compute_many for it: equal-width layers through cp_prune_layers, 8 at a time
 
 For the layers that dominate (conv4/conv5 sizes) the ROWS of one layer can be spread over the ranks instead
 ("secondary"):
@@ -43,8 +44,59 @@ def assign_layers(costs, world):
     return owner
 
 
-def prune_sharded(specs, compute_fn, dist=None, device=None):
-    """specs: list of dicts with at least N, c, n, k, rank; compute_fn(spec) -> (idxs, W, b).
+class GpuLayerBatches:
+    """compute_many for prune_sharded: this rank's layers on the GPU, those of equal channel count `max_batch` at a
+    time through cp_prune_layers (their alpha searches side by side in one launch).
+
+        operands(spec) -> (X[N,c,k,k], W2[n,c,k,k], Y[N,n])   host arrays of one layer
+        seed(spec)     -> the seed of the layer's own RNG stream (parity is per layer: SURVEY.md section 8e)
+
+    Returns [(idxs, newW2, newB2), ...] in the order of the specs it was given; .alphas holds the accepted alphas."""
+
+    def __init__(self, ctx, operands, seed=lambda s: 1234 + s["layer_id"], max_batch=8, alpha_in=1e-3, rank_tol=.1,
+                 flags=None):
+        from . import capi
+        self.ctx, self.operands, self.seed = ctx, operands, seed
+        self.max_batch, self.alpha_in, self.rank_tol = int(max_batch), alpha_in, rank_tol
+        self.flags = (capi.CP_CD_RECIPROCAL | capi.CP_CD_DELTA) if flags is None else flags
+        self.alphas = {}
+
+    def __call__(self, specs):
+        from .pruner import LayerProblem, prune_layers_batched
+        out = [None] * len(specs)
+        by_width = {}
+        for i, s in enumerate(specs):
+            by_width.setdefault(int(s["c"]), []).append(i)
+        siblings = [self.ctx.sibling() for _ in range(min(self.max_batch, max(map(len, by_width.values()), default=1)) - 1)]
+        ctxs = [self.ctx] + siblings
+        try:
+            for c, members in sorted(by_width.items()):
+                for g0 in range(0, len(members), self.max_batch):
+                    group = members[g0:g0 + self.max_batch]
+                    probs = []
+                    try:
+                        for cx, i in zip(ctxs, group):
+                            X, W2, Y = self.operands(specs[i])
+                            probs.append(LayerProblem(cx, X, W2, Y, flags=self.flags))
+                        rngs = [np.random.RandomState(self.seed(specs[i])) for i in group]
+                        res = prune_layers_batched(probs, [specs[i]["rank"] for i in group],
+                                                   [specs[i].get("alpha_in", self.alpha_in) for i in group], rngs,
+                                                   rank_tol=self.rank_tol)
+                        for i, (idxs, W, b, alpha) in zip(group, res):
+                            out[i] = (idxs, W, b)
+                            self.alphas[specs[i].get("layer_id", i)] = alpha
+                    finally:
+                        for pr in probs:
+                            pr.free()
+        finally:
+            for cx in siblings:
+                cx.close()
+        return out
+
+
+def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None):
+    """specs: list of dicts with at least N, c, n, k, rank; compute_fn(spec) -> (idxs, W, b), or
+    compute_many(list of this rank's specs) -> list of (idxs, W, b) (e.g. a GpuLayerBatches).
     Every rank returns the full list of results in layer order.  `dist` is an initialised
     torch.distributed module (None = single process)."""
     world = dist.get_world_size() if dist is not None else 1
@@ -52,10 +104,13 @@ def prune_sharded(specs, compute_fn, dist=None, device=None):
     costs = [layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"]) for s in specs]
     owner = assign_layers(costs, world)
     mine = {}
-    for i, s in enumerate(specs):
-        if owner[i] == rank:
-            idxs, W, b = compute_fn(s)
-            mine[i] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
+    own = [i for i in range(len(specs)) if owner[i] == rank]
+    if compute_many is not None:
+        got = compute_many([specs[i] for i in own])
+    else:
+        got = [compute_fn(specs[i]) for i in own]
+    for i, (idxs, W, b) in zip(own, got):
+        mine[i] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
     if dist is None:
         return [mine[i] for i in range(len(specs))]
     import torch

@@ -621,3 +621,24 @@ def test_prune_layers_rejects_mixed_widths_and_foreign_streams(ctx):
     finally:
         sib.close()
         other.close()
+
+
+def test_prune_sharded_with_gpu_batches_matches_reference_golden(ctx):
+    """The multi-layer driver with the GPU batch engine (single process): layers of mixed widths are grouped by channel
+    count, each group goes through cp_prune_layers, results come back in layer order and equal the goldens."""
+    from cpmi355.shard import GpuLayerBatches, prune_sharded
+    names = ["s01_c32_k3", "s02_c64_k3", "s06_dead", "s12_c96_n40", "s10_alpha_carry", "s03_c64_k1"]
+    cases = {nm: load_case(nm) for nm in names}
+    specs = []
+    for nm in names:
+        g, p, X, W2, Y, B2 = cases[nm]
+        specs.append(dict(name=nm, layer_id=p["layer_id"], N=p["N"], c=p["c"], n=p["n"], k=p["k"], rank=p["rank"],
+                          alpha_in=p.get("alpha_in", 1e-3)))
+    engine = GpuLayerBatches(ctx, lambda s: (cases[s["name"]][2].astype(np.float64), cases[s["name"]][3], cases[s["name"]][4]),
+                             max_batch=2)          # 3 layers of width 32 -> a batch of 2 and a batch of 1
+    res = prune_sharded(specs, compute_many=engine)
+    for nm, s, (idxs, W, b) in zip(names, specs, res):
+        g = cases[nm][0]
+        assert np.array_equal(idxs, g["idxs"]), nm
+        assert relfro(W, g["newW2"]) <= REL_W and relfro(b, g["newB2"]) <= REL_W, nm
+        assert engine.alphas[s["layer_id"]] == float(g["alpha_out"]), nm
