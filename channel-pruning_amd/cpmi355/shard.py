@@ -9,7 +9,7 @@ hundred bytes each, plus the reconstructed weights) over torch.distributed -- ba
     assign_layers(costs, world)        longest-processing-time-first assignment
     layer_cost(N, c, n, k, rank)       FLOP model of SURVEY.md section 8d (plus the serial CD term)
     prune_sharded(specs, compute_fn)   run this rank's share, all-gather every result
-    GpuLayerBatches(ctx, operands)     compute_many for it: equal-width layers through cp_prune_layers, 8 at a time
+    GpuLayerBatches(ctx, operands)     compute_many for it: equal-width layers through cp_prune_layers, up to 16 at a time
 
 For the layers that dominate (conv4/conv5 sizes) the ROWS of one layer can be spread over the ranks instead
 ("secondary"):
@@ -53,7 +53,7 @@ class GpuLayerBatches:
 
     Returns [(idxs, newW2, newB2), ...] in the order of the specs it was given; .alphas holds the accepted alphas."""
 
-    def __init__(self, ctx, operands, seed=lambda s: 1234 + s["layer_id"], max_batch=8, alpha_in=1e-3, rank_tol=.1,
+    def __init__(self, ctx, operands, seed=lambda s: 1234 + s["layer_id"], max_batch=16, alpha_in=1e-3, rank_tol=.1,
                  flags=None):
         from . import capi
         self.ctx, self.operands, self.seed = ctx, operands, seed

@@ -1556,7 +1556,7 @@ struct CdSearchArgs {
     int *fits_used;
     double *alpha_out;
 };
-constexpr int CP_CD_MAX_BATCH = 8;
+constexpr int CP_CD_MAX_BATCH = 16;
 struct CdSearchBatch {
     CdSearchArgs a[CP_CD_MAX_BATCH];
 };

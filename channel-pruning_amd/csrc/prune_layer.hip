@@ -115,7 +115,7 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
 extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_job *jobs, cp_prune_result *results) {
     if (!ctxs || !jobs || !results || n_jobs <= 0 || !ctxs[0]) return CP_ERR_ARG;
     cp_ctx *ctx0 = ctxs[0];
-    if (n_jobs > 8) return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: at most 8 jobs per call (got %d)", n_jobs);
+    if (n_jobs > CP_MAX_JOBS) return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: at most %d jobs per call (got %d)", CP_MAX_JOBS, n_jobs);
     for (int l = 0; l < n_jobs; ++l) {
         const cp_prune_job &j = jobs[l];
         if (!ctxs[l] || !j.X || !j.W2 || !j.Y || !j.mask_out || !j.W_out || !j.b_out)
@@ -134,10 +134,10 @@ extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_j
     const size_t cc = size_t(c);
     struct Ws {
         double *Q, *q, *stats, *w, *Wd, *bd;
-    } ws[8];
-    cp_search_job sj[8];
-    cp_ctx *sctx[8];
-    int smap[8], n_search = 0;
+    } ws[CP_MAX_JOBS];
+    cp_search_job sj[CP_MAX_JOBS];
+    cp_ctx *sctx[CP_MAX_JOBS];
+    int smap[CP_MAX_JOBS], n_search = 0;
     for (int l = 0; l < n_jobs; ++l) {
         const cp_prune_job &j = jobs[l];
         cp_ctx *ctx = ctxs[l];
@@ -187,7 +187,7 @@ extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_j
         }
     }
     // refits: every layer's front (means, centring, Gram, X^T Y) is enqueued, then the batch factors and substitutes
-    cp_refit_info info[8];
+    cp_refit_info info[CP_MAX_JOBS];
     for (int l = 0; l < n_jobs; ++l) {
         if (results[l].fits_used < 0) continue;
         const cp_prune_job &j = jobs[l];

@@ -531,7 +531,7 @@ struct PotrfJob {
     double *TI, *TIT;
     int *info;
 };
-constexpr int CP_REFIT_MAX_BATCH = 8;
+constexpr int CP_REFIT_MAX_BATCH = 16;
 struct PotrfBatch {
     PotrfJob j[CP_REFIT_MAX_BATCH];
 };

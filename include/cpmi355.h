@@ -243,7 +243,8 @@ int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, in
  * workspace and pinned result block.  A stream runs one kernel at a time and most of a layer's time is its
  * single-workgroup alpha search, so the searches of the batch are the workgroups of one launch; the host waits twice
  * per call.  results[i] as cp_prune_layer's (fits_used == -1: that layer's search did not settle, nothing else of
- * results[i] / its outputs is valid).  At most 8 jobs per call. */
+ * results[i] / its outputs is valid).  At most CP_MAX_JOBS jobs per call. */
+#define CP_MAX_JOBS 16
 typedef struct cp_prune_job {
     const void *X;
     int32_t x_dtype;
