@@ -79,9 +79,9 @@ def _launch(world, names):
     procs = [mpc.Process(target=_worker, args=(r, world, port, names, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=300) for _ in procs)
+    got = dict(q.get(timeout=900) for _ in procs)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     return got
 
