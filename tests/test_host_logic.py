@@ -123,9 +123,9 @@ def test_sharded_pruning_world_size_2_gloo():
     procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in procs]
+    got = [q.get(timeout=900) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     got.sort()
     calls = sorted(got[0][1] + got[1][1])
@@ -243,9 +243,9 @@ def test_row_sharded_layer_world_size_2_gloo():
     procs = [ctx.Process(target=_row_shard_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=180) for _ in procs)
+    got = dict(q.get(timeout=900) for _ in procs)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     for lid, (N, c, n, k, r) in enumerate([(600, 16, 12, 3, 8), (500, 24, 16, 1, 10), (400, 12, 12, 3, 12)], start=1):
         X, W2, Y, B2 = cp_oracle.synth_layer(lid, N, c, n, k)
