@@ -287,6 +287,74 @@ def test_alpha_search_rng_rewind_matches_reference_consumption():
     assert after == ref.randint(0, 2147483647)
 
 
+def test_batched_pruning_consumes_each_layers_rng_like_the_reference(monkeypatch):
+    """prune_layers_batched (cp_prune_layers stubbed out): every layer's own generator ends 1 + F draws further (the
+    sample subset, one seed per fit the search used), the seeds handed to the library are the next MAX_FITS draws of
+    that generator, rank == c layers draw only their samples, and a layer whose search did not settle is rewound and
+    replayed fit by fit."""
+    from cpmi355 import capi, pruner
+    seen = {}
+
+    class Prob:
+        def __init__(self, c, n, N, unsettled=False):
+            self.ctx, self.c, self.n, self.N, self.k, self.kk = object(), c, n, N, 3, 9
+            self.Xd = self.W2d = self.Yd = None
+            self.x_dtype = self.w_dtype = 0
+            self.flags, self.unsettled, self.replayed, self.fits = 0, unsettled, [], []
+
+        def lasso_gram(self, samples):
+            self.replayed.append(("gram", len(samples)))
+
+        def alpha_search(self, rank, alpha_in, rank_tol, rng, mode):
+            self.replayed.append(("search", mode))
+            rng.randint(0, pruner.RAND_R_MAX)          # the replay used one fit
+            return 0.5
+
+        def mask(self):
+            return np.arange(self.c) < 3
+
+        def refit(self, idxs, ridge=0.0):
+            return np.zeros((self.n, 3 * self.kk)), np.zeros(self.n)
+
+    def fake_prune_layers(jobs):
+        out = []
+        for i, j in enumerate(jobs):
+            seen[i] = (np.array(j["samples"]), np.array(j["seeds"]))
+            r = capi.PruneResult()
+            prob = probs[i]
+            if prob.unsettled:
+                r.fits_used = -1
+                out.append((r, None, None, None))
+                continue
+            r.fits_used = 0 if j["rank"] == j["c"] else 3 + i
+            r.p, r.alpha = 2 * j["kk"], 0.25
+            mask = np.arange(j["c"]) < 2
+            out.append((r, mask, np.zeros((j["n"], 2 * j["kk"])), np.zeros(j["n"])))
+        return out
+
+    monkeypatch.setattr(capi.Context, "prune_layers", staticmethod(fake_prune_layers))
+    probs = [Prob(8, 4, 400), Prob(8, 4, 400), Prob(8, 4, 400, unsettled=True), Prob(8, 4, 400)]
+    ranks = [4, 4, 4, 8]
+    rngs = [np.random.RandomState(100 + i) for i in range(4)]
+    res = pruner.prune_layers_batched(probs, ranks, [1e-3] * 4, rngs)
+    for i in range(4):
+        ref = np.random.RandomState(100 + i)
+        samples = ref.randint(0, 400, 20)
+        assert np.array_equal(seen[i][0], samples)
+        if ranks[i] != 8:
+            state = ref.get_state()
+            seeds = np.array([ref.randint(0, pruner.RAND_R_MAX) for _ in range(pruner.MAX_FITS)], dtype=np.uint32)
+            assert np.array_equal(seen[i][1], seeds)
+            ref.set_state(state)
+        used = {0: 3, 1: 4, 2: 1, 3: 0}[i]                    # layer 2: replayed on the host, one fit
+        for _ in range(used):
+            ref.randint(0, pruner.RAND_R_MAX)
+        assert rngs[i].randint(0, 1 << 30) == ref.randint(0, 1 << 30), i
+    assert probs[2].replayed == [("gram", 20), ("search", "host")] and res[2][3] == 0.5
+    assert res[0][3] == 0.25 and res[3][3] == 1e-4              # rank == c: the alpha argument's default, no search
+    assert res[0][1].shape == (4, 2, 3, 3) and res[2][1].shape == (4, 3, 3, 3)
+
+
 def test_cheap_rng_bookkeeping_equals_numpy_semantics():
     """draw_seeds (one vectorised randint) leaves the values and the generator state that the same number of scalar
     rng.randint(0, 2147483647) calls leave -- the reference draws them one per Lasso.fit (_cd_fast.pyx:164) -- and
