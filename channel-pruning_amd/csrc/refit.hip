@@ -300,12 +300,7 @@ __device__ __forceinline__ void potrf_body(const double *G, double *Uout, double
         if (task > 0) {
             const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
             int *flag = info + 1 + blk;
-            if (tid == 0) {
-                for (int spin = 0; spin < (1 << 24); ++spin) {
-                    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
+            if (tid == 0) flag_wait(flag, info);  // bounded; running out is reported as a failed factorisation
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const int j = blk + task;
