@@ -64,6 +64,9 @@ CASES = {
     # ResNet-50 bottleneck 1x1 with the residual-aware target (configs[3]) and the 20000-sample refit of configs[4]
     "L06_res3_1x1_resid": dict(layer_id=36, N=5000, c=512, n=128, k=1, rank=256, residual=True, large=True),
     "L07_conv3_N20000": dict(layer_id=37, N=20000, c=256, n=256, k=3, rank=102, large=True),
+    # the remaining (c, n) pairs of SURVEY 8c at full sample count: conv1_2 -> conv2_1 and conv2_1 -> conv2_2
+    "L08_conv1_2_conv2_1": dict(layer_id=38, N=5000, c=64, n=128, k=3, rank=32, large=True),
+    "L09_conv2_1_conv2_2_q": dict(layer_id=39, N=5000, c=128, n=128, k=3, rank=32, large=True),
 }
 
 
