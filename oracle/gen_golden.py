@@ -67,6 +67,8 @@ CASES = {
     # the remaining (c, n) pairs of SURVEY 8c at full sample count: conv1_2 -> conv2_1 and conv2_1 -> conv2_2
     "L08_conv1_2_conv2_1": dict(layer_id=38, N=5000, c=64, n=128, k=3, rank=32, large=True),
     "L09_conv2_1_conv2_2_q": dict(layer_id=39, N=5000, c=128, n=128, k=3, rank=32, large=True),
+    # configs[2]'s (256, 512) pair: conv3_3 -> conv4_1 (n = 512 outputs: wider right-hand sides and strips)
+    "L10_conv3_3_conv4_1": dict(layer_id=40, N=5000, c=256, n=512, k=3, rank=128, large=True),
 }
 
 
