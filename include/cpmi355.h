@@ -239,8 +239,9 @@ int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, in
 
 /* The same for several independent layers at once (e.g. the equal-shaped layers of a ResNet stage, or one layer of
  * several networks): jobs[i] is exactly the argument list of cp_prune_layer.  All jobs must have the same channel
- * count c; ctxs[i] are DISTINCT contexts bound to ONE stream (cp_ctx_set_stream) on one device -- each keeps its own
- * workspace and pinned result block.  A stream runs one kernel at a time and most of a layer's time is its
+ * count c; ctxs[i] are DISTINCT contexts on ONE stream and device (a context and its cp_ctx_create_sibling()s, or
+ * contexts bound to a caller-owned stream with cp_ctx_set_stream) -- each keeps its own workspace and pinned result
+ * block.  No reference counterpart: the reference prunes one layer per dictionary() call (lib/net.py:1443).  A stream runs one kernel at a time and most of a layer's time is its
  * single-workgroup alpha search, so the searches of the batch are the workgroups of one launch; the host waits twice
  * per call.  results[i] as cp_prune_layer's (fits_used == -1: that layer's search did not settle, nothing else of
  * results[i] / its outputs is valid).  At most CP_MAX_JOBS jobs per call. */
