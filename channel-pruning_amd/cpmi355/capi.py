@@ -199,6 +199,7 @@ class Context:
         h = _vp()
         self._check(self.lib.cp_ctx_create_sibling(self.h, ctypes.byref(h)), "cp_ctx_create_sibling")
         other.h, other.device, other.pid = h.value, self.device, self.pid
+        other._parent = self       # the stream belongs to `self`: keep it alive as long as the sibling
         return other
 
     def close(self):
