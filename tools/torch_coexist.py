@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "channel-pruning_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "channel-pruning_amd"))
 order = sys.argv[1]
 import numpy as np
 def maps():
