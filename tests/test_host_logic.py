@@ -399,3 +399,40 @@ def test_cheap_rng_bookkeeping_equals_numpy_semantics():
     o.s = 5
     pruner.rng_rewind(o, m)
     assert o.s == 0
+
+
+def test_torch_sequential_provider_is_live_and_wired_like_the_reference():
+    """lib/provider.py: conv blobs are pre-ReLU, <conv>_relu / pool blobs feed the consumers, and the blobs follow the
+    weights the net holds at call time (what Net.R3's decomposition steps rely on).  CPU only: no Net method that
+    needs the GPU is called."""
+    import torch
+    import torch.nn.functional as F
+    from lib.net import ConvSpec, Net
+    from lib.provider import TorchSequentialProvider
+    rs = np.random.RandomState(0)
+    specs = [ConvSpec("conv1_1", rs.randn(4, 3, 3, 3) * .2, rs.randn(4) * .1, "data"),
+             ConvSpec("conv1_2", rs.randn(6, 4, 3, 3) * .2, rs.randn(6) * .1, "conv1_1_relu"),
+             ConvSpec("conv2_1", rs.randn(5, 6, 3, 3) * .2, rs.randn(5) * .1, "pool1")]
+    data = [rs.randn(2, 3, 8, 8).astype(np.float32) for _ in range(2)]
+    prov = TorchSequentialProvider(data, pools={"conv1_2": ("pool1", 2, 2)}, num_threads=1)
+    net = Net(specs, prov, nBatches=2, nPointsPerLayer=2)
+    assert net._live and len(prov) == 2
+    blobs = net.forward(1)
+    x = torch.from_numpy(data[1])
+    y1 = F.conv2d(x, torch.from_numpy(specs[0].W), torch.from_numpy(specs[0].b), padding=1)
+    y2 = F.conv2d(F.relu(y1), torch.from_numpy(specs[1].W), torch.from_numpy(specs[1].b), padding=1)
+    p1 = F.max_pool2d(F.relu(y2), 2, 2)
+    y3 = F.conv2d(p1, torch.from_numpy(specs[2].W), torch.from_numpy(specs[2].b), padding=1)
+    assert np.array_equal(blobs["conv1_1"], y1.numpy()) and np.array_equal(blobs["conv1_2"], y2.numpy())
+    assert np.array_equal(blobs["pool1"], p1.numpy()) and np.array_equal(blobs["conv2_1"], y3.numpy())
+    assert blobs["conv2_1"].shape == (2, 5, 4, 4) and (blobs["conv1_1"] < 0).any()      # pre-ReLU responses
+    # live: a weight change shows up in the next forward (the cache is dropped by set_param_data)
+    net.set_param_data("conv1_2", np.zeros_like(specs[1].W))
+    again = net.forward(1)
+    assert np.array_equal(again["conv1_2"], np.broadcast_to(specs[1].b[None, :, None, None], (2, 6, 8, 8)))
+    # features sampled through the net's own extraction code, frozen points reused for a second extraction
+    np.random.seed(3)
+    feats, points = net.extract_features(["conv1_1", "conv2_1"], save=1)
+    assert feats["conv1_1"].shape == (2 * 2 * 2, 4) and feats["conv2_1"].shape == (8, 5)
+    feats2, _ = net.extract_features(["conv1_1"], points_dict=points, save=1)
+    assert np.array_equal(feats["conv1_1"], feats2["conv1_1"])

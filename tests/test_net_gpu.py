@@ -130,11 +130,10 @@ def _wire(blobs, name, y):
 
 
 def make_live_net(seed=0, B=4, HW=12, nBatches=10, nPoints=8):
-    """provider(batch, net): torch CPU forward with the net's CURRENT weights (what the reference's Caffe net does)"""
-    import torch
-    import torch.nn.functional as F
+    """lib/provider.py::TorchSequentialProvider: torch CPU forward with the net's CURRENT weights (what the
+    reference's Caffe net does)"""
     from lib.net import ConvSpec, Net
-    torch.set_num_threads(1)      # tiny convolutions: the intra-op thread pool of a many-core host costs 30 ms per call
+    from lib.provider import TorchSequentialProvider
     rs = np.random.RandomState(seed)
     specs = []
     for name, cin, cout in CHANS_3C:
@@ -142,15 +141,8 @@ def make_live_net(seed=0, B=4, HW=12, nBatches=10, nPoints=8):
         b = (rs.randn(cout) * 0.1).astype(np.float32)
         specs.append(ConvSpec(name, W, b, BOTTOMS_3C[name], pad=1, stride=1))
     data = [rs.randn(B, 3, HW, HW).astype(np.float32) for _ in range(nBatches)]
-
-    def provider(batch, net):
-        blobs = {"data": data[batch]}
-        for name, _, _ in CHANS_3C:
-            y = F.conv2d(torch.from_numpy(blobs[BOTTOMS_3C[name]]), torch.from_numpy(net.param_data(name)),
-                         torch.from_numpy(net.param_b_data(name)), padding=1)
-            _wire(blobs, name, y)
-        return blobs
-
+    # one thread: tiny convolutions, the intra-op thread pool of a many-core host costs 30 ms per call
+    provider = TorchSequentialProvider(data, pools={"conv1_2": ("pool1", 2, 2), "conv2_2": ("pool2", 2, 2)}, num_threads=1)
     return Net(specs, provider, nBatches=nBatches, nPointsPerLayer=nPoints), data
 
 
