@@ -436,3 +436,45 @@ def test_torch_sequential_provider_is_live_and_wired_like_the_reference():
     assert feats["conv1_1"].shape == (2 * 2 * 2, 4) and feats["conv2_1"].shape == (8, 5)
     feats2, _ = net.extract_features(["conv1_1"], points_dict=points, save=1)
     assert np.array_equal(feats["conv1_1"], feats2["conv1_1"])
+
+
+def test_gpu_layer_batches_groups_by_width_and_keeps_layer_order(monkeypatch):
+    """cpmi355.shard.GpuLayerBatches (device calls stubbed out): layers are grouped by channel count, each group is
+    cut into calls of at most max_batch layers on a context and its siblings, every layer gets its own seeded RNG and
+    the results come back in the order of the specs."""
+    from cpmi355 import pruner, shard
+    calls, freed, closed = [], [], []
+
+    class FakeCtx:
+        def __init__(self, name):
+            self.name = name
+
+        def sibling(self):
+            return FakeCtx(self.name + "'")
+
+        def close(self):
+            closed.append(self.name)
+
+    class FakeProb:
+        def __init__(self, ctx, X, W2, Y, flags=0):
+            self.ctx, self.tag = ctx, X
+
+        def free(self):
+            freed.append(self.tag)
+
+    def fake_batched(probs, ranks, alpha_ins, rngs, rank_tol=.1):
+        calls.append(([p.tag for p in probs], list(ranks), [int(r.randint(0, 1 << 30)) for r in rngs], len({id(p.ctx) for p in probs})))
+        return [(np.array([True]), np.full((1, 1, 1, 1), p.tag), np.zeros(1), 0.1 * p.tag) for p in probs]
+
+    monkeypatch.setattr(pruner, "LayerProblem", FakeProb)
+    monkeypatch.setattr(pruner, "prune_layers_batched", fake_batched)
+    specs = [dict(layer_id=i, N=100, c=c, n=4, k=3, rank=2) for i, c in enumerate([32, 64, 32, 32, 64, 16, 32])]
+    eng = shard.GpuLayerBatches(FakeCtx("root"), lambda s: (s["layer_id"], None, None), max_batch=3, flags=0)
+    out = shard.prune_sharded(specs, compute_many=eng)
+    assert [int(W[0, 0, 0, 0]) for _, W, _ in out] == list(range(7))              # layer order restored
+    assert [c[0] for c in calls] == [[5], [0, 2, 3], [6], [1, 4]]                  # by width, at most 3 per call
+    assert all(c[3] == len(c[0]) for c in calls)                                  # distinct contexts within a call
+    for tags, _, draws, _ in calls:
+        assert draws == [int(np.random.RandomState(1234 + t).randint(0, 1 << 30)) for t in tags]
+    assert sorted(freed) == list(range(7)) and len(closed) == 2                    # 2 siblings for batches of 3
+    assert eng.alphas[4] == pytest.approx(0.4)
