@@ -1,28 +1,30 @@
-"""bench.py -- layers pruned per second on the BASELINE.json metric.
+"""bench.py -- conv layers pruned per second (BASELINE.json metric) on MI355X.
 
-Workload (BASELINE.json configs[1]): the VGG-16 conv3_x block, 4x prune (rank = c/2), 5000
-synthetic samples per layer, i.e. three dictionary() problems per step
-    conv2_2 -> conv3_1   X[5000,128,3,3]  W2[256,128,3,3]  rank  64
-    conv3_1 -> conv3_2   X[5000,256,3,3]  W2[256,256,3,3]  rank 128
-    conv3_2 -> conv3_3   X[5000,256,3,3]  W2[256,256,3,3]  rank 128
-generated by the SURVEY.md section 8d generator (oracle/cp_oracle.py::synth_layer), float32 X and W2
-(exactly what the reference's float64 arrays hold), float64 Y, all resident in HBM before the
-timed region.  One step = one pass over the block = all three layers pruned (mask + refit weights +
-bias back on the host).  Layers are independent units and a single-wave
-coordinate-descent search occupies one SIMD of 1024, so many are kept in flight, exactly as the 13 / 50
-layers of a whole VGG-16 / ResNet-50 prune would be: --inflight worker groups (default 6) of three host
-threads / HIP streams (one per layer of the block), each worker pruning --batch independent copies of its
-layer per foreign call (default 8: cp_prune_layers runs their alpha searches as one launch; --batch 1 = one
-cp_prune_layer call per layer).  Every copy has its own operands, workspace and RNG stream.
-`ms_per_pass_one_at_a_time` is the latency of a pass with nothing else on the GPU (cp_prune_layer).  With --gpus N every
-rank prunes its own copy of the block (layers shard with no data-path collective): weak scaling,
-value = 3 N layers / max-over-ranks step time.
+Two workloads, both built from SURVEY.md section 8d's synthetic generator (float32 X and W2 -- exactly what the
+reference's float64 arrays hold -- float64 Y), operands RESIDENT in HBM before the timed region, results (mask,
+weights, bias) back on the host inside it:
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant MFMA kernel (the f64 Gram
-GEMM of the refit, symmetric half): flops from the launch shapes, time from HIP events recorded
-around that kernel inside libcpmi355 during the timed steps.  `cpu_baseline` times the CPU port
-of the reference path (oracle/cp_oracle.py with scikit-learn's own Lasso / LinearRegression, the
-arithmetic the reference runs) on the same three layers on this box's host cores.
+--workload vgg16 (default; north_star's job, BASELINE.json configs[2] on one node)
+    ONE instance of the whole-network job: the 12 conv -> conv pairs of VGG-16 with the reference's 3C-4x kept-channel
+    count d_c = max(int(c / 1.15), rank) (/root/reference/lib/net.py:1309-1327, 1346-1349), N = 5000 samples per
+    layer.  One job = 12 dictionary() problems (c = 64, 64, 128, 128, 256 x3, 512 x5).  With --gpus N the layers are
+    sharded over the ranks (cpmi355.shard.prune_sharded: LPT assignment, ONE uint8 all_gather of the channel masks and
+    one packed (W, b) broadcast per owner rank on RCCL) -- STRONG scaling: the same 12 layers whatever N is.  On a rank
+    all its layers are in flight together (cpmi355.shard.ResidentLayerSet: a HIP stream + host thread per chunk of
+    equal-width layers, the alpha searches of a chunk as the workgroups of one launch).
+    A "step" is `jobs_per_step` back-to-back jobs (chosen during warm-up so that the timed region is >= 2 s);
+    value = 12 * jobs / elapsed = layers/s of a single job instance, job_ms = its wall-clock.
+
+--workload block (BASELINE.json configs[1]: the VGG-16 conv3_x block, rank = c/2)
+    single_instance: the three layers of ONE block instance, one after another with nothing else on the chip;
+    value: replica throughput -- many independent copies of the block in flight (--inflight groups x --batch copies),
+    the regime of a job with hundreds of equal layers; the line says how many really ran.
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant MFMA kernel (the f64 Gram GEMM of the refit, symmetric half):
+algorithmic flops N p^2 per launch / the HIP-event time of that launch recorded inside libcpmi355 on its launch stream
+during the timed steps.  `cpu_baseline` = the CPU port of the reference path (oracle/cp_oracle.py driving scikit-learn's
+own Lasso / LinearRegression: the arithmetic the reference runs) on a bounded sample of the same layers on this box's
+host cores (--cpu-full: every layer of the job).
 """
 import argparse
 import ctypes
@@ -39,16 +41,38 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # one hardware queue per stre
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
 
-LAYERS = [  # (layer_id, c, n, rank)  -- ids match tests/golden/L0[123]_*.npz
-    (31, 128, 256, 64),
-    (32, 256, 256, 128),
-    (33, 256, 256, 128),
-]
-GOLDEN = {31: "L01_conv2_2_conv3_1", 32: "L02_conv3_1_conv3_2", 33: "L03_conv3_2_conv3_3"}
 N_SAMPLES, KSIZE = 5000, 3
 CD_FLAGS = int(os.environ.get("CP_BENCH_CD_FLAGS", "3"))   # CP_CD_RECIPROCAL | CP_CD_DELTA (library default)
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X public FP64 matrix figure (the guide lists no f64 row); the
                               # measured v_mfma_f64_16x16x4_f64 issue rate is reported next to it
+MIN_TIMED_SECONDS = 2.0
+
+# ---- workload tables ------------------------------------------------------------------------------------------
+BLOCK_LAYERS = [  # (layer_id, c, n, rank)  -- ids match tests/golden/L0[123]_*.npz
+    (31, 128, 256, 64),
+    (32, 256, 256, 128),
+    (33, 256, 256, 128),
+]
+BLOCK_GOLDEN = {31: "L01_conv2_2_conv3_1", 32: "L02_conv3_1_conv3_2", 33: "L03_conv3_2_conv3_3"}
+
+# the reference's VGG-16 rank table (net.py:1309-1321) scaled by 4/3 (:1323-1326) never exceeds int(c / 1.15), so
+# d_c = int(c / 1.15) for every pair (net.py:1346-1349): 55, 55, 111, 111, 222 x3, 445 x5
+VGG16_PAIRS = [("conv1_1", "conv1_2", 64, 64), ("conv1_2", "conv2_1", 64, 128), ("conv2_1", "conv2_2", 128, 128),
+               ("conv2_2", "conv3_1", 128, 256), ("conv3_1", "conv3_2", 256, 256), ("conv3_2", "conv3_3", 256, 256),
+               ("conv3_3", "conv4_1", 256, 512), ("conv4_1", "conv4_2", 512, 512), ("conv4_2", "conv4_3", 512, 512),
+               ("conv4_3", "conv5_1", 512, 512), ("conv5_1", "conv5_2", 512, 512), ("conv5_2", "conv5_3", 512, 512)]
+VGG16_RANKDIC = {'conv1_1': 17, 'conv1_2': 17, 'conv2_1': 37, 'conv2_2': 47, 'conv3_1': 83, 'conv3_2': 89, 'conv3_3': 106,
+                 'conv4_1': 175, 'conv4_2': 192, 'conv4_3': 227, 'conv5_1': 398, 'conv5_2': 390, 'conv5_3': 379}
+
+
+def vgg16_specs():
+    specs = []
+    for i, (prod, cons, c, n) in enumerate(VGG16_PAIRS):
+        rank = VGG16_RANKDIC[prod] if 'conv5' in prod else int(VGG16_RANKDIC[prod] * 4. / 3.)
+        d_c = max(int(c / 1.15), rank)
+        specs.append(dict(layer_id=101 + i, name="V%02d_%s_%s" % (i + 1, prod, cons), N=N_SAMPLES, c=c, n=n, k=KSIZE,
+                          rank=d_c))
+    return specs
 
 
 def synth(layer_id, c, n):
@@ -63,6 +87,357 @@ def synth(layer_id, c, n):
     return X, W2, Y, B2
 
 
+def sketch_matrix(p):
+    """the seeded test matrix of the sketched weight goldens (oracle/cp_oracle.py::sketch_matrix, restated)"""
+    return np.random.RandomState(777).randn(int(p), 32)
+
+
+def golden_check(name, idxs, newW2):
+    """-> (mask identical, weight rel. Frobenius error [estimated from the sketch when the golden holds no full tensor])"""
+    gpath = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.isfile(gpath):
+        return None, None
+    g = np.load(gpath)
+    same = bool(np.array_equal(idxs, g["idxs"]))
+    if not same:
+        return False, None
+    wm = newW2.reshape(newW2.shape[0], -1)
+    if "newW2_sketch" in g.files:
+        sk = wm @ sketch_matrix(wm.shape[1])
+        return True, float(np.linalg.norm(sk - g["newW2_sketch"]) / np.linalg.norm(g["newW2_sketch"]))
+    return True, float(np.linalg.norm(newW2 - g["newW2"]) / np.linalg.norm(g["newW2"]))
+
+
+def layer_flops(c, n, pp, N=N_SAMPLES, kk=KSIZE * KSIZE):
+    """(SURVEY.md 8d algorithmic flops of one dictionary() call [full-matrix counts], flops the launches execute
+    [symmetric halves, 128-padded tiles])"""
+    S = min(400, N // 20)
+    alg = (2.0 * c * S * kk * n + 2.0 * S * n * c * c + 2.0 * S * n * c + 2.0 * N * pp * pp + 2.0 * N * pp * n
+           + pp ** 3 / 3.0 + 2.0 * pp * pp * n)
+    pad = lambda v, a: (v + a - 1) // a * a   # noqa: E731
+    ck, P, n_pad, Np = pad(c * kk, 128), pad(pp, 128), pad(n, 128), pad(N, 16)
+    tri = lambda m: m // 128 * (m // 128 + 1) // 2 * 128.0 * 128.0   # noqa: E731
+    exe = (tri(ck) * 2.0 * (pad(S, 16) + n) + 2.0 * S * n * ck + tri(P) * 2.0 * Np + 2.0 * P * n_pad * Np
+           + P ** 3 / 3.0 + 2.0 * P * P * n_pad)
+    return alg, exe
+
+
+def algorithmic_bytes(c, n, pp, N=N_SAMPLES, kk=KSIZE * KSIZE):
+    """inputs once at f32 (+ the f64 Y the caller hands over) and the outputs at f64"""
+    return 4.0 * (N * c * kk + N * n + n * c * kk) + 4.0 * N * n + 8.0 * (n * pp + n) + c
+
+
+def host_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([i.get("num_threads", 1) for i in threadpool_info()] + [1]))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_port_seconds(layers):
+    """CPU port of the reference path: seconds per layer.  layers: [(layer_id, c, n, rank)]"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cp_oracle
+    secs = []
+    for layer_id, c, n, rank in layers:
+        X, W2, Y, B2 = synth(layer_id, c, n)
+        X64 = X.astype(np.float64)
+        np.random.seed(1234 + layer_id)
+        t0 = time.perf_counter()
+        cp_oracle.dictionary_oracle(X64, W2, Y, rank, B2, alpha_in=1e-3, lasso="sklearn", ls="sklearn")
+        secs.append(time.perf_counter() - t0)
+    return secs
+
+
+# ==================================================================================================================
+# distributed plumbing
+# ==================================================================================================================
+class Env:
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = os.environ.get("CP_BENCH_DIST_BACKEND", "nccl")   # "gloo": several ranks on ONE GPU (flow test)
+        self.dist = None
+        self.torch = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                self.local_rank = self.local_rank % max(1, torch.cuda.device_count())
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group(self.backend)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, value):
+        if self.dist is None:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def bcast_int(self, value):
+        if self.dist is None:
+            return int(value)
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.broadcast(t, src=0)
+        return int(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def pmc_traffic(pattern, round_tag):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 counter passes (separate --pmc runs
+    of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads,
+    WRITE_SIZE as reported).  None when the profile files are absent."""
+    out = {}
+    for key, fname, scale in (("fetch", "%s_pmc_fetch_size_kb.md" % round_tag, 2.0),
+                              ("write", "%s_pmc_write_size_kb.md" % round_tag, 1.0)):
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.isfile(path):
+            return None
+        for line in open(path):
+            if pattern in line:
+                try:
+                    out[key] = float(line.split("|")[3]) * 1024.0 * scale
+                except (ValueError, IndexError):
+                    pass
+    if len(out) != 2:
+        return None
+    return out["fetch"] + out["write"]
+
+
+def roofline_object(g_ms, g_fl, ctx0, note, traffic):
+    if not g_ms or sum(g_ms) <= 0:
+        return None
+    achieved = sum(g_fl) / (sum(g_ms) * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_gemm_tn_f64 (refit Gram G = Xs^T Xs, f64 MFMA 16x16x4)",
+            "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + "
+                            "WRITE_SIZE passes committed under profiles/",
+            "avg_launch_ms": round(sum(g_ms) / len(g_ms), 4), "launches": len(g_ms),
+            "flops_per_launch": "N*p^2 (symmetric half of 2*N*p^2), p = kept*9",
+            "peak_measured_probe": round(ctx0.probe_mfma_f64(), 2), "note": note}
+
+
+# ==================================================================================================================
+# workload: vgg16 (the north_star job)
+# ==================================================================================================================
+def bench_vgg16(args, env):
+    import cpmi355
+    from cpmi355 import shard
+    from cpmi355.pruner import prune_layer, rng_rewind
+
+    specs = vgg16_specs()
+    for s in specs:       # measured single-layer latencies (ms, profiles/r02_*) as LPT costs; model when absent
+        s["cost"] = VGG16_COST_MS.get(s["c"], None) or shard.layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"])
+    owner = shard.plan_owners(specs, env.world)
+    own = [i for i in range(len(specs)) if owner[i] == env.rank]
+    host_data = {}
+
+    def operands(spec):
+        X, W2, Y, _ = synth(spec["layer_id"], spec["c"], spec["n"])
+        host_data[spec["layer_id"]] = (X, W2, Y)
+        return X, W2, Y
+
+    t_up0 = time.perf_counter()
+    rset = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in own], operands, per_stream=args.per_stream,
+                                  flags=CD_FLAGS)
+    probs = rset.problems()           # index in `own` order -> LayerProblem
+    ctxs = [cx for ch in rset.chunks for cx in ch["ctxs"]]
+    roots = [ch["ctxs"][0] for ch in rset.chunks]
+
+    def one_job():
+        return shard.prune_sharded(specs, compute_many=rset, dist=env.dist, owner=owner)
+
+    def sync_all():
+        for cx in roots:
+            cx.sync()
+
+    # ---- warm-up: W jobs (>= 2), then choose jobs_per_step so that K steps take >= MIN_TIMED_SECONDS ----
+    one_job()
+    sync_all()
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.warmup)):
+        one_job()
+    sync_all()
+    env.barrier()
+    job_s = env.max_over_ranks((time.perf_counter() - t0) / max(1, args.warmup))
+    reps = args.jobs_per_step or max(1, int(np.ceil(MIN_TIMED_SECONDS / max(job_s * args.steps, 1e-9))))
+    reps = env.bcast_int(reps)
+
+    for cx in ctxs:
+        cx.enable_stage_timing(2)      # timed region: only the two events around the roofline kernel
+    g_ms, g_fl = [], []
+    sync_all()
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for _ in range(reps):
+            results = one_job()
+            for j, pr in probs.items():
+                for name, ms in pr.ctx.last_stage_times():
+                    if name == "refit_gram_gemm":
+                        g_ms.append(ms)
+                        g_fl.append(float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
+    sync_all()
+    env.barrier()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    jobs = args.steps * reps
+    job_ms = elapsed / jobs * 1e3
+    chunk_report = rset.chunk_report()
+
+    # ---- outside the timed region: every layer of this rank ALONE (latency, per-stage times, roofline kernel alone) ----
+    per_layer = {}
+    alone_g_ms, alone_g_fl = [], []
+    stage_by_c = {}
+    for j, pr in probs.items():
+        spec = specs[own[j]]
+        pr.ctx.enable_stage_timing(1)
+        ch = [c_ for c_ in rset.chunks if j in c_["members"]][0]
+        rng, mark = ch["rngs"][ch["members"].index(j)], ch["marks"][ch["members"].index(j)]
+        ts = []
+        for _ in range(2):
+            rng_rewind(rng, mark)
+            t1 = time.perf_counter()
+            prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=rng, mode="device")
+            ts.append((time.perf_counter() - t1) * 1e3)
+        st = dict(pr.ctx.last_stage_times())
+        steps_cd = sum(f[2] for f in pr.fits) * spec["c"]
+        per_layer[spec["name"]] = {"ms_alone": round(min(ts), 3), "kept": int(pr.refit_info.p) // 9, "fits": len(pr.fits),
+                                   "cd_steps": int(steps_cd), "alpha_search_ms": round(st.get("cd_alpha_search", 0.0), 3),
+                                   "cd_us_per_step": round(st.get("cd_alpha_search", 0.0) * 1e3 / max(1, steps_cd), 4),
+                                   "refit_ms": round(sum(v for k_, v in st.items() if k_.startswith("refit")), 3)}
+        stage_by_c.setdefault(spec["c"], st)
+        if "refit_gram_gemm" in st:
+            alone_g_ms.append(st["refit_gram_gemm"])
+            alone_g_fl.append(float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
+
+    # ---- PCIe-inclusive: upload of a layer's operands from pageable host memory + its pruning, layer after layer ----
+    pcie = None
+    if env.world == 1:
+        from cpmi355.pruner import LayerProblem
+        ctx0 = roots[0]
+        t1 = time.perf_counter()
+        h2d = 0
+        for j in sorted(probs):
+            spec = specs[own[j]]
+            X, W2, Y = host_data[spec["layer_id"]]
+            pr = LayerProblem(ctx0, X, W2, Y, flags=CD_FLAGS)
+            h2d += pr.h2d_bytes
+            prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
+            pr.free()
+        t_seq = time.perf_counter() - t1
+        pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "h2d_bytes": int(h2d),
+                "layers_per_s_with_h2d": round(len(specs) / t_seq, 2),
+                "note": "every layer uploaded from pageable host memory (hipMemcpy) and pruned, one after another on one "
+                        "stream: what the drop-in dictionary() does per call; never part of `value`"}
+
+    # ---- verification on rank 0 (outside the timed region) ----
+    out = None
+    if env.rank == 0:
+        parity, werrs, recon = True, {}, {}
+        for spec, (idxs, newW2, newB2) in zip(specs, results):
+            same, werr = golden_check(spec["name"], idxs, newW2)
+            werrs[spec["name"]] = werr
+            if same is not None:
+                parity = parity and same and werr is not None and werr <= 1e-5
+            if spec["layer_id"] in host_data:
+                X, _, Y = host_data[spec["layer_id"]]
+                Xs = X[:, idxs].reshape(N_SAMPLES, -1).astype(np.float64)
+                res = Xs @ newW2.reshape(spec["n"], -1).T + newB2 - Y
+                recon[spec["name"]] = round(float(np.linalg.norm(res) / np.linalg.norm(Y)), 6)
+        layers_per_s = len(specs) * jobs / elapsed
+        fl = [layer_flops(s["c"], s["n"], int(r[0].sum()) * 9) for s, r in zip(specs, results)]
+        by = [algorithmic_bytes(s["c"], s["n"], int(r[0].sum()) * 9) for s, r in zip(specs, results)]
+        alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
+        roof = roofline_object(g_ms, g_fl, roots[0],
+                               "launch duration over the timed region, i.e. while the other layers of the job share the "
+                               "CUs; alone = the same kernel of every layer with the chip to itself; job_mfma = the "
+                               "whole job against the same peak", pmc_traffic("k_gemm_tn_f64<1, 2,", "r02"))
+        if roof is not None and alone_g_ms:
+            a1 = sum(alone_g_fl) / (sum(alone_g_ms) * 1e-3) / 1e12
+            roof["alone"] = {"achieved": round(a1, 3), "frac": round(a1 / F64_MFMA_PEAK_TFLOPS, 4),
+                             "avg_launch_ms": round(sum(alone_g_ms) / len(alone_g_ms), 4)}
+        out = {
+            "metric": "conv layers pruned/sec (VGG-16 4x, 5k samples)",
+            "value": round(layers_per_s, 3), "unit": "layers/s", "n_gpus": env.world, "steps": args.steps,
+            "warmup": max(1, args.warmup) + 1, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "vgg16: ONE instance of the whole-network job = the 12 conv->conv pairs of VGG-16, "
+                                   "kept channels d_c = int(c/1.15) (the reference's 3C-4x table), N=5000 samples/layer, "
+                                   "k=3; 1 job = 12 dictionary() calls; 1 step = jobs_per_step back-to-back jobs",
+                       "layers_per_job": len(specs), "jobs_per_step": reps, "jobs_timed": jobs,
+                       "timed_region_s": round(elapsed, 3),
+                       "streams_per_gpu": len(rset.chunks), "layers_in_flight_per_gpu": len(own),
+                       "layers_per_call": sorted({len(ch["members"]) for ch in rset.chunks}),
+                       "owner_rank_of_layer": owner, "parallelism": "layers sharded x%d (LPT), masks all_gather + "
+                                                                    "packed (W,b) broadcast per owner" % env.world},
+            "job_ms": round(job_ms, 3),
+            "mask_parity_vs_reference_golden": parity,
+            "weights_rel_frobenius_vs_reference_golden": werrs,
+            "reconstruction_rel_frobenius_err": recon,
+            "roofline": roof,
+            "job_mfma": {"gflop_per_job_algorithmic": round(alg_job / 1e9, 1), "gflop_per_job_executed_model": round(exe_job / 1e9, 1),
+                         "sustained_tflops_algorithmic": round(alg_job / (job_ms * 1e-3) / 1e12, 2),
+                         "frac_of_peak_algorithmic": round(alg_job / (job_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS / env.world, 4),
+                         "algorithmic_bytes_per_job": int(sum(by)),
+                         "note": "SURVEY.md 8d flop / byte formulas summed over the 12 layers (full-matrix counts)"},
+            "per_layer_rank0": per_layer,
+            "chunks_rank0_last_job": chunk_report,
+            "stage_ms_alone_by_width_rank0": {str(c): {k_: round(v, 4) for k_, v in st.items()} for c, st in stage_by_c.items()},
+            "pcie_inclusive": pcie,
+            "upload_and_setup_s": round(t0 - t_up0, 2),
+        }
+        if env.world == 1 and not args.no_cpu_baseline:
+            sample = specs if args.cpu_full else [s for s in specs if s["c"] <= 256]
+            secs = cpu_port_seconds([(s["layer_id"], s["c"], s["n"], s["rank"]) for s in sample])
+            gpu_ms_same = sum(per_layer[s["name"]]["ms_alone"] for s in sample)
+            out["cpu_baseline"] = {
+                "value": round(len(sample) / sum(secs), 4), "unit": "layers/s", "cores": host_threads(), "kind": "port",
+                "sample": "%s of the job's 12 layers (%s), one pass, sklearn Lasso (single-threaded CD) + "
+                          "LinearRegression/gelsd (BLAS threads = cores): %.1f s total, per layer %s s" % (
+                              "all 12" if args.cpu_full else "the 7 layers with c <= 256", ", ".join(s["name"][:3] for s in sample),
+                              sum(secs), [round(x, 2) for x in secs]),
+                "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+                "gpu_ms_same_layers_one_at_a_time": round(gpu_ms_same, 2),
+                "speedup_same_layers_latency": round(sum(secs) * 1e3 / gpu_ms_same, 1)}
+            if args.cpu_full:
+                out["cpu_baseline"]["job_speedup_wall_clock"] = round(sum(secs) * 1e3 / job_ms, 1)
+    rset.close()
+    return out
+
+
+# measured ms of one layer alone by channel count (profiles/r02_*): the LPT costs of the vgg16 job
+VGG16_COST_MS = {}
+
+
+# ==================================================================================================================
+# workload: block (configs[1], conv3_x) -- single instance + replica throughput
+# ==================================================================================================================
 class LayerWorker(threading.Thread):
     """One layer shape, one HIP stream, one host thread driving it.  batch > 1: the worker holds `batch` independent
     copies of the layer (own operands, own sibling context on the same stream) and prunes them with ONE
@@ -90,12 +465,15 @@ class LayerWorker(threading.Thread):
         self.collect = False
         self.single = False          # True: one cp_prune_layer call per pruning even when batch > 1
         self.todo = 1
+        self.calls, self.layers_done = 0, 0
 
     def prune(self, count):
         """`count` (<= batch) independent prunings of this layer; every one starts from the reference's RNG state"""
         rngs = self.rngs[:count]
         for r, mark in zip(rngs, self.rng0):  # = np.random.seed(1234 + id) before every call, without re-seeding
             self.cpmi355.pruner.rng_rewind(r, mark)
+        self.calls += 1
+        self.layers_done += count
         if count == 1:
             return [self.cpmi355.prune_layer(self.prob, self.rank, 1e-3, rank_tol=.1, rng=rngs[0], mode="device")]
         return self.cpmi355.prune_layers_batched(self.probs[:count], [self.rank] * count, [1e-3] * count, rngs, rank_tol=.1)
@@ -130,13 +508,13 @@ class LayerWorker(threading.Thread):
             self.done.set()
 
 
-def run_steps(groups, steps):
-    """`steps` passes over the block.  Pass s is worker group s % D's (own contexts / HIP streams and
-    operand copies); every worker runs its share back to back, so up to D independent passes -- 3 D
-    layers -- are in flight on the GPU (D = 1: strictly one pass at a time)."""
+def run_passes(groups, passes):
+    """`passes` passes over the block.  Pass s is worker group s % D's (own contexts / HIP streams and
+    operand copies); every worker runs its share back to back, so up to D x batch independent passes are in flight
+    on the GPU (D = 1, batch = 1: strictly one pass at a time)."""
     active = []
     for g, group in enumerate(groups):
-        cnt = len(range(g, steps, len(groups)))
+        cnt = len(range(g, passes, len(groups)))
         if cnt == 0:
             continue
         for w in group:
@@ -150,238 +528,63 @@ def run_steps(groups, steps):
             raise w.error
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 counter passes
-    (separate --pmc runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for 16-B/lane streaming reads, WRITE_SIZE as reported -- calibrated 1:1 on k_build_z's known
-    131 MB).  None when the profile files are absent."""
-    out = {}
-    for key, fname, scale in (("fetch", "r01_pmc_fetch_size_kb.md", 2.0), ("write", "r01_pmc_write_size_kb.md", 1.0)):
-        path = os.path.join(ROOT, "profiles", fname)
-        if not os.path.isfile(path):
-            return None
-        for line in open(path):
-            if "k_gemm_tn_f64<1, 2," in line:
-                out[key] = float(line.split("|")[3]) * 1024.0 * scale
-    if len(out) != 2:
-        return None
-    return out["fetch"] + out["write"]
-
-
-def cpu_baseline():
-    """CPU port of the reference path on the same three layers (bounded: one pass, ~15-25 s)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cp_oracle
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    secs = []
-    for layer_id, c, n, rank in LAYERS:
-        X, W2, Y, B2 = synth(layer_id, c, n)
-        X64 = X.astype(np.float64)
-        np.random.seed(1234 + layer_id)
-        t0 = time.perf_counter()
-        cp_oracle.dictionary_oracle(X64, W2, Y, rank, B2, alpha_in=1e-3, lasso="sklearn", ls="sklearn")
-        secs.append(time.perf_counter() - t0)
-    total = sum(secs)
-    return {"value": len(LAYERS) / total, "unit": "layers/s", "cores": int(threads), "kind": "port",
-            "sample": "one pass over the 3 conv3_x layers (N=5000), sklearn Lasso (single-threaded CD) + "
-                      "LinearRegression/gelsd (BLAS threads = cores); %.1f s total, per layer %s s" % (
-                          total, [round(s, 2) for s in secs]),
-            "host_cpus": os.cpu_count()}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=48)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("CP_BENCH_INFLIGHT", "6")),
-                    help="worker groups (3 HIP streams each) running passes over the block concurrently (1 = one at a time)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CP_BENCH_BATCH", "8")),
-                    help="passes a worker group prunes per cp_prune_layers call (1 = cp_prune_layer per layer)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    torch = None
-    backend = os.environ.get("CP_BENCH_DIST_BACKEND", "nccl")   # "gloo": several ranks on ONE GPU (flow test only)
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            local_rank = local_rank % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # each rank prunes its own copy of the block (distinct data per rank: layer ids shifted)
-    depth = max(1, min(args.inflight, args.steps))
-    groups = [[LayerWorker(local_rank, lid + 100 * rank if rank else lid, c, n, r, batch=max(1, args.batch))
-               for lid, c, n, r in LAYERS]
-              for _ in range(depth)]
-    workers = [w for g in groups for w in g]
-    for w in workers:
+def block_single_instance(device, passes=5):
+    """ONE instance of the conv3_x block: its three layers one after another (cp_prune_layer), nothing else on the
+    chip.  -> dict (ms per pass, layers/s, per-stage ms, fits, CD steps)"""
+    group = [LayerWorker(device, lid, c, n, r, batch=1) for lid, c, n, r in BLOCK_LAYERS]
+    for w in group:
         w.start()
-
-    warm = max(args.warmup, depth * max(1, args.batch))   # every problem copy runs at least once before the timed region
-    run_steps(groups, warm)
-    for w in workers:
-        for cx in w.ctxs:
-            cx.enable_stage_timing(2)    # timed region: only the two events around the roofline kernel
-        w.collect = True
-    for w in workers:
-        w.ctx.sync()
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(groups, args.steps)
-    for w in workers:
-        w.ctx.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- one pass at a time on group 0 (outside the timed region): single-pass latency and the
-    #      roofline kernel without other passes sharing the chip ----
-    timed_acc = [(w.stage_acc, w.gram_flops, w.gram_exec) for w in workers]
-    for w in workers:
-        w.stage_acc, w.gram_flops, w.gram_exec = {}, [], []
-    for w in groups[0]:
         w.single = True
-        for cx in w.ctxs:
-            cx.enable_stage_timing(1)    # every stage, for the per-stage breakdown
-    t1 = time.perf_counter()
-    run_steps(groups[:1], 3)
-    for w in groups[0]:
-        w.ctx.sync()
-    single_ms = (time.perf_counter() - t1) / 3 * 1e3
-    single_g_ms = [ms for w in groups[0] for ms in w.stage_acc.get("refit_gram_gemm", [])]
-    single_g_fl = [f for w in groups[0] for f in w.gram_flops]
-    single_g_ex = [f for w in groups[0] for f in w.gram_exec]
-    single_stages = {}
-    for w in groups[0]:
-        for name, v in w.stage_acc.items():
-            single_stages.setdefault(name, []).extend(v)
-    for w, (sa, gf, ge) in zip(workers, timed_acc):
-        w.stage_acc, w.gram_flops, w.gram_exec = sa, gf, ge
+    try:
+        for cx in (w.ctx for w in group):
+            cx.enable_stage_timing(1)
+        ts = []
+        for i in range(passes + 1):
+            t1 = time.perf_counter()
+            for w in group:                      # strictly one layer at a time
+                w.collect = i > 0
+                w.todo = 1
+                w.done.clear()
+                w.go.set()
+                w.done.wait()
+                if w.error is not None:
+                    raise w.error
+            if i > 0:
+                ts.append((time.perf_counter() - t1) * 1e3)
+        stages = {}
+        for w in group:
+            for name, v in w.stage_acc.items():
+                stages.setdefault(name, []).extend(v)
+        g_ms = [ms for w in group for ms in w.stage_acc.get("refit_gram_gemm", [])]
+        g_fl = [f for w in group for f in w.gram_flops]
+        g_ex = [f for w in group for f in w.gram_exec]
+        cd_steps = [sum(f[2] for f in w.prob.fits) * w.c for w in group]
+        cd_ms = [float(np.mean(w.stage_acc.get("cd_alpha_search", [0.0]))) for w in group]
+        parity, werrs = True, []
+        for w in group:
+            idxs, newW2, _, _ = w.result
+            same, werr = golden_check(BLOCK_GOLDEN[w.layer_id], idxs, newW2)
+            werrs.append(werr)
+            parity = parity and bool(same) and werr is not None and werr <= 1e-5
+        ms = float(np.median(ts))
+        return {"ms_per_pass": round(ms, 3), "layers_per_s": round(len(BLOCK_LAYERS) / ms * 1e3, 2),
+                "stage_ms_avg": {k: round(sum(v) / len(v), 4) for k, v in stages.items()},
+                "lasso_fits_per_layer": [len(w.prob.fits) for w in group], "cd_steps_per_layer": cd_steps,
+                "cd_us_per_step": [round(m * 1e3 / max(1, s), 4) for m, s in zip(cd_ms, cd_steps)],
+                "mask_parity_vs_reference_golden": parity, "weights_rel_frobenius_vs_reference_golden": werrs,
+                "roofline_kernel_alone": ({"achieved": round(sum(g_fl) / (sum(g_ms) * 1e-3) / 1e12, 3),
+                                           "frac": round(sum(g_fl) / (sum(g_ms) * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
+                                           "executed_tflops": round(sum(g_ex) / (sum(g_ms) * 1e-3) / 1e12, 3),
+                                           "avg_launch_ms": round(sum(g_ms) / len(g_ms), 4)} if g_ms and sum(g_ms) > 0 else None),
+                "host_ms_avg": ({k: round(float(np.mean([h[i] for w in group for h in w.host_acc])), 4) for i, k in
+                                 enumerate(("lasso_operands_enqueue", "alpha_search_host", "refit_enqueue",
+                                            "copy_back_and_wait"))} if any(w.host_acc for w in group) else None)}, group
+    except BaseException:
+        close_workers(group)
+        raise
 
-    # ---- verification on rank 0 (outside the timed region) ----
-    parity = None
-    recon = []
-    werrs = []
-    if rank == 0:
-        parity = True
-        for w in workers:
-            idxs, newW2, newB2, _ = w.result
-            gpath = os.path.join(ROOT, "tests", "golden", GOLDEN[w.layer_id] + ".npz")
-            if os.path.isfile(gpath):
-                g = np.load(gpath)
-                same = bool(np.array_equal(idxs, g["idxs"]))
-                werr = float(np.linalg.norm(newW2 - g["newW2"]) / np.linalg.norm(g["newW2"])) if same else None
-                werrs.append(werr)
-                parity = parity and same and werr is not None and werr <= 1e-5
-            Xs = w.X[:, idxs].reshape(N_SAMPLES, -1).astype(np.float64)
-            res = Xs @ newW2.reshape(w.n, -1).T + newB2 - w.Y
-            recon.append(float(np.linalg.norm(res) / np.linalg.norm(w.Y)))
 
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        layers_per_s = len(LAYERS) * world / (elapsed / args.steps)
-        # dominant MFMA kernel: refit Gram GEMM (k_gemm_tn_f64, symmetric lower tiles)
-        g_ms = [ms for w in workers for ms in w.stage_acc.get("refit_gram_gemm", [])]
-        g_fl = [f for w in workers for f in w.gram_flops]
-        roof = None
-        if g_ms and sum(g_ms) > 0:
-            achieved = sum(g_fl) / (sum(g_ms) * 1e-3) / 1e12
-            ctx0 = workers[0].ctx
-            roof = {"bound": "mfma", "kernel": "k_gemm_tn_f64 (refit Gram G = Xs^T Xs, f64 MFMA 16x16x4)",
-                    "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
-                    "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read "
-                                    "correction) + WRITE_SIZE passes committed under profiles/r01_pmc_*.md",
-                    "avg_launch_ms": round(sum(g_ms) / len(g_ms), 4), "launches": len(g_ms),
-                    "flops_per_launch": "N*p^2 (symmetric half of 2*N*p^2), p = kept*9",
-                    "peak_measured_probe": round(ctx0.probe_mfma_f64(), 2),
-                    "note": "launch duration over the timed region, i.e. while the other layers in flight (config."
-                            "steps_in_flight x 3) share the CUs with this launch; one_pass_at_a_time = the same kernel with "
-                            "the chip to itself; job_mfma = the whole job against the same peak"}
-            if single_g_ms and sum(single_g_ms) > 0:
-                a1 = sum(single_g_fl) / (sum(single_g_ms) * 1e-3) / 1e12
-                roof["one_pass_at_a_time"] = {"achieved": round(a1, 3), "frac": round(a1 / F64_MFMA_PEAK_TFLOPS, 4),
-                                              "executed_tflops": round(sum(single_g_ex) / (sum(single_g_ms) * 1e-3) / 1e12, 3),
-                                              "avg_launch_ms": round(sum(single_g_ms) / len(single_g_ms), 4),
-                                              "note": "same kernel, 3 untimed passes with no other pass in flight; "
-                                                      "executed = the 128-padded lower tiles the launch computes "
-                                                      "(compare with peak_measured_probe)"}
-        # whole job against the f64 MFMA peak: SURVEY.md section 8d's flop count of one dictionary() call (full-matrix
-        # counts, as written there) and the flops the launches really execute (symmetric halves, 128-padded tiles)
-        def layer_flops(w):
-            c, n, kk, S, N = w.c, w.n, 9, min(400, N_SAMPLES // 20), N_SAMPLES
-            pp = int(w.prob.refit_info.p)
-            alg = (2.0 * c * S * kk * n + 2.0 * S * n * c * c + 2.0 * S * n * c + 2.0 * N * pp * pp + 2.0 * N * pp * n
-                   + pp ** 3 / 3.0 + 2.0 * pp * pp * n)
-            pad = lambda v, a: (v + a - 1) // a * a   # noqa: E731
-            ck, P, n_pad, Np = pad(c * kk, 128), pad(pp, 128), pad(n, 128), pad(N, 16)
-            tri = lambda m: m // 128 * (m // 128 + 1) // 2 * 128.0 * 128.0   # noqa: E731
-            exe = (tri(ck) * 2.0 * (pad(S, 16) + n) + 2.0 * S * n * ck          # GX, GW (upper tiles), T = Ys Wf
-                   + tri(P) * 2.0 * Np + 2.0 * P * n_pad * Np                    # refit Gram (lower tiles), Xs^T Yc
-                   + P ** 3 / 3.0 + 2.0 * P * P * n_pad)                         # Cholesky tiles, two block substitutions
-            return alg, exe
-        fl = [layer_flops(w) for w in groups[0]]
-        alg_l, exe_l = sum(f[0] for f in fl) / len(fl), sum(f[1] for f in fl) / len(fl)
-        per_gpu = layers_per_s / world
-        job = {"flops_per_layer_algorithmic": round(alg_l / 1e9, 2), "flops_per_layer_executed_model": round(exe_l / 1e9, 2),
-               "unit": "GFLOP", "sustained_tflops_algorithmic_per_gpu": round(per_gpu * alg_l / 1e12, 2),
-               "sustained_tflops_executed_per_gpu": round(per_gpu * exe_l / 1e12, 2),
-               "frac_of_peak_algorithmic": round(per_gpu * alg_l / 1e12 / F64_MFMA_PEAK_TFLOPS, 4),
-               "note": "algorithmic = SURVEY.md 8d formula (full-matrix counts of the two Gram products); executed = "
-                       "what the launches compute (symmetric halves, 128-padded tiles); compare the latter with "
-                       "roofline.peak_measured_probe, the back-to-back f64 MFMA rate this chip sustains"}
-        stage_ms = {k: round(sum(v) / len(v), 4) for k, v in single_stages.items()}
-        fits = [len(w.prob.fits) for w in groups[0]]
-        cd_steps = [sum(f[2] for f in w.prob.fits) * w.c for w in groups[0]]
-        out = {
-            "metric": "conv layers pruned/sec (VGG-16 4x, 5k samples)",
-            "value": round(layers_per_s, 3), "unit": "layers/s", "n_gpus": world, "steps": args.steps,
-            "warmup": warm, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "VGG-16 conv3_x block 4x prune (3 layers: 128->256, 256->256, 256->256; "
-                                   "k=3, rank=c/2), N=5000 samples/layer, 1 step = 3 dictionary() calls",
-                       "layers_per_step_per_gpu": len(LAYERS), "steps_in_flight": depth * max(1, args.batch),
-                       "streams": 3 * depth, "layers_per_call": max(1, args.batch),
-                       "parallelism": "layers x%d" % world},
-            "mask_parity_vs_reference_golden": parity,
-            "weights_rel_frobenius_vs_reference_golden": werrs[:len(LAYERS)],
-            "reconstruction_rel_frobenius_err": [round(r, 6) for r in recon[:len(LAYERS)]],
-            "roofline": roof,
-            "job_mfma": job,
-            "ms_per_pass_one_at_a_time": round(single_ms, 3),
-            "stage_ms_avg_one_pass_at_a_time": stage_ms,
-            "host_ms_avg": ({k: round(float(np.mean([h[i] for w in workers for h in w.host_acc])), 4) for i, k in
-                             enumerate(("lasso_operands_enqueue", "alpha_search_host", "refit_enqueue",
-                                        "copy_back_and_wait"))} if any(w.host_acc for w in workers) else None),
-            "lasso_fits_per_layer": fits, "cd_steps_per_layer": cd_steps,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["speedup_vs_cpu_baseline"] = round(layers_per_s / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
-
+def close_workers(workers):
     for w in workers:
         w.stop = True
         w.go.set()
@@ -392,8 +595,132 @@ def main():
             prob.free()
         for cx in reversed(w.ctxs):      # siblings before the context that owns the stream
             cx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+
+
+def bench_block(args, env):
+    rank, world = env.rank, env.world
+    depth = max(1, args.inflight)
+    batch = max(1, args.batch)
+    groups = [[LayerWorker(env.local_rank, lid + 100 * rank if rank else lid, c, n, r, batch=batch)
+               for lid, c, n, r in BLOCK_LAYERS] for _ in range(depth)]
+    workers = [w for g in groups for w in g]
+    for w in workers:
+        w.start()
+    per_round = depth * batch                      # passes one round of calls covers (every copy once)
+    run_passes(groups, per_round)                  # every problem copy runs once
+    for w in workers:
+        w.ctx.sync()
+    t0 = time.perf_counter()
+    run_passes(groups, per_round)
+    for w in workers:
+        w.ctx.sync()
+    round_s = time.perf_counter() - t0
+    for _ in range(max(0, args.warmup - 2)):
+        run_passes(groups, per_round)
+    # one step = `rounds` full rounds (depth x batch passes each): K steps take >= MIN_TIMED_SECONDS
+    rounds = max(1, int(np.ceil(MIN_TIMED_SECONDS / max(round_s * args.steps, 1e-9))))
+    rounds = env.bcast_int(rounds)
+    for w in workers:
+        for cx in w.ctxs:
+            cx.enable_stage_timing(2)    # timed region: only the two events around the roofline kernel
+        w.collect = True
+        w.calls, w.layers_done = 0, 0
+    for w in workers:
+        w.ctx.sync()
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_passes(groups, per_round * rounds)
+    for w in workers:
+        w.ctx.sync()
+    env.barrier()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    passes = args.steps * per_round * rounds
+    out = None
+    if rank == 0:
+        parity, werrs, recon = True, [], []
+        for w in groups[0]:
+            idxs, newW2, newB2, _ = w.result
+            same, werr = golden_check(BLOCK_GOLDEN.get(w.layer_id, "-"), idxs, newW2)
+            werrs.append(werr)
+            if same is not None:
+                parity = parity and same and werr is not None and werr <= 1e-5
+            Xs = w.X[:, idxs].reshape(N_SAMPLES, -1).astype(np.float64)
+            res = Xs @ newW2.reshape(w.n, -1).T + newB2 - w.Y
+            recon.append(round(float(np.linalg.norm(res) / np.linalg.norm(w.Y)), 6))
+        layers_per_s = len(BLOCK_LAYERS) * world * passes / elapsed
+        g_ms = [ms for w in workers for ms in w.stage_acc.get("refit_gram_gemm", [])]
+        g_fl = [f for w in workers for f in w.gram_flops]
+        roof = roofline_object(g_ms, g_fl, workers[0].ctx,
+                               "launch duration over the timed region, i.e. while the other layers in flight share the CUs",
+                               pmc_traffic("k_gemm_tn_f64<1, 2,", "r02"))
+        fl = [layer_flops(w.c, w.n, int(w.prob.refit_info.p)) for w in groups[0]]
+        alg_l = sum(f[0] for f in fl) / len(fl)
+        calls = sum(w.calls for w in workers)
+        out = {
+            "metric": "conv layers pruned/sec (VGG-16 4x, 5k samples)",
+            "value": round(layers_per_s, 3), "unit": "layers/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(2, args.warmup), "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "block: REPLICA THROUGHPUT of the VGG-16 conv3_x block 4x prune (3 layers: 128->256, "
+                                   "256->256, 256->256; k=3, rank=c/2, N=5000) -- independent copies of the block in "
+                                   "flight; see single_instance for one block alone",
+                       "passes_timed": passes, "passes_per_step": per_round * rounds, "timed_region_s": round(elapsed, 3),
+                       "block_copies_in_flight": depth * batch, "layers_in_flight": 3 * depth * batch, "streams": 3 * depth,
+                       "layers_per_call_actual": round(sum(w.layers_done for w in workers) / max(1, calls), 2),
+                       "foreign_calls_timed": calls, "parallelism": "replicas x%d" % world},
+            "mask_parity_vs_reference_golden": parity, "weights_rel_frobenius_vs_reference_golden": werrs,
+            "reconstruction_rel_frobenius_err": recon, "roofline": roof,
+            "job_mfma": {"gflop_per_layer_algorithmic": round(alg_l / 1e9, 2),
+                         "sustained_tflops_algorithmic_per_gpu": round(layers_per_s / world * alg_l / 1e12, 2),
+                         "frac_of_peak_algorithmic": round(layers_per_s / world * alg_l / 1e12 / F64_MFMA_PEAK_TFLOPS, 4)},
+        }
+    close_workers(workers)
+    if rank == 0:
+        single, group = block_single_instance(env.local_rank)
+        close_workers(group)
+        out["single_instance"] = single
+        out["single_instance_layers_per_s"] = single["layers_per_s"]
+        if world == 1 and not args.no_cpu_baseline:
+            secs = cpu_port_seconds(BLOCK_LAYERS)
+            out["cpu_baseline"] = {"value": round(len(BLOCK_LAYERS) / sum(secs), 4), "unit": "layers/s", "cores": host_threads(),
+                                   "kind": "port", "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+                                   "sample": "one pass over the 3 conv3_x layers (N=5000), sklearn Lasso (single-threaded CD) "
+                                             "+ LinearRegression/gelsd (BLAS threads = cores); %.1f s total, per layer %s s" % (
+                                                 sum(secs), [round(s, 2) for s in secs]),
+                                   "speedup_single_instance_latency": round(sum(secs) * 1e3 / single["ms_per_pass"], 1)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("vgg16", "block"), default=os.environ.get("CP_BENCH_WORKLOAD", "vgg16"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="vgg16: time the CPU port on all 12 layers (about 2-3 min)")
+    ap.add_argument("--no-block", action="store_true", help="vgg16: skip the conv3_x single-instance figures")
+    ap.add_argument("--per-stream", type=int, default=int(os.environ.get("CP_BENCH_PER_STREAM", "2")),
+                    help="vgg16: equal-width layers per stream / cp_prune_layers call")
+    ap.add_argument("--jobs-per-step", type=int, default=0, help="vgg16: fixed jobs per step (0 = fill >= 2 s)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("CP_BENCH_INFLIGHT", "6")),
+                    help="block: worker groups (3 HIP streams each) running passes over the block concurrently")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CP_BENCH_BATCH", "8")),
+                    help="block: block copies a worker group prunes per cp_prune_layers call")
+    args = ap.parse_args()
+    env = Env()
+    if args.workload == "vgg16":
+        out = bench_vgg16(args, env)
+        if out is not None and not args.no_block and env.world == 1:
+            single, group = block_single_instance(env.local_rank)
+            close_workers(group)
+            out["conv3_block_single_instance"] = single
+    else:
+        out = bench_block(args, env)
+    if env.rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+    env.close()
     sys.stdout.flush()
     sys.stderr.flush()
 

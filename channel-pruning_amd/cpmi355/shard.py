@@ -8,8 +8,11 @@ hundred bytes each, plus the reconstructed weights) over torch.distributed -- ba
 
     assign_layers(costs, world)        longest-processing-time-first assignment
     layer_cost(N, c, n, k, rank)       FLOP model of SURVEY.md section 8d (plus the serial CD term)
-    prune_sharded(specs, compute_fn)   run this rank's share, all-gather every result
+    prune_sharded(specs, compute_fn)   run this rank's share, then exchange_results(): one mask all_gather + one packed
+                                       (W, b) broadcast per owner rank
     GpuLayerBatches(ctx, operands)     compute_many for it: equal-width layers through cp_prune_layers, up to 16 at a time
+    ResidentLayerSet(device, specs, ..) the same with the operands resident in HBM and every width group on its own
+                                       stream(s) + host thread, all in flight together (bench.py --workload vgg16)
 
 For the layers that dominate (conv4/conv5 sizes) the ROWS of one layer can be spread over the ranks instead
 ("secondary"):
@@ -94,15 +97,181 @@ class GpuLayerBatches:
         return out
 
 
-def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None):
+class ResidentLayerSet:
+    """This rank's layers RESIDENT in HBM, pruned as one job.
+
+    The layers are grouped by channel count (cp_prune_layers wants equal c) and every group is cut into chunks of at
+    most `per_stream` layers; a chunk owns a Context (= one HIP stream / hardware queue) plus sibling contexts and a
+    host thread, so all chunks -- all widths -- are in flight together: the alpha searches of a chunk are the
+    workgroups of one launch, the refits of different chunks overlap.  Operands are uploaded once (constructor);
+    run() prunes every layer once and returns [(idxs, newW2, newB2, alpha), ...] in the order of `specs`; parity is
+    per layer (own RandomState(seed(spec)), fixed alpha_in: SURVEY.md section 8e).
+
+        operands(spec) -> (X[N,c,k,k], W2[n,c,k,k], Y[N,n]) host arrays, called once per layer."""
+
+    def __init__(self, device, specs, operands, seed=lambda s: 1234 + s["layer_id"], per_stream=2, alpha_in=1e-3,
+                 rank_tol=.1, flags=None):
+        import threading
+
+        from . import capi
+        from .pruner import LayerProblem, rng_mark
+        self.specs = list(specs)
+        self.alpha_in, self.rank_tol = alpha_in, rank_tol
+        flags = (capi.CP_CD_RECIPROCAL | capi.CP_CD_DELTA) if flags is None else flags
+        by_width = {}
+        for i, s in enumerate(self.specs):
+            by_width.setdefault(int(s["c"]), []).append(i)
+        self.chunks = []                 # dicts: members, ctxs, probs, rngs, marks, thread plumbing
+        for c, members in sorted(by_width.items(), key=lambda kv: -kv[0]):     # widest (slowest) first
+            per = max(1, min(int(per_stream), capi_max_jobs()))
+            for g0 in range(0, len(members), per):
+                group = members[g0:g0 + per]
+                root = capi.Context(device)
+                ctxs = [root] + [root.sibling() for _ in group[1:]]
+                probs, rngs = [], []
+                for cx, i in zip(ctxs, group):
+                    X, W2, Y = operands(self.specs[i])
+                    probs.append(LayerProblem(cx, X, W2, Y, flags=flags))
+                    rngs.append(np.random.RandomState(seed(self.specs[i])))
+                self.chunks.append(dict(members=group, ctxs=ctxs, probs=probs, rngs=rngs,
+                                        marks=[rng_mark(r) for r in rngs], go=threading.Event(), done=threading.Event(),
+                                        out=None, error=None, ms=0.0))
+        self._stop = False
+        self._threads = []
+        for ch in self.chunks:
+            t = threading.Thread(target=self._worker, args=(ch,), daemon=True)
+            t.start()
+            self._threads.append(t)
+
+    def _prune_chunk(self, ch):
+        import time
+
+        from .pruner import prune_layer, prune_layers_batched, rng_rewind
+        for r, m in zip(ch["rngs"], ch["marks"]):          # every run starts from the layer's own seed
+            rng_rewind(r, m)
+        specs = [self.specs[i] for i in ch["members"]]
+        t0 = time.perf_counter()
+        if len(specs) == 1:
+            s = specs[0]
+            out = [prune_layer(ch["probs"][0], s["rank"], s.get("alpha_in", self.alpha_in), rank_tol=self.rank_tol,
+                               rng=ch["rngs"][0], mode="device")]
+        else:
+            out = prune_layers_batched(ch["probs"], [s["rank"] for s in specs],
+                                       [s.get("alpha_in", self.alpha_in) for s in specs], ch["rngs"],
+                                       rank_tol=self.rank_tol)
+        ch["ms"] = (time.perf_counter() - t0) * 1e3
+        return out
+
+    def _worker(self, ch):
+        while True:
+            ch["go"].wait()
+            ch["go"].clear()
+            if self._stop:
+                return
+            try:
+                ch["out"] = self._prune_chunk(ch)
+            except BaseException as e:   # noqa
+                ch["error"] = e
+            ch["done"].set()
+
+    def run(self):
+        for ch in self.chunks:
+            ch["done"].clear()
+            ch["error"] = None
+            ch["go"].set()
+        out = [None] * len(self.specs)
+        for ch in self.chunks:
+            ch["done"].wait()
+            if ch["error"] is not None:
+                raise ch["error"]
+            for i, r in zip(ch["members"], ch["out"]):
+                out[i] = r
+        return out
+
+    def __call__(self, specs=None):
+        """compute_many of prune_sharded (the specs are the ones given to the constructor)."""
+        return [(idxs, W, b) for idxs, W, b, _ in self.run()]
+
+    def chunk_report(self):
+        return [dict(layers=[self.specs[i].get("name", self.specs[i].get("layer_id", i)) for i in ch["members"]],
+                     c=int(self.specs[ch["members"][0]]["c"]), ms=round(ch["ms"], 3)) for ch in self.chunks]
+
+    def problems(self):
+        """{index in specs: LayerProblem} (fit logs, refit_info of the last run)"""
+        return {i: pr for ch in self.chunks for i, pr in zip(ch["members"], ch["probs"])}
+
+    def close(self):
+        self._stop = True
+        for ch in self.chunks:
+            ch["go"].set()
+        for t in self._threads:
+            t.join(timeout=10)
+        for ch in self.chunks:
+            for pr in ch["probs"]:
+                pr.free()
+            for cx in reversed(ch["ctxs"]):
+                cx.close()
+        self.chunks = []
+
+
+def capi_max_jobs():
+    return 16      # CP_MAX_JOBS (include/cpmi355.h)
+
+
+def exchange_results(specs, owner, mine, dist, device=None):
+    """Every rank ends with every layer's (mask, W, b).  Two collectives on the data the job produces:
+    (1) ONE fixed-size uint8 all_gather of the channel masks (the "trivial gather of selected-channel masks"),
+    (2) per owner rank ONE broadcast of its packed float64 results (all its W and b back to back; sizes follow from
+    the masks, so nothing else has to be negotiated).  backend "nccl" = RCCL over xGMI: the packed buffer is staged to
+    the device once per owner; "gloo": host tensors."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
+    cmax = max(s["c"] for s in specs)
+    local = torch.zeros((len(specs), cmax), dtype=torch.uint8)
+    for i, (idxs, _, _) in mine.items():
+        local[i, : idxs.shape[0]] = torch.from_numpy(idxs.astype(np.uint8))
+    local = local.to(dev)
+    gathered = torch.empty((world,) + tuple(local.shape), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(gathered, local) if on_gpu else dist.all_gather(list(gathered.unbind(0)), local)
+    gathered = gathered.cpu().numpy()
+    masks = [gathered[owner[i], i, : specs[i]["c"]].astype(bool) for i in range(len(specs))]
+    shapes = [(s["n"], int(m.sum()), s["k"], s["k"]) for s, m in zip(specs, masks)]
+    results = [None] * len(specs)
+    for src in range(world):
+        ids = [i for i in range(len(specs)) if owner[i] == src]
+        if not ids:
+            continue
+        total = sum(int(np.prod(shapes[i])) + specs[i]["n"] for i in ids)
+        if src == rank:
+            packed = np.concatenate([np.concatenate([np.asarray(mine[i][1], dtype=np.float64).ravel(),
+                                                     np.asarray(mine[i][2], dtype=np.float64).ravel()]) for i in ids])
+            t = torch.from_numpy(packed).to(dev)
+        else:
+            t = torch.empty(total, dtype=torch.float64, device=dev)
+        dist.broadcast(t, src=src)
+        flat = t.cpu().numpy()
+        off = 0
+        for i in ids:
+            nw = int(np.prod(shapes[i]))
+            W = flat[off:off + nw].reshape(shapes[i])
+            b = flat[off + nw:off + nw + specs[i]["n"]]
+            off += nw + specs[i]["n"]
+            results[i] = (masks[i], W, b)
+    return results
+
+
+def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None, owner=None):
     """specs: list of dicts with at least N, c, n, k, rank; compute_fn(spec) -> (idxs, W, b), or
-    compute_many(list of this rank's specs) -> list of (idxs, W, b) (e.g. a GpuLayerBatches).
+    compute_many(list of this rank's specs) -> list of (idxs, W, b) (a GpuLayerBatches or a ResidentLayerSet).
     Every rank returns the full list of results in layer order.  `dist` is an initialised
-    torch.distributed module (None = single process)."""
+    torch.distributed module (None = single process); owner[i] (default: LPT over layer_cost) says which rank
+    prunes layer i."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    costs = [layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"]) for s in specs]
-    owner = assign_layers(costs, world)
+    if owner is None:
+        owner = plan_owners(specs, world)
     mine = {}
     own = [i for i in range(len(specs)) if owner[i] == rank]
     if compute_many is not None:
@@ -111,32 +280,15 @@ def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=N
         got = [compute_fn(specs[i]) for i in own]
     for i, (idxs, W, b) in zip(own, got):
         mine[i] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
-    if dist is None:
+    if dist is None or world == 1:
         return [mine[i] for i in range(len(specs))]
-    import torch
-    results = [None] * len(specs)
-    # masks: one fixed-size uint8 all_gather (the "trivial gather of selected-channel masks")
-    cmax = max(s["c"] for s in specs)
-    local = torch.zeros((len(specs), cmax), dtype=torch.uint8, device=device)
-    for i, (idxs, _, _) in mine.items():
-        local[i, : idxs.shape[0]] = torch.from_numpy(idxs.astype(np.uint8)).to(local.device)
-    gathered = [torch.zeros_like(local) for _ in range(world)]
-    dist.all_gather(gathered, local)
-    masks = [gathered[owner[i]][i, : specs[i]["c"]].cpu().numpy().astype(bool) for i in range(len(specs))]
-    # weights / biases: variable size -> broadcast from the owner
-    for i, s in enumerate(specs):
-        kept = int(masks[i].sum())
-        shape = (s["n"], kept, s["k"], s["k"])
-        if owner[i] == rank:
-            W = torch.from_numpy(np.ascontiguousarray(mine[i][1].reshape(shape))).to(local.device)
-            b = torch.from_numpy(np.ascontiguousarray(mine[i][2])).to(local.device)
-        else:
-            W = torch.empty(shape, dtype=torch.float64, device=local.device)
-            b = torch.empty((s["n"],), dtype=torch.float64, device=local.device)
-        dist.broadcast(W, src=owner[i])
-        dist.broadcast(b, src=owner[i])
-        results[i] = (masks[i], W.cpu().numpy(), b.cpu().numpy())
-    return results
+    return exchange_results(specs, owner, mine, dist, device)
+
+
+def plan_owners(specs, world):
+    """owner[i] of every layer: LPT over the cost model (a spec may carry a measured "cost" that overrides it)."""
+    costs = [s.get("cost", layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"])) for s in specs]
+    return assign_layers(costs, world)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -242,6 +242,8 @@ def fc_kernel(X, Y, copy_X=True, W=None, B=None, ret_reg=False, fit_intercept=Tr
         prob.Wout = ctx.empty(n * p * 8)
         prob.bout = ctx.empty(n * 8)
         coef, intercept = prob.refit(np.ones(p, dtype=bool), ridge=float(dcfgs.fc_ridge))
+        ri = prob.refit_info
+        last_call_info["refit_info"] = dict(p=int(ri.p), rank=int(ri.rank), fallback=int(ri.fallback))
     finally:
         prob.free()
     if np.ndim(Y) == 1:

@@ -438,8 +438,48 @@ def dictionary_oracle(X, W2, Y, rank, B2=None, alpha=1e-4, alpha_in=1e-3, rank_t
     return idxs, newW2, newB2, alpha                          # decompose.py:626-627, 634
 
 
+SKETCH_COLS = 32
+
+
+def sketch_matrix(p):
+    """Seeded Gaussian test matrix Omega[p, 32] of the sketched weight goldens (tests/golden/V*.npz, L13):
+    ||(W - Wref) Omega||_F / ||Wref Omega||_F estimates the relative Frobenius error of W (E[||A Omega||^2] = 32 ||A||^2)."""
+    return np.random.RandomState(777).randn(int(p), SKETCH_COLS)
+
+
+def mix_channels(X, rs, mix):
+    """Ill-conditioned channel structure for the q* goldens (float64 in, float64 out; X[N,c,k,k]):
+       kappa   : channels mixed by a c x c matrix with log-spaced singular values 1 .. 1/kappa
+       dup     : three channels are copies of three others + eps * noise (eps = 0: exact copies, rank-deficient)
+       relumix : relu of a rank-r mixture of latent maps + delta of its own full-rank remainder"""
+    N, c = X.shape[0], X.shape[1]
+    kind = mix["kind"]
+    if kind == "kappa":
+        U, _ = np.linalg.qr(rs.randn(c, c))
+        V, _ = np.linalg.qr(rs.randn(c, c))
+        T = (U * np.logspace(0, -np.log10(mix["kappa"]), c)) @ V.T
+        return np.einsum("nikl,ij->njkl", X, T) * np.sqrt(c)
+    if kind == "dup":
+        X = X.copy()
+        for (i, j) in ((1, 9), (4, 5), (20, 2)):
+            X[:, j] = X[:, i] + mix["eps"] * rs.randn(*X[:, i].shape)
+        return X
+    if kind == "relumix":
+        r = mix["r"]
+        G = rs.randn(N, r, X.shape[2], X.shape[3])
+        A = rs.randn(r, c) / np.sqrt(r)
+        low = np.maximum(np.einsum("nrkl,rc->nckl", G, A), 0.)
+        flat = low.reshape(N, -1)
+        fc = flat - flat.mean(0)
+        Uu, ss, Vt = np.linalg.svd(fc, full_matrices=False)
+        rr = r * X.shape[2] * X.shape[3]
+        lo = (Uu[:, :rr] * ss[:rr]) @ Vt[:rr]
+        return (flat.mean(0) + lo + mix["delta"] * (fc - lo)).reshape(X.shape)
+    raise ValueError(kind)
+
+
 def synth_layer(layer_id, N, c, n, k, relu=True, dtype=np.float32, noise=0.01, dead=0,
-                residual=False):
+                residual=False, mix=None):
     """Synthetic operands of SURVEY.md section 8d / BASELINE.md section 2 (the generator the
     CPU probes used): seeds RandomState(1000+layer_id).  dead>0 zeroes that many channels
     of X (ReLU-dead channels); residual adds a dense extra term to Y and skips the ReLU
@@ -449,6 +489,8 @@ def synth_layer(layer_id, N, c, n, k, relu=True, dtype=np.float32, noise=0.01, d
     if relu and not residual:
         X = np.maximum(X, 0.)
     X = X.astype(dtype)
+    if mix is not None:
+        X = mix_channels(X.astype(np.float64), rs, mix)
     if dead:
         X[:, rs.choice(c, dead, replace=False)] = 0
     W2 = (rs.randn(n, c, k, k) * 0.05).astype(np.float32)

@@ -69,6 +69,38 @@ CASES = {
     "L09_conv2_1_conv2_2_q": dict(layer_id=39, N=5000, c=128, n=128, k=3, rank=32, large=True),
     # configs[2]'s (256, 512) pair: conv3_3 -> conv4_1 (n = 512 outputs: wider right-hand sides and strips)
     "L10_conv3_3_conv4_1": dict(layer_id=40, N=5000, c=256, n=512, k=3, rank=128, large=True),
+    # ---- round 2 ----
+    # conv4-sized pair at the full sample count (configs[2]) and the first pair of the network
+    "L11_conv4_2_conv4_3": dict(layer_id=41, N=5000, c=512, n=512, k=3, rank=256, large=True),
+    "L12_conv1_1_conv1_2": dict(layer_id=42, N=5000, c=64, n=64, k=3, rank=32, large=True),
+    # configs[4]: conv4_2 of the 5x model, 512 -> 276 channels at 20000 samples (temp/channel_pruning.prototxt:226)
+    "L13_conv4_2_N20000": dict(layer_id=43, N=20000, c=512, n=512, k=3, rank=276, large=True, sketch=True),
+    # configs[3]: ResNet-50 res3 3x3 consumer, 128 -> 106 kept (temp/resnet-50-cp.prototxt:763), residual target, no ReLU
+    "L14_res3_3x3_resid": dict(layer_id=44, N=5000, c=128, n=128, k=3, rank=106, residual=True, large=True),
+    # the reference's own 3C-4x d_c = int(c / 1.15) at c = 512 (net.py:1327, 1346): p = 4005+
+    "L15_conv5_dc445": dict(layer_id=46, N=5000, c=512, n=512, k=3, rank=445, large=True),
+    "s18_rank_tol_02": dict(layer_id=45, N=400, c=32, n=24, k=3, rank=16, rank_tol=.2),   # decompose.py:498-501
+    # ill-conditioned channel structure through the whole dictionary() call (X float64: conditioning beyond float32)
+    "q01_mix_kappa1e4": dict(layer_id=51, N=1200, c=32, n=24, k=3, rank=16, mix=dict(kind="kappa", kappa=1e4)),
+    "q02_mix_kappa1e6": dict(layer_id=52, N=1200, c=32, n=24, k=3, rank=16, mix=dict(kind="kappa", kappa=1e6)),
+    "q03_mix_kappa1e8": dict(layer_id=53, N=1200, c=32, n=24, k=3, rank=16, mix=dict(kind="kappa", kappa=1e8)),
+    "q04_dup_1e-7": dict(layer_id=54, N=1200, c=32, n=24, k=3, rank=20, mix=dict(kind="dup", eps=1e-7)),
+    "q05_dup_exact": dict(layer_id=55, N=1200, c=32, n=24, k=3, rank=20, mix=dict(kind="dup", eps=0.0)),
+    "q06_relumix": dict(layer_id=56, N=1500, c=48, n=32, k=3, rank=30, mix=dict(kind="relumix", r=12, delta=1e-5)),
+    # the whole-network job of bench.py --workload vgg16: the 12 conv -> conv pairs of VGG-16 with the reference's
+    # 3C-4x kept-channel count d_c = max(int(c / 1.15), rank) (net.py:1309-1327, 1346-1349), N = 5000
+    "V01_conv1_1_conv1_2": dict(layer_id=101, N=5000, c=64, n=64, k=3, rank=55, large=True, sketch=True),
+    "V02_conv1_2_conv2_1": dict(layer_id=102, N=5000, c=64, n=128, k=3, rank=55, large=True, sketch=True),
+    "V03_conv2_1_conv2_2": dict(layer_id=103, N=5000, c=128, n=128, k=3, rank=111, large=True, sketch=True),
+    "V04_conv2_2_conv3_1": dict(layer_id=104, N=5000, c=128, n=256, k=3, rank=111, large=True, sketch=True),
+    "V05_conv3_1_conv3_2": dict(layer_id=105, N=5000, c=256, n=256, k=3, rank=222, large=True, sketch=True),
+    "V06_conv3_2_conv3_3": dict(layer_id=106, N=5000, c=256, n=256, k=3, rank=222, large=True, sketch=True),
+    "V07_conv3_3_conv4_1": dict(layer_id=107, N=5000, c=256, n=512, k=3, rank=222, large=True, sketch=True),
+    "V08_conv4_1_conv4_2": dict(layer_id=108, N=5000, c=512, n=512, k=3, rank=445, large=True, sketch=True),
+    "V09_conv4_2_conv4_3": dict(layer_id=109, N=5000, c=512, n=512, k=3, rank=445, large=True, sketch=True),
+    "V10_conv4_3_conv5_1": dict(layer_id=110, N=5000, c=512, n=512, k=3, rank=445, large=True, sketch=True),
+    "V11_conv5_1_conv5_2": dict(layer_id=111, N=5000, c=512, n=512, k=3, rank=445, large=True, sketch=True),
+    "V12_conv5_2_conv5_3": dict(layer_id=112, N=5000, c=512, n=512, k=3, rank=445, large=True, sketch=True),
 }
 
 
@@ -83,7 +115,7 @@ def run_reference(p):
     D, cfgs = ref_loader.load()
     from sklearn.linear_model import Lasso
     X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"],
-                                         dead=p.get("dead", 0), residual=p.get("residual", False))
+                                         dead=p.get("dead", 0), residual=p.get("residual", False), mix=p.get("mix"))
     fits = []
     orig_fit = Lasso.fit
 
@@ -138,12 +170,19 @@ def main():
         w = r["newW2"]
         # large cases: weights kept as float32 (rounding 6e-8 << the 1e-5 parity budget)
         wstore = w.astype(np.float32) if p.get("large") else w
+        extra = {}
+        if p.get("sketch"):
+            # no full weight tensor for these (8 MB each at c = 512): a seeded Gaussian sketch W Omega (relative
+            # Frobenius differences are preserved in expectation), the row norms and the bias
+            wm = w.reshape(w.shape[0], -1)
+            extra = dict(newW2_sketch=wm @ cp_oracle.sketch_matrix(wm.shape[1]), newW2_rownorm=np.linalg.norm(wm, axis=1))
+            wstore = np.zeros(0, dtype=np.float32)
         np.savez_compressed(
             os.path.join(GOLDEN_DIR, name + ".npz"),
             params=json.dumps(p), versions=json.dumps(versions()),
             idxs=r["idxs"], newW2=wstore, newB2=r["newB2"], fits=r["fits"],
             samples=r["samples"], alpha_out=r["alpha_out"], rng_next=r["rng_next"],
-            ref_seconds=r["seconds"], newW2_fro=float(np.linalg.norm(w)))
+            ref_seconds=r["seconds"], newW2_fro=float(np.linalg.norm(w)), **extra)
         print("%-24s kept %4d/%4d  fits %2d  %.2fs  alpha_out %.6g" % (
             name, int(r["idxs"].sum()), p["c"], len(r["fits"]), r["seconds"], r["alpha_out"]))
 
