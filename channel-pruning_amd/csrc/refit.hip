@@ -12,13 +12,21 @@
 //   Cholesky G = U^T U, blocked by 128: diagonal block factorised + inverted in LDS by one
 //   workgroup, panel solve and trailing update are cp_gemm_tn_f64 calls      MFMA / launch bound
 //   block forward / backward substitution with the inverted diagonal blocks  MFMA / launch bound
-// Rank deficiency (dead channels, N < p): a pivot below 1e-10 of its original diagonal flags the
-// factorisation; the solve is then redone by iterated Tikhonov regularisation
-//   W_0 = 0,  W_{k+1} = W_k + (G + eI)^-1 (R - G W_k),   e = 1e-9 * max diag(G),  5 sweeps,
-// which stays in range(G) and converges to the minimum-norm solution G^+ R that gelsd returns:
-// an eigen-direction lambda is reproduced up to (e/(lambda+e))^5, directions with lambda << e
-// (numerical null space) are left at zero; exactly zero columns give exactly zero weights.
-// Each sweep also acts as iterative refinement for the (moderately conditioned) G + eI solve.
+// The normal equations square the condition number, so they are only trusted while every Cholesky pivot stays
+// above PIV_TOL (1e-6) of its original diagonal (error about eps / pivot ratio <= 1e-9).  Otherwise, and when
+// N - 1 < p, the solve is redone by refit_robust() below, which is as accurate as the reference's gelsd
+// (error ~ cond * eps, not cond^2 * eps) and reproduces its rank decision sigma_i <= max(N,p) * eps * sigma_max
+// (sklearn/linear_model/_base.py:700-702 -> scipy.linalg.lstsq, decompose.py:665-666):
+//   stage 1  R1 = chol(G + s I), s = 4 max(N,p) eps ||G||_inf; X1 = Xs R1^-1 explicitly (forward substitution on
+//            Xs^T with N right-hand sides): a shifted-Cholesky-QR step, cond(X1) ~ sqrt(cond(Xs)^2 s) at worst
+//   stage 2  G2 = X1^T X1, C2 = X1^T Yc from the preconditioned rows
+//     path 1 (full column rank: chol(G2) keeps every pivot above 1e-11): Z = G2^-1 C2, W = R1^-1 Z
+//     path 2 (numerically rank deficient: copies of channels, N <= p, ...): G2 = V T^2 V^T (one-sided Jacobi),
+//            Xs = (X1 V T^-1)(T V^T R1) = Q B with Q orthonormal, B = Ub S Vb^T (one-sided Jacobi on the rows of B):
+//            the singular values S ARE those of Xs; W = Vb S^+ Ub^T Q^T Yc over S_i > max(N,p) eps S_0 --
+//            the minimum-norm solution and the rank gelsd reports.
+// The ridge branch and the row-sharded tail (no access to the rows) keep the older fallback: iterated Tikhonov
+//   W_{k+1} = W_k + (G + eI)^-1 (R - G W_k),  e = 1e-9 max diag(G),  5 sweeps (exact for spectra with a clean gap).
 #include "cp_common.h"
 
 namespace {
@@ -649,6 +657,8 @@ struct StripFinal {  // optional tail of k_solve_strips: what k_finalize does, f
     int *info_host;
 };
 
+// SWEEPS: bit 0 = forward (U^T y = r), bit 1 = backward (U w = y); 3 = both (the normal-equation solve)
+template <int SWEEPS = 3>
 __device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
                                                   const double *__restrict__ TI, const double *__restrict__ TIT,
                                                   int nblk, double *R, int n_pad, const StripFinal &fin) {
@@ -657,6 +667,7 @@ __device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, 
     const int fk = lane >> 4, fi = lane & 15;
     const int col0 = blockIdx.x * 16, row0 = wave * 16;
     for (int sweep = 0; sweep < 2; ++sweep) {
+        if (!(SWEEPS & (1 << sweep))) continue;
         const double *Tri = sweep == 0 ? U : Lt;      // element (kk of block k, m of block b) at Tri[(k NB + kk) ld + b NB + m]
         const double *Dinv = sweep == 0 ? TI : TIT;   // a-operand of the diagonal solve: Dinv_b[j, m]
         for (int step = 0; step < nblk; ++step) {
@@ -728,10 +739,11 @@ __device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, 
     }
 }
 
+template <int SWEEPS>
 __global__ void __launch_bounds__(512) k_solve_strips(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
                                                       const double *__restrict__ TI, const double *__restrict__ TIT,
                                                       int nblk, double *R, int n_pad, StripFinal fin) {
-    solve_strips_body(U, Lt, ld, TI, TIT, nblk, R, n_pad, fin);
+    solve_strips_body<SWEEPS>(U, Lt, ld, TI, TIT, nblk, R, n_pad, fin);
 }
 
 struct StripJob {
@@ -752,10 +764,70 @@ __global__ void __launch_bounds__(512) k_solve_strips_batch(StripBatch b) {  // 
     solve_strips_body(a.U, a.Lt, a.ld, a.TI, a.TIT, a.nblk, a.R, a.n_pad, a.fin);
 }
 
-int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad, const StripFinal &fin = StripFinal{}) {
-    k_solve_strips<<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad, fin);
+int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad, const StripFinal &fin = StripFinal{},
+               int sweeps = 3) {
+    if (sweeps == 1)
+        k_solve_strips<1><<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad, fin);
+    else if (sweeps == 2)
+        k_solve_strips<2><<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad, fin);
+    else
+        k_solve_strips<3><<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad, fin);
     CP_LAUNCH_CHECK(ctx);
     return CP_OK;
+}
+
+constexpr double PIV_TOL = 1e-6;   // normal equations are trusted while pivot / original diagonal stays above this
+
+// ---- helpers of the rank-revealing path --------------------------------------------------------------------
+// gn[0] = max_i sum_j |G[i,j]| over the leading p x p part (one workgroup per row, fixed-order combine by the caller's
+// second launch with rows = 1)
+__global__ void __launch_bounds__(RT) k_abs_row_sums(const double *__restrict__ G, int ld, int p, double *__restrict__ out) {
+    __shared__ double red[RT / 64];
+    const int i = blockIdx.x;
+    double sacc = 0;
+    for (int j = threadIdx.x; j < p; j += RT) sacc += fabs(G[size_t(i) * ld + j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sacc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[i] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(RT) k_max_of(const double *__restrict__ v, int count, double *__restrict__ out) {
+    __shared__ double red[RT / 64];
+    double m = 0;
+    for (int i = threadIdx.x; i < count; i += RT) m = fmax(m, v[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+// dst[c, r] = src[r, c] for r < rows, c < cols, zero elsewhere in the dst_rows x dst_cols (both % 32 == 0) target
+__global__ void __launch_bounds__(RT) k_transpose_pad(const double *__restrict__ src, int rows, int cols, int ld_src,
+                                                      double *__restrict__ dst, int ld_dst) {
+    __shared__ double t[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;   // tile of src
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int y = ty; y < 32; y += 8) t[y][tx] = (r0 + y < rows && c0 + tx < cols) ? src[size_t(r0 + y) * ld_src + c0 + tx] : 0.0;
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) dst[size_t(c0 + y) * ld_dst + r0 + tx] = t[tx][y];
+}
+// ref[i] = max(ref[i], rel * gmax[0]): a column of the preconditioned design that is pure rounding noise (an exact copy
+// of earlier columns: norm^2 ~ eps^2 / shift ~ 1e-20 of the largest) must not pass the RELATIVE pivot test
+__global__ void __launch_bounds__(RT) k_floor_ref(double *__restrict__ ref, int p, const double *__restrict__ gmax, double rel) {
+    const int i = blockIdx.x * RT + threadIdx.x;
+    if (i < p) ref[i] = fmax(ref[i], rel * gmax[0]);
+}
+// M[i, :] *= f(scale[i]) for i < rows; rows in [rows, rows_total) are zeroed.  mode 0: * s, 1: / s, 2: / s^2
+__global__ void __launch_bounds__(RT) k_scale_rows(double *__restrict__ M, int ld, int rows, int cols,
+                                                   const double *__restrict__ scale, int mode) {
+    const int i = blockIdx.x;
+    double f = 0.0;
+    if (i < rows) {
+        const double sv = scale[i];
+        f = mode == 0 ? sv : (mode == 1 ? 1.0 / sv : 1.0 / (sv * sv));
+    }
+    for (int j = threadIdx.x; j < cols; j += RT) M[size_t(i) * ld + j] = i < rows ? M[size_t(i) * ld + j] * f : 0.0;
 }
 
 }  // namespace
@@ -780,7 +852,188 @@ struct RefitSolve {
     double *W_out, *b_out;
     int *info_host;
     double *b_host, *W_host;
+    // the centred rows themselves (null in the row-sharded tail, which only sees the reduced Gram)
+    const double *Xs = nullptr, *Yc = nullptr;
+    int64_t N_pad = 0;
 };
+
+// scratch of the rank-revealing path: its own device allocation swapped in as the context's arena for the duration
+// (the regular arena keeps Xs / Yc / means alive; this path is rare, so a hipMalloc per call is fine)
+struct ArenaSwap {
+    cp_ctx *ctx;
+    char *old_arena;
+    size_t old_bytes, old_used;
+    char *mine = nullptr;
+    explicit ArenaSwap(cp_ctx *c) : ctx(c), old_arena(c->arena), old_bytes(c->arena_bytes), old_used(c->arena_used) {}
+    int open(size_t bytes) {
+        bytes = cp_align_up(bytes + (1 << 20), 1 << 20);
+        if (hipMalloc(reinterpret_cast<void **>(&mine), bytes) != hipSuccess)
+            return cp_set_error(ctx, CP_ERR_NOMEM, "refit (rank-revealing path): hipMalloc(%zu)", bytes);
+        ctx->arena = mine;
+        ctx->arena_bytes = bytes;
+        ctx->arena_used = 0;
+        return CP_OK;
+    }
+    ~ArenaSwap() {
+        if (mine) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->arena = old_arena;
+            ctx->arena_bytes = old_bytes;
+            ctx->arena_used = old_used;
+            (void)hipFree(mine);
+        }
+    }
+};
+
+int read_back(cp_ctx *ctx, void *host, const void *dev, size_t bytes) {
+    CP_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    return CP_OK;
+}
+
+// Least squares as accurate as gelsd on ill-conditioned and rank-deficient designs (see the header of this file).
+// G0: pristine Gram buffer (overwritten), everything else of `rs` is reused as work space; outputs through finalize().
+template <class NormalEquations, class Finalize>
+int refit_robust(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal_equations, Finalize &&finalize,
+                 cp_refit_info *info) {
+    const int p = rs.p, p_pad = rs.p_pad, n_pad = rs.n_pad, nblk = rs.nblk;
+    const int64_t N = rs.N, N_pad = rs.N_pad;
+    const int Nr = int(cp_align_up(size_t(N_pad), 128));
+    const double eps = 2.220446049250313e-16;
+    const size_t g_c = size_t(p_pad) * p_pad, r_c = size_t(p_pad) * n_pad, x_c = size_t(Nr) * p_pad,
+                 ti_c = size_t(nblk) * NB * NB;
+    // pristine Gram (G0) and right-hand side (R2) from the regular arena; the diagonal is prepared (pad = 1, dg0, gmax)
+    CP_TRY(normal_equations(rs.G0, rs.R2, false));
+    size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
+                         cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, p_pad, p_pad, CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE));
+    ArenaSwap tmp(ctx);
+    CP_TRY(tmp.open((2 * x_c + 9 * g_c + 3 * r_c + 2 * ti_c + 8 * size_t(p_pad)) * 8 + 2 * SvdScratch::bytes(p_pad, p_pad) +
+                    size_t(chol_info_count(nblk) + 64) * 4 + ws + (1 << 20)));
+    double *XsT = cp_arena_take_t<double>(ctx, x_c), *X1 = cp_arena_take_t<double>(ctx, x_c);
+    double *G2 = cp_arena_take_t<double>(ctx, g_c), *Gw = cp_arena_take_t<double>(ctx, g_c);
+    double *U2 = cp_arena_take_t<double>(ctx, g_c), *Lt2 = cp_arena_take_t<double>(ctx, g_c);
+    double *TI2 = cp_arena_take_t<double>(ctx, ti_c), *TIT2 = cp_arena_take_t<double>(ctx, ti_c);
+    double *rowsum = cp_arena_take_t<double>(ctx, p_pad), *gnorm = cp_arena_take_t<double>(ctx, 8);
+    double *dg2 = cp_arena_take_t<double>(ctx, p_pad), *gmax2 = cp_arena_take_t<double>(ctx, 8);
+    int *dinfo2 = cp_arena_take_t<int>(ctx, chol_info_count(nblk) + 16);
+    if (!XsT || !X1 || !G2 || !Gw || !U2 || !Lt2 || !TI2 || !TIT2 || !rowsum || !gnorm || !dg2 || !gmax2 || !dinfo2)
+        return cp_set_error(ctx, CP_ERR_NOMEM, "refit (rank-revealing path): scratch");
+
+    // ---- stage 1: R1 = chol(G + s I) into (Uf, Lt, TI, TIT) ----
+    k_abs_row_sums<<<p, RT, 0, ctx->stream>>>(rs.G0, p_pad, p, rowsum);
+    CP_LAUNCH_CHECK(ctx);
+    k_max_of<<<1, RT, 0, ctx->stream>>>(rowsum, p, gnorm);
+    CP_LAUNCH_CHECK(ctx);
+    Chol ch1{rs.G, rs.Uf, rs.Lt, rs.TI, rs.TIT, rs.dg0, rs.gmax, rs.dinfo, p, p_pad, nblk};
+    double rel = 4.0 * double(std::max<int64_t>(N, p)) * eps;
+    int h = 0;
+    for (int attempt = 0; attempt < 4; ++attempt, rel *= 100.0) {
+        CP_HIP(ctx, hipMemcpyAsync(rs.G, rs.G0, g_c * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        CP_HIP(ctx, hipMemsetAsync(rs.Uf, 0, g_c * 8, ctx->stream));   // B = T V^T R1 below reads the whole of R1
+        k_add_diag_scaled<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(rs.G, p_pad, p, gnorm, rel, rs.dg0, rs.dinfo,
+                                                                    chol_info_count(nblk));
+        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(chol_factor(ctx, ch1, 0.0));
+        CP_TRY(read_back(ctx, &h, rs.dinfo, sizeof(int)));
+        if (h == 0) break;
+    }
+    if (h != 0) return cp_set_error(ctx, CP_ERR_NUMERIC, "refit: shifted factorisation broke down at column %d", h - 1);
+    // X1 = Xs R1^-1: forward substitution U1^T X1^T = Xs^T with the N rows as right-hand sides
+    k_transpose_pad<<<dim3(Nr / 32, p_pad / 32), RT, 0, ctx->stream>>>(rs.Xs, int(N_pad), p_pad, p_pad, XsT, Nr);
+    CP_LAUNCH_CHECK(ctx);
+    CP_TRY(chol_solve(ctx, ch1, XsT, nullptr, Nr, StripFinal{}, 1));
+    k_transpose_pad<<<dim3(p_pad / 32, Nr / 32), RT, 0, ctx->stream>>>(XsT, p_pad, Nr, Nr, X1, p_pad);
+    CP_LAUNCH_CHECK(ctx);
+    // ---- stage 2: normal equations of the preconditioned rows ----
+    CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, X1, p_pad, X1, p_pad, 0.0, G2, p_pad, CP_TRI_LOWER_MIRROR));
+    CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, X1, p_pad, rs.Yc, n_pad, 0.0, rs.R2, n_pad, CP_TRI_NONE));
+    CP_HIP(ctx, hipMemcpyAsync(Gw, G2, g_c * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gw, p_pad, p, p_pad, 0.0, dg2, gmax2, dinfo2, chol_info_count(nblk));
+    CP_LAUNCH_CHECK(ctx);
+    k_floor_ref<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(dg2, p, gmax2, 1e-5);   // pivot <= max(1e-11 diag, 1e-16 max diag)
+    CP_LAUNCH_CHECK(ctx);
+    Chol ch2{Gw, U2, Lt2, TI2, TIT2, dg2, gmax2, dinfo2, p, p_pad, nblk};
+    CP_TRY(chol_factor(ctx, ch2, 1e-11));
+    CP_TRY(read_back(ctx, &h, dinfo2, sizeof(int)));
+    if (h == 0) {   // path 1: full column rank
+        CP_HIP(ctx, hipMemcpyAsync(rs.Rm, rs.R2, r_c * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        CP_TRY(chol_solve(ctx, ch2, rs.Rm, nullptr, n_pad));                       // Z = G2^-1 C2
+        CP_TRY(chol_solve(ctx, ch1, rs.Rm, nullptr, n_pad, StripFinal{}, 2));      // W = R1^-1 Z
+        cp_stage_mark(ctx, "refit_robust_cholqr");
+        CP_HIP(ctx, hipMemsetAsync(rs.dinfo, 0, sizeof(int), ctx->stream));
+        CP_TRY(finalize());
+        info->p = p;
+        info->rank = p;
+        info->fallback = 2;
+        info->reserved = 0;
+        return CP_OK;
+    }
+    // ---- path 2: rank revealing.  G2 = V T^2 V^T ----
+    const int p_e = p;   // rows taking part in the decompositions
+    double *lam = cp_arena_take_t<double>(ctx, p_pad), *Vt = cp_arena_take_t<double>(ctx, g_c);
+    double *SH = cp_arena_take_t<double>(ctx, g_c);
+    SvdScratch sc;
+    if (!lam || !Vt || !SH || !sc.take(ctx, p_pad, p_pad))
+        return cp_set_error(ctx, CP_ERR_NOMEM, "refit (rank-revealing path): scratch (decomposition)");
+    CP_HIP(ctx, hipMemsetAsync(Vt, 0, g_c * 8, ctx->stream));
+    CP_HIP(ctx, hipMemsetAsync(SH, 0, g_c * 8, ctx->stream));
+    CP_TRY(cp_svd_rows_impl(ctx, G2, p_pad, p_e, p_pad, p_e, lam, Vt, p_pad, SH, p_pad, sc, nullptr));
+    std::vector<double> hl(p_e);
+    CP_TRY(read_back(ctx, hl.data(), lam, size_t(p_e) * 8));
+    int r = 0;
+    while (r < p_e && hl[r] > 10.0 * double(p) * eps * hl[0] && hl[r] > 0.0) ++r;
+    int k = 0;
+    if (r > 0) {
+        std::vector<double> tau(r);
+        for (int i = 0; i < r; ++i) tau[i] = std::sqrt(hl[i]);
+        double *dtau = lam;   // reuse: tau_i on the device
+        CP_HIP(ctx, hipMemcpyAsync(dtau, tau.data(), size_t(r) * 8, hipMemcpyHostToDevice, ctx->stream));
+        const int r_pad = int(cp_align_up(size_t(r), 128));
+        // V_L as a [p_pad, r_pad] k-major operand, B = T V_L^T R1 (r x p), C = T^-1 V_L^T C2 (r x n)  [Gw, U2 reused]
+        double *Vtr = Gw, *B = U2, *Cm = Lt2;   // r_pad x p_pad <= p_pad x p_pad each; Cm: r_pad x n_pad <= needs r_c
+        double *Cbuf = cp_arena_take_t<double>(ctx, std::max(r_c, g_c)), *Dm = cp_arena_take_t<double>(ctx, std::max(r_c, g_c));
+        if (!Cbuf || !Dm) return cp_set_error(ctx, CP_ERR_NOMEM, "refit (rank-revealing path): scratch (products)");
+        Cm = Cbuf;
+        k_transpose_pad<<<dim3(r_pad / 32, p_pad / 32), RT, 0, ctx->stream>>>(Vt, r, p_pad, p_pad, Vtr, r_pad);
+        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(cp_gemm_tn_f64(ctx, r_pad, p_pad, p_pad, 1.0, Vtr, r_pad, rs.Uf, p_pad, 0.0, B, p_pad, CP_TRI_NONE));
+        k_scale_rows<<<r_pad, RT, 0, ctx->stream>>>(B, p_pad, r, p_pad, dtau, 0);
+        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(cp_gemm_tn_f64(ctx, r_pad, n_pad, p_pad, 1.0, Vtr, r_pad, rs.R2, n_pad, 0.0, Cm, n_pad, CP_TRI_NONE));
+        k_scale_rows<<<r_pad, RT, 0, ctx->stream>>>(Cm, n_pad, r, n_pad, dtau, 1);
+        CP_LAUNCH_CHECK(ctx);
+        // B = Ub S Vb^T: S [r], Ubt [r, r] (row i = i-th left vector), SH = diag(S) Vb^T [r, p]
+        double *Sg = rowsum, *Ubt = Vt;    // Vt is free once Vtr exists
+        CP_HIP(ctx, hipMemsetAsync(SH, 0, g_c * 8, ctx->stream));
+        CP_TRY(cp_svd_rows_impl(ctx, B, p_pad, r, p_pad, r, Sg, Ubt, r_pad, SH, p_pad, sc, nullptr));
+        std::vector<double> hs(r);
+        CP_TRY(read_back(ctx, hs.data(), Sg, size_t(r) * 8));
+        const double cut = double(std::max<int64_t>(N, p)) * eps * hs[0];     // _base.py:700-702 / gelsd's rcond
+        while (k < r && hs[k] > cut) ++k;
+        if (k > 0) {
+            const int k_pad = int(cp_align_up(size_t(k), 128));
+            double *Ubtr = Gw;   // [r_pad, k_pad]: Ubtr[j, i] = Ubt[i, j], i < k   (Vtr no longer needed)
+            k_transpose_pad<<<dim3(k_pad / 32, r_pad / 32), RT, 0, ctx->stream>>>(Ubt, k, r, r_pad, Ubtr, k_pad);
+            CP_LAUNCH_CHECK(ctx);
+            CP_TRY(cp_gemm_tn_f64(ctx, k_pad, n_pad, r_pad, 1.0, Ubtr, k_pad, Cm, n_pad, 0.0, Dm, n_pad, CP_TRI_NONE));
+            k_scale_rows<<<k_pad, RT, 0, ctx->stream>>>(Dm, n_pad, k, n_pad, Sg, 2);   // / S_i^2: SH rows carry one S_i
+            CP_LAUNCH_CHECK(ctx);
+            const int k16 = int(cp_align_up(size_t(k), 16));
+            CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, k16, 1.0, SH, p_pad, Dm, n_pad, 0.0, rs.Rm, n_pad, CP_TRI_NONE));
+        }
+    }
+    if (k == 0) CP_HIP(ctx, hipMemsetAsync(rs.Rm, 0, r_c * 8, ctx->stream));
+    cp_stage_mark(ctx, "refit_robust_jacobi");
+    CP_HIP(ctx, hipMemsetAsync(rs.dinfo, 0, sizeof(int), ctx->stream));
+    CP_TRY(finalize());
+    info->p = p;
+    info->rank = k;
+    info->fallback = 3;
+    info->reserved = 0;
+    return CP_OK;
+}
 
 template <class NormalEquations>
 int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal_equations, cp_refit_info *info) {
@@ -817,7 +1070,7 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
             info->reserved = 0;
             return CP_OK;
         }
-        CP_TRY(chol_factor(ctx, ch, 1e-10));
+        CP_TRY(chol_factor(ctx, ch, PIV_TOL));
         cp_stage_mark(ctx, "refit_cholesky");
         StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
         CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin));  // substitutions + coefficient lay-out + intercept in one launch
@@ -827,6 +1080,11 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
         if (hinfo != 0) fallback = true;
     }
     int rank = p;
+    if (fallback && ridge == 0.0 && rs.Xs != nullptr) {
+        CP_TRY(refit_robust(ctx, rs, normal_equations, finalize, info));
+        if (hinfo != 0) return cp_set_error(ctx, CP_ERR_NUMERIC, "refit: rank-revealing path failed (%d)", hinfo);
+        return CP_OK;
+    }
     if (fallback) {
         // iterated Tikhonov on an untouched Gram G0 and right-hand side R2 (recomputed: this path is rare)
         double *Wacc = cp_arena_take_t<double>(ctx, size_t(p_pad) * n_pad);
@@ -878,7 +1136,7 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
         if (!c || !c->refit_pending) continue;
         if (!ctx0) ctx0 = c;
         const cp_refit_deferred &d = c->deferred;
-        pb.j[nj] = PotrfJob{d.G, d.U, d.Lt, d.p_pad, d.nblk, d.dg0, 1e-10, d.TI, d.TIT, d.info};
+        pb.j[nj] = PotrfJob{d.G, d.U, d.Lt, d.p_pad, d.nblk, d.dg0, PIV_TOL, d.TI, d.TIT, d.info};
         sb.j[nj] = StripJob{d.U, d.Lt, d.p_pad, d.TI, d.TIT, d.nblk, d.Rm, d.n_pad,
                             StripFinal{d.p, d.n, d.xmean, d.ymean, d.W_out, d.b_out, d.W_host, d.b_host, d.info, d.info_host}};
         max_tasks = std::max(max_tasks, d.nblk * (d.nblk + 1) / 2);
@@ -903,7 +1161,7 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
             if (!c || !c->refit_pending) continue;
             const cp_refit_deferred &d = c->deferred;
             Chol ch{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
-            CP_TRY(chol_factor(c, ch, 1e-10));
+            CP_TRY(chol_factor(c, ch, PIV_TOL));
         }
     }
     // the substitutions of every layer of the batch: one launch (no workgroup waits for another one)
@@ -1013,6 +1271,9 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
 
     RefitSolve rs{G, G0, Lt, Uf, Yt, Rm, R2, TI, TIT, xmean, ymean, dg0, gmax, dinfo, p, p_pad, n, n_pad, nblk, N, ridge,
                   W_out, b_out, info_host, b_host, W_host};
+    rs.Xs = Xs;
+    rs.Yc = Yc;
+    rs.N_pad = N_pad;
     return refit_solve_tail(ctx, rs, normal_equations, info);
 }
 
