@@ -51,6 +51,18 @@ class solvers:
     lightning = 'lightning'
 
 
+class pruning_options:           # cfgs.py:47-51
+    prb = 0
+    vgg = 3
+    resnet = 4
+    single = 10
+
+
+class Data:
+    lmdb = 'lmdb'
+    pro = 'pro'
+
+
 class Models:
     vgg = 'vgg'
     xception = 'xception'
@@ -66,7 +78,7 @@ class vgg:
 
 
 c.dic = edict()
-c.dic.option = 0
+c.dic.option = pruning_options.prb
 c.dic.layeralpha = 1
 c.dic.debug = 0
 c.dic.afterconv = False
@@ -102,10 +114,10 @@ c.model = ''
 c.cd_mode = 'device'             # 'device': one foreign call per dictionary() (cp_prune_layer, alpha search in one
                                  # launch); 'steps': same search via the individual entry points; 'host': one launch per fit
 # rounding variants of the coordinate update (all reproduce every reference golden mask and per-fit
-# (nnz, n_iter) log; each is bit-identical to the matching mode of the CPU oracle):
-c.cd_reciprocal = 1              # 1: multiply by 1/(Qii+l2) instead of dividing (<= 1 ulp per step)
-c.cd_delta = 1                   # 1: one axpy with (w_new - w_old) instead of sklearn's two
-                                 # set both to 0 for sklearn's exact operation sequence
+# (nnz, n_iter) log; each is bit-identical to the matching mode of the CPU oracle).  The drop-in default is sklearn's
+# own operation sequence (both 0); bench.py and the batched engines opt into the faster forms (-80 cycles per step):
+c.cd_reciprocal = 0              # 1: multiply by 1/(Qii+l2) instead of dividing (<= 1 ulp per step)
+c.cd_delta = 0                   # 1: one axpy with (w_new - w_old) instead of sklearn's two
 
 
 def set_nBatches(n):

@@ -38,9 +38,8 @@ def _flags():
     return (_capi.CP_CD_RECIPROCAL if dcfgs.cd_reciprocal else 0) | (_capi.CP_CD_DELTA if dcfgs.cd_delta else 0)
 
 
-def dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, verbose=0):
-    """Channel selection by LASSO + least-squares reconstruction of W2 on the kept channels."""
-    rank_tol = dcfgs.dic.rank_tol                       # decompose.py:393
+def _refit_mode():
+    """Validate the dcfgs flags of dictionary() (decompose.py:393-416, 605-623) and pick the refit branch."""
     if dcfgs.autodet:
         raise NotImplementedError("dcfgs.autodet (single LASSO solve at fixed alpha) is not on the "
                                   "accelerated path")
@@ -49,24 +48,40 @@ def dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, v
                                   "(dic.alter=0, ls='linear', solver='sklearn')")
     if dcfgs.nonlinear_fc and dcfgs.fc_ridge:
         raise NotImplementedError("nonlinear_fc with fc_ridge > 0")
-    refit = "nonlinear" if dcfgs.nonlinear_fc else ("none" if dcfgs.nofc else "linear")   # decompose.py:615-623
+    return "nonlinear" if dcfgs.nonlinear_fc else ("none" if dcfgs.nofc else "linear")   # decompose.py:615-623
+
+
+def prune_resident(prob, rank, W2_host, alpha=1e-4):
+    """The body of dictionary() on operands that are already resident (a cpmi355.LayerProblem): used by dictionary()
+    below and by Net.dictionary_kernel (lib/net.py), so both honour the same dcfgs flags (rank_tol, fc_ridge,
+    nonlinear_fc, nofc, cd_mode), consume numpy's global RNG identically and carry cfgs.alpha (decompose.py:626-627)."""
+    refit = _refit_mode()
+    idxs, newW2, newB2, alpha_out = prune_layer(prob, rank, cfgs.alpha, rank_tol=dcfgs.dic.rank_tol, rng=np.random,
+                                                ridge=float(dcfgs.fc_ridge), mode=dcfgs.cd_mode,
+                                                alpha_arg=alpha, refit=refit, W2_host=W2_host)
+    last_call_info.clear()
+    ri = prob.refit_info
+    last_call_info.update(fits=list(prob.fits), samples=prob.samples,
+                          fallback=int(ri.fallback) if ri is not None else 0,
+                          rank=int(ri.rank) if ri is not None else -1,
+                          p=int(ri.p) if ri is not None else int(idxs.sum()) * prob.kk)
+    cfgs.alpha = alpha_out                               # decompose.py:626-627
+    return idxs, newW2, newB2
+
+
+def dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, verbose=0):
+    """Channel selection by LASSO + least-squares reconstruction of W2 on the kept channels.
+    (rank_tol is overridden by dcfgs.dic.rank_tol exactly as decompose.py:393 does.)"""
+    _refit_mode()
     X = np.asarray(X)
     W2 = np.asarray(W2)
     if X.shape[2] != X.shape[-1]:
         raise ValueError("square kernels only (the reference assumes w = h, decompose.py:401-402)")
     prob = LayerProblem(default_context(), X, W2, Y, flags=_flags())
     try:
-        idxs, newW2, newB2, alpha_out = prune_layer(prob, rank, cfgs.alpha, rank_tol=rank_tol, rng=np.random,
-                                                    ridge=float(dcfgs.fc_ridge), mode=dcfgs.cd_mode,
-                                                    alpha_arg=alpha, refit=refit, W2_host=W2)
-        last_call_info.clear()
-        ri = prob.refit_info
-        last_call_info.update(fits=list(prob.fits), samples=prob.samples,
-                              fallback=int(ri.fallback) if ri is not None else 0,
-                              p=int(ri.p) if ri is not None else int(idxs.sum()) * prob.kk)
+        idxs, newW2, newB2 = prune_resident(prob, rank, W2, alpha=alpha)
     finally:
         prob.free()
-    cfgs.alpha = alpha_out                               # decompose.py:626-627
     if DEBUG:
         return X[:, idxs, ...], newW2, newB2             # decompose.py:629-632
     return idxs, newW2, newB2

@@ -11,7 +11,14 @@ names, argument meaning and return contracts:
     Net.extract_XY(X_name, Y_name)     sampled-point im2col                    net.py:534-684   [HIP: cp_patch_gather]
     Net.dictionary_kernel(X_name, None, d_prime, Y_name, None)                 net.py:1685-1735 [HIP: cp_assemble_y + dictionary]
     Net.R3()                           the VGG "3C" driver loop, pruning step  net.py:1292-1471
+    Net.appresb / invBN / getBNaff     ResNet residual-aware target             net.py:1641-1683, 1200-1217, 1106-1112
+    Net.W1keep / W2keep / select / combineHP   write-back bookkeeping           net.py:1521-1630, 1473-1504
     Net.pruning_kernel / param accessors used by the above
+
+Networks with more than a plain conv stack (BatchNorm / Scale / Eltwise shortcuts: ResNet) pass ``graph`` -- the
+ordered list of ALL layers as plain dicts (lib/provider.py describes the format) -- from which the facade derives what
+the reference reads off the prototxt: ``bns``, ``affines``, ``sums``, ``pools``, ``bottom_names`` and the BatchNorm /
+Scale parameters.
 
 ``Net.R3()`` runs the whole "3C" loop of the reference (net.py:1292-1471) -- spatial decomposition (VH_decompose),
 channel decomposition (ITQ_decompose), channel pruning (dictionary) per conv, in that order -- when the provider is
@@ -57,8 +64,13 @@ class ConvSpec(object):
 
 
 class Net(object):
-    def __init__(self, convs, provider, nBatches=None, nPointsPerLayer=None, device=None, model='vgg'):
-        """convs: iterable of ConvSpec in network order; provider: batch -> {blob: f32[B,C,H,W]}."""
+    def __init__(self, convs, provider, nBatches=None, nPointsPerLayer=None, device=None, model='vgg', graph=None):
+        """convs: iterable of ConvSpec in network order (None: taken from the Convolution entries of `graph`);
+        provider: batch -> {blob: f32[B,C,H,W]}; graph: optional list of layer dicts (every layer of the network)."""
+        self.graph = list(graph) if graph is not None else None
+        if convs is None:
+            convs = [ConvSpec(L["name"], L["W"], L["b"], L["bottom"][0], pad=L.get("pad", 0), stride=L.get("stride", 1))
+                     for L in self.graph if L["type"] == "Convolution"]
         self.layers = OrderedDict((cv.name, cv) for cv in convs)
         self.convs = list(self.layers.keys())
         self.provider = provider
@@ -72,6 +84,30 @@ class Net(object):
         self.WPQ = dict()
         self.selection = dict()
         self.bottom_names = dict((n, [cv.bottom]) for n, cv in self.layers.items())
+        self.nonWPQ = dict()
+        self.bottoms2ch = []
+        self.num_output = dict()         # set_conv(num_output=...) bookkeeping (the reference edits the prototxt)
+        self.removed = []                # layers combineHP() merged away
+        self.aux = dict()                # BatchNorm: [mean, var]; Scale: [k, b]  (float32, like Caffe blobs)
+        self.bns, self.affines, self.sums, self.pools, self.relus = [], [], [], [], []
+        self._layer_bottom = dict((n, cv.bottom) for n, cv in self.layers.items())
+        if self.graph is not None:
+            for L in self.graph:
+                t, name = L["type"], L["name"]
+                self.bottom_names[name] = list(L["bottom"])
+                self._layer_bottom[name] = L["bottom"][0] if len(L["bottom"]) == 1 else list(L["bottom"])
+                if t == "BatchNorm":
+                    self.bns.append(name)
+                    self.aux[name] = [np.array(L["mean"], dtype=np.float32), np.array(L["var"], dtype=np.float32)]
+                elif t == "Scale":
+                    self.affines.append(name)
+                    self.aux[name] = [np.array(L["k"], dtype=np.float32), np.array(L["b"], dtype=np.float32)]
+                elif t == "Eltwise":
+                    self.sums.append(name)
+                elif t == "Pooling":
+                    self.pools.append(name)
+                elif t == "ReLU":
+                    self.relus.append(name)
         self._blob_cache = (None, None)
         try:    # provider(batch, net): blobs follow the net's current weights (needed by the full 3C loop)
             self._live = len([p for p in inspect.signature(provider).parameters.values()
@@ -84,10 +120,22 @@ class Net(object):
         return default_context(self._device)
 
     def param_data(self, name):
+        if name in self.aux:
+            return self.aux[name][0]
         return self.layers[name].W
 
     def param_b_data(self, name):
+        if name in self.aux:
+            return self.aux[name][1]
         return self.layers[name].b
+
+    def layer_bottom(self, name):
+        return self._layer_bottom[name]
+
+    def set_conv(self, conv, num_output=0, **kwargs):
+        """net.py:308-341 edits the prototxt; here only the output count is remembered (emit_layers reads the weights)"""
+        if num_output:
+            self.num_output[conv] = int(num_output)
 
     def param_shape(self, name):
         return self.layers[name].W.shape
@@ -117,9 +165,13 @@ class Net(object):
 
     # ---- feature sampling (net.py:368-532) -----------------------------------------------------
     def extract_features(self, names=[], nBatches=None, points_dict=None, save=0):
-        """Sample nPointsPerLayer random (x, y) per layer per batch and collect the blob values
-        there: feats_dict[name][N, C] float64, row order [batch][point][image] (net.py:505-510).
-        Points come from numpy's global RNG (net.py:464-465) unless frozen in points_dict."""
+        """Sample nPointsPerLayer random (x, y) per layer per batch and collect the blob values there:
+        feats_dict[name][N, C] float64, row order [batch][point][image] (net.py:505-510).  Points come from numpy's
+        global RNG (net.py:464-465) unless frozen in points_dict.  With save, points_dict gets the reference's keys:
+        "nPointsPerLayer", "nBatches", "data" / "label" (blob shapes), (batch, 0) / (batch, 1) (the images and labels
+        of every batch, net.py:431-433) and (batch, name, "randx" / "randy").  dcfgs.dic.option == resnet: a shortcut
+        blob (Eltwise sum / branch1 BatchNorm) is sampled at the points of the branch2c conv it is added to
+        (net.py:466-487), so that appresb() can subtract row by row."""
         if not isinstance(names, list):
             names = [names]
         assert len(names) > 0
@@ -128,33 +180,63 @@ class Net(object):
             nP, nB = points_dict["nPointsPerLayer"], points_dict["nBatches"]
         else:
             nP, nB = self.nPointsPerLayer, (self.nBatches if nBatches is None else nBatches)
-            points_dict = {"nPointsPerLayer": nP, "nBatches": nB}
+            points_dict = {"nPointsPerLayer": nP, "nBatches": nB} if save else None
         feats_dict = dict()
         idx = 0
         for batch in range(nB):
             blobs = self.forward(batch)
+            if save and not frozen:
+                data = np.asarray(blobs["data"])
+                label = np.asarray(blobs["label"]) if "label" in blobs else np.zeros((data.shape[0], 1, 1, 1), dtype=np.float32)
+                if batch == 0:
+                    points_dict["data"] = tuple(data.shape)
+                    points_dict["label"] = tuple(label.shape)
+                points_dict[(batch, 0)] = data.copy()
+                points_dict[(batch, 1)] = label.copy()
             for name in names:
                 feat = blobs[name]
                 B, C, H, W = feat.shape
                 if name not in feats_dict:
                     feats_dict[name] = np.ndarray(shape=(nP * B * nB, C))
-                if (batch, name, "randx") in points_dict:
+                if save and (batch, name, "randx") in points_dict:
                     randx, randy = points_dict[(batch, name, "randx")], points_dict[(batch, name, "randy")]
                 else:
                     randx = np.random.randint(0, H, nP)
                     randy = np.random.randint(0, W, nP)
-                    points_dict[(batch, name, "randx")] = randx.copy()
-                    points_dict[(batch, name, "randy")] = randy.copy()
+                    if save:
+                        shared = self._shared_points_name(name, names)
+                        if shared is not None:                       # drawn, then replaced: the RNG stream of net.py:464-487
+                            randx = points_dict[(batch, shared, "randx")]
+                            randy = points_dict[(batch, shared, "randy")]
+                        points_dict[(batch, name, "randx")] = randx.copy()
+                        points_dict[(batch, name, "randy")] = randy.copy()
                 for point, x, y in zip(range(nP), randx, randy):
                     i_from = idx + point * B
                     feats_dict[name][i_from:(i_from + B)] = feat[:, :, x, y].reshape((B, -1))
             idx += nP * feat.shape[0]
-        if save or frozen:
+        if save:
             return feats_dict, points_dict
         return feats_dict
 
+    def _shared_points_name(self, name, names):
+        """net.py:466-483: which layer's sample points a shortcut blob re-uses (ResNet option only)"""
+        if dcfgs.dic.option != cfgs.pruning_options.resnet:
+            return None
+        if name in self.sums:
+            nextblock = self.sums[self.sums.index(name) + 1]
+            if nextblock + '_branch1' not in names:
+                return nextblock + '_branch2c'           # the previous sum and branch2c will be identical
+        elif name in self.bns:
+            tag = name.split('bn')[1].split('_')[0]
+            if dcfgs.model == cfgs.Models.xception:
+                return 'interstellar' + tag + '_branch2c'
+            if dcfgs.model == cfgs.Models.resnet:
+                return 'res' + tag + '_branch2c'
+        return None
+
     def freeze_images(self, path=None, convs=None):
-        """extract_features(save=1) + pickle [feats_dict, points_dict] (net.py:749-802)."""
+        """extract_features(save=1) + pickle [feats_dict, points_dict], protocol 4 (net.py:749-802): the file is
+        interchangeable with the reference's frozen<nBatches>.pickle."""
         feats_dict, points_dict = self.extract_features(names=convs or self.convs, save=1)
         if path is not None:
             with open(path, 'wb') as f:
@@ -163,13 +245,19 @@ class Net(object):
         return path
 
     def load_frozen(self, path=None, feats_dict=None, points_dict=None):
-        """net.py:839-876: adopt frozen features / points (from memory or from the pickle)."""
+        """net.py:839-876: adopt frozen features / points (from memory or from the pickle).  A provider that can be
+        re-pointed (``set_batches``) is handed the frozen images (batch, 0) -- the reference feeds exactly those
+        through its MemoryData layer (net.py:420-421, 622-625)."""
         if feats_dict is None:
             with open(path, 'rb') as f:
                 feats_dict, points_dict = pickle.load(f)
         self._feats_dict = feats_dict
         self._points_dict = points_dict
         self._mem = True
+        if hasattr(self.provider, "set_batches") and (0, 0) in points_dict:
+            self.provider.set_batches([points_dict[(b, 0)] for b in range(points_dict["nBatches"])],
+                                      [points_dict[(b, 1)] for b in range(points_dict["nBatches"])])
+            self._blob_cache = (None, None)
 
     # ---- sampled-point im2col (net.py:534-684) -----------------------------------------------------
     def _gather_patches_device(self, X, Y, relu=0):
@@ -204,51 +292,212 @@ class Net(object):
         Xd.free()
         return np.moveaxis(X4, 1, -1).reshape((N * k * k, C)).astype(np.float64)
 
-    # ---- residual target hook (net.py:1641-1683); VGG has none ------------------------------------
+    # ---- residual-aware target (net.py:1641-1683, 1200-1217, 1106-1112) ---------------------------------
+    def getBNaff(self, bn, affine, scale=1.):
+        eps = 1e-9                                                   # the reference's constant (net.py:1107)
+        mean = scale * self.param_data(bn)
+        variance = (scale * self.param_b_data(bn) + eps) ** .5
+        return mean, variance, self.param_data(affine), self.param_b_data(affine)
+
     def appresb(self, Y_name):
-        return 0
+        """What the shortcut of a residual block has drifted by since the features were frozen (the earlier layers were
+        pruned): frozen - current features of the shortcut blob, sampled at Y_name's points.  0 unless
+        dcfgs.res.short == 1 (net.py:1641-1683)."""
+        residual_B = 0
+
+        def extractResB(a):
+            feats_dict, _ = self.extract_features([a], points_dict=self._points_dict, save=1)
+            return self._feats_dict[a] - feats_dict[a]
+
+        if dcfgs.res.short == 1:
+            if dcfgs.dic.option == cfgs.pruning_options.resnet:
+                b2c = '_branch2c'
+                if b2c in Y_name:
+                    b1sum = Y_name.partition(b2c)[0]
+                    if b1sum + '_branch1' in self.convs:
+                        if len(self.bns) == 0:
+                            residual_B = extractResB(b1sum + '_branch1')
+                        else:
+                            for bn in self.bottom_names[b1sum]:
+                                if bn in self.bns and 'branch1' in bn:
+                                    residual_B = extractResB(bn)
+                                    for k in range(self._points_dict["nBatches"]):
+                                        assert np.array_equal(self._points_dict[(k, Y_name, "randx")],
+                                                              self._points_dict[(k, bn, "randx")])
+                                    break
+                    else:
+                        residual_B = extractResB(self.sums[self.sums.index(b1sum) - 1])
+            elif dcfgs.dic.option == 1:
+                b2c = '_conv1'
+                if Y_name.endswith(b2c):
+                    fsums = ['first_conv'] + self.sums
+                    blockname = Y_name.partition(b2c)[0]
+                    blockproj = blockname + '_proj'
+                    b1sum = fsums[fsums.index(blockname + '_sum') - 1]
+                    if blockproj in self.convs:
+                        b1sum = blockproj
+                    residual_B = extractResB(b1sum)
+        return residual_B
+
+    def invBN(self, arr, Y_name):
+        """The residual lives behind branch2c's BatchNorm + Scale; the regression target is the conv's own output:
+        arr * std / k (net.py:1200-1217)."""
+        if isinstance(arr, int) or len(self.bns) == 0 or len(self.affines) == 0:
+            return arr
+        interstellar = Y_name.split('_')[0]
+        bn = affine = None
+        for i in self.bottom_names[interstellar]:
+            if i in self.bns and 'branch2c' in i:
+                bn = i
+                break
+        for i in self.affines:
+            if self.layer_bottom(i) == bn:
+                affine = i
+                break
+        mean, std, k, b = self.getBNaff(bn, affine)
+        return arr * std / k
 
     # ---- wrapper (net.py:1685-1735) ---------------------------------------------------------------
     def dictionary_kernel(self, X_name, weights, d_prime, Y_name, Y, DEBUG=0):
         """Channel-pruning wrapper: which channels of X_name to keep so that conv Y_name can still
-        reproduce its sampled responses.  Returns (idxs, newW2, newB2) like the reference."""
+        reproduce its sampled responses.  Returns (idxs, newW2, newB2) like the reference; goes through the same
+        body as lib.decompose.dictionary(), so dcfgs.nonlinear_fc / nofc / fc_ridge / dic.rank_tol apply."""
         if not self._mem:
             feats_dict, points_dict = self.extract_features([X_name, Y_name], save=1)
             self.load_frozen(feats_dict=feats_dict, points_dict=points_dict)
         ctx = self.ctx()
-        relu_x = self.model not in (cfgs.Models.xception, cfgs.Models.resnet)   # net.py:1717-1720
-        Xd, N, C, k = self._gather_patches_device(X_name, Y_name, relu=relu_x)     # relu(newX) fused
+        resnet_like = dcfgs.model in (cfgs.Models.xception, cfgs.Models.resnet) or \
+            self.model in (cfgs.Models.xception, cfgs.Models.resnet)
         W2 = self.param_data(Y_name)
         b2 = self.param_b_data(Y_name)
         n = W2.shape[0]
         feats = self._feats_dict[Y_name]
-        resY = self.appresb(Y_name)
+        resY = self.appresb(Y_name)                                                 # net.py:1715
+        if resnet_like:
+            resY = self.invBN(resY, Y_name)                                         # net.py:1716-1718
+        Xd, N, C, k = self._gather_patches_device(X_name, Y_name, relu=not resnet_like)   # relu(newX) fused (net.py:1720)
         # Y = feats - bias (+ resY) on the device when the features are float32-representable
         # (they are: they were sampled from float32 blobs); otherwise assemble in float64 on the host.
         f32 = feats.astype(np.float32)
         Yd = ctx.empty(N * n * 8)
         if np.array_equal(f32.astype(np.float64), feats):
             fd, bd = ctx.to_device(f32), ctx.to_device(b2)
-            rd = None if isinstance(resY, int) and resY == 0 else ctx.to_device(np.asarray(resY, dtype=np.float64))
+            rd = None if isinstance(resY, int) and resY == 0 else ctx.to_device(np.ascontiguousarray(resY, dtype=np.float64))
             ctx.assemble_y(fd, bd, rd, N, n, Yd)
         else:
             ctx.to_device(np.ascontiguousarray(feats - b2 + resY, dtype=np.float64), Yd)
-        prob = LayerProblem.from_device(ctx, Xd, _capi.CP_F32, N, C, k, W2, Yd,
-                                        flags=(_capi.CP_CD_RECIPROCAL if dcfgs.cd_reciprocal else 0)
-                                        | (_capi.CP_CD_DELTA if dcfgs.cd_delta else 0))
+        prob = LayerProblem.from_device(ctx, Xd, _capi.CP_F32, N, C, k, W2, Yd, flags=_decompose._flags())
         try:
-            idxs, newW2, newB2, alpha_out = prune_layer(prob, d_prime, cfgs.alpha, rank_tol=dcfgs.dic.rank_tol,
-                                                        rng=np.random, ridge=float(dcfgs.fc_ridge),
-                                                        mode=dcfgs.cd_mode)
-            _decompose.last_call_info.clear()
-            _decompose.last_call_info.update(fits=list(prob.fits), samples=prob.samples,
-                                             fallback=int(prob.refit_info.fallback), p=int(prob.refit_info.p))
+            return _decompose.prune_resident(prob, d_prime, W2)
         finally:
             prob.free()
             Xd.free()
             Yd.free()
-        cfgs.alpha = alpha_out
-        return idxs, newW2, newB2
+
+    # ---- write-back bookkeeping of the layer-by-layer drivers (net.py:1521-1630) ------------------------------
+    def W1keep(self, conv, idxs):
+        """Keep only the filters `idxs` of the PRODUCER behind blob `conv` (and the matching BatchNorm / Scale entries):
+        WPQ gets the compact arrays, the live parameters are zeroed outside idxs (net.py:1521-1608)."""
+        idxs = np.asarray(idxs, dtype=bool)
+        if conv in (self.sums + self.pools):
+            if dcfgs.model in [cfgs.Models.resnet] or self.model == cfgs.Models.resnet:
+                sconv = None
+                for i in self.convs:
+                    if self.layer_bottom(i) == conv:
+                        sconv = i
+                self.bottoms2ch.append([conv, sconv, idxs])
+                return
+            conv = self.layer_bottom(conv)                       # vgg: the pooling layer's bottom
+        bn = affine = None
+        if conv in self.bns:
+            bn = conv
+            for i in self.affines:
+                if self.layer_bottom(i) == bn:
+                    affine = i
+                    break
+        if conv not in self.convs:
+            conv = self.bottom_names[conv][0]
+            if conv not in self.convs and conv in self._layer_bottom:      # e.g. a ReLU blob: its conv is one further up
+                conv = self.layer_bottom(conv)
+        else:
+            for i in self.affines:
+                if self.layer_bottom(i) == conv:
+                    affine = i
+                    break
+            for i in self.bns:
+                if self.layer_bottom(i) == conv:
+                    bn = i
+                    break
+            if affine is None and bn is not None:      # Scale reading the BatchNorm's own top (non-in-place lay-out)
+                for i in self.affines:
+                    if self.layer_bottom(i) == bn:
+                        affine = i
+                        break
+        W1 = self.param_data(conv)[idxs, ...]
+        b = self.param_b_data(conv)[idxs]
+        self.WPQ[(conv, 0)] = self.WPQ[(conv, 0)][idxs, ...].copy() if (conv, 0) in self.WPQ else W1.copy()
+        self.WPQ[(conv, 1)] = self.WPQ[(conv, 1)][idxs].copy() if (conv, 1) in self.WPQ else b.copy()
+        for extra in (bn, affine):
+            if extra is not None:
+                self.WPQ[(extra, 0)] = self.param_data(extra)[idxs].copy()
+                self.WPQ[(extra, 1)] = self.param_b_data(extra)[idxs].copy()
+        Wl, bl = self.param_data(conv), self.param_b_data(conv)
+        Wl[~idxs, ...] = 0.
+        bl[~idxs] = 0.
+        for extra in (bn, affine):
+            if extra is not None:
+                self.param_data(extra)[~idxs] = 0.
+                self.param_b_data(extra)[~idxs] = 0.
+        self._blob_cache = (None, None)
+        self.set_conv(conv, num_output=len(self.WPQ[(conv, 1)]))
+
+    def W2keep(self, top, idxs, W2, B2=None, layerbylayer=False):
+        """The CONSUMER `top` keeps the input channels idxs with the refitted weights W2 (net.py:1610-1625); its bias
+        becomes B2 + its old bias unless layerbylayer."""
+        idxs = np.asarray(idxs, dtype=bool)
+        Wt = self.param_data(top)
+        Wt[:, ~idxs, ...] = 0
+        Wt[:, idxs, ...] = W2
+        self.WPQ[(top, 0)] = np.array(W2, copy=True)
+        if B2 is not None:
+            newB2 = np.array(B2, dtype=np.float64, copy=True)
+            if (not layerbylayer) and (dcfgs.ls != cfgs.solvers.gd or not self._mem):
+                newB2 += self.param_b_data(top)
+            self.set_param_b(top, newB2)
+            self.WPQ[(top, 1)] = newB2.copy()
+        self._blob_cache = (None, None)
+
+    def select(self, name, nextname, idxs):
+        """A channel-selection ("Filter") layer between blob `name` and its consumer `nextname` (net.py:1627-1630; the
+        reference inserts it into the prototxt, lib/builder.py:666-672): remembered in nonWPQ under the filter's name."""
+        fname = underline(name, 'filter')
+        self.nonWPQ[fname] = np.asarray(idxs).astype(int)
+        self._layer_bottom[nextname] = fname
+        return fname
+
+    def combineHP(self):
+        """Fold the 1x1 conv_P back into conv_H where that is cheaper, 3 m >= 2 o (net.py:1473-1504): operates on the
+        decomposed layers held in WPQ after R3()."""
+        H = [k[0] for k in self.WPQ if isinstance(k, tuple) and k[1] == 0 and k[0].endswith('_H')]
+        merged = []
+        for h in H:
+            pname = h[:-2] + '_P'
+            if (pname, 0) not in self.WPQ:
+                continue
+            Hw_full, Pw_full = np.asarray(self.WPQ[(h, 0)]), np.asarray(self.WPQ[(pname, 0)])
+            m, o = Hw_full.shape[0], Pw_full.shape[0]
+            if 3 * m >= 2 * o:
+                newshape = list(Hw_full.shape)
+                newshape[0] = o
+                Hw, Pw = Hw_full.reshape((m, -1)), Pw_full.reshape((o, -1))
+                Hb, pb = np.asarray(self.WPQ[(h, 1)]), np.asarray(self.WPQ[(pname, 1)])
+                self.WPQ[(h, 0)] = Pw.dot(Hw).reshape(newshape)
+                self.WPQ[(h, 1)] = pb + Pw.dot(Hb)
+                self.set_conv(h, num_output=o)
+                del self.WPQ[(pname, 0)], self.WPQ[(pname, 1)]
+                self.removed.append(pname)
+                merged.append(h)
+        return merged
 
     # ---- baseline pruner (net.py:1632-1639) -------------------------------------------------------
     def pruning_kernel(self, X_name, d_prime, Y_name):

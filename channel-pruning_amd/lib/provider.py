@@ -13,6 +13,14 @@ cpmi355/capi.py::load).  torch is plumbing here: the forward pass is not on the 
 """
 import numpy as np
 
+"""Layer-description format shared by ``Net(graph=...)`` and ``TorchGraphProvider`` (one dict per layer, network order):
+    {"name", "type", "bottom": [blob, ..], "top": [blob], ...}
+      Convolution  W float32[n, c, k, k], b float32[n], pad, stride
+      ReLU | Pooling (kernel, stride; max) | Eltwise (sum of two bottoms)
+      BatchNorm    mean[c], var[c], eps          (Caffe blobs 0 and 1 with scale factor 1)
+      Scale        k[c], b[c]
+A top equal to the bottom means "in place" (Caffe's in-place ReLU / Scale): the blob is overwritten."""
+
 
 class TorchSequentialProvider(object):
     def __init__(self, batches, pools=None, device="cpu", num_threads=None):
@@ -47,3 +55,62 @@ class TorchSequentialProvider(object):
                 pname, kernel, stride = self.pools[name]
                 blobs[pname] = F.max_pool2d(r, kernel, stride)
         return dict((k, v.detach().cpu().numpy()) for k, v in blobs.items())
+
+
+class TorchGraphProvider(object):
+    """Live provider for arbitrary layer graphs (ResNet blocks: BatchNorm / Scale / Eltwise shortcuts) on torch --
+    ``device="cuda"`` runs the forward pass on the MI355X through torch-ROCm (import torch BEFORE the first cpmi355
+    Context, see cpmi355/capi.py::load), ``"cpu"`` anywhere.  Parameters are read from the net on every call
+    (``net.param_data`` / ``param_b_data``: conv weights, BatchNorm mean / variance, Scale k / b), so the blobs follow
+    whatever the pruning steps wrote back.  ``set_batches`` re-points it at the images of a frozen pickle."""
+
+    def __init__(self, layers, batches, labels=None, device="cpu", num_threads=None):
+        import torch
+        self.torch = torch
+        self.layers = list(layers)
+        self.device = torch.device(device)
+        if num_threads is not None:
+            torch.set_num_threads(int(num_threads))
+        self.set_batches(batches, labels)
+
+    def set_batches(self, batches, labels=None):
+        self.batches = [np.ascontiguousarray(b, dtype=np.float32) for b in batches]
+        self.labels = None if labels is None else [np.asarray(v, dtype=np.float32) for v in labels]
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __call__(self, batch, net):
+        torch = self.torch
+        F = torch.nn.functional
+        dev = self.device
+
+        def t(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        blobs = {"data": t(self.batches[batch])}
+        for L in self.layers:
+            kind, name = L["type"], L["name"]
+            x = [blobs[b] for b in L["bottom"]]
+            if kind == "Convolution":
+                y = F.conv2d(x[0], t(net.param_data(name)), t(net.param_b_data(name)), stride=L.get("stride", 1),
+                             padding=L.get("pad", 0))
+            elif kind == "ReLU":
+                y = F.relu(x[0])
+            elif kind == "Pooling":
+                y = F.max_pool2d(x[0], L["kernel"], L["stride"])
+            elif kind == "Eltwise":
+                y = x[0] + x[1]
+            elif kind == "BatchNorm":
+                mean, var = t(net.param_data(name)), t(net.param_b_data(name))
+                y = (x[0] - mean[None, :, None, None]) / torch.sqrt(var + L.get("eps", 1e-5))[None, :, None, None]
+            elif kind == "Scale":
+                k, b = t(net.param_data(name)), t(net.param_b_data(name))
+                y = x[0] * k[None, :, None, None] + b[None, :, None, None]
+            else:
+                raise ValueError("layer type %r" % kind)
+            blobs[L["top"][0]] = y
+        out = dict((k, v.detach().cpu().numpy()) for k, v in blobs.items())
+        B = self.batches[batch].shape[0]
+        out["label"] = self.labels[batch] if self.labels is not None else np.zeros((B, 1, 1, 1), dtype=np.float32)
+        return out

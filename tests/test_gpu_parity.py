@@ -283,7 +283,7 @@ def _run_dropin(p, X, W2, Y, B2, mode, exact_ops=False):
         dcfgs.nofc = 0
         dcfgs.dic.rank_tol = .1
         dcfgs.cd_mode = 'device'
-        dcfgs.cd_reciprocal = dcfgs.cd_delta = 1
+        dcfgs.cd_reciprocal = dcfgs.cd_delta = 0      # the drop-in default: sklearn's operation sequence
     rng_next = int(np.random.randint(0, 2147483647))
     return idxs, newW2, newB2, float(cfgs.alpha), rng_next, dict(D.last_call_info)
 
