@@ -701,7 +701,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="vgg16: time the CPU port on all 12 layers (about 2-3 min)")
     ap.add_argument("--no-block", action="store_true", help="vgg16: skip the conv3_x single-instance figures")
-    ap.add_argument("--per-stream", type=int, default=int(os.environ.get("CP_BENCH_PER_STREAM", "2")),
+    ap.add_argument("--per-stream", type=int, default=int(os.environ.get("CP_BENCH_PER_STREAM", "1")),
                     help="vgg16: equal-width layers per stream / cp_prune_layers call")
     ap.add_argument("--jobs-per-step", type=int, default=0, help="vgg16: fixed jobs per step (0 = fill >= 2 s)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("CP_BENCH_INFLIGHT", "6")),

@@ -15,6 +15,7 @@
 // so that the batch can run them as ONE launch each for all of its layers
 struct cp_refit_deferred {
     double *G, *U, *Lt, *TI, *TIT, *dg0, *gmax, *Rm;
+    double *part;   // scratch of the tiled lay-out kernel ((p_pad / 32) * n_pad doubles)
     int *info;
     int p, p_pad, nblk, n, n_pad;
     const double *xmean, *ymean;

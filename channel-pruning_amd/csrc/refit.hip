@@ -154,7 +154,7 @@ typedef double v4f64c __attribute__((ext_vector_type(4)));
 constexpr int PNB = 16, NPAN = NB / PNB, DLD = 136;
 constexpr int PT = 512;  // threads of the factorisation kernel (8 waves)
 // info[0] first failed pivot, info[1 + b] diagonal block b done, then one flag per tile (row-major nblk x nblk)
-constexpr int chol_info_count(int nblk) { return 1 + nblk + nblk * nblk; }
+constexpr int chol_info_count(int nblk) { return 8 + 2 * nblk + 4 * nblk * nblk; }  // covers both flag lay-outs below
 
 #ifndef CP_POTRF_TIMERS
 #define CP_POTRF_TIMERS 0
@@ -581,6 +581,399 @@ __global__ void __launch_bounds__(RT) k_finalize(const double *__restrict__ W, i
     (void)n;
 }
 
+// =============================================================================================================
+// Cholesky as ONE launch of persistent workgroups over an ordered task queue, 64 x 64 tiles.
+//
+// The serial chain of a blocked factorisation is  (last update of the diagonal tile) -> (factor + invert it)
+// -> (apply the inverse to the panel tiles)  once per block step, and each link is one CU's worth of work: with
+// 128-tiles that is 14 + 45 + 14 us per step, 2.5 ms for p = 4350 however many CUs are idle.  64-tiles cut every
+// link by 4-8x at twice the steps.  Tasks = upper tiles (i, j), i <= j, in row-major order, LEFT-looking:
+//     S = G[i,j] - sum_{b<i} U[b,i]^T U[b,j]         on MFMA, as the rows b complete (one flag per tile)
+//     i == j : S -> LDS, U_ii = chol(S), T_i = U_ii^-1 (16-column panels, DPP broadcasts, MFMA updates), flag(i)
+//              every second diagonal tile also assembles the 128-block inverse the substitution kernels use:
+//              [T_a, -T_a U_ab T_b; 0, T_b]
+//     i <  j : wait for flag(i), U[i,j] = T_i^T S (also stored transposed into Lt[j,i]), tile flag
+// A workgroup takes its next task from an atomic counter, so a task only ever waits for LOWER-numbered tasks, all of
+// which have been claimed by workgroups that are running: no workgroup waits for one that has not been dispatched,
+// whatever else occupies the chip (the hazard of the blockIdx-ordered one-launch variant above).  37 KB of LDS per
+// workgroup (the 128-tile kernel held a CU's whole LDS while it waited).
+// info: [0] first failed pivot + 1, [1] task counter, [2 + d] diagonal flags, [2 + n64 + i n64 + j] tile flags.
+constexpr int TB = 64, TLD = 72, T_NPAN = TB / PNB, PT64 = 256;
+struct Potrf64Job {
+    const double *G;
+    double *U, *Lt;
+    int ld, n64;
+    const double *dg0;
+    double piv_tol;
+    double *TI, *TIT;   // 128-block inverses (nblk x 128 x 128), as the substitution kernels expect them
+    int *info;
+};
+
+__device__ __forceinline__ bool flag_ready(const int *flag) {
+    return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+__device__ void potrf64_task(const Potrf64Job &a, int i, int j, double *sm, int *sh_i) {
+    double *A = sm;                          // TB x TLD
+    double *Tl = sm + TB * TLD;              // T_NPAN x 16 x 16
+    double *dinv = Tl + T_NPAN * PNB * PNB;  // TB
+    double *dref = dinv + TB;                // TB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
+    const int ld = a.ld, n64 = a.n64;
+    int *diag_flag = a.info + 2, *tile_flag = a.info + 2 + n64;
+#if CP_POTRF_TIMERS
+    unsigned long long t_last = __builtin_readcyclecounter();
+#define CP_T64(slot) { const unsigned long long tn_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_potrf_debug[slot], tn_ - t_last); t_last = tn_; }
+#else
+#define CP_T64(slot)
+#endif
+    // ---- S = G[i,j] - sum_b U[b,i]^T U[b,j]: wave w owns rows 16 w .. 16 w + 15 ----
+    v4f64c acc[TB / 16];
+    {
+        const double *Gij = a.G + (size_t(i) * TB + wave * 16 + fk) * ld + size_t(j) * TB + fi;
+#pragma unroll
+        for (int t = 0; t < TB / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = Gij[size_t(4 * r) * ld + 16 * t];
+    }
+    int b = 0;
+    while (b < i) {
+        if (tid == 0) {   // how many further rows are complete (at least one: wait for it)
+            int e = b;
+            while (e < i && flag_ready(tile_flag + e * n64 + i) && (j == i || flag_ready(tile_flag + e * n64 + j))) ++e;
+            if (e == b) {
+                flag_wait(tile_flag + b * n64 + i, a.info);
+                if (j != i) flag_wait(tile_flag + b * n64 + j, a.info);
+                e = b + 1;
+            }
+            *sh_i = e;
+        }
+        __syncthreads();
+        const int e = *sh_i;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (; b < e; ++b) {
+            const double *Ubi = a.U + size_t(b) * TB * ld + size_t(i) * TB + wave * 16 + fi;
+            const double *Ubj = a.U + size_t(b) * TB * ld + size_t(j) * TB + fi;
+#pragma unroll 4
+            for (int q = 0; q < TB / 4; ++q) {
+                const double av = -Ubi[size_t(4 * q + fk) * ld];
+#pragma unroll
+                for (int t = 0; t < TB / 16; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ubj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // sh_i is rewritten next round
+    }
+#pragma unroll
+    for (int t = 0; t < TB / 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(wave * 16 + fk + 4 * r) * TLD + 16 * t + fi] = acc[t][r];
+    const int B128 = i >> 1, half = i & 1;
+    double *TIb = a.TI + size_t(B128) * NB * NB, *TITb = a.TIT + size_t(B128) * NB * NB;
+    if (i != j) {
+        CP_T64(3)
+        // ---- panel tile: U[i,j] = T_i^T S ----
+        if (tid == 0) flag_wait(diag_flag + i, a.info);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        CP_T64(4)
+        const double *Ti = TIb + size_t(half) * (TB * NB + TB) + wave * 16 + fi;   // T_i[k][m] at Ti[k * NB + m]
+#pragma unroll
+        for (int t = 0; t < TB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
+#pragma unroll 4
+        for (int q = 0; q < TB / 4; ++q) {
+            const double av = Ti[size_t(4 * q + fk) * NB];
+#pragma unroll
+            for (int t = 0; t < TB / 16; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, A[(4 * q + fk) * TLD + 16 * t + fi], acc[t], 0, 0, 0);
+        }
+        double *Uij = a.U + size_t(i) * TB * ld + size_t(j) * TB + fi;
+        double *Ltj = a.Lt + size_t(j) * TB * ld + size_t(i) * TB + wave * 16;
+#pragma unroll
+        for (int t = 0; t < TB / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Uij[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
+                Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(tile_flag + i * n64 + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        CP_T64(5)
+        if (tid == 0) atomicAdd(&g_potrf_debug[7], 1ull);
+        return;
+    }
+    CP_T64(0)
+    // ---- diagonal tile: factor in LDS ----
+    if (tid < TB) dref[tid] = a.dg0[i * TB + tid];
+    __syncthreads();
+    for (int p = 0; p < T_NPAN; ++p) {
+        const int k0 = p * PNB;
+        if (wave == 0) {   // 16 x 16 diagonal sub-block in registers: lane j (< 16) owns column j
+            double c[PNB];
+#pragma unroll
+            for (int r = 0; r < PNB; ++r) c[r] = A[(k0 + r) * TLD + k0 + fi];
+            const double refv = dref[k0 + fi];
+#pragma unroll
+            for (int k = 0; k < PNB; ++k) {
+                double piv = row_bcast_i(c[k], k);
+                const double ref = row_bcast_i(refv, k);
+                if (!(piv > a.piv_tol * ref)) {
+                    if (lane == 0) atomicCAS(a.info, 0, i * TB + k0 + k + 1);
+                    piv = ref > 0 ? ref : 1.0;   // harmless pivot; the result is discarded by the caller
+                }
+                const double inv = rsqrt_nr(piv);
+                const double u = c[k] * inv;
+                c[k] = fi == k ? piv * inv : u;
+#pragma unroll
+                for (int r = k + 1; r < PNB; ++r) c[r] = fma(-row_bcast_i(u, r), u, c[r]);
+                if (lane == 0) dinv[k0 + k] = inv;
+            }
+            if (lane < PNB) {
+#pragma unroll
+                for (int r = 0; r < PNB; ++r)
+                    if (fi >= r) A[(k0 + r) * TLD + k0 + fi] = c[r];
+            }
+        }
+        __syncthreads();
+        const int rest = TB - k0 - PNB;
+        if (tid < rest) {   // U12 = U11^-T A12, one column per thread
+            const int col = k0 + PNB + tid;
+            double x[PNB];
+#pragma unroll
+            for (int r = 0; r < PNB; ++r) x[r] = A[(k0 + r) * TLD + col];
+#pragma unroll
+            for (int r = 0; r < PNB; ++r) {
+                double sacc = x[r];
+#pragma unroll
+                for (int k = 0; k < r; ++k) sacc = fma(-A[(k0 + k) * TLD + k0 + r], x[k], sacc);
+                x[r] = sacc * dinv[k0 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < PNB; ++r) A[(k0 + r) * TLD + col] = x[r];
+        }
+        __syncthreads();
+        const int rt = rest / PNB, ntile = rt * (rt + 1) / 2;   // A22 -= U12^T U12 on the upper 16-tiles
+        for (int e = wave; e < ntile; e += PT64 / 64) {
+            int aa = 0;
+            while ((aa + 1) * (aa + 2) / 2 <= e) ++aa;
+            const int bb = e - aa * (aa + 1) / 2;
+            const int ci = k0 + PNB + bb * PNB, cj = k0 + PNB + aa * PNB;
+            v4f64c u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = A[(ci + fk + 4 * r) * TLD + cj + fi];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                u = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(k0 + kk * 4 + fk) * TLD + ci + fi], A[(k0 + kk * 4 + fk) * TLD + cj + fi], u, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(ci + fk + 4 * r) * TLD + cj + fi] = u[r];
+        }
+        __syncthreads();
+    }
+    CP_T64(1)
+    // T_p = U_pp^-1 (upper 16 x 16): task = (panel, column), 4 lanes per task split the k-sum
+    {
+        const int task = tid >> 2, g = tid & 3;
+        const int p = task >> 4, jj = task & 15, k0 = p * PNB;
+        double *Tp = Tl + p * PNB * PNB;
+        for (int r = PNB - 1; r >= 0; --r) {
+            double sacc = 0.0;
+            for (int k = r + 1 + g; k <= jj; k += 4) sacc = fma(A[(k0 + r) * TLD + k0 + k], Tp[k * PNB + jj], sacc);
+            sacc += __shfl_xor(sacc, 1, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            const double tv = r <= jj ? ((r == jj ? 1.0 : 0.0) - sacc) * dinv[k0 + r] : 0.0;
+            if (g == 0) Tp[r * PNB + jj] = tv;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // off-diagonal 16-blocks of V = U^-1: V_ij = -T_ii sum_{k=i+1..j} U_ik V_kj, stored at block (j, i) of A's lower part;
+    // block column jb = 3 - wave
+    {
+        const int jb = T_NPAN - 1 - wave;
+        if (jb >= 1) {
+            for (int ib = jb - 1; ib >= 0; --ib) {
+                v4f64c Sx = {0., 0., 0., 0.};
+                for (int kb = ib + 1; kb <= jb; ++kb) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double av = A[(ib * PNB + fi) * TLD + kb * PNB + kk * 4 + fk];
+                        const double bv = kb == jb ? Tl[jb * PNB * PNB + (kk * 4 + fk) * PNB + fi]
+                                                   : A[(jb * PNB + kk * 4 + fk) * TLD + kb * PNB + fi];
+                        Sx = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Sx, 0, 0, 0);
+                    }
+                }
+                v4f64c V = {0., 0., 0., 0.};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    V = __builtin_amdgcn_mfma_f64_16x16x4f64(-Tl[ib * PNB * PNB + fi * PNB + kk * 4 + fk], Sx[kk], V, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(jb * PNB + fk + 4 * r) * TLD + ib * PNB + fi] = V[r];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+    // write U_ii (lower part zeroed), gather V = U_ii^-1 (upper) per thread, then overwrite A with V
+    double vreg[TB * TB / PT64];
+    double *Ub = a.U + size_t(i) * TB * ld + size_t(i) * TB;
+#pragma unroll
+    for (int q = 0; q < TB * TB / PT64; ++q) {
+        const int e = q * PT64 + tid, r = e / TB, cc = e - r * TB;
+        const int rb = r >> 4, cb = cc >> 4, ri = r & 15, ci = cc & 15;
+        vreg[q] = rb < cb ? A[(cb * PNB + ri) * TLD + rb * PNB + ci] : (rb == cb ? Tl[rb * PNB * PNB + ri * PNB + ci] : 0.0);
+        Ub[size_t(r) * ld + cc] = cc >= r ? A[r * TLD + cc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TB * TB / PT64; ++q) {
+        const int e = q * PT64 + tid, r = e / TB, cc = e - r * TB;
+        A[r * TLD + cc] = vreg[q];
+    }
+    __syncthreads();
+    // the diagonal quadrant of the 128-block inverse and of its transpose; the empty quadrant below / left of it
+    {
+        double *TIq = TIb + size_t(half) * (TB * NB + TB), *TITq = TITb + size_t(half) * (TB * NB + TB);
+        for (int e = tid; e < TB * TB; e += PT64) {
+            const int r = e / TB, cc = e - r * TB;
+            TIq[r * NB + cc] = A[r * TLD + cc];
+            TITq[r * NB + cc] = A[cc * TLD + r];
+            if (!half) {
+                TIb[(TB + r) * NB + cc] = 0.0;    // TI  bottom-left
+                TITb[r * NB + TB + cc] = 0.0;     // TIT top-right
+            }
+        }
+    }
+    if (half) {   // off-diagonal quadrant: -T_a U_ab T_b, with T_a from the previous diagonal task, T_b = A
+        const double *Uab = a.U + size_t(i - 1) * TB * ld + size_t(i) * TB;
+        v4f64c x[TB / 16];
+#pragma unroll
+        for (int t = 0; t < TB / 16; ++t) x[t] = v4f64c{0., 0., 0., 0.};
+#pragma unroll 4
+        for (int q = 0; q < TB / 4; ++q) {   // X[m][n] = sum_k U_ab[m][k] T_b[k][n]
+            const double av = Uab[size_t(wave * 16 + fi) * ld + 4 * q + fk];
+#pragma unroll
+            for (int t = 0; t < TB / 16; ++t)
+                x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, A[(4 * q + fk) * TLD + 16 * t + fi], x[t], 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TB / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(wave * 16 + fk + 4 * r) * TLD + 16 * t + fi] = x[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TB / 16; ++t) x[t] = v4f64c{0., 0., 0., 0.};
+#pragma unroll 4
+        for (int q = 0; q < TB / 4; ++q) {   // TR[m][n] = -sum_k T_a[m][k] X[k][n]
+            const double av = -TIb[size_t(wave * 16 + fi) * NB + 4 * q + fk];
+#pragma unroll
+            for (int t = 0; t < TB / 16; ++t)
+                x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, A[(4 * q + fk) * TLD + 16 * t + fi], x[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < TB / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = wave * 16 + fk + 4 * r, n = 16 * t + fi;
+                TIb[m * NB + TB + n] = x[t][r];         // TI  top-right
+                TITb[(TB + n) * NB + m] = x[t][r];      // TIT bottom-left
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(diag_flag + i, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    CP_T64(2)
+    if (tid == 0) atomicAdd(&g_potrf_debug[6], 1ull);
+#undef CP_T64
+}
+
+struct Potrf64Batch {
+    Potrf64Job j[16];
+};
+__global__ void __launch_bounds__(PT64) k_potrf64(Potrf64Batch bt) {   // blockIdx.y = job; persistent over the job's task queue
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int sh[2];
+    const Potrf64Job &a = bt.j[blockIdx.y];
+    const int n64 = a.n64, ntasks = n64 * (n64 + 1) / 2;
+    for (;;) {
+        if (threadIdx.x == 0) sh[0] = atomicAdd(a.info + 1, 1);
+        __syncthreads();
+        const int task = sh[0];
+        __syncthreads();
+        if (task >= ntasks) return;
+        int i = 0, t = task;
+        while (t >= n64 - i) {
+            t -= n64 - i;
+            ++i;
+        }
+        potrf64_task(a, i, i + t, sm, sh + 1);
+        __syncthreads();
+    }
+}
+
+// The same for large (p, n): 32 x 32 tiles through LDS so that both the reads of W (rows of n_pad) and the writes of coef
+// (rows of p, also into the pinned host copy) are coalesced; the intercept from per-tile partial sums, fixed order.
+__global__ void __launch_bounds__(RT) k_finalize_tile(const double *__restrict__ W, int ldw, int p, int n,
+                                                      const double *__restrict__ xmean, double *__restrict__ coef,
+                                                      double *__restrict__ coef_host, double *__restrict__ part, int ld_part) {
+    __shared__ double t[32][33];
+    __shared__ double red[8][33];
+    const int col0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double sacc = 0.0;
+    for (int y = ty; y < 32; y += 8) {
+        const int col = col0 + y;
+        const double v = (col < p && j0 + tx < n) ? W[size_t(col) * ldw + j0 + tx] : 0.0;
+        t[y][tx] = v;
+        if (col < p) sacc = fma(xmean[col], v, sacc);
+    }
+    red[ty][tx] = sacc;
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) {
+        const int j = j0 + y, col = col0 + tx;
+        if (j < n && col < p) {
+            const double v = t[tx][y];
+            coef[size_t(j) * p + col] = v;
+            if (coef_host) coef_host[size_t(j) * p + col] = v;
+        }
+    }
+    if (ty == 0 && j0 + tx < n) {
+        double tot = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tot += red[r][tx];
+        part[size_t(blockIdx.x) * ld_part + j0 + tx] = tot;
+    }
+}
+__global__ void __launch_bounds__(RT) k_finalize_bias(const double *__restrict__ part, int nparts, int ld_part, int n,
+                                                      const double *__restrict__ ymean, double *__restrict__ b,
+                                                      double *__restrict__ b_host, const int *__restrict__ info,
+                                                      int *__restrict__ info_host) {
+    const int j = blockIdx.x * RT + threadIdx.x;
+    if (j == 0) info_host[0] = info[0];
+    if (j >= n) return;
+    double tot = 0;
+    for (int r = 0; r < nparts; ++r) tot += part[size_t(r) * ld_part + j];
+    b[j] = ymean[j] - tot;
+    if (b_host) b_host[j] = ymean[j] - tot;
+}
+// W [p_pad, n_pad] -> coef / b (+ pinned host copies): tiled for large outputs (part: scratch of (p_pad / 32) * n_pad doubles)
+int finalize_launch(cp_ctx *ctx, const double *W, int n_pad, int p, int n, const double *xmean, const double *ymean,
+                    double *coef, double *b, double *coef_host, double *b_host, const int *info, int *info_host,
+                    double *part) {
+    if (part && size_t(p) * n >= (1u << 18)) {
+        const int gx = (p + 31) / 32, gy = (n + 31) / 32;
+        k_finalize_tile<<<dim3(gx, gy), RT, 0, ctx->stream>>>(W, n_pad, p, n, xmean, coef, coef_host, part, n_pad);
+        CP_LAUNCH_CHECK(ctx);
+        k_finalize_bias<<<(n + RT - 1) / RT, RT, 0, ctx->stream>>>(part, gx, n_pad, n, ymean, b, b_host, info, info_host);
+        CP_LAUNCH_CHECK(ctx);
+    } else {
+        k_finalize<<<n, RT, 0, ctx->stream>>>(W, n_pad, p, n, xmean, ymean, coef, b, coef_host, b_host, info, info_host);
+        CP_LAUNCH_CHECK(ctx);
+    }
+    return CP_OK;
+}
+
 struct Chol {
     double *G;   // p_pad x p_pad working matrix (trailing Schur complements)
     double *U;   // the factor (upper), written block row by block row (never in place: the panel
@@ -592,12 +985,39 @@ struct Chol {
     int p, p_pad, nblk;
 };
 
+bool chol_tasks_requested() {
+    static const bool on = [] {
+        const char *e = getenv("CP_CHOL_TASKS");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 bool chol_fused_requested() {
     static const bool on = [] {
         const char *e = getenv("CP_CHOL_FUSED");
         return e && e[0] == '1';
     }();
     return on;
+}
+
+// one launch for up to 16 factorisations (grid.y = job): persistent workgroups over each job's ordered task queue
+int chol_factor_tasks(cp_ctx *ctx, const Chol *chs, int count, double piv_tol) {
+    const size_t lds = (size_t(TB) * TLD + size_t(T_NPAN) * PNB * PNB + 2 * TB) * sizeof(double);
+    static const int cap_mult = getenv("CP_CHOL_WG_PER_CU") ? atoi(getenv("CP_CHOL_WG_PER_CU")) : 2;
+    Potrf64Batch bt;
+    memset(&bt, 0, sizeof(bt));
+    int max_tasks = 0;
+    for (int l = 0; l < count; ++l) {
+        const Chol &ch = chs[l];
+        const int n64 = ch.p_pad / TB;
+        bt.j[l] = Potrf64Job{ch.G, ch.U, ch.Lt, ch.p_pad, n64, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info};
+        max_tasks = std::max(max_tasks, n64 * (n64 + 1) / 2);
+    }
+    const int per_job = std::max(1, std::min(max_tasks, ctx->cu_count * cap_mult / count));
+    k_potrf64<<<dim3(per_job, count), PT64, lds, ctx->stream>>>(bt);
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
 }
 
 // G = U^T U (upper, into ch.U), TI/TIT per diagonal block, and the off-diagonal blocks of Lt = U^T.
@@ -617,6 +1037,12 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     // two launches can hold the slots each other's next workgroups need, and only the bounded spins get them out.
     // The default (diagonal block + panel in one launch, trailing update as a GEMM) has no such cycle: a panel
     // workgroup waits only for workgroup 0 of its own launch, which an XCD always dispatches before its later ones.
+    // CP_CHOL_TASKS=1: the one-launch task-queue factorisation (k_potrf64).  Correct (the whole GPU suite passes on it) and
+    // free of the dispatch-order hazard, but measured SLOWER than the two-launches-per-block-step scheme below: 1.40 vs 0.94 ms
+    // at p = 1179, 5.0 vs 4.3 ms at p = 4140 -- per 64-column step its chain is 17 us (factor) + 20 us (invert, publish) +
+    // 15-20 us (panel tile: dependent loads of T_i, scattered Lt stores, agent-scope release) against 94 us per 128 columns
+    // here (tests/tools/potrf64_phases.py).  Kept opt-in.
+    if (chol_tasks_requested()) return chol_factor_tasks(ctx, &ch, 1, piv_tol);
     static const bool fused = chol_fused_requested();
     if (fused) {  // one launch, left-looking, a workgroup per tile
         k_potrf<true><<<ch.nblk * (ch.nblk + 1) / 2, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, ch.nblk, ch.dg0, piv_tol,
@@ -661,7 +1087,11 @@ struct StripFinal {  // optional tail of k_solve_strips: what k_finalize does, f
 template <int SWEEPS = 3>
 __device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
                                                   const double *__restrict__ TI, const double *__restrict__ TIT,
-                                                  int nblk, double *R, int n_pad, const StripFinal &fin) {
+                                                  int nblk, double *R, int n_pad, const StripFinal &fin, int b0 = 0,
+                                                  int b1 = -1) {
+    // [b0, b1): the band of 128-row blocks this launch substitutes through (default: all of them).  A band launch only
+    // accounts for the couplings INSIDE the band; chol_solve_blocked applies the others as chip-filling GEMMs.
+    if (b1 < 0) b1 = nblk;
     __shared__ double S[NB][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fk = lane >> 4, fi = lane & 15;
@@ -670,13 +1100,13 @@ __device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, 
         if (!(SWEEPS & (1 << sweep))) continue;
         const double *Tri = sweep == 0 ? U : Lt;      // element (kk of block k, m of block b) at Tri[(k NB + kk) ld + b NB + m]
         const double *Dinv = sweep == 0 ? TI : TIT;   // a-operand of the diagonal solve: Dinv_b[j, m]
-        for (int step = 0; step < nblk; ++step) {
-            const int b = sweep == 0 ? step : nblk - 1 - step;
+        for (int step = 0; step < b1 - b0; ++step) {
+            const int b = sweep == 0 ? b0 + step : b1 - 1 - step;
             double *Rb = R + (size_t(b) * NB + row0) * n_pad + col0 + fi;
             v4f64c acc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = Rb[size_t(fk + 4 * r) * n_pad];
-            const int k_lo = sweep == 0 ? 0 : b + 1, k_hi = sweep == 0 ? b : nblk;
+            const int k_lo = sweep == 0 ? b0 : b + 1, k_hi = sweep == 0 ? b : b1;
             for (int k = k_lo; k < k_hi; ++k) {
                 const double *Ak = Tri + size_t(k) * NB * ld + size_t(b) * NB + row0 + fi;
                 const double *Yk = R + size_t(k) * NB * n_pad + col0 + fi;
@@ -742,8 +1172,8 @@ __device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, 
 template <int SWEEPS>
 __global__ void __launch_bounds__(512) k_solve_strips(const double *__restrict__ U, const double *__restrict__ Lt, int ld,
                                                       const double *__restrict__ TI, const double *__restrict__ TIT,
-                                                      int nblk, double *R, int n_pad, StripFinal fin) {
-    solve_strips_body<SWEEPS>(U, Lt, ld, TI, TIT, nblk, R, n_pad, fin);
+                                                      int nblk, double *R, int n_pad, StripFinal fin, int b0 = 0, int b1 = -1) {
+    solve_strips_body<SWEEPS>(U, Lt, ld, TI, TIT, nblk, R, n_pad, fin, b0, b1);
 }
 
 struct StripJob {
@@ -773,6 +1203,51 @@ int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad, con
     else
         k_solve_strips<3><<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ch.p_pad, ch.TI, ch.TIT, ch.nblk, Rm, n_pad, fin);
     CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}
+
+// Both substitutions for LARGE factors.  The one-launch strips above read the whole factor once per 16 right-hand
+// sides (n/16 x p^2/2 x 8 B per sweep: 4.8 GB at p = 4350, n = 512 -- load bound on 32 workgroups, 4.6 ms).  Here the
+// rows are processed in bands of OB = 4 blocks: inside a band the strips kernel (short: 4 block steps), and the
+// band's contribution to every remaining row as ONE chip-filling f64 MFMA GEMM with K = 512
+//   forward   R[rows below] -= U[band, below]^T Y[band]       backward   R[rows above] -= (Lt[band, above])^T W[band]
+// so the factor is read once per sweep.  The coefficient lay-out / intercept tail is the caller's (k_finalize).
+constexpr int SOLVE_OB = 4;
+int solve_blocked_min_blocks() {
+    static const int v = [] {
+        const char *e = getenv("CP_SOLVE_BLOCKED_MIN_NBLK");
+        return e ? atoi(e) : 16;
+    }();
+    return v;
+}
+size_t chol_solve_blocked_workspace(const cp_ctx *ctx, int p_pad, int n_pad) {
+    return cp_gemm_tn_workspace(ctx, p_pad, n_pad, SOLVE_OB * NB, CP_TRI_NONE);
+}
+int chol_solve_blocked(cp_ctx *ctx, const Chol &ch, double *Rm, int n_pad, int sweeps = 3) {
+    const int ld = ch.p_pad, nblk = ch.nblk;
+    const StripFinal none{};
+    if (sweeps & 1) {
+        for (int b0 = 0; b0 < nblk; b0 += SOLVE_OB) {
+            const int b1 = std::min(nblk, b0 + SOLVE_OB);
+            k_solve_strips<1><<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ld, ch.TI, ch.TIT, nblk, Rm, n_pad, none, b0, b1);
+            CP_LAUNCH_CHECK(ctx);
+            const int below = (nblk - b1) * NB;
+            if (below > 0)
+                CP_TRY(cp_gemm_tn_f64(ctx, below, n_pad, (b1 - b0) * NB, -1.0, ch.U + size_t(b0) * NB * ld + size_t(b1) * NB, ld,
+                                      Rm + size_t(b0) * NB * n_pad, n_pad, 1.0, Rm + size_t(b1) * NB * n_pad, n_pad, CP_TRI_NONE));
+        }
+    }
+    if (sweeps & 2) {
+        for (int b1 = nblk; b1 > 0; b1 -= SOLVE_OB) {
+            const int b0 = std::max(0, b1 - SOLVE_OB);
+            k_solve_strips<2><<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ld, ch.TI, ch.TIT, nblk, Rm, n_pad, none, b0, b1);
+            CP_LAUNCH_CHECK(ctx);
+            const int above = b0 * NB;
+            if (above > 0)
+                CP_TRY(cp_gemm_tn_f64(ctx, above, n_pad, (b1 - b0) * NB, -1.0, ch.Lt + size_t(b0) * NB * ld, ld,
+                                      Rm + size_t(b0) * NB * n_pad, n_pad, 1.0, Rm, n_pad, CP_TRI_NONE));
+        }
+    }
     return CP_OK;
 }
 
@@ -831,6 +1306,14 @@ __global__ void __launch_bounds__(RT) k_scale_rows(double *__restrict__ M, int l
 }
 
 }  // namespace
+
+extern "C" int cp_debug_potrf_reset(cp_ctx *ctx) {
+    if (!ctx) return CP_ERR_ARG;
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    CP_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_potrf_debug), z, sizeof(z)));
+    return CP_OK;
+}
 
 extern "C" int cp_debug_potrf_cycles(cp_ctx *ctx, unsigned long long *out8) {
     if (!ctx || !out8) return CP_ERR_ARG;
@@ -1050,9 +1533,7 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
     int hinfo = 0;
     bool fallback = (ridge == 0.0) && (N - 1 < p);  // centred X has rank <= N-1
     auto finalize = [&]() -> int {
-        k_finalize<<<n, RT, 0, ctx->stream>>>(Rm, n_pad, p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo,
-                                              info_host);
-        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(finalize_launch(ctx, Rm, n_pad, p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host, Yt));
         cp_stage_mark(ctx, "refit_finalize");
         CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
         hinfo = *info_host;
@@ -1061,7 +1542,7 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
     if (!fallback) {
         CP_TRY(normal_equations(G, Rm, true));
         if (ctx->defer_refit_wait) {  // cp_prune_layers factors and substitutes all its layers with one launch each
-            ctx->deferred = cp_refit_deferred{G, Uf, Lt, TI, TIT, dg0, gmax, Rm, dinfo, p, p_pad, nblk, n, n_pad, xmean, ymean,
+            ctx->deferred = cp_refit_deferred{G, Uf, Lt, TI, TIT, dg0, gmax, Rm, Yt, dinfo, p, p_pad, nblk, n, n_pad, xmean, ymean,
                                               W_out, b_out, W_host, b_host, info_host};
             ctx->refit_pending = true;
             info->p = p;
@@ -1072,11 +1553,17 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
         }
         CP_TRY(chol_factor(ctx, ch, PIV_TOL));
         cp_stage_mark(ctx, "refit_cholesky");
-        StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
-        CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin));  // substitutions + coefficient lay-out + intercept in one launch
-        cp_stage_mark(ctx, "refit_solve");
-        CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
-        hinfo = *info_host;                // outputs are overwritten below if a pivot failed
+        if (nblk >= solve_blocked_min_blocks()) {   // large factor: banded substitution with GEMM updates, then the lay-out kernel
+            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad));
+            cp_stage_mark(ctx, "refit_solve");
+            CP_TRY(finalize());
+        } else {
+            StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
+            CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin));  // substitutions + coefficient lay-out + intercept in one launch
+            cp_stage_mark(ctx, "refit_solve");
+            CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
+            hinfo = *info_host;                // outputs are overwritten below if a pivot failed
+        }
         if (hinfo != 0) fallback = true;
     }
     int rank = p;
@@ -1137,10 +1624,11 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
         if (!ctx0) ctx0 = c;
         const cp_refit_deferred &d = c->deferred;
         pb.j[nj] = PotrfJob{d.G, d.U, d.Lt, d.p_pad, d.nblk, d.dg0, PIV_TOL, d.TI, d.TIT, d.info};
-        sb.j[nj] = StripJob{d.U, d.Lt, d.p_pad, d.TI, d.TIT, d.nblk, d.Rm, d.n_pad,
+        const bool blocked = d.nblk >= solve_blocked_min_blocks();   // large factor: banded substitution below, not a strip job
+        sb.j[nj] = StripJob{d.U, d.Lt, d.p_pad, d.TI, d.TIT, d.nblk, d.Rm, blocked ? 0 : d.n_pad,
                             StripFinal{d.p, d.n, d.xmean, d.ymean, d.W_out, d.b_out, d.W_host, d.b_host, d.info, d.info_host}};
         max_tasks = std::max(max_tasks, d.nblk * (d.nblk + 1) / 2);
-        max_strips = std::max(max_strips, d.n_pad / 16);
+        if (!blocked) max_strips = std::max(max_strips, d.n_pad / 16);
         ++nj;
     }
     if (nj == 0) return CP_OK;
@@ -1155,7 +1643,7 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
         }
         k_potrf_batch<<<dim3(max_tasks, nj), PT, lds, ctx->stream>>>(pb);
         CP_LAUNCH_CHECK(ctx);
-    } else {
+    } else if (!chol_tasks_requested()) {
         for (int l = 0; l < n_ctx; ++l) {
             cp_ctx *c = ctxs[l];
             if (!c || !c->refit_pending) continue;
@@ -1163,10 +1651,32 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
             Chol ch{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
             CP_TRY(chol_factor(c, ch, PIV_TOL));
         }
+    } else {   // every factorisation of the batch in ONE launch (grid.y = job)
+        Chol chs[CP_REFIT_MAX_BATCH];
+        int cnt = 0;
+        for (int l = 0; l < n_ctx; ++l) {
+            cp_ctx *c = ctxs[l];
+            if (!c || !c->refit_pending) continue;
+            const cp_refit_deferred &d = c->deferred;
+            chs[cnt++] = Chol{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
+        }
+        CP_TRY(chol_factor_tasks(ctx, chs, cnt, PIV_TOL));
     }
     // the substitutions of every layer of the batch: one launch (no workgroup waits for another one)
-    k_solve_strips_batch<<<dim3(max_strips, nj), 512, 0, ctx->stream>>>(sb);
-    CP_LAUNCH_CHECK(ctx);
+    if (max_strips > 0) {
+        k_solve_strips_batch<<<dim3(max_strips, nj), 512, 0, ctx->stream>>>(sb);
+        CP_LAUNCH_CHECK(ctx);
+    }
+    for (int l = 0; l < n_ctx; ++l) {   // large factors: banded substitution with GEMM updates + the lay-out kernel, layer by layer
+        cp_ctx *c = ctxs[l];
+        if (!c || !c->refit_pending) continue;
+        const cp_refit_deferred &d = c->deferred;
+        if (d.nblk < solve_blocked_min_blocks()) continue;
+        Chol ch{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
+        CP_TRY(chol_solve_blocked(c, ch, d.Rm, d.n_pad));
+        CP_TRY(finalize_launch(c, d.Rm, d.n_pad, d.p, d.n, d.xmean, d.ymean, d.W_out, d.b_out, d.W_host, d.b_host, d.info,
+                               d.info_host, d.part));
+    }
     return CP_OK;
 }
 
@@ -1196,6 +1706,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
                          cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE));
+    ws = std::max(ws, chol_solve_blocked_workspace(ctx, p_pad, n_pad));
     const size_t need = xs_b + yc_b + 4 * g_b + 4 * r_b + 2 * ti_b + part_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 +
                         size_t(kept) * 4 + size_t(chol_info_count(nblk)) * 4 + ws + (1 << 16);
     CP_TRY(cp_arena_reserve(ctx, need));
