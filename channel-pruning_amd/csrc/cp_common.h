@@ -57,6 +57,7 @@ struct cp_ctx {
     bool defer_refit_wait = false;    // cp_prune_layers: enqueue the refit, the caller waits once for the whole batch
     bool refit_pending = false;       // set by a deferred refit: factor + solve still to be launched by the batch
     cp_refit_deferred deferred = {};
+    int itq_sweeps = 0;               // Jacobi sweeps of the last cp_itq_iterate (all alternations)
     bool potrf_lds_opt_in = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
 
@@ -158,3 +159,5 @@ struct SvdScratch {
 
 int cp_svd_rows_impl(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
                      double *SH, int ldsh, SvdScratch &sc, int *sweeps_out);
+int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
+                     double *SH, int ldsh, SvdScratch &sc, int *sweeps_out, bool preinit, double rel_floor);

@@ -1307,6 +1307,8 @@ __global__ void __launch_bounds__(RT) k_scale_rows(double *__restrict__ M, int l
 
 }  // namespace
 
+extern "C" int cp_debug_itq_sweeps(cp_ctx *ctx) { return ctx ? ctx->itq_sweeps : -1; }
+
 extern "C" int cp_debug_potrf_reset(cp_ctx *ctx) {
     if (!ctx) return CP_ERR_ARG;
     CP_HIP(ctx, cp_stream_wait(ctx));
@@ -2041,61 +2043,88 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
     size_t ws = cp_gemm_tn_workspace(ctx, np_, np_, int(Nr), CP_TRI_NONE);
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, int(Nr), np_, np_, CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, np_, int(Nr), np_, CP_TRI_NONE));
-    ws = std::max(ws, cp_gemm_tn_workspace(ctx, int(Nr), np_, rp, CP_TRI_NONE));
-    const size_t need = (8 * big + 6 * sq + size_t(rp) * (np_ + size_t(Nr)) + size_t(RB) * np_ + 4 * size_t(np_) + 2 * size_t(n) * n) * 8 +
-                        SvdScratch::bytes(n, int(Nr)) + ws + (1 << 18);
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, np_, np_, np_, CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, np_, np_, rp, CP_TRI_NONE));
+    const size_t need = (7 * big + 16 * sq + size_t(rp) * np_ + size_t(RB) * np_ + 4 * size_t(np_) + 2 * size_t(n) * n) * 8 +
+                        SvdScratch::bytes(n, np_) + ws + (1 << 18);
     CP_TRY(cp_arena_reserve(ctx, need));
     double *G = cp_arena_take_t<double>(ctx, big), *GT = cp_arena_take_t<double>(ctx, big);
     double *P1 = cp_arena_take_t<double>(ctx, big), *UU = cp_arena_take_t<double>(ctx, big);
     double *Ub = cp_arena_take_t<double>(ctx, big), *Zb = cp_arena_take_t<double>(ctx, big);
-    double *XT = cp_arena_take_t<double>(ctx, big), *Tn = cp_arena_take_t<double>(ctx, big);  // XT [np_, Nr]; Tn / RU [Nr, np_]
-    double *PG = cp_arena_take_t<double>(ctx, sq), *PGi = cp_arena_take_t<double>(ctx, sq);
-    double *M1 = cp_arena_take_t<double>(ctx, sq), *T2 = cp_arena_take_t<double>(ctx, sq);
+    double *Tn = cp_arena_take_t<double>(ctx, big);                                  // RU [Nr, np_]
+    double *GtG = cp_arena_take_t<double>(ctx, sq), *PGi = cp_arena_take_t<double>(ctx, sq);
+    double *PiT = cp_arena_take_t<double>(ctx, sq), *T2 = cp_arena_take_t<double>(ctx, sq);
     double *FA = cp_arena_take_t<double>(ctx, sq), *FB = cp_arena_take_t<double>(ctx, sq);
-    double *Vtp = cp_arena_take_t<double>(ctx, size_t(rp) * np_), *SHp = cp_arena_take_t<double>(ctx, size_t(rp) * Nr);
+    double *BT = cp_arena_take_t<double>(ctx, sq), *Bm = cp_arena_take_t<double>(ctx, sq);
+    double *C1 = cp_arena_take_t<double>(ctx, sq), *Mx = cp_arena_take_t<double>(ctx, sq);
+    double *Pr = cp_arena_take_t<double>(ctx, sq), *BP = cp_arena_take_t<double>(ctx, sq);
+    double *Rp = cp_arena_take_t<double>(ctx, sq), *RpT = cp_arena_take_t<double>(ctx, sq), *Wp = cp_arena_take_t<double>(ctx, sq);
+    double *Vtp = cp_arena_take_t<double>(ctx, size_t(rp) * np_);
     double *part = cp_arena_take_t<double>(ctx, size_t(RB) * np_);
     double *ymean = cp_arena_take_t<double>(ctx, np_), *umean = cp_arena_take_t<double>(ctx, np_);
     double *sigma = cp_arena_take_t<double>(ctx, np_), *Vt = cp_arena_take_t<double>(ctx, size_t(n) * n);
-    double *SHsq = cp_arena_take_t<double>(ctx, size_t(n) * n);
+    double *SHsq = cp_arena_take_t<double>(ctx, size_t(n) * np_);
     SvdScratch sc;
-    if (!G || !GT || !P1 || !UU || !Ub || !Zb || !XT || !Tn || !PG || !PGi || !M1 || !T2 || !FA || !FB || !Vtp || !SHp ||
-        !part || !ymean || !umean || !sigma || !Vt || !SHsq || !sc.take(ctx, n, int(Nr)))
+    if (!G || !GT || !P1 || !UU || !Ub || !Zb || !Tn || !GtG || !PGi || !PiT || !T2 || !FA || !FB || !BT || !Bm || !C1 || !Mx ||
+        !Pr || !BP || !Rp || !RpT || !Wp || !Vtp || !part || !ymean || !umean || !sigma || !Vt || !SHsq || !sc.take(ctx, n, np_))
         return cp_set_error(ctx, CP_ERR_NOMEM, "itq: arena");
     cp_stage_begin(ctx);
     const int gy = (n + RT - 1) / RT;
-    // G = Y - Y_mean, Z = relu(gt); G^T; PG = pinv(G^T G); P1 = G PG (= PGGt^T)
+    const int me = n + (n & 1);
+    // G = Y - Y_mean, Z = relu(gt); G^T; GtG = G^T G; PGi = pinv(GtG); P1 = G PGi (= PGGt^T); PiT = GtG PGi
     k_colsum_plain<<<dim3(gy, RB), RT, 0, ctx->stream>>>(feature, N, n, np_, rows_per_block, part);
     CP_LAUNCH_CHECK(ctx);
     k_itq_init<<<unsigned(Nr), RT, 0, ctx->stream>>>(feature, gt_feature, part, RB, N, n, np_, 1.0 / double(N), ymean, G, Zb);
     CP_LAUNCH_CHECK(ctx);
     k_transpose_2d<<<dim3(unsigned(Nr / 32), np_ / 32), RT, 0, ctx->stream>>>(G, np_, GT, int(Nr));
     CP_LAUNCH_CHECK(ctx);
-    CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, G, np_, G, np_, 0.0, PG, np_, CP_TRI_NONE));
+    CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, G, np_, G, np_, 0.0, GtG, np_, CP_TRI_NONE));
     int sweeps = 0;
-    CP_TRY(cp_svd_rows_impl(ctx, PG, np_, n, n, n, sigma, Vt, n, SHsq, n, sc, &sweeps));
+    CP_TRY(cp_svd_rows_impl(ctx, GtG, np_, n, n, n, sigma, Vt, n, SHsq, n, sc, &sweeps));
     CP_HIP(ctx, hipMemsetAsync(FA, 0, sq * 8, ctx->stream));
     CP_HIP(ctx, hipMemsetAsync(FB, 0, sq * 8, ctx->stream));
     k_pinv_factors<<<kp, RT, 0, ctx->stream>>>(sigma, Vt, n, np_, pinv_cond, FA, FB);
     CP_LAUNCH_CHECK(ctx);
     CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, kp, 1.0, FA, np_, FB, np_, 0.0, PGi, np_, CP_TRI_NONE));
     CP_TRY(cp_gemm_tn_f64(ctx, int(Nr), np_, np_, 1.0, GT, int(Nr), PGi, np_, 0.0, P1, np_, CP_TRI_NONE));
+    CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, GtG, np_, PGi, np_, 0.0, PiT, np_, CP_TRI_NONE));
     // UU = G, U_mean = Y_mean
     CP_HIP(ctx, hipMemcpyAsync(UU, G, big * 8, hipMemcpyDeviceToDevice, ctx->stream));
     CP_HIP(ctx, hipMemcpyAsync(umean, ymean, size_t(np_) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    CP_HIP(ctx, hipMemsetAsync(SHp, 0, size_t(rp) * Nr * 8, ctx->stream));
     cp_stage_mark(ctx, "itq_setup");
+    // The reference takes the rank-truncated SVD of X = G (PGGt UU) [N, n] (decompose.py:218-220): T_X = L_r S_r R_r =
+    // X V_r V_r^T with V_r the leading right singular vectors = leading eigenvectors of X^T X = B^T (G^T G) B, B = PGGt UU
+    // [n, n].  Everything the iteration needs from it is n x n:  T = PGGt T_X = (PGi GtG) B V_r V_r^T, so the 5000-row
+    // Jacobi SVD per alternation (2.5 s per conv3 layer) becomes an n x n symmetric eigenproblem, warm-started from the
+    // previous alternation's rotation (the iterate moves little: 2-3 sweeps instead of 8-10).  Two N-sized products per
+    // alternation are left: B^T = UU^T P1 and RU = G T.
+    bool warm = false;
+    int total_sweeps = 0;
     for (int st = 0; st < n_stage; ++st)
         for (int it = 0; it < iters[st]; ++it) {
-            // X = G (PGGt UU), kept as X^T [n, Nr]
-            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, P1, np_, UU, np_, 0.0, M1, np_, CP_TRI_NONE));
-            CP_TRY(cp_gemm_tn_f64(ctx, np_, int(Nr), np_, 1.0, M1, np_, GT, int(Nr), 0.0, XT, int(Nr), CP_TRI_NONE));
-            // L, sigma, R = svd(X); T = L_r diag(sigma_r) R_r  (rows of X^T: Vt = R_r, SH = sigma_r L_r^T)
-            CP_TRY(cp_svd_rows_impl(ctx, XT, int(Nr), n, int(Nr), rank, sigma, Vt, n, SHp, int(Nr), sc, &sweeps));
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, UU, np_, P1, np_, 0.0, BT, np_, CP_TRI_NONE));      // B^T
+            k_transpose_2d<<<dim3(np_ / 32, np_ / 32), RT, 0, ctx->stream>>>(BT, np_, Bm, np_);                      // B
+            CP_LAUNCH_CHECK(ctx);
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, GtG, np_, Bm, np_, 0.0, C1, np_, CP_TRI_NONE));          // GtG B
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, Bm, np_, C1, np_, 0.0, Mx, np_, CP_TRI_NONE));           // B^T GtG B
+            if (warm) {   // Wk = R_prev Mx, R = R_prev
+                k_pad_rows<<<np_, RT, 0, ctx->stream>>>(sc.R, me, me, me, Rp, np_);
+                CP_LAUNCH_CHECK(ctx);
+                k_transpose_2d<<<dim3(np_ / 32, np_ / 32), RT, 0, ctx->stream>>>(Rp, np_, RpT, np_);
+                CP_LAUNCH_CHECK(ctx);
+                CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, RpT, np_, Mx, np_, 0.0, Wp, np_, CP_TRI_NONE));
+                CP_HIP(ctx, hipMemcpy2DAsync(sc.Wk, size_t(np_) * 8, Wp, size_t(np_) * 8, size_t(np_) * 8, size_t(me),
+                                             hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            CP_TRY(cp_svd_rows_core(ctx, Mx, np_, n, np_, rank, sigma, Vt, n, SHsq, np_, sc, &sweeps, warm, 1e-13));
+            warm = getenv("CP_ITQ_COLD") == nullptr;
+            total_sweeps += sweeps;
             k_pad_rows<<<rp, RT, 0, ctx->stream>>>(Vt, rank, n, n, Vtp, np_);
             CP_LAUNCH_CHECK(ctx);
-            CP_TRY(cp_gemm_tn_f64(ctx, int(Nr), np_, rp, 1.0, SHp, int(Nr), Vtp, np_, 0.0, Tn, np_, CP_TRI_NONE));
-            // T = PGGt T (n x n); RU = G T + U_mean; U = solve_relu(RU, Z, lambda); U_mean = mean(U); UU = U - U_mean
-            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, P1, np_, Tn, np_, 0.0, T2, np_, CP_TRI_NONE));
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, rp, 1.0, Vtp, np_, Vtp, np_, 0.0, Pr, np_, CP_TRI_NONE));           // V_r V_r^T
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, BT, np_, Pr, np_, 0.0, BP, np_, CP_TRI_NONE));            // B P_r
+            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, PiT, np_, BP, np_, 0.0, T2, np_, CP_TRI_NONE));           // T
+            // RU = G T + U_mean; U = solve_relu(RU, Z, lambda); U_mean = mean(U); UU = U - U_mean
             CP_TRY(cp_gemm_tn_f64(ctx, int(Nr), np_, np_, 1.0, GT, int(Nr), T2, np_, 0.0, Tn, np_, CP_TRI_NONE));
             k_solve_relu<<<unsigned(Nr), RT, 0, ctx->stream>>>(Tn, umean, Zb, lambdas[st], N, n, np_, Ub);
             CP_LAUNCH_CHECK(ctx);
@@ -2104,6 +2133,7 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
             k_center_u<<<unsigned(Nr), RT, 0, ctx->stream>>>(Ub, part, RB, N, n, np_, 1.0 / double(N), umean, UU);
             CP_LAUNCH_CHECK(ctx);
         }
+    ctx->itq_sweeps = total_sweeps;
     cp_stage_mark(ctx, "itq_iterations");
     CP_HIP(ctx, hipMemcpy2DAsync(T_out, size_t(n) * 8, T2, size_t(np_) * 8, size_t(n) * 8, size_t(n), hipMemcpyDeviceToDevice,
                                  ctx->stream));

@@ -39,8 +39,12 @@ __device__ __forceinline__ void round_pair(int m, int r, int k, int &i, int &j) 
     }
 }
 
+// floor2: rows whose squared norm is below floor2[0] count as converged (0 / null: off).  For the leading invariant subspace
+// of a symmetric matrix whose spectrum decays to rounding level, pairs involving such a row only shuffle noise: they kept
+// the sweep count at 15 where 6 suffice (cp_itq_iterate).
 __global__ void __launch_bounds__(JT) k_jacobi_round(double *__restrict__ Wk, int n, double *__restrict__ R, int m,
-                                                     int round, double tol, int *__restrict__ rotated) {
+                                                     int round, double tol, int *__restrict__ rotated,
+                                                     const double *__restrict__ floor2) {
     __shared__ double red[4];
     __shared__ double cs[2];
     int i, j;
@@ -56,7 +60,8 @@ __global__ void __launch_bounds__(JT) k_jacobi_round(double *__restrict__ Wk, in
     const double alpha = jblock_sum(saa, red), beta = jblock_sum(sbb, red), gamma = jblock_sum(sab, red);
     if (threadIdx.x == 0) {
         double c = 1.0, s = 0.0;
-        if (fabs(gamma) > tol * sqrt(alpha * beta) && gamma != 0.0) {
+        const double fl = floor2 ? floor2[0] : 0.0;
+        if (fabs(gamma) > tol * sqrt(alpha * beta) && gamma != 0.0 && alpha > fl && beta > fl) {
             const double zeta = (beta - alpha) / (2.0 * gamma);
             const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
             c = 1.0 / sqrt(1.0 + t * t);
@@ -79,6 +84,21 @@ __global__ void __launch_bounds__(JT) k_jacobi_round(double *__restrict__ Wk, in
         const double x = ra[col], y = rb[col];
         ra[col] = c * x - s * y;
         rb[col] = s * x + c * y;
+    }
+}
+
+// out[0] = rel^2 * max_i sig[i]^2 (sig = row norms)
+__global__ void __launch_bounds__(JT) k_norm_floor(const double *__restrict__ sig, int m, double rel, double *__restrict__ out) {
+    __shared__ double red[4];
+    double v = 0;
+    for (int i = threadIdx.x; i < m; i += JT) v = fmax(v, sig[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        out[0] = rel * rel * mx * mx;
     }
 }
 
@@ -109,21 +129,40 @@ __global__ void __launch_bounds__(JT) k_row_norms(const double *__restrict__ Wk,
 // stride ldsh); scratch from the caller (the arena is NOT re-reserved here).
 int cp_svd_rows_impl(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
                      double *SH, int ldsh, SvdScratch &sc, int *sweeps_out) {
+    return cp_svd_rows_core(ctx, M, ldm, m, n, r, sigma, Vt, ldv, SH, ldsh, sc, sweeps_out, false, 0.0);
+}
+
+// preinit: sc.Wk [me, n] and sc.R [me, me] already hold a consistent pair (Wk = R M for an orthogonal R) -- a WARM
+// START, e.g. the rotation the previous, nearby matrix ended with: Jacobi converges quadratically from there
+// (2-3 sweeps instead of 8-10).  M is then not read.
+int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
+                     double *SH, int ldsh, SvdScratch &sc, int *sweeps_out, bool preinit, double rel_floor) {
     const int me = m + (m & 1);  // even number of players: an all-zero row plays along if m is odd
     double *Wk = sc.Wk, *R = sc.R, *sig = sc.sig;
     int *rotated = sc.rotated;
     CP_TRY(cp_pinned_reserve(ctx, 4096));
-    CP_HIP(ctx, hipMemsetAsync(Wk, 0, size_t(me) * n * 8, ctx->stream));
-    CP_HIP(ctx, hipMemcpy2DAsync(Wk, size_t(n) * 8, M, size_t(ldm) * 8, size_t(n) * 8, size_t(m), hipMemcpyDeviceToDevice,
-                                 ctx->stream));
-    k_identity<<<me, JT, 0, ctx->stream>>>(R, me);
-    CP_LAUNCH_CHECK(ctx);
+    if (!preinit) {
+        CP_HIP(ctx, hipMemsetAsync(Wk, 0, size_t(me) * n * 8, ctx->stream));
+        CP_HIP(ctx, hipMemcpy2DAsync(Wk, size_t(n) * 8, M, size_t(ldm) * 8, size_t(n) * 8, size_t(m), hipMemcpyDeviceToDevice,
+                                     ctx->stream));
+        k_identity<<<me, JT, 0, ctx->stream>>>(R, me);
+        CP_LAUNCH_CHECK(ctx);
+    }
+    const double *floor2 = nullptr;   // rel_floor > 0: rows below rel_floor * (largest row norm) are left alone
+    if (rel_floor > 0.0) {
+        k_row_norms<<<me, JT, 0, ctx->stream>>>(Wk, n, sig);
+        CP_LAUNCH_CHECK(ctx);
+        double *fl = reinterpret_cast<double *>(rotated + 4);   // 16-int scratch: [0] counter, [4..5] the floor
+        k_norm_floor<<<1, JT, 0, ctx->stream>>>(sig, me, rel_floor, fl);
+        CP_LAUNCH_CHECK(ctx);
+        floor2 = fl;
+    }
     int sweeps = 0;
     const double tol = std::max(1e-14, 4e-16 * std::sqrt(double(n)));  // |a.b| <= tol |a||b|: rows orthogonal to rounding
     for (; sweeps < 40; ++sweeps) {
         CP_HIP(ctx, hipMemsetAsync(rotated, 0, sizeof(int), ctx->stream));
         for (int round = 0; round < me - 1; ++round) {
-            k_jacobi_round<<<me / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated);
+            k_jacobi_round<<<me / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2);
             CP_LAUNCH_CHECK(ctx);
         }
         CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, rotated, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

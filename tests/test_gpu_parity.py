@@ -600,6 +600,32 @@ def test_itq_decompose_matches_reference_golden(ctx):
     assert relfro(Wo2 * sgn[None, :, None, None], g["W2"]) <= REL_W
 
 
+def test_vh_and_itq_decompose_match_reference_goldens_at_conv3_size(ctx):
+    """f1 / f2 at the size the 3C loop runs them on (256 x 256 x 3 x 3, N = 5000, rank 110 = the reference's conv3_1 entry):
+    the UNMODIFIED reference's outputs (oracle/gen_golden_vh.py: v03, i02; float32 storage)."""
+    import cp_oracle
+    import lib.decompose as D
+    g = np.load(os.path.join(GOLDEN_DIR, "v03_vh_refit_conv3.npz"))
+    p = json.loads(str(g["params"]))
+    X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+    V, H, VHr, b = D.VH_decompose(W2.astype(np.float64), rank=p["rank"], X=X.astype(np.float64), Y=Y)
+    assert V.shape == g["V"].shape and H.shape == g["H"].shape and VHr.shape == g["VHr"].shape
+    V, H = _align_signs(V, H, g["V"])
+    assert relfro(VHr, g["VHr"]) <= REL_W and relfro(b, g["b"]) <= REL_W
+    assert relfro(V, g["V"]) <= 1e-6 and relfro(H, g["H"]) <= REL_W
+    g = np.load(os.path.join(GOLDEN_DIR, "i02_itq_conv3.npz"))
+    p = json.loads(str(g["params"]))
+    X, W2, Y, B2 = cp_oracle.synth_layer(p["layer_id"], p["N"], p["c"], p["n"], p["k"])
+    feature = Y + p["noise"] * np.random.RandomState(p["layer_id"]).randn(*Y.shape)
+    W1, Wo2, B, W12 = D.ITQ_decompose(feature, Y, W2.astype(np.float64), p["rank"], bias=B2.astype(np.float64))
+    assert W1.shape == g["W1"].shape and Wo2.shape == g["W2"].shape and W12.shape == g["W12"].shape
+    assert relfro(W12, g["W12"]) <= REL_W and relfro(B, g["B"]) <= REL_W
+    sgn = np.sign(np.sum(W1.reshape(W1.shape[0], -1) * g["W1"].reshape(W1.shape[0], -1), axis=1))
+    sgn[sgn == 0] = 1.0
+    assert relfro(W1 * sgn[:, None, None, None], g["W1"]) <= REL_W
+    assert relfro(Wo2 * sgn[None, :, None, None], g["W2"]) <= REL_W
+
+
 # ---------------------------------------------------------------------------------------------
 # cp_prune_layers: several layers of one width on ONE stream, their alpha searches in one launch
 # ---------------------------------------------------------------------------------------------
