@@ -109,6 +109,21 @@ enum { CP_GEMM_GENERIC = 0, CP_GEMM_LASSO_GRAM = 1, CP_GEMM_REFIT_GRAM = 2, CP_G
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda,
                    const double *B, int ldb, double beta, double *C, int ldc, int tri);
 size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri);
+// an operand given as a centred VIEW of the caller's array instead of a staged k-major f64 matrix:
+//   element (k, col) = (double) base[k * ld + (chan ? chan[col / kk] * kk + col % kk : col)] - mean[col],  0 outside nrows x ncols
+struct cp_gemm_src {
+    const void *base = nullptr;
+    int is_f32 = 0;
+    int64_t ld = 0;            // elements between consecutive rows of base
+    const int *chan = nullptr; // DEVICE kept-channel list (null: columns are taken as they are)
+    int kk = 1;
+    const double *mean = nullptr;  // DEVICE [ncols]
+    int ncols = 0;
+    int64_t nrows = 0;
+};
+bool cp_gemm_tn_src_supported(const cp_ctx *ctx, int M, int N, int K, int tri);   // false: stage the operand and use cp_gemm_tn_f64
+int cp_gemm_tn_f64_src(cp_ctx *ctx, int M, int N, int K, double alpha, const cp_gemm_src &A, const cp_gemm_src &B, double beta,
+                       double *C, int ldc, int tri);
 // two products of the same shape (different operands / K), one launch when neither needs split-K
 int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const double *A1, const double *B1, double *C1,
                         int K2, const double *A2, const double *B2, double *C2, int lda, int ldb, int ldc, int tri);

@@ -216,7 +216,7 @@ void cp_stage_begin(cp_ctx *ctx) {
 void cp_stage_mark(cp_ctx *ctx, const char *name) {
     if (!ctx->timing || ctx->n_marks >= 2 * CP_MAX_STAGES) return;
     // mode 2: only the two events that bracket the roofline kernel (every event is a packet in the stream)
-    if (ctx->timing_gram_only && strcmp(name, "refit_gather_center") != 0 && strcmp(name, "refit_gram_gemm") != 0) return;
+    if (ctx->timing_gram_only && strcmp(name, "refit_gram_begin") != 0 && strcmp(name, "refit_gram_gemm") != 0) return;
     ctx->mark_names[ctx->n_marks] = name;
     hipEventRecord(ctx->ev[ctx->n_marks], ctx->stream);
     ++ctx->n_marks;

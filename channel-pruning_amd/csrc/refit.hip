@@ -1757,6 +1757,12 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
                                                           xmean, ymean);
         CP_LAUNCH_CHECK(ctx);
         cp_stage_mark(ctx, "refit_means");
+    }
+    // The centred rows are only materialised (k_gather_center_xy: N_pad x p_pad float64) when the rank-revealing path needs
+    // them; the normal equations read X / Y in place through centred views (cp_gemm_tn_f64_src).
+    bool staged = false;
+    auto stage_rows = [&]() -> int {
+        if (staged) return CP_OK;
         if (x_dtype == CP_F32)
             k_gather_center_xy<float><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
                 static_cast<const float *>(X), Y, N, c, kk, n, dchan, p, p_pad, n_pad, xmean, ymean, Xs, Yc);
@@ -1764,18 +1770,41 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
             k_gather_center_xy<double><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
                 static_cast<const double *>(X), Y, N, c, kk, n, dchan, p, p_pad, n_pad, xmean, ymean, Xs, Yc);
         CP_LAUNCH_CHECK(ctx);
-        cp_stage_mark(ctx, "refit_gather_center");
-    }
+        staged = true;
+        return CP_OK;
+    };
+    // CP_REFIT_VIEWS=1: no staging copy, the GEMM loader gathers / converts / centres X itself.  Bit-identical results and
+    // 174 MB less HBM traffic per c = 512 layer, but every operand element is then gathered and converted once per tile that
+    // uses it (34x at p = 4250) with 4-byte scalar loads instead of 16-byte ones: the Gram went 2.20 -> 3.77 ms (c = 512),
+    // 0.50 -> 0.79 ms (c = 256) and the vgg16 job 34.6 -> 42.4 ms, so the 0.09 ms staging pass stays the default.
+    static const bool views_wanted = getenv("CP_REFIT_VIEWS") && getenv("CP_REFIT_VIEWS")[0] == '1';
+    const bool use_views = views_wanted && cp_gemm_tn_src_supported(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR) &&
+                           cp_gemm_tn_src_supported(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE);
+    cp_gemm_src vx, vy;
+    vx.base = X; vx.is_f32 = x_dtype == CP_F32; vx.ld = int64_t(c) * kk; vx.chan = dchan; vx.kk = kk; vx.mean = xmean;
+    vx.ncols = p; vx.nrows = N;
+    vy.base = Y; vy.is_f32 = 0; vy.ld = n; vy.chan = nullptr; vy.kk = 1; vy.mean = ymean; vy.ncols = n; vy.nrows = N;
     // Gram and right-hand side into (Gd, Rd), diagonal prepared (ridge, unit pad diagonal, dg0, gmax, info = 0)
     auto normal_equations = [&](double *Gd, double *Rd, bool mark) -> int {
+        if (!use_views || !mark) {   // the fallback paths work on the rows themselves
+            CP_TRY(stage_rows());
+            if (mark) cp_stage_mark(ctx, "refit_gather_center");
+        }
+        if (mark) cp_stage_mark(ctx, "refit_gram_begin");   // opens the bracket of the roofline kernel (timing mode 2)
         ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
         ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
-        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad,
-                              CP_TRI_LOWER_MIRROR));
+        if (use_views && mark)
+            CP_TRY(cp_gemm_tn_f64_src(ctx, p_pad, p_pad, int(N_pad), 1.0, vx, vx, 0.0, Gd, p_pad, CP_TRI_LOWER_MIRROR));
+        else
+            CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad,
+                                  CP_TRI_LOWER_MIRROR));
         if (mark) cp_stage_mark(ctx, "refit_gram_reduce");
         ctx->gemm_tag = CP_GEMM_REFIT_XTY;
         ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
-        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
+        if (use_views && mark)
+            CP_TRY(cp_gemm_tn_f64_src(ctx, p_pad, n_pad, int(N_pad), 1.0, vx, vy, 0.0, Rd, n_pad, CP_TRI_NONE));
+        else
+            CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
         if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
         k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
