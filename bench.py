@@ -16,7 +16,7 @@ weights, bias) back on the host inside it:
     value = 12 * jobs / elapsed = layers/s of a single job instance, job_ms = its wall-clock.
 
 --workload block (BASELINE.json configs[1]: the VGG-16 conv3_x block, rank = c/2)
-    single_instance: the three layers of ONE block instance, one after another with nothing else on the chip;
+    single_instance: the three layers of ONE block instance side by side, nothing else on the chip;
     value: replica throughput -- many independent copies of the block in flight (--inflight groups x --batch copies),
     the regime of a job with hundreds of equal layers; the line says how many really ran.
 
@@ -312,9 +312,9 @@ def bench_vgg16(args, env):
 
     # ---- outside the timed region: every layer of this rank ALONE (latency, per-stage times, roofline kernel alone) ----
     per_layer = {}
-    alone_g_ms, alone_g_fl = [], []
+    alone_g_ms, alone_g_fl, alone_g_ex = [], [], []
     stage_by_c = {}
-    for j, pr in probs.items():
+    for j, pr in ([] if args.profile_mode else probs.items()):
         spec = specs[own[j]]
         pr.ctx.enable_stage_timing(1)
         ch = [c_ for c_ in rset.chunks if j in c_["members"]][0]
@@ -335,10 +335,13 @@ def bench_vgg16(args, env):
         if "refit_gram_gemm" in st:
             alone_g_ms.append(st["refit_gram_gemm"])
             alone_g_fl.append(float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
+            # latency mode: the launch computed the Gram of ALL c channels during the alpha search (CP_REFIT_PRECOMPUTE)
+            alone_g_ex.append(float(N_SAMPLES) * (spec["c"] * 9) ** 2 if "refit_gather_normal_eq" in st
+                              else float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
 
     # ---- PCIe-inclusive: upload of a layer's operands from pageable host memory + its pruning, layer after layer ----
     pcie = None
-    if env.world == 1:
+    if env.world == 1 and not args.profile_mode:
         from cpmi355.pruner import LayerProblem
         ctx0 = roots[0]
         t1 = time.perf_counter()
@@ -381,7 +384,11 @@ def bench_vgg16(args, env):
         if roof is not None and alone_g_ms:
             a1 = sum(alone_g_fl) / (sum(alone_g_ms) * 1e-3) / 1e12
             roof["alone"] = {"achieved": round(a1, 3), "frac": round(a1 / F64_MFMA_PEAK_TFLOPS, 4),
-                             "avg_launch_ms": round(sum(alone_g_ms) / len(alone_g_ms), 4)}
+                             "avg_launch_ms": round(sum(alone_g_ms) / len(alone_g_ms), 4),
+                             "executed_tflops": round(sum(alone_g_ex) / (sum(alone_g_ms) * 1e-3) / 1e12, 3),
+                             "note": "one layer at a time = latency mode: the launch computes the Gram of ALL c channels on the "
+                                     "side stream during the alpha search (executed N (9c)^2); achieved counts only the "
+                                     "algorithmic N p^2 of the kept channels"}
         out = {
             "metric": "conv layers pruned/sec (VGG-16 4x, 5k samples)",
             "value": round(layers_per_s, 3), "unit": "layers/s", "n_gpus": env.world, "steps": args.steps,
@@ -412,7 +419,7 @@ def bench_vgg16(args, env):
             "pcie_inclusive": pcie,
             "upload_and_setup_s": round(t0 - t_up0, 2),
         }
-        if env.world == 1 and not args.no_cpu_baseline:
+        if env.world == 1 and not args.no_cpu_baseline and not args.profile_mode:
             sample = specs if args.cpu_full else [s for s in specs if s["c"] <= 256]
             secs = cpu_port_seconds([(s["layer_id"], s["c"], s["n"], s["rank"]) for s in sample])
             gpu_ms_same = sum(per_layer[s["name"]]["ms_alone"] for s in sample)
@@ -475,7 +482,8 @@ class LayerWorker(threading.Thread):
         self.calls += 1
         self.layers_done += count
         if count == 1:
-            return [self.cpmi355.prune_layer(self.prob, self.rank, 1e-3, rank_tol=.1, rng=rngs[0], mode="device")]
+            return [self.cpmi355.prune_layer(self.prob, self.rank, 1e-3, rank_tol=.1, rng=rngs[0], mode="device",
+                                             latency_mode=self.single)]
         return self.cpmi355.prune_layers_batched(self.probs[:count], [self.rank] * count, [1e-3] * count, rngs, rank_tol=.1)
 
     def run(self):
@@ -529,8 +537,8 @@ def run_passes(groups, passes):
 
 
 def block_single_instance(device, passes=5):
-    """ONE instance of the conv3_x block: its three layers one after another (cp_prune_layer), nothing else on the
-    chip.  -> dict (ms per pass, layers/s, per-stage ms, fits, CD steps)"""
+    """ONE instance of the conv3_x block: its three (independent) layers side by side on three streams through
+    cp_prune_layer, nothing else on the chip.  -> dict (ms per pass, layers/s, per-stage ms, fits, CD steps)"""
     group = [LayerWorker(device, lid, c, n, r, batch=1) for lid, c, n, r in BLOCK_LAYERS]
     for w in group:
         w.start()
@@ -541,11 +549,12 @@ def block_single_instance(device, passes=5):
         ts = []
         for i in range(passes + 1):
             t1 = time.perf_counter()
-            for w in group:                      # strictly one layer at a time
+            for w in group:                      # the three layers of ONE block instance, concurrently (own streams)
                 w.collect = i > 0
                 w.todo = 1
                 w.done.clear()
                 w.go.set()
+            for w in group:
                 w.done.wait()
                 if w.error is not None:
                     raise w.error
@@ -701,6 +710,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="vgg16: time the CPU port on all 12 layers (about 2-3 min)")
     ap.add_argument("--no-block", action="store_true", help="vgg16: skip the conv3_x single-instance figures")
+    ap.add_argument("--profile-mode", action="store_true",
+                    help="vgg16: only whole jobs (1 + warmup + steps x jobs_per_step of them), nothing else on the GPU: for rocprofv3")
     ap.add_argument("--per-stream", type=int, default=int(os.environ.get("CP_BENCH_PER_STREAM", "1")),
                     help="vgg16: equal-width layers per stream / cp_prune_layers call")
     ap.add_argument("--jobs-per-step", type=int, default=0, help="vgg16: fixed jobs per step (0 = fill >= 2 s)")
@@ -712,7 +723,7 @@ def main():
     env = Env()
     if args.workload == "vgg16":
         out = bench_vgg16(args, env)
-        if out is not None and not args.no_block and env.world == 1:
+        if out is not None and not args.no_block and not args.profile_mode and env.world == 1:
             single, group = block_single_instance(env.local_rank)
             close_workers(group)
             out["conv3_block_single_instance"] = single

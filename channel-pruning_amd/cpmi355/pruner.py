@@ -21,6 +21,20 @@ RAND_R_MAX = 2147483647  # sklearn/linear_model/_cd_fast.pyx:26
 MAX_FITS = 64
 
 
+def precompute_flag(latency_mode):
+    """CP_REFIT_PRECOMPUTE: the normal equations over ALL c channels are computed on the device's side stream WHILE the
+    (single-workgroup) alpha search runs; the refit then gathers the kept rows / columns and goes straight to the
+    factorisation.  It costs (c / kept)^2 times the flops of the masked Gram, which is free when ONE layer has the chip
+    to itself (the drop-in dictionary(): measured 18.8 -> 16.5 ms for a c = 512 layer) and a loss when many layers
+    already fill it (the vgg16 job: 34.9 -> 37.2 ms) -- so: on for single-layer calls, off for batches / resident sets.
+    CP_REFIT_PRECOMPUTE=0 / 1 in the environment forces it."""
+    import os
+    force = os.environ.get("CP_REFIT_PRECOMPUTE", "")
+    if force in ("0", "1"):
+        return capi.CP_REFIT_PRECOMPUTE if force == "1" else 0
+    return capi.CP_REFIT_PRECOMPUTE if latency_mode else 0
+
+
 # ---- RNG bookkeeping on the host (it sits under the interpreter lock of every worker thread, so it has to be cheap) ----
 _MT_STATE_BYTES = 624 * 4 + 4    # numpy's mt19937_state: uint32 key[624]; int pos
 
@@ -165,7 +179,7 @@ class LayerProblem:
         return lbound, rbound
 
     # -- the whole call in one foreign call (cp_prune_layer) ------------------------------
-    def prune_fused(self, rank, alpha_right0, rank_tol, rng, samples, ridge=0.0):
+    def prune_fused(self, rank, alpha_right0, rank_tol, rng, samples, ridge=0.0, latency_mode=True):
         """-> (idxs, W[n,p], b, alpha) or None when the device search did not settle within MAX_FITS
         (the RNG is then back where it was before the seeds were drawn)."""
         lbound, rbound = self.rank_bounds(rank, rank_tol)
@@ -174,7 +188,7 @@ class LayerProblem:
         seeds = draw_seeds(rng, MAX_FITS)
         res, idxs, W, b = self.ctx.prune_layer(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype,
                                                self.n, self.Yd, samples, alpha_right0, rank, lbound, rbound, seeds,
-                                               ridge, flags=self.flags)
+                                               ridge, flags=self.flags | precompute_flag(latency_mode))
         rng_rewind(rng, mark)
         if res.fits_used < 0:
             return None
@@ -256,10 +270,11 @@ GLOBAL_RNG = np.random  # module-level legacy RandomState: randint / get_state /
 
 
 def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="device", alpha_arg=1e-4,
-                refit="linear", W2_host=None):
+                refit="linear", W2_host=None, latency_mode=True):
     """dictionary() on a resident LayerProblem -> (idxs, newW2[n,nnz,k,k], newB2, alpha_out).
 
     refit: "linear" (fc_kernel), "nonlinear" (nonlinear_fc) or "none" (dcfgs.nofc: W2[:, idxs], zero bias).
+    latency_mode: this layer has the GPU to itself (see precompute_flag); callers that keep many layers in flight pass False.
     mode "device": the whole call is ONE foreign call (cp_prune_layer; linear refit only); "steps": the same device
     search through the individual entry points (lasso_gram / alpha search / refit); "host": one
     launch per LASSO fit, the host deciding the next alpha."""
@@ -273,7 +288,7 @@ def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="de
         prob.fits = []
     else:
         if mode == "device" and refit == "linear":
-            fused = prob.prune_fused(rank, alpha_in, rank_tol, rng, samples, ridge)
+            fused = prob.prune_fused(rank, alpha_in, rank_tol, rng, samples, ridge, latency_mode=latency_mode)
             if fused is not None:
                 idxs, W, b, alpha = fused
                 return idxs, W.reshape((n, int(idxs.sum()), k, k)), b, alpha
@@ -308,7 +323,8 @@ def prune_layers_batched(probs, ranks, alpha_ins, rngs, rank_tol=.1, ridge=0.0, 
         samples_l.append(samples)
         jobs.append(dict(ctx=prob.ctx, X=prob.Xd, x_dtype=prob.x_dtype, N=prob.N, c=prob.c, kk=prob.kk, W2=prob.W2d,
                          w_dtype=prob.w_dtype, n=prob.n, Y=prob.Yd, samples=samples, alpha_right0=alpha_in, rank=rank,
-                         lbound=lbound, rbound=rbound, seeds=seeds, ridge=ridge, flags=prob.flags))
+                         lbound=lbound, rbound=rbound, seeds=seeds, ridge=ridge,
+                         flags=prob.flags | precompute_flag(False)))
     raw = capi.Context.prune_layers(jobs)
     out = []
     for i, (prob, rank, alpha_in, rng) in enumerate(zip(probs, ranks, alpha_ins, rngs)):

@@ -154,7 +154,7 @@ class ResidentLayerSet:
         if len(specs) == 1:
             s = specs[0]
             out = [prune_layer(ch["probs"][0], s["rank"], s.get("alpha_in", self.alpha_in), rank_tol=self.rank_tol,
-                               rng=ch["rngs"][0], mode="device")]
+                               rng=ch["rngs"][0], mode="device", latency_mode=len(self.chunks) <= 2)]
         else:
             out = prune_layers_batched(ch["probs"], [s["rank"] for s in specs],
                                        [s.get("alpha_in", self.alpha_in) for s in specs], ch["rngs"],

@@ -23,6 +23,23 @@ struct cp_refit_deferred {
     int *info_host;
 };
 
+// The normal equations of a layer over ALL its c channels, computed on the device's shared side stream WHILE the layer's
+// (single-workgroup, latency-bound) alpha search runs: once the mask is known the refit only gathers the kept rows /
+// columns (cp_refit_precompute_enqueue, refit.hip).
+struct cp_ctx;
+struct cp_precompute {
+    bool ready = false;            // set by enqueue, consumed (one shot) by the next matching cp_lstsq_refit_impl
+    const void *X = nullptr;
+    const double *Y = nullptr;
+    int64_t N = 0;
+    int c = 0, kk = 0, n = 0, x_dtype = 0, P = 0, P_pad = 0, n_pad = 0;
+    char *buf = nullptr;           // persistent: xmean [P_pad] | ymean [n_pad] | G [P_pad^2] | R [P_pad n_pad]
+    size_t buf_bytes = 0;
+    double *xmean = nullptr, *ymean = nullptr, *G = nullptr, *R = nullptr;
+    hipEvent_t done = nullptr;
+    cp_ctx *worker = nullptr;      // own arena, bound to the side stream
+};
+
 struct cp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -57,6 +74,8 @@ struct cp_ctx {
     bool defer_refit_wait = false;    // cp_prune_layers: enqueue the refit, the caller waits once for the whole batch
     bool refit_pending = false;       // set by a deferred refit: factor + solve still to be launched by the batch
     cp_refit_deferred deferred = {};
+    cp_precompute pre;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // hand-offs to / from the shared CU-masked stream of the long GEMMs
     int itq_sweeps = 0;               // Jacobi sweeps of the last cp_itq_iterate (all alternations)
     bool potrf_lds_opt_in = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
@@ -78,6 +97,33 @@ int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
     } while (0)
 
 #define CP_LAUNCH_CHECK(ctx) CP_HIP(ctx, hipGetLastError())
+
+// The device's shared stream for the LONG chip-filling GEMMs (refit Gram, X^T Y: workgroups that live for a millisecond),
+// created with a CU mask that leaves CP_WIDE_RESERVE CUs (default 0 = feature off, nullptr) to everybody else: a
+// one-workgroup helper or a Cholesky diagonal block of another layer otherwise waits for such a workgroup to retire.
+hipStream_t cp_wide_stream(cp_ctx *ctx);
+hipStream_t cp_side_stream(cp_ctx *ctx);   // the device's shared stream for work that overlaps a context's own chain (never null)
+int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n);
+void cp_precompute_release(cp_ctx *ctx);
+// run `body` (launches on ctx->stream) on the wide stream instead, ordered after / before the context's own stream
+template <class F>
+static inline int cp_on_wide_stream(cp_ctx *ctx, F &&body) {
+    hipStream_t wide = cp_wide_stream(ctx);
+    if (!wide) return body();
+    if (!ctx->ev_fork) {
+        if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+            return body();
+    }
+    hipStream_t own = ctx->stream;
+    if (hipEventRecord(ctx->ev_fork, own) != hipSuccess || hipStreamWaitEvent(wide, ctx->ev_fork, 0) != hipSuccess) return body();
+    ctx->stream = wide;
+    const int rc = body();
+    ctx->stream = own;
+    if (hipEventRecord(ctx->ev_join, wide) != hipSuccess || hipStreamWaitEvent(own, ctx->ev_join, 0) != hipSuccess)
+        return cp_set_error(ctx, CP_ERR_HIP, "wide stream join failed");
+    return rc;
+}
 
 // hipStreamSynchronize(ctx->stream), with the time spent blocked added to ctx->wait_ms
 hipError_t cp_stream_wait(cp_ctx *ctx);

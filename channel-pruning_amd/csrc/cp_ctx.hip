@@ -42,6 +42,43 @@ extern "C" int cp_device_count(int *count) {
     return CP_OK;
 }
 
+#include <mutex>
+hipStream_t cp_wide_stream(cp_ctx *ctx) {
+    static const int reserve = getenv("CP_WIDE_RESERVE") ? atoi(getenv("CP_WIDE_RESERVE")) : 0;
+    if (reserve <= 0 || reserve >= ctx->cu_count) return nullptr;
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    static bool tried[64] = {};
+    if (ctx->device < 0 || ctx->device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tried[ctx->device]) {
+        tried[ctx->device] = true;
+        const int words = (ctx->cu_count + 31) / 32;
+        std::vector<uint32_t> mask(words, 0xffffffffu);
+        const int stride = ctx->cu_count / reserve;     // clear every stride-th CU bit: spread over the XCDs whatever the order
+        for (int i = 0; i < reserve; ++i) {
+            const int bit = i * stride + stride - 1;
+            mask[bit / 32] &= ~(1u << (bit % 32));
+        }
+        hipStream_t st = nullptr;
+        if (hipExtStreamCreateWithCUMask(&st, uint32_t(words), mask.data()) == hipSuccess) streams[ctx->device] = st;
+    }
+    return streams[ctx->device];
+}
+
+hipStream_t cp_side_stream(cp_ctx *ctx) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    if (ctx->device < 0 || ctx->device >= 64) return ctx->stream;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[ctx->device]) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return ctx->stream;
+        streams[ctx->device] = st;
+    }
+    return streams[ctx->device];
+}
+
 extern "C" int cp_ctx_create(int device, cp_ctx **out) {
     if (!out) return CP_ERR_ARG;
     *out = nullptr;
@@ -94,11 +131,14 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     if (!ctx) return CP_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    cp_precompute_release(ctx);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->layer_ws) hipFree(ctx->layer_ws);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     for (int i = 0; i < 2 * CP_MAX_STAGES; ++i)
         if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return CP_OK;
@@ -230,6 +270,7 @@ extern "C" int cp_enable_stage_timing(cp_ctx *ctx, int on) {
     ctx->timing_gram_only = on == 2;
     ctx->n_marks = 0;
     ctx->n_stages = 0;
+    if (ctx->pre.worker) cp_enable_stage_timing(ctx->pre.worker, on);
     return CP_OK;
 }
 
@@ -247,6 +288,18 @@ extern "C" int cp_last_stage_times(cp_ctx *ctx, int *count, float *ms) {
         ++ctx->n_stages;
     }
     ctx->n_marks = 0;
+    if (cp_ctx *w = ctx->pre.worker) {   // the stages of the overlapped precompute (side stream) belong to this call too
+        hipStreamSynchronize(w->stream);
+        for (int i = 1; i < w->n_marks && ctx->n_stages < CP_MAX_STAGES; ++i) {
+            if (!w->mark_names[i]) continue;
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, w->ev[i - 1], w->ev[i]) != hipSuccess) t = -1.f;
+            ctx->stage_names[ctx->n_stages] = w->mark_names[i];
+            ctx->stage_ms[ctx->n_stages] = t;
+            ++ctx->n_stages;
+        }
+        w->n_marks = 0;
+    }
     *count = ctx->n_stages;
     for (int i = 0; i < ctx->n_stages; ++i) ms[i] = ctx->stage_ms[i];
     return CP_OK;

@@ -69,6 +69,7 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
             return cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer: samples / seeds missing");
         const double t0 = now_ms(), w0 = ctx->wait_ms;
         CP_TRY(cp_lasso_gram(ctx, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, S, Q, q, stats));
+        if ((flags & CP_REFIT_PRECOMPUTE) && ridge == 0.0) CP_TRY(cp_refit_precompute_enqueue(ctx, X, x_dtype, N, c, kk, Y, n));
         const double t1 = now_ms();
         ctx->host_ms[0] = t1 - t0;
         int fits_used = 0;
@@ -159,6 +160,13 @@ extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_j
         if (!j.samples || j.S <= 0 || !j.seeds || j.max_fits == 0)
             return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: samples / seeds missing in job %d", l);
         CP_TRY(cp_lasso_gram(ctx, j.X, j.x_dtype, j.N, c, j.kk, j.W2, j.w_dtype, j.n, j.Y, j.samples, j.S, w.Q, w.q, w.stats));
+        if ((j.flags & CP_REFIT_PRECOMPUTE) && j.ridge == 0.0) {
+            const int rc = cp_refit_precompute_enqueue(ctx, j.X, j.x_dtype, j.N, c, j.kk, j.Y, j.n);
+            if (rc != CP_OK) {
+                if (ctx != ctx0) cp_set_error(ctx0, rc, "cp_prune_layers: job %d: %s", l, ctx->err);
+                return rc;
+            }
+        }
         cp_search_job &s = sj[n_search];
         s.Q = w.Q; s.ldq = c; s.q = w.q; s.stats = w.stats; s.c = c; s.M = double(j.S) * double(j.n);
         s.alpha_right0 = j.alpha_right0; s.rank = j.rank; s.lbound = j.lbound; s.rbound = j.rbound; s.seeds = j.seeds;

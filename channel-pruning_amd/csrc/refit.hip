@@ -1682,6 +1682,146 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
     return CP_OK;
 }
 
+// ---- full normal equations during the alpha search ------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(RT) k_iota(int *__restrict__ v, int count) {
+    const int i = blockIdx.x * RT + threadIdx.x;
+    if (i < count) v[i] = i;
+}
+// G[i, j] = Gf[col(i), col(j)], R[i, :] = Rf[col(i), :], xmean[i] = xf[col(i)] for i, j < p (col(i) = chan[i / kk] kk + i % kk);
+// zero in the padding.  One workgroup per output row i < p_pad.
+__global__ void __launch_bounds__(RT) k_gather_normal_eq(const double *__restrict__ Gf, int ldf, const double *__restrict__ Rf,
+                                                         const double *__restrict__ xf, const int *__restrict__ chan, int kk,
+                                                         int p, int p_pad, int n_pad, double *__restrict__ G,
+                                                         double *__restrict__ R, double *__restrict__ xmean) {
+    const int i = blockIdx.x;
+    const bool live = i < p;
+    const int ci = live ? chan[i / kk] * kk + i % kk : 0;
+    for (int j = threadIdx.x; j < p_pad; j += RT) {
+        double v = 0.0;
+        if (live && j < p) v = Gf[size_t(ci) * ldf + chan[j / kk] * kk + j % kk];
+        G[size_t(i) * p_pad + j] = v;
+    }
+    for (int t = threadIdx.x; t < n_pad; t += RT) R[size_t(i) * n_pad + t] = live ? Rf[size_t(ci) * n_pad + t] : 0.0;
+    if (threadIdx.x == 0) xmean[i] = live ? xf[ci] : 0.0;
+}
+
+}  // namespace
+
+void cp_precompute_release(cp_ctx *ctx) {
+    cp_precompute &pc = ctx->pre;
+    if (pc.worker) {
+        hipStreamSynchronize(pc.worker->stream);
+        if (pc.worker->arena) hipFree(pc.worker->arena);
+        if (pc.worker->pinned) hipHostFree(pc.worker->pinned);
+        for (int i = 0; i < 2 * CP_MAX_STAGES; ++i)
+            if (pc.worker->ev[i]) hipEventDestroy(pc.worker->ev[i]);
+        delete pc.worker;
+        pc.worker = nullptr;
+    }
+    if (pc.buf) hipFree(pc.buf);
+    if (pc.done) hipEventDestroy(pc.done);
+    pc = cp_precompute{};
+}
+
+// Enqueue, on the device's shared side stream, the normal equations of the layer over ALL c channels:
+//   xmean_all, ymean, G_full = Xc^T Xc (P x P, P = c kk), R_full = Xc^T Yc (P x n)  -- 1 / (kept fraction)^2 times the
+// flops of the masked Gram, but off the critical path: the alpha search that decides the mask is one workgroup busy for
+// milliseconds, the rest of the chip is idle meanwhile.  Ordered after everything already on ctx->stream; the refit
+// (cp_lstsq_refit_impl) waits for it and gathers.  Skipped (returns CP_OK, pre.ready = false) when N - 1 < P.
+int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n) {
+    cp_precompute &pc = ctx->pre;
+    pc.ready = false;
+    const int P = c * kk;
+    if (N - 1 < P) return CP_OK;
+    const int P_pad = int(cp_align_up(size_t(P), NB)), n_pad = int(cp_align_up(size_t(n), 128));
+    const int64_t N_pad = int64_t(cp_align_up(size_t(N), 16));
+    if (!pc.worker) {
+        cp_ctx *w = new cp_ctx();
+        w->device = ctx->device;
+        w->cu_count = ctx->cu_count;
+        w->own_stream = nullptr;
+        w->stream = cp_side_stream(ctx);
+        for (int i = 0; i < 2 * CP_MAX_STAGES; ++i) hipEventCreate(&w->ev[i]);
+        w->timing = ctx->timing;
+        w->timing_gram_only = ctx->timing_gram_only;
+        pc.worker = w;
+        CP_HIP(ctx, hipEventCreateWithFlags(&pc.done, hipEventDisableTiming));
+    }
+    if (!ctx->ev_fork) {
+        CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    cp_ctx *w = pc.worker;
+    const size_t elems = size_t(P_pad) + n_pad + size_t(P_pad) * P_pad + size_t(P_pad) * n_pad;
+    if (elems * 8 > pc.buf_bytes) {
+        CP_HIP(ctx, hipStreamSynchronize(w->stream));
+        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (pc.buf) CP_HIP(ctx, hipFree(pc.buf));
+        pc.buf = nullptr;
+        pc.buf_bytes = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&pc.buf), elems * 8) != hipSuccess)
+            return cp_set_error(ctx, CP_ERR_NOMEM, "refit precompute: hipMalloc(%zu)", elems * 8);
+        pc.buf_bytes = elems * 8;
+    }
+    pc.xmean = reinterpret_cast<double *>(pc.buf);
+    pc.ymean = pc.xmean + P_pad;
+    pc.G = pc.ymean + n_pad;
+    pc.R = pc.G + size_t(P_pad) * P_pad;
+    // worker scratch: centred copies of ALL columns and of Y, partial sums, identity channel list, split-K planes
+    const int RB = 64, rows_per_block = int((N + RB - 1) / RB);
+    size_t ws = std::max(cp_gemm_tn_workspace(w, P_pad, P_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
+                         cp_gemm_tn_workspace(w, P_pad, n_pad, int(N_pad), CP_TRI_NONE));
+    CP_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // after whatever still reads the previous precompute
+    CP_HIP(ctx, hipStreamWaitEvent(w->stream, ctx->ev_fork, 0));
+    if (cp_arena_reserve(w, (size_t(N_pad) * (P_pad + n_pad) + size_t(RB) * (P_pad + n_pad)) * 8 + size_t(c) * 4 + ws + (1 << 16)) != CP_OK)
+        return cp_set_error(ctx, CP_ERR_NOMEM, "refit precompute: arena");
+    double *Xs = cp_arena_take_t<double>(w, size_t(N_pad) * P_pad), *Yc = cp_arena_take_t<double>(w, size_t(N_pad) * n_pad);
+    double *part_x = cp_arena_take_t<double>(w, size_t(RB) * P_pad), *part_y = cp_arena_take_t<double>(w, size_t(RB) * n_pad);
+    int *dchan = cp_arena_take_t<int>(w, c);
+    if (!Xs || !Yc || !part_x || !part_y || !dchan) return cp_set_error(ctx, CP_ERR_NOMEM, "refit precompute: arena carve");
+    cp_stage_begin(w);
+    k_iota<<<(c + RT - 1) / RT, RT, 0, w->stream>>>(dchan, c);
+    CP_LAUNCH_CHECK(ctx);
+    const int gx = (P + RT - 1) / RT, gy = (n + RT - 1) / RT;
+    if (x_dtype == CP_F32) {
+        k_colsum_xy<float><<<dim3(gx + gy, RB), RT, 0, w->stream>>>(static_cast<const float *>(X), Y, N, c, kk, n, dchan, P, gx,
+                                                                    rows_per_block, part_x, P_pad, part_y, n_pad);
+    } else {
+        k_colsum_xy<double><<<dim3(gx + gy, RB), RT, 0, w->stream>>>(static_cast<const double *>(X), Y, N, c, kk, n, dchan, P, gx,
+                                                                     rows_per_block, part_x, P_pad, part_y, n_pad);
+    }
+    CP_LAUNCH_CHECK(ctx);
+    k_mean_finish_xy<<<gx + gy, RT, 0, w->stream>>>(part_x, P_pad, P, part_y, n_pad, n, gx, RB, 1.0 / double(N), pc.xmean, pc.ymean);
+    CP_LAUNCH_CHECK(ctx);
+    cp_stage_mark(w, "refit_means");
+    if (x_dtype == CP_F32)
+        k_gather_center_xy<float><<<unsigned(N_pad), RT, 0, w->stream>>>(static_cast<const float *>(X), Y, N, c, kk, n, dchan, P,
+                                                                           P_pad, n_pad, pc.xmean, pc.ymean, Xs, Yc);
+    else
+        k_gather_center_xy<double><<<unsigned(N_pad), RT, 0, w->stream>>>(static_cast<const double *>(X), Y, N, c, kk, n, dchan, P,
+                                                                            P_pad, n_pad, pc.xmean, pc.ymean, Xs, Yc);
+    CP_LAUNCH_CHECK(ctx);
+    cp_stage_mark(w, "refit_gather_center");
+    cp_stage_mark(w, "refit_gram_begin");
+    w->gemm_tag = CP_GEMM_REFIT_GRAM;
+    w->gemm_mark = "refit_gram_gemm";
+    if (cp_gemm_tn_f64(w, P_pad, P_pad, int(N_pad), 1.0, Xs, P_pad, Xs, P_pad, 0.0, pc.G, P_pad, CP_TRI_LOWER_MIRROR) != CP_OK)
+        return cp_set_error(ctx, CP_ERR_HIP, "refit precompute: %s", w->err);
+    cp_stage_mark(w, "refit_gram_reduce");
+    w->gemm_tag = CP_GEMM_REFIT_XTY;
+    w->gemm_mark = "refit_xty_gemm";
+    if (cp_gemm_tn_f64(w, P_pad, n_pad, int(N_pad), 1.0, Xs, P_pad, Yc, n_pad, 0.0, pc.R, n_pad, CP_TRI_NONE) != CP_OK)
+        return cp_set_error(ctx, CP_ERR_HIP, "refit precompute: %s", w->err);
+    cp_stage_mark(w, "refit_xty_reduce");
+    CP_HIP(ctx, hipEventRecord(pc.done, w->stream));
+    pc.X = X; pc.Y = Y; pc.N = N; pc.c = c; pc.kk = kk; pc.n = n; pc.x_dtype = x_dtype;
+    pc.P = P; pc.P_pad = P_pad; pc.n_pad = n_pad;
+    pc.ready = true;
+    return CP_OK;
+}
+
 // host_out: also leave b (n) and W (n x p) in the context's pinned block at offset 64 (cp_prune_layer)
 int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
                         const double *Y, int n, double ridge, double *W_out, double *b_out, cp_refit_info *info,
@@ -1743,7 +1883,15 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     double *W_host = host_out ? b_host + n : nullptr;
     cp_stage_begin(ctx);
     CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
-    {   // column means, then gather + centre (three launches)
+    // full normal equations already under way on the side stream (cp_refit_precompute_enqueue): one shot
+    cp_precompute &pc = ctx->pre;
+    const bool from_pre = pc.ready && pc.X == X && pc.Y == Y && pc.N == N && pc.c == c && pc.kk == kk && pc.n == n &&
+                          pc.x_dtype == x_dtype && pc.n_pad == n_pad && ridge == 0.0;
+    pc.ready = false;
+    if (from_pre) {
+        CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, pc.done, 0));
+        CP_HIP(ctx, hipMemcpyAsync(ymean, pc.ymean, size_t(n_pad) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {   // column means, then gather + centre (three launches)
         const int gx = (p + RT - 1) / RT, gy = (n + RT - 1) / RT;
         dim3 gs(gx + gy, RB);
         if (x_dtype == CP_F32)
@@ -1786,26 +1934,40 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     vy.base = Y; vy.is_f32 = 0; vy.ld = n; vy.chan = nullptr; vy.kk = 1; vy.mean = ymean; vy.ncols = n; vy.nrows = N;
     // Gram and right-hand side into (Gd, Rd), diagonal prepared (ridge, unit pad diagonal, dg0, gmax, info = 0)
     auto normal_equations = [&](double *Gd, double *Rd, bool mark) -> int {
+        if (from_pre && mark) {   // the kept rows / columns of the precomputed full normal equations
+            k_gather_normal_eq<<<p_pad, RT, 0, ctx->stream>>>(pc.G, pc.P_pad, pc.R, pc.xmean, dchan, kk, p, p_pad, n_pad, Gd, Rd, xmean);
+            CP_LAUNCH_CHECK(ctx);
+            cp_stage_mark(ctx, "refit_gather_normal_eq");
+            k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
+            CP_LAUNCH_CHECK(ctx);
+            return CP_OK;
+        }
         if (!use_views || !mark) {   // the fallback paths work on the rows themselves
             CP_TRY(stage_rows());
             if (mark) cp_stage_mark(ctx, "refit_gather_center");
         }
-        if (mark) cp_stage_mark(ctx, "refit_gram_begin");   // opens the bracket of the roofline kernel (timing mode 2)
-        ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
-        ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
-        if (use_views && mark)
-            CP_TRY(cp_gemm_tn_f64_src(ctx, p_pad, p_pad, int(N_pad), 1.0, vx, vx, 0.0, Gd, p_pad, CP_TRI_LOWER_MIRROR));
-        else
-            CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad,
-                                  CP_TRI_LOWER_MIRROR));
-        if (mark) cp_stage_mark(ctx, "refit_gram_reduce");
-        ctx->gemm_tag = CP_GEMM_REFIT_XTY;
-        ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
-        if (use_views && mark)
-            CP_TRY(cp_gemm_tn_f64_src(ctx, p_pad, n_pad, int(N_pad), 1.0, vx, vy, 0.0, Rd, n_pad, CP_TRI_NONE));
-        else
-            CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
-        if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
+        auto products = [&]() -> int {
+            if (mark) cp_stage_mark(ctx, "refit_gram_begin");   // opens the bracket of the roofline kernel (timing mode 2)
+            ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
+            ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
+            if (use_views && mark)
+                CP_TRY(cp_gemm_tn_f64_src(ctx, p_pad, p_pad, int(N_pad), 1.0, vx, vx, 0.0, Gd, p_pad, CP_TRI_LOWER_MIRROR));
+            else
+                CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad,
+                                      CP_TRI_LOWER_MIRROR));
+            if (mark) cp_stage_mark(ctx, "refit_gram_reduce");
+            ctx->gemm_tag = CP_GEMM_REFIT_XTY;
+            ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
+            if (use_views && mark)
+                CP_TRY(cp_gemm_tn_f64_src(ctx, p_pad, n_pad, int(N_pad), 1.0, vx, vy, 0.0, Rd, n_pad, CP_TRI_NONE));
+            else
+                CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
+            if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
+            return CP_OK;
+        };
+        // the two long products of a big layer go to the device's shared CU-masked stream (when enabled)
+        if (nblk >= 8) CP_TRY(cp_on_wide_stream(ctx, products));
+        else CP_TRY(products());
         k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;

@@ -105,6 +105,10 @@ typedef struct cp_cd_result {
 
 #define CP_CD_RECIPROCAL 1 /* multiply by 1/(Qii+l2) instead of dividing (<=1 ulp/step) */
 #define CP_CD_DELTA 2      /* one axpy H += (w_new - w_old) Q[ii] instead of sklearn's two (rounding-level) */
+/* cp_prune_layer / cp_prune_layers only (same flags word): compute the normal equations over ALL c channels on the device's
+ * side stream while the single-workgroup alpha search runs; the refit then gathers the kept rows / columns instead of
+ * running its two N-sized products after the search.  (c / kept)^2 times the Gram flops, off the critical path. */
+#define CP_REFIT_PRECOMPUTE 4
 
 /* Replaces Lasso.fit as called by solve() (lib/decompose.py:453-466):
  * sklearn/_cd_fast.pyx:564-737 with random coordinate order from our_rand_r
