@@ -439,7 +439,7 @@ def bench_vgg16(args, env):
 
 
 # measured ms of one layer alone by channel count (profiles/r02_*): the LPT costs of the vgg16 job
-VGG16_COST_MS = {}
+VGG16_COST_MS = {64: 1.5, 128: 3.0, 256: 6.8, 512: 15.5}
 
 
 # ==================================================================================================================

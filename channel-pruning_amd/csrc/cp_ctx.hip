@@ -43,8 +43,11 @@ extern "C" int cp_device_count(int *count) {
 }
 
 #include <mutex>
+hipStream_t cp_side_stream(cp_ctx *ctx);
 hipStream_t cp_wide_stream(cp_ctx *ctx) {
     static const int reserve = getenv("CP_WIDE_RESERVE") ? atoi(getenv("CP_WIDE_RESERVE")) : 0;
+    static const bool shared = getenv("CP_GRAM_SHARED_STREAM") && getenv("CP_GRAM_SHARED_STREAM")[0] == '1';
+    if (shared) return cp_side_stream(ctx);   // no CU mask: the long products of all layers simply take turns
     if (reserve <= 0 || reserve >= ctx->cu_count) return nullptr;
     static std::mutex mu;
     static hipStream_t streams[64] = {};

@@ -93,6 +93,14 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
         z = xcd + 8 * (slot / n_tiles);
         tile = slot % n_tiles;
+    } else if (n_tiles >= 64) {
+        // XCD-aware: workgroup L runs on XCD L % 8 (each XCD has its own L2).  Give every XCD a CONTIGUOUS range of the
+        // row-major tile list -- a band of tile rows -- so that the row panel of a band is read from HBM by one L2 instead
+        // of by all eight (PMC: the p = 4250 refit Gram fetched 2.8 GB for 0.31 GB of operands with the plain order).
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int base = n_tiles >> 3, rem = n_tiles & 7;
+        tile = xcd * base + (xcd < rem ? xcd : rem) + slot;
+        z = 0;
     } else {
         tile = blockIdx.x;
         z = 0;
