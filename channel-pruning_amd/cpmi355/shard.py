@@ -110,7 +110,7 @@ class ResidentLayerSet:
         operands(spec) -> (X[N,c,k,k], W2[n,c,k,k], Y[N,n]) host arrays, called once per layer."""
 
     def __init__(self, device, specs, operands, seed=lambda s: 1234 + s["layer_id"], per_stream=2, alpha_in=1e-3,
-                 rank_tol=.1, flags=None):
+                 rank_tol=.1, flags=None, precompute_heaviest=None):
         import threading
 
         from . import capi
@@ -136,6 +136,16 @@ class ResidentLayerSet:
                 self.chunks.append(dict(members=group, ctxs=ctxs, probs=probs, rngs=rngs,
                                         marks=[rng_mark(r) for r in rngs], go=threading.Event(), done=threading.Event(),
                                         out=None, error=None, ms=0.0))
+        # The heaviest layers' alpha searches are the idle head of the job (one workgroup each for milliseconds): that many
+        # of them get their full normal equations computed on the side stream meanwhile (pruner.precompute_flag); more
+        # than the idle head can absorb only adds flops to a chip that is busy afterwards.
+        if precompute_heaviest is None:
+            import os
+            precompute_heaviest = int(os.environ.get("CP_JOB_PRECOMPUTE", "2"))
+        single = [ch for ch in self.chunks if len(ch["members"]) == 1]
+        single.sort(key=lambda ch: -layer_cost(*[self.specs[ch["members"][0]][k] for k in ("N", "c", "n", "k", "rank")]))
+        self._latency_chunks = set(id(ch) for ch in single[:max(0, precompute_heaviest)]) if len(self.chunks) > 2 else \
+            set(id(ch) for ch in single)
         self._stop = False
         self._threads = []
         for ch in self.chunks:
@@ -154,7 +164,7 @@ class ResidentLayerSet:
         if len(specs) == 1:
             s = specs[0]
             out = [prune_layer(ch["probs"][0], s["rank"], s.get("alpha_in", self.alpha_in), rank_tol=self.rank_tol,
-                               rng=ch["rngs"][0], mode="device", latency_mode=len(self.chunks) <= 2)]
+                               rng=ch["rngs"][0], mode="device", latency_mode=id(ch) in self._latency_chunks)]
         else:
             out = prune_layers_batched(ch["probs"], [s["rank"] for s in specs],
                                        [s.get("alpha_in", self.alpha_in) for s in specs], ch["rngs"],

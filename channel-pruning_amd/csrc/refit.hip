@@ -523,6 +523,37 @@ __global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, dou
     potrf_body<FUSED>(G, Uout, Lt, ld, blk_or_nblk, dg0, piv_tol, TI, TIT, info, int(blockIdx.x));
 }
 
+// The panel of block step `blk` as its own launch: U[blk, j] = U_bb^-T G[blk, j] (and the transposed copy into Lt) for
+// j = blk + 1 + blockIdx.x.  No LDS: with the panel inside the diagonal block's launch every panel workgroup reserved the
+// 158 KB that kernel declares and sat on a CU spinning for the diagonal block; in a busy chip each of them first had to
+// find a CU with no GEMM workgroup on it (k_potrf 173 us per launch in the vgg16 job against 59 us alone).
+__global__ void __launch_bounds__(PT) k_potrf_panel(const double *G, double *Uout, double *Lt, int ld, int blk,
+                                                    const double *__restrict__ TI) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
+    const int j = blk + 1 + blockIdx.x;
+    const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
+    const double *Gbj = G + size_t(blk) * NB * ld + size_t(j) * NB + fi;
+    double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
+    v4f64c acc[NB / 16];
+#pragma unroll
+    for (int t = 0; t < NB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
+#pragma unroll 2
+    for (int q = 0; q < NB / 4; ++q) {
+        const double av = TIb[size_t(4 * q + fk) * NB];
+#pragma unroll
+        for (int t = 0; t < NB / 16; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Gbj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
+    }
+    double *Ltj = Lt + size_t(j) * NB * ld + size_t(blk) * NB + wave * 16;
+#pragma unroll
+    for (int t = 0; t < NB / 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
+            Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
+        }
+}
+
 // several factorisations in one launch (cp_prune_layers): blockIdx.y = job, blockIdx.x = its tile task.  Workgroups
 // are dispatched x-fastest, so a job's tasks still start in task order.
 struct PotrfJob {
@@ -1050,11 +1081,22 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;
     }
+    // CP_CHOL_PANEL_SPLIT=1: the panel as its own LDS-free launch.  Measured neutral (4.30 vs 4.29 ms alone at p = 4250, vgg16
+    // job 32.7 vs 32.8 ms), so the one-launch form stays.
+    static const bool split_panel = getenv("CP_CHOL_PANEL_SPLIT") && getenv("CP_CHOL_PANEL_SPLIT")[0] == '1';
     for (int b = 0; b < ch.nblk; ++b) {
-        // diagonal block + its panel U12 = U11^-T G12 (workgroups 1..)
-        k_potrf<false><<<ch.nblk - b, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT,
-                                                              ch.info);
-        CP_LAUNCH_CHECK(ctx);
+        if (split_panel) {   // diagonal block (one workgroup), then its panel U12 = U11^-T G12 as a light launch of its own
+            k_potrf<false><<<1, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
+            CP_LAUNCH_CHECK(ctx);
+            if (ch.nblk - b - 1 > 0) {
+                k_potrf_panel<<<ch.nblk - b - 1, PT, 0, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.TI);
+                CP_LAUNCH_CHECK(ctx);
+            }
+        } else {             // diagonal block + its panel in one launch (workgroups 1.. wait for workgroup 0's flag)
+            k_potrf<false><<<ch.nblk - b, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT,
+                                                                  ch.info);
+            CP_LAUNCH_CHECK(ctx);
+        }
         const int rest = (ch.nblk - b - 1) * NB;
         if (rest > 0) {
             double *U12 = ch.U + size_t(b) * NB * ld + size_t(b + 1) * NB;
