@@ -350,7 +350,9 @@ class RowShardEngine:
 
     def buffer(self, elems):
         import torch
-        return torch.zeros(int(elems), dtype=torch.float64, device=self.device)
+        t = torch.zeros(int(elems), dtype=torch.float64, device=self.device)
+        torch.cuda.synchronize(self.device)   # the fill runs on torch's stream, the library writes on its own (non-blocking) one
+        return t
 
     def select(self, Xs, W2, Ys, rank, alpha_in, rank_tol, rng):
         """alpha search on the S exchanged rows (identical on every rank) -> (idxs, alpha)"""

@@ -1636,6 +1636,8 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     DevResult *dres = reinterpret_cast<DevResult *>(cp_arena_take(ctx, sizeof(DevResult)));
     const bool duo = use_duo(c);
     const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
+    if (lds > 64 * 1024)   // no opt-in above the default dynamic-LDS limit is requested for these kernels
+        return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit 65536: c <= 1228)", c, lds);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     if (duo) {
@@ -1684,6 +1686,8 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     memcpy(h + off_seed, seeds, size_t(max_fits) * sizeof(uint32_t));
     const bool duo = use_duo(c);
     const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
+    if (lds > 64 * 1024)   // no opt-in above the default dynamic-LDS limit is requested for these kernels
+        return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit 65536: c <= 1228)", c, lds);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     if (duo) {
@@ -1758,6 +1762,8 @@ int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_sear
     }
     const bool duo = use_duo(c);
     const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
+    if (lds > 64 * 1024)   // no opt-in above the default dynamic-LDS limit is requested for these kernels
+        return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit 65536: c <= 1228)", c, lds);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     if (duo) {

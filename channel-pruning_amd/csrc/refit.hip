@@ -1679,12 +1679,9 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
     cp_ctx *ctx = ctx0;
     if (chol_fused_requested()) {  // all factorisations as one launch (see chol_factor for why this is opt-in)
         const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
-        static bool opt_in = false;  // > 64 KB of dynamic LDS needs an explicit opt-in (idempotent)
-        if (!opt_in) {
-            CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_batch),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-            opt_in = true;
-        }
+        // > 64 KB of dynamic LDS needs an explicit opt-in: per device, idempotent, a few microseconds -- done on every call
+        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_batch),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         k_potrf_batch<<<dim3(max_tasks, nj), PT, lds, ctx->stream>>>(pb);
         CP_LAUNCH_CHECK(ctx);
     } else if (!chol_tasks_requested()) {
