@@ -200,15 +200,16 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
 
 // one-sided Jacobi SVD (svd_jacobi.hip) with caller-provided scratch -----------------------------------
 // Scratch of one decomposition (device): Wk [me, n], R [me, me], sig [me], rotated [16 ints], order [me ints]
+static inline int cp_svd_me(int m) { return (m + 15) / 16 * 16; }   // rows the Jacobi kernels work on (zero rows pad)
 struct SvdScratch {
     double *Wk, *R, *sig;
     int *rotated, *order;
     static size_t bytes(int m, int n) {
-        const size_t me = size_t(m + (m & 1));
+        const size_t me = size_t(cp_svd_me(m));
         return (me * n + me * me + me) * 8 + 64 + me * 4 + 1024;
     }
     bool take(cp_ctx *ctx, int m, int n) {
-        const size_t me = size_t(m + (m & 1));
+        const size_t me = size_t(cp_svd_me(m));
         Wk = cp_arena_take_t<double>(ctx, me * n);
         R = cp_arena_take_t<double>(ctx, me * me);
         sig = cp_arena_take_t<double>(ctx, me);

@@ -1506,7 +1506,8 @@ int refit_robust(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal_equ
         return cp_set_error(ctx, CP_ERR_NOMEM, "refit (rank-revealing path): scratch (decomposition)");
     CP_HIP(ctx, hipMemsetAsync(Vt, 0, g_c * 8, ctx->stream));
     CP_HIP(ctx, hipMemsetAsync(SH, 0, g_c * 8, ctx->stream));
-    CP_TRY(cp_svd_rows_impl(ctx, G2, p_pad, p_e, p_pad, p_e, lam, Vt, p_pad, SH, p_pad, sc, nullptr));
+    // eigenvalues below 10 p eps are dropped below anyway: rows at that level are noise and only keep the sweeps going
+    CP_TRY(cp_svd_rows_core(ctx, G2, p_pad, p_e, p_pad, p_e, lam, Vt, p_pad, SH, p_pad, sc, nullptr, false, 1e-14));
     std::vector<double> hl(p_e);
     CP_TRY(read_back(ctx, hl.data(), lam, size_t(p_e) * 8));
     int r = 0;
@@ -2300,7 +2301,7 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
         return cp_set_error(ctx, CP_ERR_NOMEM, "itq: arena");
     cp_stage_begin(ctx);
     const int gy = (n + RT - 1) / RT;
-    const int me = n + (n & 1);
+    const int me = cp_svd_me(n);
     // G = Y - Y_mean, Z = relu(gt); G^T; GtG = G^T G; PGi = pinv(GtG); P1 = G PGi (= PGGt^T); PiT = GtG PGi
     k_colsum_plain<<<dim3(gy, RB), RT, 0, ctx->stream>>>(feature, N, n, np_, rows_per_block, part);
     CP_LAUNCH_CHECK(ctx);

@@ -5,9 +5,12 @@
 //   singular values  sigma_k = |row k of R M|,   V = R^T (column k = row k of R),   diag(sigma) H = R M
 // -- the reference needs exactly V[:, :rank] and diag(sigma) H[:rank] (decompose.py:105-112), so the rows are
 // never normalised.  High relative accuracy (no Gram squaring).
-// One launch per round of the round-robin ordering: m/2 disjoint row pairs, one workgroup per pair
-// (three dot products -> rotation -> both rows of the work matrix and of R).  A sweep is m-1 rounds; sweeps
-// repeat until no pair exceeds the orthogonality tolerance.  Rows are contiguous, so every access is coalesced.
+// BLOCK form: rows in blocks of 8, one launch per round of the round-robin ordering over the blocks, one workgroup per
+// block pair.  The workgroup forms the 16 x 16 Gram of its 16 rows on MFMA, diagonalises it in LDS (two-sided cyclic
+// Jacobi with the same rotation formula, 8 disjoint pairs at a time), and applies the accumulated 16 x 16 rotation to the
+// rows of the work matrix and of R on MFMA.  A sweep is (m/8 - 1) launches instead of (m - 1): 31 instead of 255 at
+// m = 256, where the scalar form was bound by its 255 dependent launches per sweep (ITQ: 350 sweeps per layer).  Sweeps
+// repeat until no block pair holds an off-diagonal above the orthogonality tolerance.
 #include "cp_common.h"
 
 #include <algorithm>
@@ -102,6 +105,129 @@ __global__ void __launch_bounds__(JT) k_norm_floor(const double *__restrict__ si
     }
 }
 
+typedef double v4f64j __attribute__((ext_vector_type(4)));
+// hardware estimate + two Newton steps: full double accuracy at a fraction of the software sqrt / divide sequences
+__device__ __forceinline__ double jrsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+__device__ __forceinline__ double jrcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * fma(-x, y, 2.0);
+    y = y * fma(-x, y, 2.0);
+    return y;
+}
+constexpr int JB = 8;   // rows per block
+
+__global__ void __launch_bounds__(JT) k_jacobi_block_round(double *__restrict__ Wk, int n, double *__restrict__ R, int me,
+                                                           int round, double tol, int *__restrict__ rotated,
+                                                           const double *__restrict__ floor2, int inner_sweeps) {
+    __shared__ double A[16][17], Q[16][17], part[4][16][17];
+    __shared__ int any_rot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
+    int bi, bj;
+    round_pair(me / JB, round, blockIdx.x, bi, bj);
+    auto row_of = [&](int mloc) { return mloc < JB ? bi * JB + mloc : bj * JB + (mloc - JB); };
+    // ---- Gram of the 16 rows: wave w takes the column groups 4 w, 4 w + 16, ... ----
+    {
+        v4f64j acc = {0., 0., 0., 0.};
+        const double *rowp = Wk + size_t(row_of(fi)) * n;
+        for (int col0 = wave * 4; col0 < n; col0 += 16) {
+            const int c = col0 + fk;
+            const double v = c < n ? rowp[c] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][fk + 4 * r][fi] = acc[r];
+    }
+    if (tid == 0) any_rot = 0;
+    __syncthreads();
+    {
+        const int mloc = tid >> 4, nloc = tid & 15;
+        A[mloc][nloc] = part[0][mloc][nloc] + part[1][mloc][nloc] + part[2][mloc][nloc] + part[3][mloc][nloc];
+        Q[mloc][nloc] = mloc == nloc ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const double fl = floor2 ? floor2[0] : 0.0;
+    // ---- diagonalise A: Q A Q^T, Q accumulated (rows of the work matrix become Q W).  ONE wave, no workgroup barriers
+    // (a wave's LDS operations execute in order; 270 __syncthreads made this phase 40 us): per inner round lanes 0..7
+    // compute the 8 disjoint rotations, then every lane updates two (pair, column) entries of the rows of A, of the rows
+    // of Q and of the columns of A. ----
+    if (wave == 0) {
+        bool any = false;
+        const int k = lane >> 3;
+        for (int isw = 0; isw < inner_sweeps; ++isw) {
+            bool rot = false;
+            for (int ir = 0; ir < 15; ++ir) {
+                // every lane of a pair's group computes that pair's rotation itself (no hand-off through LDS): reads of this
+                // instruction precede the writes of the later ones across the whole wave
+                int p, q;
+                round_pair(16, ir, k, p, q);
+                const double app = A[p][p], aqq = A[q][q], apq = A[p][q];
+                double c = 1.0, sn = 0.0;
+                if (apq * apq > tol * tol * app * aqq && app > fl && aqq > fl) {
+                    const double zeta = (aqq - app) * 0.5 * jrcp(apq);
+                    const double z2 = fma(zeta, zeta, 1.0);
+                    const double t = copysign(1.0, zeta) * jrcp(fabs(zeta) + z2 * jrsqrt(z2));
+                    c = jrsqrt(fma(t, t, 1.0));
+                    sn = c * t;
+                }
+                rot = rot || __builtin_amdgcn_ballot_w64(sn != 0.0) != 0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {   // rows p, q of A and of Q
+                    const int j = (lane & 7) * 2 + e;
+                    const double x = A[p][j], y = A[q][j];
+                    A[p][j] = c * x - sn * y;
+                    A[q][j] = sn * x + c * y;
+                    const double u = Q[p][j], v = Q[q][j];
+                    Q[p][j] = c * u - sn * v;
+                    Q[q][j] = sn * u + c * v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {   // columns p, q of A
+                    const int i = (lane & 7) * 2 + e;
+                    const double x = A[i][p], y = A[i][q];
+                    A[i][p] = c * x - sn * y;
+                    A[i][q] = sn * x + c * y;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (!rot) break;
+            any = true;
+        }
+        if (lane == 0) any_rot = any ? 1 : 0;
+    }
+    __syncthreads();
+    if (!any_rot) return;
+    if (tid == 0) atomicAdd(rotated, 1);
+    // ---- rows <- Q rows, for the work matrix (n columns) and for R (me columns): 16-column tiles per wave ----
+    for (int which = 0; which < 2; ++which) {
+        double *Mat = which == 0 ? Wk : R;
+        const int ncol = which == 0 ? n : me;
+        for (int col0 = wave * 16; col0 < ncol; col0 += 64) {
+            const int cc = col0 + fi;
+            v4f64j acc = {0., 0., 0., 0.};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double av = Q[fi][4 * ks + fk];
+                const double bv = cc < ncol ? Mat[size_t(row_of(4 * ks + fk)) * ncol + cc] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+            if (cc < ncol) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Mat[size_t(row_of(fk + 4 * r)) * ncol + cc] = acc[r];
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(JT) k_identity(double *__restrict__ R, int m) {
     const int r = blockIdx.x;
     for (int col = threadIdx.x; col < m; col += JT) R[size_t(r) * m + col] = col == r ? 1.0 : 0.0;
@@ -137,7 +263,7 @@ int cp_svd_rows_impl(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r,
 // (2-3 sweeps instead of 8-10).  M is then not read.
 int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
                      double *SH, int ldsh, SvdScratch &sc, int *sweeps_out, bool preinit, double rel_floor) {
-    const int me = m + (m & 1);  // even number of players: an all-zero row plays along if m is odd
+    const int me = cp_svd_me(m);  // whole 8-row blocks, an even number of them: all-zero rows play along
     double *Wk = sc.Wk, *R = sc.R, *sig = sc.sig;
     int *rotated = sc.rotated;
     CP_TRY(cp_pinned_reserve(ctx, 4096));
@@ -159,11 +285,21 @@ int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r,
     }
     int sweeps = 0;
     const double tol = std::max(1e-14, 4e-16 * std::sqrt(double(n)));  // |a.b| <= tol |a||b|: rows orthogonal to rounding
-    for (; sweeps < 40; ++sweeps) {
+    for (; sweeps < 60; ++sweeps) {
         CP_HIP(ctx, hipMemsetAsync(rotated, 0, sizeof(int), ctx->stream));
-        for (int round = 0; round < me - 1; ++round) {
-            k_jacobi_round<<<me / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2);
-            CP_LAUNCH_CHECK(ctx);
+        static const bool scalar = getenv("CP_JACOBI_SCALAR") && getenv("CP_JACOBI_SCALAR")[0] == '1';
+        if (scalar) {
+            for (int round = 0; round < me - 1; ++round) {
+                k_jacobi_round<<<me / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2);
+                CP_LAUNCH_CHECK(ctx);
+            }
+        } else {
+            const int nb = me / JB;
+            static const int inner = getenv("CP_JACOBI_INNER") ? atoi(getenv("CP_JACOBI_INNER")) : 1;
+            for (int round = 0; round < nb - 1; ++round) {
+                k_jacobi_block_round<<<nb / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2, inner);
+                CP_LAUNCH_CHECK(ctx);
+            }
         }
         CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, rotated, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         CP_HIP(ctx, cp_stream_wait(ctx));
@@ -172,7 +308,7 @@ int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r,
         if (nrot == 0) break;
     }
     if (sweeps_out) *sweeps_out = sweeps;
-    if (sweeps >= 40) return cp_set_error(ctx, CP_ERR_NUMERIC, "svd_rows: no convergence in 40 sweeps");
+    if (sweeps >= 60) return cp_set_error(ctx, CP_ERR_NUMERIC, "svd_rows: no convergence in 60 sweeps");
     // singular values = row norms; order descending on the host (m numbers), gather the leading r rows
     k_row_norms<<<me, JT, 0, ctx->stream>>>(Wk, n, sig);
     CP_LAUNCH_CHECK(ctx);
