@@ -222,4 +222,4 @@ struct SvdScratch {
 int cp_svd_rows_impl(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
                      double *SH, int ldsh, SvdScratch &sc, int *sweeps_out);
 int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
-                     double *SH, int ldsh, SvdScratch &sc, int *sweeps_out, bool preinit, double rel_floor);
+                     double *SH, int ldsh, SvdScratch &sc, int *sweeps_out, bool preinit, double rel_floor, double tol_in);

@@ -1507,7 +1507,7 @@ int refit_robust(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal_equ
     CP_HIP(ctx, hipMemsetAsync(Vt, 0, g_c * 8, ctx->stream));
     CP_HIP(ctx, hipMemsetAsync(SH, 0, g_c * 8, ctx->stream));
     // eigenvalues below 10 p eps are dropped below anyway: rows at that level are noise and only keep the sweeps going
-    CP_TRY(cp_svd_rows_core(ctx, G2, p_pad, p_e, p_pad, p_e, lam, Vt, p_pad, SH, p_pad, sc, nullptr, false, 1e-14));
+    CP_TRY(cp_svd_rows_core(ctx, G2, p_pad, p_e, p_pad, p_e, lam, Vt, p_pad, SH, p_pad, sc, nullptr, false, 1e-14, 0.0));
     std::vector<double> hl(p_e);
     CP_TRY(read_back(ctx, hl.data(), lam, size_t(p_e) * 8));
     int r = 0;
@@ -2331,6 +2331,7 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
     // alternation are left: B^T = UU^T P1 and RU = G T.
     bool warm = false;
     int total_sweeps = 0;
+    static const double itq_tol = getenv("CP_ITQ_TOL") ? atof(getenv("CP_ITQ_TOL")) : 0.0;   // 0: the standard rounding-level tolerance (1e-12 / 1e-10 measured no faster)
     for (int st = 0; st < n_stage; ++st)
         for (int it = 0; it < iters[st]; ++it) {
             CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, UU, np_, P1, np_, 0.0, BT, np_, CP_TRI_NONE));      // B^T
@@ -2347,7 +2348,7 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
                 CP_HIP(ctx, hipMemcpy2DAsync(sc.Wk, size_t(np_) * 8, Wp, size_t(np_) * 8, size_t(np_) * 8, size_t(me),
                                              hipMemcpyDeviceToDevice, ctx->stream));
             }
-            CP_TRY(cp_svd_rows_core(ctx, Mx, np_, n, np_, rank, sigma, Vt, n, SHsq, np_, sc, &sweeps, warm, 1e-13));
+            CP_TRY(cp_svd_rows_core(ctx, Mx, np_, n, np_, rank, sigma, Vt, n, SHsq, np_, sc, &sweeps, warm, 1e-13, itq_tol));
             warm = getenv("CP_ITQ_COLD") == nullptr;
             total_sweeps += sweeps;
             k_pad_rows<<<rp, RT, 0, ctx->stream>>>(Vt, rank, n, n, Vtp, np_);

@@ -134,10 +134,15 @@ __global__ void __launch_bounds__(JT) k_jacobi_block_round(double *__restrict__ 
     {
         v4f64j acc = {0., 0., 0., 0.};
         const double *rowp = Wk + size_t(row_of(fi)) * n;
-        for (int col0 = wave * 4; col0 < n; col0 += 16) {
-            const int c = col0 + fk;
-            const double v = c < n ? rowp[c] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+        for (int col0 = wave * 4; col0 < n; col0 += 64) {   // four column groups' loads in flight per step
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = col0 + 16 * u + fk;
+                v[u] = c < n ? rowp[c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][fk + 4 * r][fi] = acc[r];
@@ -207,22 +212,34 @@ __global__ void __launch_bounds__(JT) k_jacobi_block_round(double *__restrict__ 
     __syncthreads();
     if (!any_rot) return;
     if (tid == 0) atomicAdd(rotated, 1);
-    // ---- rows <- Q rows, for the work matrix (n columns) and for R (me columns): 16-column tiles per wave ----
+    // ---- rows <- Q rows, for the work matrix (n columns) and for R (me columns): 16-column tiles per wave, four tiles'
+    // loads in flight before the first product (tile after tile the compiler orders every load behind the previous
+    // tile's stores: 8 dependent round trips per launch) ----
+    double qa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qa[ks] = Q[fi][4 * ks + fk];
     for (int which = 0; which < 2; ++which) {
         double *Mat = which == 0 ? Wk : R;
         const int ncol = which == 0 ? n : me;
-        for (int col0 = wave * 16; col0 < ncol; col0 += 64) {
-            const int cc = col0 + fi;
-            v4f64j acc = {0., 0., 0., 0.};
+        for (int base = wave * 16; base < ncol; base += 256) {
+            double bv[4][4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const double av = Q[fi][4 * ks + fk];
-                const double bv = cc < ncol ? Mat[size_t(row_of(4 * ks + fk)) * ncol + cc] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                const int cc = base + 64 * t + fi;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    bv[t][ks] = cc < ncol ? Mat[size_t(row_of(4 * ks + fk)) * ncol + cc] : 0.0;
             }
-            if (cc < ncol) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Mat[size_t(row_of(fk + 4 * r)) * ncol + cc] = acc[r];
+            for (int t = 0; t < 4; ++t) {
+                const int cc = base + 64 * t + fi;
+                v4f64j acc = {0., 0., 0., 0.};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ks], bv[t][ks], acc, 0, 0, 0);
+                if (cc < ncol) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Mat[size_t(row_of(fk + 4 * r)) * ncol + cc] = acc[r];
+                }
             }
         }
     }
@@ -255,14 +272,14 @@ __global__ void __launch_bounds__(JT) k_row_norms(const double *__restrict__ Wk,
 // stride ldsh); scratch from the caller (the arena is NOT re-reserved here).
 int cp_svd_rows_impl(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
                      double *SH, int ldsh, SvdScratch &sc, int *sweeps_out) {
-    return cp_svd_rows_core(ctx, M, ldm, m, n, r, sigma, Vt, ldv, SH, ldsh, sc, sweeps_out, false, 0.0);
+    return cp_svd_rows_core(ctx, M, ldm, m, n, r, sigma, Vt, ldv, SH, ldsh, sc, sweeps_out, false, 0.0, 0.0);
 }
 
 // preinit: sc.Wk [me, n] and sc.R [me, me] already hold a consistent pair (Wk = R M for an orthogonal R) -- a WARM
 // START, e.g. the rotation the previous, nearby matrix ended with: Jacobi converges quadratically from there
 // (2-3 sweeps instead of 8-10).  M is then not read.
 int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
-                     double *SH, int ldsh, SvdScratch &sc, int *sweeps_out, bool preinit, double rel_floor) {
+                     double *SH, int ldsh, SvdScratch &sc, int *sweeps_out, bool preinit, double rel_floor, double tol_in) {
     const int me = cp_svd_me(m);  // whole 8-row blocks, an even number of them: all-zero rows play along
     double *Wk = sc.Wk, *R = sc.R, *sig = sc.sig;
     int *rotated = sc.rotated;
@@ -284,7 +301,8 @@ int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r,
         floor2 = fl;
     }
     int sweeps = 0;
-    const double tol = std::max(1e-14, 4e-16 * std::sqrt(double(n)));  // |a.b| <= tol |a||b|: rows orthogonal to rounding
+    // |a.b| <= tol |a||b|: rows orthogonal to rounding (tol_in > 0: the caller needs less, e.g. an invariant subspace only)
+    const double tol = tol_in > 0.0 ? tol_in : std::max(1e-14, 4e-16 * std::sqrt(double(n)));
     for (; sweeps < 60; ++sweeps) {
         CP_HIP(ctx, hipMemsetAsync(rotated, 0, sizeof(int), ctx->stream));
         static const bool scalar = getenv("CP_JACOBI_SCALAR") && getenv("CP_JACOBI_SCALAR")[0] == '1';
