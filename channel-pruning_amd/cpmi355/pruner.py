@@ -270,11 +270,12 @@ GLOBAL_RNG = np.random  # module-level legacy RandomState: randint / get_state /
 
 
 def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="device", alpha_arg=1e-4,
-                refit="linear", W2_host=None, latency_mode=True):
+                refit="linear", W2_host=None, latency_mode=True, fixed_alpha=None):
     """dictionary() on a resident LayerProblem -> (idxs, newW2[n,nnz,k,k], newB2, alpha_out).
 
     refit: "linear" (fc_kernel), "nonlinear" (nonlinear_fc) or "none" (dcfgs.nofc: W2[:, idxs], zero bias).
     latency_mode: this layer has the GPU to itself (see precompute_flag); callers that keep many layers in flight pass False.
+    fixed_alpha: dcfgs.autodet (decompose.py:395-416, 582-585): ONE fit at that alpha decides the kept channels, no search.
     mode "device": the whole call is ONE foreign call (cp_prune_layer; linear refit only); "steps": the same device
     search through the individual entry points (lasso_gram / alpha search / refit); "host": one
     launch per LASSO fit, the host deciding the next alpha."""
@@ -282,7 +283,14 @@ def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="de
     N, c, n, k = prob.N, prob.c, prob.n, prob.k
     samples = rng.randint(0, N, min(400, N // 20))               # decompose.py:425
     prob.samples = samples
-    if rank == c:                                                 # decompose.py:487-488
+    if fixed_alpha is not None:                                   # decompose.py:582-585: idxs, rank = solve(alpha)
+        prob.lasso_gram(samples)
+        prob.fits = []
+        prob.reset_w()
+        prob.solve(fixed_alpha, rng.randint(0, RAND_R_MAX))
+        idxs = prob.mask()
+        alpha = fixed_alpha
+    elif rank == c:                                               # decompose.py:487-488
         idxs = np.array([True] * rank)
         alpha = alpha_arg
         prob.fits = []

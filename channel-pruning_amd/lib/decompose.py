@@ -40,9 +40,6 @@ def _flags():
 
 def _refit_mode():
     """Validate the dcfgs flags of dictionary() (decompose.py:393-416, 605-623) and pick the refit branch."""
-    if dcfgs.autodet:
-        raise NotImplementedError("dcfgs.autodet (single LASSO solve at fixed alpha) is not on the "
-                                  "accelerated path")
     if dcfgs.dic.alter or dcfgs.ls != 'linear' or dcfgs.solver != cfgs.solvers.sk or dcfgs.dic.debug:
         raise NotImplementedError("only the sklearn/linear configuration of the reference is accelerated "
                                   "(dic.alter=0, ls='linear', solver='sklearn')")
@@ -56,16 +53,20 @@ def prune_resident(prob, rank, W2_host, alpha=1e-4):
     below and by Net.dictionary_kernel (lib/net.py), so both honour the same dcfgs flags (rank_tol, fc_ridge,
     nonlinear_fc, nofc, cd_mode), consume numpy's global RNG identically and carry cfgs.alpha (decompose.py:626-627)."""
     refit = _refit_mode()
+    fixed = None
+    if dcfgs.autodet:                                    # decompose.py:395-397, 414-415: no rank, one fit at a derived alpha
+        fixed = cfgs.alpha / prob.c ** dcfgs.dic.layeralpha
     idxs, newW2, newB2, alpha_out = prune_layer(prob, rank, cfgs.alpha, rank_tol=dcfgs.dic.rank_tol, rng=np.random,
                                                 ridge=float(dcfgs.fc_ridge), mode=dcfgs.cd_mode,
-                                                alpha_arg=alpha, refit=refit, W2_host=W2_host)
+                                                alpha_arg=alpha, refit=refit, W2_host=W2_host, fixed_alpha=fixed)
     last_call_info.clear()
     ri = prob.refit_info
     last_call_info.update(fits=list(prob.fits), samples=prob.samples,
                           fallback=int(ri.fallback) if ri is not None else 0,
                           rank=int(ri.rank) if ri is not None else -1,
                           p=int(ri.p) if ri is not None else int(idxs.sum()) * prob.kk)
-    cfgs.alpha = alpha_out                               # decompose.py:626-627
+    if not dcfgs.autodet:
+        cfgs.alpha = alpha_out                           # decompose.py:626-627 (`if not norank`)
     return idxs, newW2, newB2
 
 

@@ -378,7 +378,7 @@ def itq_decompose_oracle(feature, gt_feature, weight, rank, bias=None, Wr=None):
 
 
 def dictionary_oracle(X, W2, Y, rank, B2=None, alpha=1e-4, alpha_in=1e-3, rank_tol=.1, rng=None,
-                      lasso="sklearn", ls="sklearn", ridge=0.0, log=None, refit="linear"):
+                      lasso="sklearn", ls="sklearn", ridge=0.0, log=None, refit="linear", autodet=False, layeralpha=1):
     """Restatement of lib/decompose.py:386-634 (live path).
 
     alpha_in plays the role of the module global ``cfgs.alpha`` on entry (decompose.py:491);
@@ -396,7 +396,13 @@ def dictionary_oracle(X, W2, Y, rank, B2=None, alpha=1e-4, alpha_in=1e-3, rank_t
     reY = Y[samples].reshape(-1)
     if log is not None:
         log.append(("samples", samples.copy()))
-    if rank == c:                                             # decompose.py:487-488
+    if autodet:                                               # decompose.py:395-397, 414-415, 582-585
+        alpha = alpha_in / c ** layeralpha
+        eng = _LassoEngine(Z, reY, lasso, rng)
+        idxs, rank, n_iter, seed = eng.solve(alpha)
+        if log is not None:
+            log.append(("fit", alpha, rank, n_iter, seed))
+    elif rank == c:                                           # decompose.py:487-488
         idxs = np.array([True] * rank)
     else:
         eng = _LassoEngine(Z, reY, lasso, rng)
@@ -435,6 +441,8 @@ def dictionary_oracle(X, W2, Y, rank, B2=None, alpha=1e-4, alpha_in=1e-3, rank_t
     else:
         newW2, newB2 = fc_kernel_oracle(X[:, idxs, ...].reshape((N, -1)), Y, ridge=ridge, engine=ls)
     newW2 = newW2.reshape((n, rank, h, w))                    # decompose.py:622-623
+    if autodet:
+        return idxs, newW2, newB2, alpha_in                   # `if not norank: cfgs.alpha = alpha` (decompose.py:626)
     return idxs, newW2, newB2, alpha                          # decompose.py:626-627, 634
 
 

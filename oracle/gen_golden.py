@@ -80,6 +80,8 @@ CASES = {
     # the reference's own 3C-4x d_c = int(c / 1.15) at c = 512 (net.py:1327, 1346): p = 4005+
     "L15_conv5_dc445": dict(layer_id=46, N=5000, c=512, n=512, k=3, rank=445, large=True),
     "s18_rank_tol_02": dict(layer_id=45, N=400, c=32, n=24, k=3, rank=16, rank_tol=.2),   # decompose.py:498-501
+    # dcfgs.autodet: no target rank, ONE fit at alpha = cfgs.alpha / c ** layeralpha (decompose.py:395-397, 414-415, 582-585)
+    "s19_autodet": dict(layer_id=49, N=400, c=32, n=24, k=3, rank=16, autodet=1, alpha_in=0.32),
     # ill-conditioned channel structure through the whole dictionary() call (X float64: conditioning beyond float32)
     "q01_mix_kappa1e4": dict(layer_id=51, N=1200, c=32, n=24, k=3, rank=16, mix=dict(kind="kappa", kappa=1e4)),
     "q02_mix_kappa1e6": dict(layer_id=52, N=1200, c=32, n=24, k=3, rank=16, mix=dict(kind="kappa", kappa=1e6)),
@@ -131,6 +133,7 @@ def run_reference(p):
     D.dcfgs.fc_ridge = p.get("fc_ridge", 0)
     D.dcfgs.nonlinear_fc = p.get("nonlinear_fc", 0)
     D.dcfgs.nofc = p.get("nofc", 0)
+    D.dcfgs.autodet = bool(p.get("autodet", 0))
     np.random.seed(1234 + p["layer_id"])
     state0 = np.random.get_state()
     Lasso.fit = logging_fit
@@ -144,6 +147,7 @@ def run_reference(p):
         D.dcfgs.dic.rank_tol = .1
         D.dcfgs.nonlinear_fc = 0
         D.dcfgs.nofc = 0
+        D.dcfgs.autodet = False
     alpha_out = float(cfgs.alpha)
     rng_next = int(np.random.randint(0, 2147483647))
     # recover `samples` (first draw) by replaying the stream

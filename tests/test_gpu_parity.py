@@ -273,6 +273,7 @@ def _run_dropin(p, X, W2, Y, B2, mode, exact_ops=False):
     dcfgs.fc_ridge = p.get("fc_ridge", 0)
     dcfgs.nonlinear_fc = p.get("nonlinear_fc", 0)
     dcfgs.nofc = p.get("nofc", 0)
+    dcfgs.autodet = bool(p.get("autodet", 0))
     dcfgs.cd_mode = mode
     np.random.seed(1234 + p["layer_id"])
     try:
@@ -281,6 +282,7 @@ def _run_dropin(p, X, W2, Y, B2, mode, exact_ops=False):
         dcfgs.fc_ridge = 0
         dcfgs.nonlinear_fc = 0
         dcfgs.nofc = 0
+        dcfgs.autodet = False
         dcfgs.dic.rank_tol = .1
         dcfgs.cd_mode = 'device'
         dcfgs.cd_reciprocal = dcfgs.cd_delta = 0      # the drop-in default: sklearn's operation sequence

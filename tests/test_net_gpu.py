@@ -433,3 +433,36 @@ def test_resnet_residual_target_matches_reference_net_py(ctx):
         assert int(np.random.randint(0, 2147483647)) == int(g["rng_next"])
     finally:
         dcfgs.model, dcfgs.res.short, dcfgs.dic.option = '', 0, cfgs.pruning_options.prb
+
+
+def test_dictionary_kernel_honours_the_refit_flags_of_dictionary(ctx):
+    """Net.dictionary_kernel goes through the body of lib.decompose.dictionary(): dcfgs.nonlinear_fc / nofc give the same
+    result on the Net path as calling dictionary() on the same operands (the reference routes both through dictionary(),
+    net.py:1728 -> decompose.py:615-620)."""
+    import lib.cfgs as cfgs
+    import lib.decompose as D
+    from lib.cfgs import c as dcfgs
+    net, _ = make_net(seed=4, nBatches=12, nPoints=8)
+    np.random.seed(21)
+    net.freeze_images(convs=net.convs)
+    X = net.extract_XY("conv2_1", "conv2_2")
+    newX = np.maximum(np.rollaxis(X.reshape((-1, 3, 3, X.shape[1])), 3, 1), 0)
+    W2, b2 = net.param_data("conv2_2"), net.param_b_data("conv2_2")
+    Y = net._feats_dict["conv2_2"] - b2
+    for flag in ("nonlinear_fc", "nofc"):
+        setattr(dcfgs, flag, 1)
+        try:
+            cfgs.alpha = 1e-3
+            np.random.seed(5)
+            ref = D.dictionary(newX, W2, Y, rank=16, B2=b2)
+            cfgs.alpha = 1e-3
+            np.random.seed(5)
+            got = net.dictionary_kernel("conv2_1", None, 16, "conv2_2", None)
+        finally:
+            setattr(dcfgs, flag, 0)
+        assert np.array_equal(got[0], ref[0])
+        assert np.allclose(got[1], ref[1], rtol=1e-9, atol=1e-12) and np.allclose(got[2], ref[2], rtol=1e-9, atol=1e-12)
+    cfgs.alpha = 1e-3
+    np.random.seed(5)
+    lin = net.dictionary_kernel("conv2_1", None, 16, "conv2_2", None)
+    assert not np.allclose(lin[1], got[1])      # the flags do change the answer

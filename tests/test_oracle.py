@@ -35,7 +35,8 @@ def run_oracle(name, lasso, ls):
     idxs, newW2, newB2, alpha_out = cp_oracle.dictionary_oracle(
         X.astype(np.float64), W2, Y, p["rank"], B2, alpha_in=p.get("alpha_in", 1e-3),
         rank_tol=p.get("rank_tol", .1), lasso=lasso, ls=ls, ridge=p.get("fc_ridge", 0.0), log=log,
-        refit="nonlinear" if p.get("nonlinear_fc") else ("none" if p.get("nofc") else "linear"))
+        refit="nonlinear" if p.get("nonlinear_fc") else ("none" if p.get("nofc") else "linear"),
+        autodet=bool(p.get("autodet", 0)))
     rng_next = int(np.random.randint(0, 2147483647))
     fits = np.array([(f[1], f[2], f[3]) for f in log if f[0] == "fit"], dtype=np.float64).reshape(-1, 3)
     return g, idxs, newW2, newB2, alpha_out, rng_next, fits
