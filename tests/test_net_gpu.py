@@ -466,3 +466,52 @@ def test_dictionary_kernel_honours_the_refit_flags_of_dictionary(ctx):
     np.random.seed(5)
     lin = net.dictionary_kernel("conv2_1", None, 16, "conv2_2", None)
     assert not np.allclose(lin[1], got[1])      # the flags do change the answer
+
+
+_ROCM_PROVIDER_SCRIPT = r'''
+import os, sys, json
+import torch                                   # BEFORE the first cpmi355 Context: the first HIP runtime in the process serves both
+ROOT = sys.argv[1]
+sys.path[:0] = [os.path.join(ROOT, "channel-pruning_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import numpy as np
+import portable_net
+import lib.cfgs as cfgs
+from lib.net import Net
+from lib.provider import TorchGraphProvider
+assert torch.cuda.is_available()
+g = np.load(os.path.join(ROOT, "tests/golden/n01_vgg_pruning.npz"))
+p = json.loads(str(g["params"]))
+layers, batches = portable_net.vgg_like(seed=p["seed"], chans=[tuple(c) for c in p["chans"]], B=p["B"], HW=p["HW"], nBatches=p["nBatches"])
+net = Net(None, TorchGraphProvider(layers, batches, device="cuda"), nBatches=p["nBatches"], nPointsPerLayer=p["nPoints"], graph=layers)
+ref = portable_net.forward(layers, batches[2])
+got = net.forward(2)
+err = max(float(np.abs(got[k] - v).max() / max(1.0, np.abs(v).max())) for k, v in ref.items())
+np.random.seed(3)
+net.freeze_images(convs=net.convs)
+cfgs.alpha = 1e-3
+np.random.seed(77)
+X_name, Y_name, d_prime = json.loads(str(g["pairs"]))[0]
+idxs, W2, B2 = net.dictionary_kernel(X_name, None, d_prime, Y_name, None)
+W = net.param_data(Y_name)
+res_new = np.linalg.norm(net._feats_dict[Y_name] - net.param_b_data(Y_name))
+print(json.dumps(dict(forward_err=err, kept=int(idxs.sum()), same_mask=bool(np.array_equal(idxs, g["idxs0"])),
+                      w_rel=float(np.linalg.norm(W2 - g["W0"]) / np.linalg.norm(g["W0"])))))
+'''
+
+
+def test_torch_rocm_provider_drives_the_facade():
+    """f3: the activation provider on torch-ROCm (lib/provider.py::TorchGraphProvider(device="cuda")) next to libcpmi355 in one
+    process (torch imported first).  Its float32 convolutions differ from the bit-portable forward pass in the last bits, so
+    the check is: blobs within 1e-5, and the pruning of the first pair lands on the reference's mask / weights up to what
+    that noise moves (masks are compared, not asserted equal)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _ROCM_PROVIDER_SCRIPT, ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["forward_err"] <= 1e-5
+    assert abs(out["kept"] - 22) <= 2
+    if out["same_mask"]:
+        assert out["w_rel"] <= 1e-3
