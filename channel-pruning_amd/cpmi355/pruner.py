@@ -21,18 +21,21 @@ RAND_R_MAX = 2147483647  # sklearn/linear_model/_cd_fast.pyx:26
 MAX_FITS = 64
 
 
-def precompute_flag(latency_mode):
+def precompute_flag(latency_mode, rank=None, c=None):
     """CP_REFIT_PRECOMPUTE: the normal equations over ALL c channels are computed on the device's side stream WHILE the
     (single-workgroup) alpha search runs; the refit then gathers the kept rows / columns and goes straight to the
     factorisation.  It costs (c / kept)^2 times the flops of the masked Gram, which is free when ONE layer has the chip
     to itself (the drop-in dictionary(): measured 18.8 -> 16.5 ms for a c = 512 layer) and a loss when many layers
     already fill it (the vgg16 job: 34.9 -> 37.2 ms) -- so: on for single-layer calls, off for batches / resident sets.
-    CP_REFIT_PRECOMPUTE=0 / 1 in the environment forces it."""
+    Only when at least 70 % of the channels are to be kept (full Gram <= 2x the masked one): at rank = c / 2 the 4x Gram
+    running next to the search slows the search itself (it reads Q from L2 every step: 96 -> 120 ns per step, conv3_x block
+    7.6 -> 10.3 ms).  CP_REFIT_PRECOMPUTE=0 / 1 in the environment forces it."""
     import os
     force = os.environ.get("CP_REFIT_PRECOMPUTE", "")
     if force in ("0", "1"):
         return capi.CP_REFIT_PRECOMPUTE if force == "1" else 0
-    return capi.CP_REFIT_PRECOMPUTE if latency_mode else 0
+    dense = rank is None or c is None or (rank < c and rank >= 0.7 * c)
+    return capi.CP_REFIT_PRECOMPUTE if latency_mode and dense else 0
 
 
 # ---- RNG bookkeeping on the host (it sits under the interpreter lock of every worker thread, so it has to be cheap) ----
@@ -188,7 +191,7 @@ class LayerProblem:
         seeds = draw_seeds(rng, MAX_FITS)
         res, idxs, W, b = self.ctx.prune_layer(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype,
                                                self.n, self.Yd, samples, alpha_right0, rank, lbound, rbound, seeds,
-                                               ridge, flags=self.flags | precompute_flag(latency_mode))
+                                               ridge, flags=self.flags | precompute_flag(latency_mode, rank, self.c))
         rng_rewind(rng, mark)
         if res.fits_used < 0:
             return None
