@@ -1,5 +1,6 @@
 """CPU: host-side logic of the product (no GPU compute): config mirror, Worker, layer sharding
 (world_size-2 gloo), RNG-stream bookkeeping of the alpha search, loud failure without a GPU."""
+import json
 import os
 import sys
 
@@ -478,3 +479,76 @@ def test_gpu_layer_batches_groups_by_width_and_keeps_layer_order(monkeypatch):
         assert draws == [int(np.random.RandomState(1234 + t).randint(0, 1 << 30)) for t in tags]
     assert sorted(freed) == list(range(7)) and len(closed) == 2                    # 2 siblings for batches of 3
     assert eng.alphas[4] == pytest.approx(0.4)
+
+
+def test_resident_layer_set_chunks_streams_and_latency_layers(monkeypatch):
+    """cpmi355.shard.ResidentLayerSet (device calls stubbed out): equal-width layers are cut into chunks of `per_stream`, every
+    chunk has its own context (= stream) + siblings and host thread, single-layer chunks go through prune_layer, the others
+    through prune_layers_batched, only the `precompute_heaviest` heaviest single-layer chunks run in latency mode, every run
+    restarts each layer's RNG stream, results come back in the order of the specs."""
+    from cpmi355 import capi, pruner, shard
+    created, calls = [], []
+
+    class FakeCtx:
+        def __init__(self, device=0, name=None):
+            self.name = name or "ctx%d" % len(created)
+            created.append(self.name)
+
+        def sibling(self):
+            return FakeCtx(name=self.name + "'")
+
+        def close(self):
+            pass
+
+    class FakeProb:
+        def __init__(self, ctx, X, W2, Y, flags=0):
+            self.ctx, self.tag, self.fits = ctx, X, []
+
+        def free(self):
+            pass
+
+    def fake_single(prob, rank, alpha_in, rank_tol=.1, rng=None, mode="device", latency_mode=True, **kw):
+        calls.append(("single", [prob.tag], latency_mode, [int(rng.randint(0, 1 << 30))]))
+        return np.array([True]), np.full((1, 1, 1, 1), prob.tag), np.zeros(1), 0.5
+
+    def fake_batched(probs, ranks, alpha_ins, rngs, rank_tol=.1):
+        calls.append(("batch", [p.tag for p in probs], False, [int(r.randint(0, 1 << 30)) for r in rngs]))
+        return [(np.array([True]), np.full((1, 1, 1, 1), p.tag), np.zeros(1), 0.5) for p in probs]
+
+    monkeypatch.setattr(capi, "Context", FakeCtx)
+    monkeypatch.setattr(pruner, "LayerProblem", FakeProb)
+    monkeypatch.setattr(pruner, "prune_layer", fake_single)
+    monkeypatch.setattr(pruner, "prune_layers_batched", fake_batched)
+    widths = [64, 64, 128, 256, 256, 256, 512, 512]
+    specs = [dict(layer_id=i, N=5000, c=c, n=c, k=3, rank=int(c / 1.15)) for i, c in enumerate(widths)]
+    rset = shard.ResidentLayerSet(0, specs, lambda s: (s["layer_id"], None, None), per_stream=2, precompute_heaviest=1)
+    try:
+        assert [len(ch["members"]) for ch in rset.chunks] == [2, 2, 1, 1, 2]          # widest first: 512x2 | 256x2, 256 | 128 | 64x2
+        assert len(created) == 5 + 3                                                  # a context per chunk + a sibling per extra layer
+        for _ in range(2):                                                            # repeated runs replay the same RNG streams
+            calls.clear()
+            out = rset.run()
+            assert [int(W[0, 0, 0, 0]) for _, W, _, _ in out] == list(range(8))
+            singles = [c for c in calls if c[0] == "single"]
+            assert sorted(c[1][0] for c in singles) == [2, 5] and sorted(tuple(c[1]) for c in calls if c[0] == "batch") == [(0, 1), (3, 4), (6, 7)]
+            assert [c[2] for c in singles if c[1] == [5]] == [True] and [c[2] for c in singles if c[1] == [2]] == [False]
+            for _, tags, _, draws in calls:
+                assert draws == [int(np.random.RandomState(1234 + t).randint(0, 1 << 30)) for t in tags]
+        assert [(r["c"], len(r["layers"])) for r in rset.chunk_report()] == [(512, 2), (256, 2), (256, 1), (128, 1), (64, 2)]
+    finally:
+        rset.close()
+
+
+def test_bench_vgg16_job_is_the_reference_rank_table():
+    """bench.py's whole-network job: d_c = max(int(c / 1.15), rank) with the reference's rank table x 4/3 (net.py:1309-1327,
+    1346-1349) for the 12 conv -> conv pairs; golden names V01..V12 exist for every layer."""
+    import bench
+    specs = bench.vgg16_specs()
+    assert [(s["c"], s["n"], s["rank"]) for s in specs] == [
+        (64, 64, 55), (64, 128, 55), (128, 128, 111), (128, 256, 111), (256, 256, 222), (256, 256, 222), (256, 512, 222),
+        (512, 512, 445), (512, 512, 445), (512, 512, 445), (512, 512, 445), (512, 512, 445)]
+    for s in specs:
+        g = np.load(os.path.join(ROOT, "tests", "golden", s["name"] + ".npz"))
+        p = json.loads(str(g["params"]))
+        assert (p["layer_id"], p["c"], p["n"], p["rank"], p["N"]) == (s["layer_id"], s["c"], s["n"], s["rank"], s["N"])
+        assert "newW2_sketch" in g.files and g["idxs"].shape == (s["c"],)
