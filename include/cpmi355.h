@@ -136,15 +136,21 @@ int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, const double *q
 /* ---- a5: least-squares refit ---------------------------------------------------- */
 typedef struct cp_refit_info {
     int32_t p;        /* columns = kept channels * kk */
-    int32_t rank;     /* numerical rank found (== p on the Cholesky path) */
-    int32_t fallback; /* 0 = Cholesky, 1 = rank-revealing minimum-norm path */
+    int32_t rank;     /* numerical rank: p on the Cholesky paths, gelsd's rank (sigma_i > max(N,p) eps sigma_max) on path 3,
+                         -1 on path 1 (not determined) */
+    int32_t fallback; /* 0 = Cholesky of the normal equations (every pivot above 1e-6 of its diagonal);
+                         2 = shifted-Cholesky-QR preconditioning, then Cholesky (ill-conditioned, full column rank);
+                         3 = preconditioning + two one-sided Jacobi decompositions: minimum-norm solution with gelsd's
+                             cut-off (rank-deficient: copies of channels, N <= p, ...);
+                         1 = iterated Tikhonov (ridge > 0, and the row-sharded tail, which never sees the rows) */
     int32_t reserved;
 } cp_refit_info;
 
 /* Replaces fc_kernel(X[:,idxs].reshape(N,-1), Y) (lib/decompose.py:622, 636-669):
  * LinearRegression(fit_intercept=True) -> centre, minimum-norm least squares
  * (scipy gelsd, cut-off max(N,p)*eps), intercept = ybar - xbar.coef^T; ridge > 0 selects
- * the Ridge branch (decompose.py:662-663).  X DEVICE [N,c,kk] (x_dtype), mask HOST
+ * the Ridge branch (decompose.py:662-663).  As accurate as gelsd (error ~ cond * eps) whatever the
+ * conditioning: see cp_refit_info.fallback.  X DEVICE [N,c,kk] (x_dtype), mask HOST
  * uint8[c] (non-zero = keep), Y DEVICE [N,n] f64.  Outputs DEVICE: W_out [n, p] f64
  * (p = kept*kk, caller reshapes to [n, kept, k, k]), b_out [n] f64; info HOST. */
 int cp_lstsq_refit(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk,
