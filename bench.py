@@ -9,7 +9,7 @@ weights, bias) back on the host inside it:
     count d_c = max(int(c / 1.15), rank) (/root/reference/lib/net.py:1309-1327, 1346-1349), N = 5000 samples per
     layer.  One job = 12 dictionary() problems (c = 64, 64, 128, 128, 256 x3, 512 x5).  With --gpus N the layers are
     sharded over the ranks (cpmi355.shard.prune_sharded: LPT assignment, ONE uint8 all_gather of the channel masks and
-    one packed (W, b) broadcast per owner rank on RCCL) -- STRONG scaling: the same 12 layers whatever N is.  On a rank
+    ONE all_gather of the owners' packed (W, b) on RCCL) -- STRONG scaling: the same 12 layers whatever N is.  On a rank
     all its layers are in flight together (cpmi355.shard.ResidentLayerSet: a HIP stream + host thread per chunk of
     equal-width layers, the alpha searches of a chunk as the workgroups of one launch).
     A "step" is `jobs_per_step` back-to-back jobs (chosen during warm-up so that the timed region is >= 2 s);
@@ -42,7 +42,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
 
 N_SAMPLES, KSIZE = 5000, 3
-CD_FLAGS = int(os.environ.get("CP_BENCH_CD_FLAGS", "3"))   # CP_CD_RECIPROCAL | CP_CD_DELTA (library default)
+# 0 = sklearn's own operation order in the CD step (the drop-in's default, lib/cfgs.py); 3 = CP_CD_RECIPROCAL | CP_CD_DELTA
+# (rounding-level differences, same masks on every golden, ~4 % faster job)
+CD_FLAGS = int(os.environ.get("CP_BENCH_CD_FLAGS", "0"))
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X public FP64 matrix figure (the guide lists no f64 row); the
                               # measured v_mfma_f64_16x16x4_f64 issue rate is reported next to it
 MIN_TIMED_SECONDS = 2.0
@@ -264,13 +266,14 @@ def bench_vgg16(args, env):
 
     t_up0 = time.perf_counter()
     rset = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in own], operands, per_stream=args.per_stream,
-                                  flags=CD_FLAGS)
+                                  flags=CD_FLAGS, borrow_results=True)
     probs = rset.problems()           # index in `own` order -> LayerProblem
     ctxs = [cx for ch in rset.chunks for cx in ch["ctxs"]]
     roots = [ch["ctxs"][0] for ch in rset.chunks]
 
     def one_job():
-        return shard.prune_sharded(specs, compute_many=rset, dist=env.dist, owner=owner)
+        return shard.prune_sharded(specs, compute_many=rset, dist=env.dist, owner=owner,
+                                   staging="device" if env.dist is not None else None)
 
     def sync_all():
         for cx in roots:
@@ -291,13 +294,15 @@ def bench_vgg16(args, env):
 
     for cx in ctxs:
         cx.enable_stage_timing(2)      # timed region: only the two events around the roofline kernel
-    g_ms, g_fl = [], []
+    g_ms, g_fl, exch_ms = [], [], []
     sync_all()
     env.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for _ in range(reps):
             results = one_job()
+            if env.dist is not None:
+                exch_ms.append(shard.LAST_EXCHANGE_MS.get("total", 0.0))
             for j, pr in probs.items():
                 for name, ms in pr.ctx.last_stage_times():
                     if name == "refit_gram_gemm":
@@ -309,6 +314,8 @@ def bench_vgg16(args, env):
     jobs = args.steps * reps
     job_ms = elapsed / jobs * 1e3
     chunk_report = rset.chunk_report()
+    # the layers of this rank are views of their contexts' result blocks (borrow_results): keep them past the runs below
+    results = [(m, np.array(W), np.array(b)) for m, W, b in results]
 
     # ---- outside the timed region: every layer of this rank ALONE (latency, per-stage times, roofline kernel alone) ----
     per_layer = {}
@@ -402,8 +409,12 @@ def bench_vgg16(args, env):
                        "streams_per_gpu": len(rset.chunks), "layers_in_flight_per_gpu": len(own),
                        "layers_per_call": sorted({len(ch["members"]) for ch in rset.chunks}),
                        "owner_rank_of_layer": owner, "parallelism": "layers sharded x%d (LPT), masks all_gather + "
-                                                                    "packed (W,b) broadcast per owner" % env.world},
+                                                                    "ONE all_gather of the packed (W,b)" % env.world},
             "job_ms": round(job_ms, 3),
+            "exchange_rank0": None if not exch_ms else dict(
+                {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard.LAST_EXCHANGE_MS.items()},
+                avg_total_ms=round(float(np.mean(exch_ms)), 3),
+                note="host wall time of cpmi355.shard.exchange_results on rank 0 (includes waiting for the slowest rank)"),
             "mask_parity_vs_reference_golden": parity,
             "weights_rel_frobenius_vs_reference_golden": werrs,
             "reconstruction_rel_frobenius_err": recon,

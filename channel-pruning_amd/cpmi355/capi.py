@@ -101,6 +101,8 @@ SIGNATURES = {
                                 _c_dbl, _c_dbl, _c_dbl, _c_dbl, _vp, _c_int, _c_int, _c_dbl, _c_int, _c_dbl,
                                 _vp, _vp, _vp, ctypes.POINTER(PruneResult)]),
     "cp_prune_layers": (_c_int, [_c_int, ctypes.POINTER(_vp), _vp, _vp]),
+    "cp_result_host": (_c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_c_int),
+                                ctypes.POINTER(_c_int)]),
     "cp_probe_mfma_f64": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
     "cp_probe_hbm_copy": (_c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_c_dbl)]),
     "cp_last_stage_times": (_c_int, [_vp, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_float)]),
@@ -384,16 +386,38 @@ class Context:
             for bfr in (Fd, Gd, Td, yd, ud):
                 bfr.free()
 
+    def result_host(self):
+        """(W [n, p], b [n]) of the last prune_layer on this context as VIEWS of the context's page-locked result
+        block (cp_result_host): no copy, DMA-able; valid until the next call on the context / its close()."""
+        pb, pw, n, p = _vp(), _vp(), _c_int(), _c_int()
+        self._check(self.lib.cp_result_host(self.h, ctypes.byref(pb), ctypes.byref(pw), ctypes.byref(n),
+                                            ctypes.byref(p)), "cp_result_host")
+        b = np.frombuffer((ctypes.c_double * n.value).from_address(pb.value), dtype=np.float64)
+        W = np.frombuffer((ctypes.c_double * (n.value * p.value)).from_address(pw.value), dtype=np.float64)
+        return W.reshape(n.value, p.value), b
+
     def prune_layer(self, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, alpha_right0, rank, lbound, rbound,
-                    seeds, ridge, flags=0, max_iter=1000, tol=1e-4):
+                    seeds, ridge, flags=0, max_iter=1000, tol=1e-4, borrow=False):
         """One dictionary() worth of device work in a single foreign call (cp_prune_layer).
-        -> (PruneResult, mask bool[c], W f64[n, p], b f64[n]); res.fits_used == -1: search did not settle."""
+        -> (PruneResult, mask bool[c], W f64[n, p], b f64[n]); res.fits_used == -1: search did not settle.
+        borrow: W, b are result_host() views instead of fresh arrays."""
         samples = np.ascontiguousarray(samples, dtype=np.int64)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
         mask = np.zeros(int(c), dtype=np.uint8)
+        res = PruneResult()
+        if borrow:
+            self._check(self.lib.cp_prune_layer(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), _ptr(W2), w_dtype,
+                                                int(n), _ptr(Y), samples.ctypes.data, int(samples.shape[0]),
+                                                float(alpha_right0), float(rank), float(lbound), float(rbound),
+                                                seeds.ctypes.data, int(seeds.shape[0]), int(max_iter), float(tol),
+                                                int(flags), float(ridge), mask.ctypes.data, None, None,
+                                                ctypes.byref(res)), "cp_prune_layer")
+            if res.fits_used < 0:
+                return res, None, None, None
+            W, b = self.result_host()
+            return res, mask.astype(bool), W, b
         W = np.empty(int(n) * int(c) * int(kk), dtype=np.float64)
         b = np.empty(int(n), dtype=np.float64)
-        res = PruneResult()
         self._check(self.lib.cp_prune_layer(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), _ptr(W2), w_dtype,
                                             int(n), _ptr(Y), samples.ctypes.data, int(samples.shape[0]),
                                             float(alpha_right0), float(rank), float(lbound), float(rbound),
@@ -417,8 +441,9 @@ class Context:
             seeds = np.ascontiguousarray(j["seeds"], dtype=np.uint32)
             c, n, kk = int(j["c"]), int(j["n"]), int(j["kk"])
             mask = np.zeros(c, dtype=np.uint8)
-            W = np.empty(n * c * kk, dtype=np.float64)
-            b = np.empty(n, dtype=np.float64)
+            borrow = bool(j.get("borrow", False))
+            W = None if borrow else np.empty(n * c * kk, dtype=np.float64)
+            b = None if borrow else np.empty(n, dtype=np.float64)
             keep.append((samples, seeds, mask, W, b))
             a = arr[i]
             a.X, a.x_dtype, a.c, a.N, a.kk = _ptr(j["X"]), j["x_dtype"], c, int(j["N"]), kk
@@ -427,7 +452,8 @@ class Context:
             a.lbound, a.rbound, a.seeds = float(j["lbound"]), float(j["rbound"]), seeds.ctypes.data
             a.max_fits, a.max_iter, a.tol = seeds.shape[0], int(j.get("max_iter", 1000)), float(j.get("tol", 1e-4))
             a.flags, a.ridge = int(j.get("flags", 0)), float(j.get("ridge", 0.0))
-            a.mask_out, a.W_out, a.b_out = mask.ctypes.data, W.ctypes.data, b.ctypes.data
+            a.mask_out = mask.ctypes.data
+            a.W_out, a.b_out = (None, None) if borrow else (W.ctypes.data, b.ctypes.data)
             ctxs[i] = j["ctx"].h
         res = (PruneResult * B)()
         ctx0 = jobs[0]["ctx"]
@@ -437,6 +463,9 @@ class Context:
             r = res[i]
             if r.fits_used < 0:
                 out.append((r, None, None, None))
+            elif W is None:
+                Wv, bv = jobs[i]["ctx"].result_host()
+                out.append((r, mask.astype(bool), Wv, bv))
             else:
                 n, p = int(jobs[i]["n"]), int(r.p)
                 out.append((r, mask.astype(bool), W[:n * p].reshape(n, p), b))

@@ -191,7 +191,8 @@ class LayerProblem:
         seeds = draw_seeds(rng, MAX_FITS)
         res, idxs, W, b = self.ctx.prune_layer(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype,
                                                self.n, self.Yd, samples, alpha_right0, rank, lbound, rbound, seeds,
-                                               ridge, flags=self.flags | precompute_flag(latency_mode, rank, self.c))
+                                               ridge, flags=self.flags | precompute_flag(latency_mode, rank, self.c),
+                                               borrow=getattr(self, "borrow_results", False))
         rng_rewind(rng, mark)
         if res.fits_used < 0:
             return None
@@ -335,7 +336,7 @@ def prune_layers_batched(probs, ranks, alpha_ins, rngs, rank_tol=.1, ridge=0.0, 
         jobs.append(dict(ctx=prob.ctx, X=prob.Xd, x_dtype=prob.x_dtype, N=prob.N, c=prob.c, kk=prob.kk, W2=prob.W2d,
                          w_dtype=prob.w_dtype, n=prob.n, Y=prob.Yd, samples=samples, alpha_right0=alpha_in, rank=rank,
                          lbound=lbound, rbound=rbound, seeds=seeds, ridge=ridge,
-                         flags=prob.flags | precompute_flag(False)))
+                         flags=prob.flags | precompute_flag(False), borrow=getattr(prob, "borrow_results", False)))
     raw = capi.Context.prune_layers(jobs)
     out = []
     for i, (prob, rank, alpha_in, rng) in enumerate(zip(probs, ranks, alpha_ins, rngs)):

@@ -8,8 +8,8 @@ hundred bytes each, plus the reconstructed weights) over torch.distributed -- ba
 
     assign_layers(costs, world)        longest-processing-time-first assignment
     layer_cost(N, c, n, k, rank)       FLOP model of SURVEY.md section 8d (plus the serial CD term)
-    prune_sharded(specs, compute_fn)   run this rank's share, then exchange_results(): one mask all_gather + one packed
-                                       (W, b) broadcast per owner rank
+    prune_sharded(specs, compute_fn)   run this rank's share, then exchange_results(): one mask all_gather + one
+                                       all_gather of the owners' packed (W, b)
     GpuLayerBatches(ctx, operands)     compute_many for it: equal-width layers through cp_prune_layers, up to 16 at a time
     ResidentLayerSet(device, specs, ..) the same with the operands resident in HBM and every width group on its own
                                        stream(s) + host thread, all in flight together (bench.py --workload vgg16)
@@ -61,7 +61,7 @@ class GpuLayerBatches:
         from . import capi
         self.ctx, self.operands, self.seed = ctx, operands, seed
         self.max_batch, self.alpha_in, self.rank_tol = int(max_batch), alpha_in, rank_tol
-        self.flags = (capi.CP_CD_RECIPROCAL | capi.CP_CD_DELTA) if flags is None else flags
+        self.flags = 0 if flags is None else flags      # 0 = sklearn's operation order (capi.CP_CD_* trade it for speed)
         self.alphas = {}
 
     def __call__(self, specs):
@@ -105,19 +105,21 @@ class ResidentLayerSet:
     host thread, so all chunks -- all widths -- are in flight together: the alpha searches of a chunk are the
     workgroups of one launch, the refits of different chunks overlap.  Operands are uploaded once (constructor);
     run() prunes every layer once and returns [(idxs, newW2, newB2, alpha), ...] in the order of `specs`; parity is
-    per layer (own RandomState(seed(spec)), fixed alpha_in: SURVEY.md section 8e).
+    per layer (own RandomState(seed(spec)), fixed alpha_in: SURVEY.md section 8e).  borrow_results: newW2 / newB2 are
+    views of each layer's page-locked result block (Context.result_host) instead of fresh arrays -- no host copy, and
+    exchange_results DMAs straight from them; they are valid until the next run() / close().
 
         operands(spec) -> (X[N,c,k,k], W2[n,c,k,k], Y[N,n]) host arrays, called once per layer."""
 
     def __init__(self, device, specs, operands, seed=lambda s: 1234 + s["layer_id"], per_stream=2, alpha_in=1e-3,
-                 rank_tol=.1, flags=None, precompute_heaviest=None):
+                 rank_tol=.1, flags=None, precompute_heaviest=None, borrow_results=False):
         import threading
 
         from . import capi
         from .pruner import LayerProblem, rng_mark
         self.specs = list(specs)
         self.alpha_in, self.rank_tol = alpha_in, rank_tol
-        flags = (capi.CP_CD_RECIPROCAL | capi.CP_CD_DELTA) if flags is None else flags
+        flags = 0 if flags is None else flags           # 0 = sklearn's operation order (capi.CP_CD_* trade it for speed)
         by_width = {}
         for i, s in enumerate(self.specs):
             by_width.setdefault(int(s["c"]), []).append(i)
@@ -132,6 +134,7 @@ class ResidentLayerSet:
                 for cx, i in zip(ctxs, group):
                     X, W2, Y = operands(self.specs[i])
                     probs.append(LayerProblem(cx, X, W2, Y, flags=flags))
+                    probs[-1].borrow_results = bool(borrow_results)
                     rngs.append(np.random.RandomState(seed(self.specs[i])))
                 self.chunks.append(dict(members=group, ctxs=ctxs, probs=probs, rngs=rngs,
                                         marks=[rng_mark(r) for r in rngs], go=threading.Event(), done=threading.Event(),
@@ -228,51 +231,111 @@ def capi_max_jobs():
     return 16      # CP_MAX_JOBS (include/cpmi355.h)
 
 
-def exchange_results(specs, owner, mine, dist, device=None):
-    """Every rank ends with every layer's (mask, W, b).  Two collectives on the data the job produces:
-    (1) ONE fixed-size uint8 all_gather of the channel masks (the "trivial gather of selected-channel masks"),
-    (2) per owner rank ONE broadcast of its packed float64 results (all its W and b back to back; sizes follow from
-    the masks, so nothing else has to be negotiated).  backend "nccl" = RCCL over xGMI: the packed buffer is staged to
-    the device once per owner; "gloo": host tensors."""
+def _all_gather_rows(dist, local):
+    """(world,) + local.shape, on local's device.  "nccl" (= RCCL): ONE all_gather_into_tensor on device memory over
+    xGMI -- all seven links of a GPU carry traffic at once, unlike a ring broadcast per owner; any other backend
+    (gloo: CPU tests, several ranks on one GPU) is staged through host tensors."""
     import torch
+    world = dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    host = local.cpu().contiguous()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host)
+    return torch.stack(parts).to(local.device)
+
+
+def result_segments(specs, owner, masks, world):
+    """Packed layout of the exchange: owner r's segment = its layers in layer order, each as W [n, kept, k, k] then b [n]
+    (float64 elements).  -> (shapes per layer, offset of every layer inside its owner's segment, segment length per rank)."""
+    shapes = [(int(s["n"]), int(np.count_nonzero(m)), int(s["k"]), int(s["k"])) for s, m in zip(specs, masks)]
+    seg = [0] * world
+    offs = [0] * len(specs)
+    for i, s in enumerate(specs):
+        offs[i] = seg[owner[i]]
+        seg[owner[i]] += int(np.prod(shapes[i])) + int(s["n"])
+    return shapes, offs, seg
+
+
+LAST_EXCHANGE_MS = {}      # wall time of the phases of this process's last exchange_results (host clock)
+
+
+def exchange_results(specs, owner, mine, dist, device=None, staging=None):
+    """Every rank ends with every layer's (mask, W, b) on the host.  Two collectives on the data the job produces:
+    (1) ONE fixed-size uint8 all_gather of the channel masks (the "trivial gather of selected-channel masks"); the
+    sizes of everything else follow from them, so nothing has to be negotiated;
+    (2) ONE all_gather of the owners' packed float64 results (result_segments), padded to the longest segment.
+    staging "device" (default with backend "nccl" = RCCL over xGMI): this rank's (W, b) go host -> HBM once (a DMA
+    straight out of the page-locked result blocks when the ResidentLayerSet lends them: borrow_results), the gather
+    runs between the GPUs, and the other ranks' segments come back through ONE page-locked host buffer whose slices
+    are the returned arrays.  staging "host" (default otherwise): NumPy buffers through the backend."""
+    import time
+
+    import torch
+    t_begin = time.perf_counter()
     world, rank = dist.get_world_size(), dist.get_rank()
-    on_gpu = dist.get_backend() == "nccl"
+    if staging is None:
+        staging = "device" if dist.get_backend() == "nccl" else "host"
+    on_gpu = staging == "device"
     dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
     cmax = max(s["c"] for s in specs)
-    local = torch.zeros((len(specs), cmax), dtype=torch.uint8)
+    local = np.zeros((len(specs), cmax), dtype=np.uint8)
     for i, (idxs, _, _) in mine.items():
-        local[i, : idxs.shape[0]] = torch.from_numpy(idxs.astype(np.uint8))
-    local = local.to(dev)
-    gathered = torch.empty((world,) + tuple(local.shape), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(gathered, local) if on_gpu else dist.all_gather(list(gathered.unbind(0)), local)
-    gathered = gathered.cpu().numpy()
+        local[i, : idxs.shape[0]] = idxs
+    gathered = _all_gather_rows(dist, torch.from_numpy(local).to(dev)).cpu().numpy()
     masks = [gathered[owner[i], i, : specs[i]["c"]].astype(bool) for i in range(len(specs))]
-    shapes = [(s["n"], int(m.sum()), s["k"], s["k"]) for s, m in zip(specs, masks)]
-    results = [None] * len(specs)
-    for src in range(world):
-        ids = [i for i in range(len(specs)) if owner[i] == src]
-        if not ids:
-            continue
-        total = sum(int(np.prod(shapes[i])) + specs[i]["n"] for i in ids)
-        if src == rank:
-            packed = np.concatenate([np.concatenate([np.asarray(mine[i][1], dtype=np.float64).ravel(),
-                                                     np.asarray(mine[i][2], dtype=np.float64).ravel()]) for i in ids])
-            t = torch.from_numpy(packed).to(dev)
-        else:
-            t = torch.empty(total, dtype=torch.float64, device=dev)
-        dist.broadcast(t, src=src)
-        flat = t.cpu().numpy()
-        off = 0
-        for i in ids:
+    shapes, offs, seg = result_segments(specs, owner, masks, world)
+    maxseg = max(1, max(seg))
+    t_masks = time.perf_counter()
+    t_gather = t_masks
+    if on_gpu:
+        send = torch.empty(maxseg, dtype=torch.float64, device=dev)
+        for i, (_, W, b) in mine.items():
             nw = int(np.prod(shapes[i]))
-            W = flat[off:off + nw].reshape(shapes[i])
-            b = flat[off + nw:off + nw + specs[i]["n"]]
-            off += nw + specs[i]["n"]
-            results[i] = (masks[i], W, b)
+            send[offs[i]:offs[i] + nw].copy_(torch.from_numpy(np.ascontiguousarray(W).reshape(-1)), non_blocking=True)
+            send[offs[i] + nw:offs[i] + nw + specs[i]["n"]].copy_(torch.from_numpy(np.ascontiguousarray(b)), non_blocking=True)
+        every = _all_gather_rows(dist, send)
+        if LAST_EXCHANGE_MS.get("split"):
+            torch.cuda.current_stream(dev).synchronize()
+        t_gather = time.perf_counter()
+        starts, total = {}, 0
+        for r in range(world):
+            if r != rank and seg[r]:
+                starts[r] = total
+                total += seg[r]
+        back = torch.empty(max(1, total), dtype=torch.float64, pin_memory=True)
+        for r, st in starts.items():
+            back[st:st + seg[r]].copy_(every[r, :seg[r]], non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        flat = back.numpy()
+    else:
+        send = np.zeros(maxseg, dtype=np.float64)
+        for i, (_, W, b) in mine.items():
+            nw = int(np.prod(shapes[i]))
+            send[offs[i]:offs[i] + nw] = np.asarray(W).reshape(-1)
+            send[offs[i] + nw:offs[i] + nw + specs[i]["n"]] = b
+        every = _all_gather_rows(dist, torch.from_numpy(send)).numpy()
+        starts = {r: r * maxseg for r in range(world)}
+        flat = every.reshape(-1)
+    results = [None] * len(specs)
+    for i, s in enumerate(specs):
+        if owner[i] == rank:
+            results[i] = (masks[i], np.asarray(mine[i][1]).reshape(shapes[i]), np.asarray(mine[i][2]))
+            continue
+        o = starts[owner[i]] + offs[i]
+        nw = int(np.prod(shapes[i]))
+        results[i] = (masks[i], flat[o:o + nw].reshape(shapes[i]), flat[o + nw:o + nw + s["n"]])
+    t_end = time.perf_counter()
+    LAST_EXCHANGE_MS.update(total=(t_end - t_begin) * 1e3, masks=(t_masks - t_begin) * 1e3,
+                            pack_and_gather=(t_gather - t_masks) * 1e3, back_to_host=(t_end - t_gather) * 1e3,
+                            bytes_sent=int(seg[rank]) * 8, bytes_received=int(sum(seg) - seg[rank]) * 8,
+                            padded_segment_bytes=int(maxseg) * 8)
     return results
 
 
-def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None, owner=None):
+def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None, owner=None, staging=None):
     """specs: list of dicts with at least N, c, n, k, rank; compute_fn(spec) -> (idxs, W, b), or
     compute_many(list of this rank's specs) -> list of (idxs, W, b) (a GpuLayerBatches or a ResidentLayerSet).
     Every rank returns the full list of results in layer order.  `dist` is an initialised
@@ -292,7 +355,7 @@ def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=N
         mine[i] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
     if dist is None or world == 1:
         return [mine[i] for i in range(len(specs))]
-    return exchange_results(specs, owner, mine, dist, device)
+    return exchange_results(specs, owner, mine, dist, device, staging)
 
 
 def plan_owners(specs, world):

@@ -52,6 +52,7 @@ struct cp_ctx {
     // per-layer outputs of cp_prune_layer (Q, q, stats, w, W, b): persistent across its sub-calls
     char *layer_ws = nullptr;
     size_t layer_ws_bytes = 0;
+    int result_n = 0, result_p = 0;    // shape of the (b, W) the last cp_prune_layer left in the pinned block
     double host_ms[4] = {0, 0, 0, 0};  // host wall time of the phases of the last cp_prune_layer
     double wait_ms = 0;                // of which: blocked in cp_stream_wait (running total)
     // pinned host staging for small D2H results

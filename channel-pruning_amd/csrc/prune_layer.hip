@@ -39,19 +39,33 @@ extern "C" int cp_debug_host_times(cp_ctx *ctx, double *out4) {
     return CP_OK;
 }
 
+// The (b, W) of the last cp_prune_layer / cp_prune_layers job on this context, where the last refit kernel left them:
+// the context's pinned host block.  Valid until the next call on the context.
+extern "C" int cp_result_host(cp_ctx *ctx, const double **b, const double **W, int *n, int *p) {
+    if (!ctx || !b || !W || !n || !p) return CP_ERR_ARG;
+    if (!ctx->pinned || ctx->result_n <= 0) return cp_set_error(ctx, CP_ERR_ARG, "cp_result_host: no result on this context");
+    const double *b_host = reinterpret_cast<const double *>(ctx->pinned + 64);
+    *b = b_host;
+    *W = b_host + ctx->result_n;
+    *n = ctx->result_n;
+    *p = ctx->result_p;
+    return CP_OK;
+}
+
 extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const void *W2,
                               int w_dtype, int n, const double *Y, const int64_t *samples, int S,
                               double alpha_right0, double rank, double lbound, double rbound,
                               const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
                               double ridge, uint8_t *mask_out, double *W_out, double *b_out,
                               cp_prune_result *res) {
-    if (!ctx || !X || !W2 || !Y || !mask_out || !W_out || !b_out || !res)
+    if (!ctx || !X || !W2 || !Y || !mask_out || !res || (W_out == nullptr) != (b_out == nullptr))
         return ctx ? cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer: null argument") : CP_ERR_ARG;
     if (c <= 0 || n <= 0 || kk <= 0 || N <= 0 || max_fits < 0 || max_fits > CP_MAX_FITS)
         return cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer: bad size (c=%d n=%d kk=%d N=%lld max_fits=%d)", c, n, kk,
                             (long long)N, max_fits);
     CP_HIP(ctx, hipSetDevice(ctx->device));
     memset(res, 0, sizeof(*res));
+    ctx->result_n = 0;
     const size_t cc = size_t(c);
     const size_t n_q = cp_align_up(cc * cc, 32), n_v = cp_align_up(cc, 32), n_w = cp_align_up(size_t(n) * cc * kk, 32),
                  n_b = cp_align_up(size_t(n), 32);
@@ -101,8 +115,12 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     res->fallback = info.fallback;
     // the last kernel of the refit wrote b and W into the pinned block itself
     const double *b_host = reinterpret_cast<const double *>(ctx->pinned + 64);
-    memcpy(b_out, b_host, size_t(n) * sizeof(double));
-    memcpy(W_out, b_host + n, size_t(n) * size_t(info.p) * sizeof(double));
+    ctx->result_n = n;
+    ctx->result_p = info.p;
+    if (W_out) {  // else: borrowed through cp_result_host
+        memcpy(b_out, b_host, size_t(n) * sizeof(double));
+        memcpy(W_out, b_host + n, size_t(n) * size_t(info.p) * sizeof(double));
+    }
     ctx->host_ms[3] = now_ms() - t3;  // copies back + last wait
     return CP_OK;
 }
@@ -119,7 +137,7 @@ extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_j
     if (n_jobs > CP_MAX_JOBS) return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: at most %d jobs per call (got %d)", CP_MAX_JOBS, n_jobs);
     for (int l = 0; l < n_jobs; ++l) {
         const cp_prune_job &j = jobs[l];
-        if (!ctxs[l] || !j.X || !j.W2 || !j.Y || !j.mask_out || !j.W_out || !j.b_out)
+        if (!ctxs[l] || !j.X || !j.W2 || !j.Y || !j.mask_out || (j.W_out == nullptr) != (j.b_out == nullptr))
             return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: null argument in job %d", l);
         if (ctxs[l]->stream != ctx0->stream || ctxs[l]->device != ctx0->device)
             return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: the contexts of a batch must share one stream "
@@ -234,8 +252,12 @@ extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_j
         results[l].refit_rank = info[l].rank;
         results[l].fallback = info[l].fallback;
         const double *b_host = reinterpret_cast<const double *>(ctx->pinned + 64);
-        memcpy(j.b_out, b_host, size_t(j.n) * sizeof(double));
-        memcpy(j.W_out, b_host + j.n, size_t(j.n) * size_t(info[l].p) * sizeof(double));
+        ctx->result_n = j.n;
+        ctx->result_p = info[l].p;
+        if (j.W_out) {
+            memcpy(j.b_out, b_host, size_t(j.n) * sizeof(double));
+            memcpy(j.W_out, b_host + j.n, size_t(j.n) * size_t(info[l].p) * sizeof(double));
+        }
     }
     return CP_OK;
 }

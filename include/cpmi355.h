@@ -239,13 +239,19 @@ typedef struct cp_prune_result {
  * int64[S]; seeds HOST uint32[max_fits] pre-drawn by the caller, who rewinds its RNG and
  * re-draws res->fits_used of them; lbound/rbound as decompose.py:493-501 computes them.
  * rank >= c skips the LASSO (decompose.py:487-488).  Outputs HOST: mask_out uint8[c],
- * W_out f64 [n, p] (capacity n*c*kk), b_out f64 [n], res.  Synchronises the stream. */
+ * W_out f64 [n, p] (capacity n*c*kk), b_out f64 [n], res.  Synchronises the stream.
+ * W_out == b_out == NULL: the results are not copied; borrow them with cp_result_host. */
 int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const void *W2,
                    int w_dtype, int n, const double *Y, const int64_t *samples, int S,
                    double alpha_right0, double rank, double lbound, double rbound,
                    const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
                    double ridge, uint8_t *mask_out, double *W_out, double *b_out,
                    cp_prune_result *res);
+
+/* HOST pointers to the b [n] and W [n, p] of the last cp_prune_layer (or cp_prune_layers job) on this context, in
+ * the context's page-locked result block, where the last refit kernel wrote them: no copy, DMA-able, valid until the
+ * next call on the context.  No reference counterpart (dictionary() returns fresh arrays, lib/decompose.py:634). */
+int cp_result_host(cp_ctx *ctx, const double **b, const double **W, int *n, int *p);
 
 /* The same for several independent layers at once (e.g. the equal-shaped layers of a ResNet stage, or one layer of
  * several networks): jobs[i] is exactly the argument list of cp_prune_layer.  All jobs must have the same channel

@@ -716,14 +716,15 @@ def test_prune_sharded_with_gpu_batches_matches_reference_golden(ctx):
         assert engine.alphas[s["layer_id"]] == float(g["alpha_out"]), nm
 
 
-def test_resident_layer_set_vgg16_job_matches_reference_goldens():
+@pytest.mark.parametrize("flags", [0, 3])
+def test_resident_layer_set_vgg16_job_matches_reference_goldens(flags):
     """The whole-network job of bench.py --workload vgg16 (12 conv->conv pairs, kept channels int(c/1.15), N=5000) through
     cpmi355.shard.ResidentLayerSet -- all widths in flight together on their own streams -- against the reference
     goldens V01..V12: masks and per-fit logs identical, weights <= 1e-5 (sketch estimate), twice (runs are repeatable)."""
     import bench
     from cpmi355 import shard
     specs = bench.vgg16_specs()
-    rset = shard.ResidentLayerSet(0, specs, lambda s: bench.synth(s["layer_id"], s["c"], s["n"])[:3], per_stream=2, flags=3)
+    rset = shard.ResidentLayerSet(0, specs, lambda s: bench.synth(s["layer_id"], s["c"], s["n"])[:3], per_stream=2, flags=flags)
     try:
         first = None
         for _ in range(2):
@@ -742,17 +743,27 @@ def test_resident_layer_set_vgg16_job_matches_reference_goldens():
             else:
                 for a, b_ in zip(first, res):
                     assert np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2])   # bitwise run to run
+        for pr in rset.problems().values():          # lent result blocks (cp_result_host) instead of copies
+            pr.borrow_results = True
+        lent = rset.run()
+        for a, b_ in zip(first, lent):
+            assert not b_[1].flags.owndata and a[1].shape == b_[1].shape
+            assert np.array_equal(a[0], b_[0]) and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2])
     finally:
         rset.close()
 
 
-def _nccl_worker(rank, world, port, q):
+def _nccl_worker(rank, world, port, q, backend="nccl"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+    gpu = rank if backend == "nccl" else 0          # "gloo": both ranks on GPU 0 (RCCL refuses to share a device)
+    torch.cuda.set_device(gpu)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     import cp_oracle
     from cpmi355 import shard
     names = ["s01_c32_k3", "s02_c64_k3", "s06_dead", "s12_c96_n40", "s04_c48_dc", "s03_c64_k1"]
@@ -765,20 +776,40 @@ def _nccl_worker(rank, world, port, q):
         specs.append(dict(layer_id=p["layer_id"], name=nm, N=p["N"], c=p["c"], n=p["n"], k=p["k"], rank=p["rank"]))
     owner = shard.plan_owners(specs, world)
     own = [s for s, o in zip(specs, owner) if o == rank]
-    rset = shard.ResidentLayerSet(rank, own, lambda s: data[s["layer_id"]], per_stream=2, flags=3)
-    res = shard.prune_sharded(specs, compute_many=rset, dist=dist, owner=owner)
-    rset.close()
+    rset = shard.ResidentLayerSet(gpu, own, lambda s: data[s["layer_id"]], per_stream=2, flags=3, borrow_results=True)
     ok = True
-    for s, (idxs, W, b) in zip(specs, res):
-        g = np.load(os.path.join(GOLDEN_DIR, s["name"] + ".npz"))
-        ok = ok and np.array_equal(idxs, g["idxs"]) and relfro(W, g["newW2"]) <= REL_W and relfro(b, g["newB2"]) <= REL_W
+    for _ in range(2):                                # twice: the lent result blocks and the staging buffers are reused
+        res = shard.prune_sharded(specs, compute_many=rset, dist=dist, owner=owner, staging="device")
+        for s, (idxs, W, b) in zip(specs, res):
+            g = np.load(os.path.join(GOLDEN_DIR, s["name"] + ".npz"))
+            ok = ok and np.array_equal(idxs, g["idxs"]) and W.shape == g["newW2"].shape
+            ok = ok and relfro(W, g["newW2"]) <= REL_W and relfro(b, g["newB2"]) <= REL_W
+    rset.close()
     q.put((rank, bool(ok), len(own)))
     dist.barrier()
     dist.destroy_process_group()
 
 
+def test_prune_sharded_device_staging_two_ranks_one_gpu():
+    """The exchange exactly as the RCCL run does it -- results lent from the page-locked result blocks, packed into an HBM
+    segment, ONE padded all_gather, the other ranks' segments back through a page-locked buffer -- with two ranks on
+    this one GPU; only the collective itself goes through gloo (RCCL does not let two ranks share a device)."""
+    import multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [mpc.Process(target=_nccl_worker, args=(r, 2, port, q, "gloo")) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = sorted(q.get(timeout=600) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert all(ok for _, ok, _ in got) and all(cnt > 0 for _, _, cnt in got)
+
+
 def test_prune_sharded_two_gpus_rccl():
-    """world size 2 on two MI355X over RCCL ("nccl"): LPT split, masks all_gather, packed (W, b) broadcasts; both ranks end
+    """world size 2 on two MI355X over RCCL ("nccl"): LPT split, masks all_gather, all_gather of the packed (W, b); both ranks end
     with every layer's reference-golden result.  Skipped on a one-GPU box (the gloo twin runs in tests/test_host_logic.py)."""
     import subprocess
     import sys
