@@ -207,14 +207,14 @@ struct SvdScratch {
     int *rotated, *order;
     static size_t bytes(int m, int n) {
         const size_t me = size_t(cp_svd_me(m));
-        return (me * n + me * me + me) * 8 + 64 + me * 4 + 1024;
+        return (me * n + me * me + me) * 8 + 512 + me * 4 + 1024;
     }
     bool take(cp_ctx *ctx, int m, int n) {
         const size_t me = size_t(cp_svd_me(m));
         Wk = cp_arena_take_t<double>(ctx, me * n);
         R = cp_arena_take_t<double>(ctx, me * me);
         sig = cp_arena_take_t<double>(ctx, me);
-        rotated = cp_arena_take_t<int>(ctx, 16);
+        rotated = cp_arena_take_t<int>(ctx, 128);   // [0] per-sweep counter, [4..5] the norm floor, [16..] the one-launch control block
         order = cp_arena_take_t<int>(ctx, me);
         return Wk && R && sig && rotated && order;
     }

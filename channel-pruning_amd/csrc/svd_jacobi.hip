@@ -121,28 +121,42 @@ __device__ __forceinline__ double jrcp(double x) {
 }
 constexpr int JB = 8;   // rows per block
 
-__global__ void __launch_bounds__(JT) k_jacobi_block_round(double *__restrict__ Wk, int n, double *__restrict__ R, int me,
-                                                           int round, double tol, int *__restrict__ rotated,
-                                                           const double *__restrict__ floor2, int inner_sweeps) {
+// One block pair of one round: the pair `pair` of round `round` of the tournament over the me / JB row blocks.
+__device__ __forceinline__ void jacobi_block_pair(double *__restrict__ Wk, int n, double *__restrict__ R, int me, int round,
+                                                  int pair, double tol, int *__restrict__ rotated,
+                                                  const double *__restrict__ floor2, int inner_sweeps) {
     __shared__ double A[16][17], Q[16][17], part[4][16][17];
     __shared__ int any_rot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
     int bi, bj;
-    round_pair(me / JB, round, blockIdx.x, bi, bj);
+    round_pair(me / JB, round, pair, bi, bj);
     auto row_of = [&](int mloc) { return mloc < JB ? bi * JB + mloc : bj * JB + (mloc - JB); };
-    // ---- Gram of the 16 rows: wave w takes the column groups 4 w, 4 w + 16, ... ----
+    // ---- Gram of the 16 rows: wave w takes the column groups 4 w, 4 w + 16, ...  Latency-bound (a few loads per lane
+    // from L2 / HBM per round): two stages of eight column groups are kept in flight, the next stage is requested before
+    // the products of the current one (n = 256: everything is requested up front) ----
     {
         v4f64j acc = {0., 0., 0., 0.};
         const double *rowp = Wk + size_t(row_of(fi)) * n;
-        for (int col0 = wave * 4; col0 < n; col0 += 64) {   // four column groups' loads in flight per step
-            double v[4];
+        constexpr int GU = 8;                               // column groups per stage and wave: 128 columns per stage
+        double v[2][GU];
+        auto fetch = [&](int stage, double *dst) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = col0 + 16 * u + fk;
-                v[u] = c < n ? rowp[c] : 0.0;
+            for (int u = 0; u < GU; ++u) {
+                const int c = stage * (16 * GU) + (u >> 2) * 64 + wave * 4 + 16 * (u & 3) + fk;
+                dst[u] = c < n ? rowp[c] : 0.0;
             }
+        };
+        const int stages = (n + 16 * GU - 1) / (16 * GU);
+        fetch(0, v[0]);
+        for (int st = 0; st < stages; st += 2) {
+            if (st + 1 < stages) fetch(st + 1, v[1]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], v[u], acc, 0, 0, 0);
+            for (int u = 0; u < GU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[0][u], v[0][u], acc, 0, 0, 0);
+            if (st + 2 < stages) fetch(st + 2, v[0]);
+            if (st + 1 < stages) {
+#pragma unroll
+                for (int u = 0; u < GU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[1][u], v[1][u], acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][fk + 4 * r][fi] = acc[r];
@@ -212,37 +226,93 @@ __global__ void __launch_bounds__(JT) k_jacobi_block_round(double *__restrict__ 
     __syncthreads();
     if (!any_rot) return;
     if (tid == 0) atomicAdd(rotated, 1);
-    // ---- rows <- Q rows, for the work matrix (n columns) and for R (me columns): 16-column tiles per wave, four tiles'
-    // loads in flight before the first product (tile after tile the compiler orders every load behind the previous
-    // tile's stores: 8 dependent round trips per launch) ----
+    // ---- rows <- Q rows, for the work matrix (n columns) and for R (me columns) ----
     double qa[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qa[ks] = Q[fi][4 * ks + fk];
-    for (int which = 0; which < 2; ++which) {
-        double *Mat = which == 0 ? Wk : R;
-        const int ncol = which == 0 ? n : me;
-        for (int base = wave * 16; base < ncol; base += 256) {
-            double bv[4][4];
+    // 16-column tiles of [work matrix | R] dealt round-robin to the waves, TF tiles' loads (both matrices alike) in flight
+    // before the first product: at n = me = 256 that is every load of the launch at once
+    constexpr int TF = 8;
+    const int tiles_w = (n + 15) / 16, tiles_all = tiles_w + (me + 15) / 16;
+    for (int t0 = wave; t0 < tiles_all; t0 += 4 * TF) {
+        double bv[TF][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int cc = base + 64 * t + fi;
+        for (int t = 0; t < TF; ++t) {
+            const int tile = t0 + 4 * t;
+            const bool in_w = tile < tiles_w;
+            const double *Mat = in_w ? Wk : R;
+            const int ncol = in_w ? n : me, cc = (in_w ? tile : tile - tiles_w) * 16 + fi;
+            const bool live = tile < tiles_all && cc < ncol;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    bv[t][ks] = cc < ncol ? Mat[size_t(row_of(4 * ks + fk)) * ncol + cc] : 0.0;
-            }
+            for (int ks = 0; ks < 4; ++ks) bv[t][ks] = live ? Mat[size_t(row_of(4 * ks + fk)) * ncol + cc] : 0.0;
+        }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int cc = base + 64 * t + fi;
-                v4f64j acc = {0., 0., 0., 0.};
+        for (int t = 0; t < TF; ++t) {
+            const int tile = t0 + 4 * t;
+            const bool in_w = tile < tiles_w;
+            double *Mat = in_w ? Wk : R;
+            const int ncol = in_w ? n : me, cc = (in_w ? tile : tile - tiles_w) * 16 + fi;
+            v4f64j acc = {0., 0., 0., 0.};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ks], bv[t][ks], acc, 0, 0, 0);
-                if (cc < ncol) {
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[ks], bv[t][ks], acc, 0, 0, 0);
+            if (tile < tiles_all && cc < ncol) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Mat[size_t(row_of(fk + 4 * r)) * ncol + cc] = acc[r];
-                }
+                for (int r = 0; r < 4; ++r) Mat[size_t(row_of(fk + 4 * r)) * ncol + cc] = acc[r];
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(JT) k_jacobi_block_round(double *__restrict__ Wk, int n, double *__restrict__ R, int me,
+                                                           int round, double tol, int *__restrict__ rotated,
+                                                           const double *__restrict__ floor2, int inner_sweeps) {
+    jacobi_block_pair(Wk, n, R, me, round, blockIdx.x, tol, rotated, floor2, inner_sweeps);
+}
+
+// ALL sweeps in ONE launch (CP_JACOBI_PERSISTENT=1): the me / (2 JB) workgroups of a round stay resident and meet at a
+// device-wide barrier after every round (rows written in a round are read by other workgroups in the next: agent-scope
+// release before arriving, acquire after leaving); the workgroups read the sweep's rotation count themselves instead of
+// the host.  59 427 launches become 206 in the ITQ profile, the time does not change (see cp_svd_rows_core).
+// ctl (ints, zeroed by the host): [0] barrier arrivals (monotone), [1] sweeps run before the first one without a rotation
+// (max_sweeps: none), [2] != 0: a barrier timed out (never observed; the host then reports an error instead of hanging),
+// [16 + s] rotations in sweep s.
+__global__ void __launch_bounds__(JT) k_jacobi_block_sweeps(double *__restrict__ Wk, int n, double *__restrict__ R, int me,
+                                                            double tol, int *__restrict__ ctl,
+                                                            const double *__restrict__ floor2, int inner_sweeps,
+                                                            int max_sweeps) {
+    __shared__ int verdict;
+    const int nb = me / JB, nwg = int(gridDim.x);
+    int arrivals = 0;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        for (int round = 0; round < nb - 1; ++round) {
+            jacobi_block_pair(Wk, n, R, me, round, blockIdx.x, tol, ctl + 16 + sweep, floor2, inner_sweeps);
+            arrivals += nwg;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                int ok = 0;
+                for (int spin = 0; spin < (1 << 24); ++spin) {
+                    if (__hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= arrivals) {
+                        ok = 1;
+                        break;
+                    }
+                    if (__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok) __hip_atomic_store(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                verdict = !ok ? -1 : (round == nb - 2 ? __hip_atomic_load(ctl + 16 + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (verdict < 0) return;
+        }
+        if (verdict == 0) {          // a whole sweep without a rotation: converged
+            if (blockIdx.x == 0 && threadIdx.x == 0) ctl[1] = sweep;
+            return;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[1] = max_sweeps;
 }
 
 __global__ void __launch_bounds__(JT) k_identity(double *__restrict__ R, int m) {
@@ -303,30 +373,51 @@ int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r,
     int sweeps = 0;
     // |a.b| <= tol |a||b|: rows orthogonal to rounding (tol_in > 0: the caller needs less, e.g. an invariant subspace only)
     const double tol = tol_in > 0.0 ? tol_in : std::max(1e-14, 4e-16 * std::sqrt(double(n)));
-    for (; sweeps < 60; ++sweeps) {
-        CP_HIP(ctx, hipMemsetAsync(rotated, 0, sizeof(int), ctx->stream));
-        static const bool scalar = getenv("CP_JACOBI_SCALAR") && getenv("CP_JACOBI_SCALAR")[0] == '1';
-        if (scalar) {
-            for (int round = 0; round < me - 1; ++round) {
-                k_jacobi_round<<<me / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2);
-                CP_LAUNCH_CHECK(ctx);
-            }
-        } else {
-            const int nb = me / JB;
-            static const int inner = getenv("CP_JACOBI_INNER") ? atoi(getenv("CP_JACOBI_INNER")) : 1;
-            for (int round = 0; round < nb - 1; ++round) {
-                k_jacobi_block_round<<<nb / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2, inner);
-                CP_LAUNCH_CHECK(ctx);
-            }
-        }
-        CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, rotated, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    constexpr int MAX_SWEEPS = 60;
+    static const bool scalar = getenv("CP_JACOBI_SCALAR") && getenv("CP_JACOBI_SCALAR")[0] == '1';
+    // opt-in: measured equal (ITQ at conv3 size 194 ms against 189 ms with per-round launches; a round is 13 us of
+    // dependent work -- Gram, the single-wave 16 x 16 diagonalisation, the update -- and the device barrier costs what
+    // the launch gap did), so the form without inter-workgroup waiting stays the default
+    static const bool per_round = !(getenv("CP_JACOBI_PERSISTENT") && getenv("CP_JACOBI_PERSISTENT")[0] == '1');
+    static const int inner = getenv("CP_JACOBI_INNER") ? atoi(getenv("CP_JACOBI_INNER")) : 1;
+    const int nb = me / JB;
+    // every workgroup of the one-launch form has to be resident at once (they wait for each other): 256 threads and ~10 KB
+    // of LDS each, so a few per CU fit; beyond that (p > ~8000 rows) the per-round launches take over
+    const bool one_launch = !scalar && !per_round && nb / 2 <= 2 * ctx->cu_count;
+    int *ctl = rotated + 16;
+    if (one_launch) {
+        CP_HIP(ctx, hipMemsetAsync(ctl, 0, (16 + MAX_SWEEPS + 4) * sizeof(int), ctx->stream));
+        k_jacobi_block_sweeps<<<nb / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, tol, ctl, floor2, inner, MAX_SWEEPS);
+        CP_LAUNCH_CHECK(ctx);
+        CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         CP_HIP(ctx, cp_stream_wait(ctx));
-        int nrot;
-        memcpy(&nrot, ctx->pinned, sizeof(int));
-        if (nrot == 0) break;
+        int head[4];
+        memcpy(head, ctx->pinned, sizeof(head));
+        if (head[2] != 0) return cp_set_error(ctx, CP_ERR_NUMERIC, "svd_rows: device barrier timed out");
+        sweeps = head[1];
+    } else {
+        for (; sweeps < MAX_SWEEPS; ++sweeps) {
+            CP_HIP(ctx, hipMemsetAsync(rotated, 0, sizeof(int), ctx->stream));
+            if (scalar) {
+                for (int round = 0; round < me - 1; ++round) {
+                    k_jacobi_round<<<me / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2);
+                    CP_LAUNCH_CHECK(ctx);
+                }
+            } else {
+                for (int round = 0; round < nb - 1; ++round) {
+                    k_jacobi_block_round<<<nb / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2, inner);
+                    CP_LAUNCH_CHECK(ctx);
+                }
+            }
+            CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, rotated, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            CP_HIP(ctx, cp_stream_wait(ctx));
+            int nrot;
+            memcpy(&nrot, ctx->pinned, sizeof(int));
+            if (nrot == 0) break;
+        }
     }
     if (sweeps_out) *sweeps_out = sweeps;
-    if (sweeps >= 60) return cp_set_error(ctx, CP_ERR_NUMERIC, "svd_rows: no convergence in 60 sweeps");
+    if (sweeps >= MAX_SWEEPS) return cp_set_error(ctx, CP_ERR_NUMERIC, "svd_rows: no convergence in 60 sweeps");
     // singular values = row norms; order descending on the host (m numbers), gather the leading r rows
     k_row_norms<<<me, JT, 0, ctx->stream>>>(Wk, n, sig);
     CP_LAUNCH_CHECK(ctx);
