@@ -16,6 +16,7 @@ CP_F32, CP_F64 = 0, 1
 CP_CD_RECIPROCAL = 1
 CP_CD_DELTA = 2
 CP_REFIT_PRECOMPUTE = 4
+CP_REFIT_PREFACTOR = 8
 CP_MAX_STAGES = 32
 
 _c_int, _c_i64, _c_dbl, _c_u32 = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32

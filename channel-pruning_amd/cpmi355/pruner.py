@@ -29,13 +29,19 @@ def precompute_flag(latency_mode, rank=None, c=None):
     already fill it (the vgg16 job: 34.9 -> 37.2 ms) -- so: on for single-layer calls, off for batches / resident sets.
     Only when at least 70 % of the channels are to be kept (full Gram <= 2x the masked one): at rank = c / 2 the 4x Gram
     running next to the search slows the search itself (it reads Q from L2 every step: 96 -> 120 ns per step, conv3_x block
-    7.6 -> 10.3 ms).  CP_REFIT_PRECOMPUTE=0 / 1 in the environment forces it."""
+    7.6 -> 10.3 ms).  CP_REFIT_PRECOMPUTE=0 / 1 in the environment forces it.
+    latency_mode True additionally sets CP_REFIT_PREFACTOR (the library applies it from rank >= 0.8 c): the FULL Gram is
+    factored during the search as well and the refit becomes a constrained solve with that factor -- 2.4 instead of 6.2 ms
+    between the end of the search and the result at c = 512, while the search itself runs 30 % slower next to the busy
+    chip (9.1 -> 12.0 ms): 16.4 -> 15.1 ms per c = 512 layer, 6.7 -> 6.3 ms at c = 256.  latency_mode "gram": the normal
+    equations only -- what a resident set uses for its heaviest layers (with the factorisation too: job 32.7 -> 34.0 ms)."""
     import os
     force = os.environ.get("CP_REFIT_PRECOMPUTE", "")
+    pre = capi.CP_REFIT_PRECOMPUTE | (capi.CP_REFIT_PREFACTOR if latency_mode is True else 0)
     if force in ("0", "1"):
-        return capi.CP_REFIT_PRECOMPUTE if force == "1" else 0
+        return pre if force == "1" else 0
     dense = rank is None or c is None or (rank < c and rank >= 0.7 * c)
-    return capi.CP_REFIT_PRECOMPUTE if latency_mode and dense else 0
+    return pre if latency_mode and dense else 0
 
 
 # ---- RNG bookkeeping on the host (it sits under the interpreter lock of every worker thread, so it has to be cheap) ----

@@ -149,6 +149,8 @@ class ResidentLayerSet:
         single.sort(key=lambda ch: -layer_cost(*[self.specs[ch["members"][0]][k] for k in ("N", "c", "n", "k", "rank")]))
         self._latency_chunks = set(id(ch) for ch in single[:max(0, precompute_heaviest)]) if len(self.chunks) > 2 else \
             set(id(ch) for ch in single)
+        # a set of one or two layers has the chip to itself: the full treatment (pruner.precompute_flag)
+        self._latency_kind = "gram" if len(self.chunks) > 2 else True
         self._stop = False
         self._threads = []
         for ch in self.chunks:
@@ -167,7 +169,8 @@ class ResidentLayerSet:
         if len(specs) == 1:
             s = specs[0]
             out = [prune_layer(ch["probs"][0], s["rank"], s.get("alpha_in", self.alpha_in), rank_tol=self.rank_tol,
-                               rng=ch["rngs"][0], mode="device", latency_mode=id(ch) in self._latency_chunks)]
+                               rng=ch["rngs"][0], mode="device",
+                               latency_mode=self._latency_kind if id(ch) in self._latency_chunks else False)]
         else:
             out = prune_layers_batched(ch["probs"], [s["rank"] for s in specs],
                                        [s.get("alpha_in", self.alpha_in) for s in specs], ch["rngs"],

@@ -38,6 +38,17 @@ struct cp_precompute {
     double *xmean = nullptr, *ymean = nullptr, *G = nullptr, *R = nullptr;
     hipEvent_t done = nullptr;
     cp_ctx *worker = nullptr;      // own arena, bound to the side stream
+    // The factorisation of the FULL Gram and the forward-substituted right-hand side, also computed during the search
+    // (rank hint >= 0.8 c): the refit then solves the kept-channel problem as an equality-constrained one with this
+    // factor (refit.hip: refit_from_full_factor) instead of factoring the kept sub-matrix after the search.
+    bool factored = false;
+    int nblk = 0;
+    char *fbuf = nullptr;          // persistent: Gw | U | Lt (P_pad^2 each) | TI | TIT | F [P_pad n_pad] | dg0 | gmax | info
+    size_t fbuf_bytes = 0;
+    double *Gw = nullptr, *U = nullptr, *Lt = nullptr, *TI = nullptr, *TIT = nullptr, *F = nullptr, *dg0 = nullptr, *gmax = nullptr;
+    int *finfo = nullptr;
+    hipStream_t chain_stream = nullptr;   // this context's own stream for the (latency-bound) factorisation chain
+    hipEvent_t gram_done = nullptr;
 };
 
 struct cp_ctx {
@@ -104,7 +115,8 @@ int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
 // one-workgroup helper or a Cholesky diagonal block of another layer otherwise waits for such a workgroup to retire.
 hipStream_t cp_wide_stream(cp_ctx *ctx);
 hipStream_t cp_side_stream(cp_ctx *ctx);   // the device's shared stream for work that overlaps a context's own chain (never null)
-int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n);
+int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n,
+                                double rank_hint = 0.0);
 void cp_precompute_release(cp_ctx *ctx);
 // run `body` (launches on ctx->stream) on the wide stream instead, ordered after / before the context's own stream
 template <class F>

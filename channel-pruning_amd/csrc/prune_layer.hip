@@ -83,7 +83,7 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
             return cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer: samples / seeds missing");
         const double t0 = now_ms(), w0 = ctx->wait_ms;
         CP_TRY(cp_lasso_gram(ctx, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, S, Q, q, stats));
-        if ((flags & CP_REFIT_PRECOMPUTE) && ridge == 0.0) CP_TRY(cp_refit_precompute_enqueue(ctx, X, x_dtype, N, c, kk, Y, n));
+        if ((flags & CP_REFIT_PRECOMPUTE) && ridge == 0.0) CP_TRY(cp_refit_precompute_enqueue(ctx, X, x_dtype, N, c, kk, Y, n, (flags & CP_REFIT_PREFACTOR) ? rank : 0.0));
         const double t1 = now_ms();
         ctx->host_ms[0] = t1 - t0;
         int fits_used = 0;

@@ -1760,19 +1760,39 @@ void cp_precompute_release(cp_ctx *ctx) {
         delete pc.worker;
         pc.worker = nullptr;
     }
+    if (pc.chain_stream) {
+        hipStreamSynchronize(pc.chain_stream);
+        hipStreamDestroy(pc.chain_stream);
+    }
     if (pc.buf) hipFree(pc.buf);
+    if (pc.fbuf) hipFree(pc.fbuf);
     if (pc.done) hipEventDestroy(pc.done);
+    if (pc.gram_done) hipEventDestroy(pc.gram_done);
     pc = cp_precompute{};
 }
+
+namespace {
+// both substitutions (or one of them: sweeps bit 0 forward, bit 1 backward) with the form that suits the factor's size
+int chol_solve_any(cp_ctx *ctx, const Chol &ch, double *Rm, int n_pad, int sweeps) {
+    if (ch.nblk >= solve_blocked_min_blocks()) return chol_solve_blocked(ctx, ch, Rm, n_pad, sweeps);
+    return chol_solve(ctx, ch, Rm, nullptr, n_pad, StripFinal{}, sweeps);
+}
+bool prefactor_wanted() {
+    static const bool on = !(getenv("CP_REFIT_PREFACTOR") && getenv("CP_REFIT_PREFACTOR")[0] == '0');
+    return on;
+}
+}  // namespace
 
 // Enqueue, on the device's shared side stream, the normal equations of the layer over ALL c channels:
 //   xmean_all, ymean, G_full = Xc^T Xc (P x P, P = c kk), R_full = Xc^T Yc (P x n)  -- 1 / (kept fraction)^2 times the
 // flops of the masked Gram, but off the critical path: the alpha search that decides the mask is one workgroup busy for
 // milliseconds, the rest of the chip is idle meanwhile.  Ordered after everything already on ctx->stream; the refit
 // (cp_lstsq_refit_impl) waits for it and gathers.  Skipped (returns CP_OK, pre.ready = false) when N - 1 < P.
-int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n) {
+int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n,
+                                double rank_hint) {
     cp_precompute &pc = ctx->pre;
     pc.ready = false;
+    pc.factored = false;
     const int P = c * kk;
     if (N - 1 < P) return CP_OK;
     const int P_pad = int(cp_align_up(size_t(P), NB)), n_pad = int(cp_align_up(size_t(n), 128));
@@ -1813,6 +1833,42 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
     const int RB = 64, rows_per_block = int((N + RB - 1) / RB);
     size_t ws = std::max(cp_gemm_tn_workspace(w, P_pad, P_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
                          cp_gemm_tn_workspace(w, P_pad, n_pad, int(N_pad), CP_TRI_NONE));
+    // Few channels are dropped (rank hint >= 0.8 c): also factor the FULL Gram and forward-substitute the right-hand side
+    // here; the refit then needs no factorisation of its own after the search (refit_from_full_factor).
+    const bool want_factor = prefactor_wanted() && rank_hint >= 0.8 * double(c) && rank_hint < double(c);
+    const int nblkF = P_pad / NB;
+    if (want_factor) {
+        ws = std::max(ws, cp_gemm_tn_workspace(w, P_pad, P_pad, NB, CP_TRI_UPPER));
+        ws = std::max(ws, chol_solve_blocked_workspace(w, P_pad, n_pad));
+        const size_t g_c = size_t(P_pad) * P_pad, ti_c = size_t(nblkF) * NB * NB;
+        const size_t felems = 3 * g_c + 2 * ti_c + size_t(P_pad) * n_pad + size_t(P_pad) + 8;
+        const size_t fbytes = felems * 8 + size_t(chol_info_count(nblkF) + 16) * 4;
+        if (fbytes > pc.fbuf_bytes) {
+            CP_HIP(ctx, hipStreamSynchronize(w->stream));
+            if (pc.chain_stream) CP_HIP(ctx, hipStreamSynchronize(pc.chain_stream));
+            CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (pc.fbuf) CP_HIP(ctx, hipFree(pc.fbuf));
+            pc.fbuf = nullptr;
+            pc.fbuf_bytes = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&pc.fbuf), fbytes) != hipSuccess)
+                return cp_set_error(ctx, CP_ERR_NOMEM, "refit precompute: hipMalloc(%zu)", fbytes);
+            pc.fbuf_bytes = fbytes;
+        }
+        pc.Gw = reinterpret_cast<double *>(pc.fbuf);
+        pc.U = pc.Gw + g_c;
+        pc.Lt = pc.U + g_c;
+        pc.TI = pc.Lt + g_c;
+        pc.TIT = pc.TI + ti_c;
+        pc.F = pc.TIT + ti_c;
+        pc.dg0 = pc.F + size_t(P_pad) * n_pad;
+        pc.gmax = pc.dg0 + P_pad;
+        pc.finfo = reinterpret_cast<int *>(pc.gmax + 8);
+        pc.nblk = nblkF;
+        if (!pc.chain_stream) {
+            CP_HIP(ctx, hipStreamCreateWithFlags(&pc.chain_stream, hipStreamNonBlocking));
+            CP_HIP(ctx, hipEventCreateWithFlags(&pc.gram_done, hipEventDisableTiming));
+        }
+    }
     CP_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // after whatever still reads the previous precompute
     CP_HIP(ctx, hipStreamWaitEvent(w->stream, ctx->ev_fork, 0));
     if (cp_arena_reserve(w, (size_t(N_pad) * (P_pad + n_pad) + size_t(RB) * (P_pad + n_pad)) * 8 + size_t(c) * 4 + ws + (1 << 16)) != CP_OK)
@@ -1855,12 +1911,153 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
     if (cp_gemm_tn_f64(w, P_pad, n_pad, int(N_pad), 1.0, Xs, P_pad, Yc, n_pad, 0.0, pc.R, n_pad, CP_TRI_NONE) != CP_OK)
         return cp_set_error(ctx, CP_ERR_HIP, "refit precompute: %s", w->err);
     cp_stage_mark(w, "refit_xty_reduce");
-    CP_HIP(ctx, hipEventRecord(pc.done, w->stream));
+    if (want_factor) {
+        // The factorisation is a chain of short dependent launches: on this context's OWN stream, so that two layers'
+        // chains run side by side while their long products take turns on the shared one.
+        CP_HIP(ctx, hipEventRecord(pc.gram_done, w->stream));
+        CP_HIP(ctx, hipStreamWaitEvent(pc.chain_stream, pc.gram_done, 0));
+        hipStream_t shared = w->stream;
+        w->stream = pc.chain_stream;
+        const size_t g_c = size_t(P_pad) * P_pad;
+        int rc = CP_OK;
+        do {
+            if (hipMemcpyAsync(pc.Gw, pc.G, g_c * 8, hipMemcpyDeviceToDevice, w->stream) != hipSuccess ||
+                hipMemcpyAsync(pc.F, pc.R, size_t(P_pad) * n_pad * 8, hipMemcpyDeviceToDevice, w->stream) != hipSuccess) {
+                rc = CP_ERR_HIP;
+                break;
+            }
+            k_diag_prepare<<<1, 1024, 0, w->stream>>>(pc.Gw, P_pad, P, P_pad, 0.0, pc.dg0, pc.gmax, pc.finfo, chol_info_count(nblkF));
+            Chol chF{pc.Gw, pc.U, pc.Lt, pc.TI, pc.TIT, pc.dg0, pc.gmax, pc.finfo, P, P_pad, nblkF};
+            if ((rc = chol_factor(w, chF, PIV_TOL)) != CP_OK) break;
+            cp_stage_mark(w, "prefactor_cholesky");
+            if ((rc = chol_solve_any(w, chF, pc.F, n_pad, 1)) != CP_OK) break;
+            cp_stage_mark(w, "prefactor_forward");
+        } while (false);
+        if (rc == CP_OK && hipEventRecord(pc.done, w->stream) != hipSuccess) rc = CP_ERR_HIP;
+        w->stream = shared;
+        if (rc != CP_OK) return cp_set_error(ctx, rc, "refit precompute (factor): %s", w->err);
+        pc.factored = true;
+    } else {
+        CP_HIP(ctx, hipEventRecord(pc.done, w->stream));
+    }
     pc.X = X; pc.Y = Y; pc.N = N; pc.c = c; pc.kk = kk; pc.n = n; pc.x_dtype = x_dtype;
     pc.P = P; pc.P_pad = P_pad; pc.n_pad = n_pad;
     pc.ready = true;
     return CP_OK;
 }
+
+namespace {
+
+// T[col(drop_i) , i] = 1 for i < d (T zeroed before): the columns of the identity that belong to the dropped channels
+__global__ void __launch_bounds__(RT) k_unit_columns(double *__restrict__ T, int ldt, const int *__restrict__ drop, int kk, int d) {
+    const int i = blockIdx.x * RT + threadIdx.x;
+    if (i < d) T[size_t(drop[i / kk] * kk + i % kk) * ldt + i] = 1.0;
+}
+// Rm[i, :] = Wf[col(i), :], xmean[i] = xf[col(i)] for i < p (col(i) = chan[i / kk] kk + i % kk); zero in the padding
+__global__ void __launch_bounds__(RT) k_gather_rows(const double *__restrict__ Wf, const double *__restrict__ xf,
+                                                    const int *__restrict__ chan, int kk, int p, int n_pad,
+                                                    double *__restrict__ Rm, double *__restrict__ xmean) {
+    const int i = blockIdx.x;
+    const bool live = i < p;
+    const int ci = live ? chan[i / kk] * kk + i % kk : 0;
+    for (int t = threadIdx.x; t < n_pad; t += RT) Rm[size_t(i) * n_pad + t] = live ? Wf[size_t(ci) * n_pad + t] : 0.0;
+    if (threadIdx.x == 0) xmean[i] = live ? xf[ci] : 0.0;
+}
+
+// The refit when the FULL normal equations were factored during the alpha search (cp_refit_precompute_enqueue with a
+// rank hint): G = L L^T over all P = c kk columns, F = L^-1 R.  The least-squares problem on the kept columns K is the full
+// one with the dropped coefficients D forced to zero,  min 1/2 w^T G w - w^T R  s.t.  E^T w = 0  (E = the unit columns of D):
+//     T = L^-1 E,   S = T^T T (= E^T G^-1 E, d x d),   lambda = S^-1 T^T F,   w = L^-T (F - T lambda),   W = w[K]
+// -- one forward substitution with d = |D| kk right-hand sides, a d x d factorisation and one backward substitution after
+// the search, instead of the Cholesky chain of the p x p kept sub-matrix (p/128 dependent block steps: 4.3 of the 6.2 ms
+// between the end of the search and the result at c = 512).  Same normal equations, same conditioning class (error
+// ~ cond(G) eps; cond(G_KK) <= cond(G)); any failed pivot -- of the full factor (e.g. a dead channel the LASSO drops) or
+// of S -- leaves *done = false and the caller continues with the kept sub-matrix as before.
+int refit_from_full_factor(cp_ctx *ctx, cp_precompute &pc, const std::vector<int> &chan, const uint8_t *mask, int c, int kk,
+                           int n, double *W_out, double *b_out, cp_refit_info *info, bool host_out, bool *done) {
+    *done = false;
+    const int kept = int(chan.size()), p = kept * kk, P_pad = pc.P_pad, n_pad = pc.n_pad;
+    std::vector<int> drop;
+    for (int i = 0; i < c; ++i)
+        if (!mask[i]) drop.push_back(i);
+    const int d = int(drop.size()) * kk;
+    const int d_pad = int(cp_align_up(size_t(std::max(d, 1)), NB));
+    if (d_pad > P_pad / 4 + NB) return CP_OK;   // many channels dropped: factoring the kept sub-matrix is cheaper
+    const int p_pad = int(cp_align_up(size_t(p), NB)), nblkS = d_pad / NB;
+    size_t ws = std::max(cp_gemm_tn_workspace(ctx, d_pad, d_pad, P_pad, CP_TRI_LOWER_MIRROR),
+                         cp_gemm_tn_workspace(ctx, d_pad, n_pad, P_pad, CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, P_pad, n_pad, d_pad, CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_tn_workspace(ctx, d_pad, d_pad, NB, CP_TRI_UPPER));
+    ws = std::max(ws, chol_solve_blocked_workspace(ctx, P_pad, std::max(n_pad, d_pad)));
+    ws = std::max(ws, chol_solve_blocked_workspace(ctx, d_pad, n_pad));
+    const size_t t_c = size_t(P_pad) * d_pad, s_c = size_t(d_pad) * d_pad, ti_c = size_t(nblkS) * NB * NB,
+                 r_c = size_t(p_pad) * n_pad;
+    const size_t need = (2 * t_c + 3 * s_c + 2 * ti_c + size_t(d_pad) * n_pad + 2 * r_c + size_t(p_pad) + size_t(d_pad) + 8) * 8 +
+                        size_t(kept + int(drop.size()) + chol_info_count(nblkS) + 32) * 4 + ws + (1 << 16);
+    CP_TRY(cp_arena_reserve(ctx, need));
+    double *T = cp_arena_take_t<double>(ctx, t_c), *TT = cp_arena_take_t<double>(ctx, t_c);
+    double *S = cp_arena_take_t<double>(ctx, s_c), *SU = cp_arena_take_t<double>(ctx, s_c), *SLt = cp_arena_take_t<double>(ctx, s_c);
+    double *STI = cp_arena_take_t<double>(ctx, ti_c), *STIT = cp_arena_take_t<double>(ctx, ti_c);
+    double *Cm = cp_arena_take_t<double>(ctx, size_t(d_pad) * n_pad);
+    double *Rm = cp_arena_take_t<double>(ctx, r_c), *part = cp_arena_take_t<double>(ctx, r_c);
+    double *xmean = cp_arena_take_t<double>(ctx, p_pad), *sdg0 = cp_arena_take_t<double>(ctx, d_pad);
+    double *sgmax = cp_arena_take_t<double>(ctx, 8);
+    int *dchan = cp_arena_take_t<int>(ctx, kept), *ddrop = cp_arena_take_t<int>(ctx, std::max<size_t>(drop.size(), 1));
+    int *sinfo = cp_arena_take_t<int>(ctx, chol_info_count(nblkS) + 16);
+    if (!T || !TT || !S || !SU || !SLt || !STI || !STIT || !Cm || !Rm || !part || !xmean || !sdg0 || !sgmax || !dchan || !ddrop || !sinfo)
+        return cp_set_error(ctx, CP_ERR_NOMEM, "refit (full factor): arena");
+    const size_t pin_b = 64 + (host_out ? (size_t(n) + size_t(n) * p) * sizeof(double) : 0);
+    CP_TRY(cp_pinned_reserve(ctx, pin_b));
+    int *info_host = reinterpret_cast<int *>(ctx->pinned);
+    int *flag_host = info_host + 4;
+    double *b_host = host_out ? reinterpret_cast<double *>(ctx->pinned + 64) : nullptr;
+    double *W_host = host_out ? b_host + n : nullptr;
+    cp_stage_begin(ctx);
+    CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, pc.done, 0));
+    CP_HIP(ctx, hipMemcpyAsync(flag_host, pc.finfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!drop.empty()) CP_HIP(ctx, hipMemcpyAsync(ddrop, drop.data(), drop.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    cp_stage_mark(ctx, "refit_wait_prefactor");
+    if (*flag_host != 0) return CP_OK;          // the full Gram is not safely positive definite
+    Chol chF{pc.Gw, pc.U, pc.Lt, pc.TI, pc.TIT, pc.dg0, pc.gmax, pc.finfo, pc.P, P_pad, pc.nblk};
+    if (d > 0) {
+        CP_HIP(ctx, hipMemsetAsync(T, 0, t_c * 8, ctx->stream));
+        k_unit_columns<<<(d + RT - 1) / RT, RT, 0, ctx->stream>>>(T, d_pad, ddrop, kk, d);
+        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(chol_solve_any(ctx, chF, T, d_pad, 1));                                   // T = L^-1 E
+        cp_stage_mark(ctx, "refit_constraint_forward");
+        CP_TRY(cp_gemm_tn_f64(ctx, d_pad, d_pad, P_pad, 1.0, T, d_pad, T, d_pad, 0.0, S, d_pad, CP_TRI_LOWER_MIRROR));
+        CP_TRY(cp_gemm_tn_f64(ctx, d_pad, n_pad, P_pad, 1.0, T, d_pad, pc.F, n_pad, 0.0, Cm, n_pad, CP_TRI_NONE));
+        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(S, d_pad, d, d_pad, 0.0, sdg0, sgmax, sinfo, chol_info_count(nblkS));
+        CP_LAUNCH_CHECK(ctx);
+        Chol chS{S, SU, SLt, STI, STIT, sdg0, sgmax, sinfo, d, d_pad, nblkS};
+        CP_TRY(chol_factor(ctx, chS, PIV_TOL));
+        CP_TRY(chol_solve_any(ctx, chS, Cm, n_pad, 3));                                   // lambda = S^-1 T^T F
+        k_transpose_pad<<<dim3(P_pad / 32, d_pad / 32), RT, 0, ctx->stream>>>(T, P_pad, d_pad, d_pad, TT, P_pad);
+        CP_LAUNCH_CHECK(ctx);
+        CP_TRY(cp_gemm_tn_f64(ctx, P_pad, n_pad, d_pad, -1.0, TT, P_pad, Cm, n_pad, 1.0, pc.F, n_pad, CP_TRI_NONE));   // F -= T lambda
+        cp_stage_mark(ctx, "refit_constraint_schur");
+    } else {
+        CP_HIP(ctx, hipMemsetAsync(sinfo, 0, sizeof(int), ctx->stream));
+    }
+    CP_TRY(chol_solve_any(ctx, chF, pc.F, n_pad, 2));                                     // w = L^-T (F - T lambda)
+    cp_stage_mark(ctx, "refit_backward");
+    k_gather_rows<<<p_pad, RT, 0, ctx->stream>>>(pc.F, pc.xmean, dchan, kk, p, n_pad, Rm, xmean);
+    CP_LAUNCH_CHECK(ctx);
+    CP_TRY(finalize_launch(ctx, Rm, n_pad, p, n, xmean, pc.ymean, W_out, b_out, W_host, b_host, sinfo, info_host, part));
+    cp_stage_mark(ctx, "refit_finalize");
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    if (*info_host != 0) return CP_OK;          // S lost a pivot: the kept sub-matrix route decides (and overwrites the outputs)
+    info->p = p;
+    info->rank = p;
+    info->fallback = 0;
+    info->reserved = 0;
+    *done = true;
+    return CP_OK;
+}
+
+}  // namespace
 
 // host_out: also leave b (n) and W (n x p) in the context's pinned block at offset 64 (cp_prune_layer)
 int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,
@@ -1881,6 +2078,19 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     const int nblk = p_pad / NB;
     const int RB = 64;
     const int rows_per_block = int((N + RB - 1) / RB);
+    {   // the full Gram was factored during the alpha search: constrained solve, no factorisation of the kept sub-matrix
+        cp_precompute &pf = ctx->pre;
+        if (pf.ready && pf.factored && !ctx->defer_refit_wait && pf.X == X && pf.Y == Y && pf.N == N && pf.c == c && pf.kk == kk &&
+            pf.n == n && pf.x_dtype == x_dtype && pf.n_pad == n_pad && ridge == 0.0) {
+            bool done = false;
+            pf.factored = false;
+            CP_TRY(refit_from_full_factor(ctx, pf, chan, mask, c, kk, n, W_out, b_out, info, host_out, &done));
+            if (done) {
+                pf.ready = false;
+                return CP_OK;
+            }
+        }
+    }
 
     const size_t xs_b = size_t(N_pad) * p_pad * 8, yc_b = size_t(N_pad) * n_pad * 8, g_b = size_t(p_pad) * p_pad * 8,
                  r_b = size_t(p_pad) * n_pad * 8, ti_b = size_t(nblk) * NB * NB * 8,

@@ -109,6 +109,10 @@ typedef struct cp_cd_result {
  * side stream while the single-workgroup alpha search runs; the refit then gathers the kept rows / columns instead of
  * running its two N-sized products after the search.  (c / kept)^2 times the Gram flops, off the critical path. */
 #define CP_REFIT_PRECOMPUTE 4
+/* with CP_REFIT_PRECOMPUTE, when rank >= 0.8 c: also factor that full Gram and forward-substitute the right-hand side
+ * during the search; the refit is then a constrained solve with the full factor (dropped coefficients forced to zero)
+ * -- no factorisation of the kept sub-matrix after the search.  Falls back to it when a pivot of the full Gram fails. */
+#define CP_REFIT_PREFACTOR 8
 
 /* Replaces Lasso.fit as called by solve() (lib/decompose.py:453-466):
  * sklearn/_cd_fast.pyx:564-737 with random coordinate order from our_rand_r

@@ -339,6 +339,36 @@ def test_dictionary_matches_reference_golden_full_size(ctx, name):
     assert np.linalg.norm(res) < np.linalg.norm(naive)
 
 
+def test_refit_with_the_prefactored_full_gram_matches_the_kept_submatrix_route(ctx):
+    """CP_REFIT_PREFACTOR (single-layer calls that keep >= 80 % of the channels): the full Gram is factored during the search
+    and the refit is a constrained solve with that factor.  Same mask and fits, weights equal to the route that factors the
+    kept sub-matrix to ~cond * eps; a dead channel (singular full Gram, the LASSO drops it) falls back to that route."""
+    import cp_oracle
+    from cpmi355 import LayerProblem, prune_layer
+    for dead, expect_full in ((0, True), (2, False)):
+        X, W2, Y, B2 = cp_oracle.synth_layer(77, 1500, 64, 48, 3, dead=dead)
+        prob = LayerProblem(ctx, X, W2, Y)
+        try:
+            ctx.enable_stage_timing(1)
+            out = {}
+            for mode in (False, "gram", True):
+                rng = np.random.RandomState(5)
+                idxs, W, b, alpha = prune_layer(prob, 56, 1e-3, rng=rng, mode="device", latency_mode=mode)
+                out[mode] = (idxs, W, b, alpha, list(prob.fits), [nm for nm, _ in ctx.last_stage_times()])
+            ref = out[False]
+            assert "refit_cholesky" in ref[5] and "refit_cholesky" in out["gram"][5]
+            assert ("refit_backward" in out[True][5]) == expect_full and ("refit_cholesky" in out[True][5]) != expect_full
+            for mode in ("gram", True):
+                got = out[mode]
+                assert np.array_equal(got[0], ref[0]) and got[3] == ref[3] and got[4] == ref[4]
+                assert relfro(got[1], ref[1]) <= 1e-10 and relfro(got[2], ref[2]) <= 1e-10
+            dead_channels = np.abs(X).reshape(1500, 64, -1).sum((0, 2)) == 0
+            assert int(ref[0].sum()) >= 56 and int(dead_channels.sum()) == dead and not ref[0][dead_channels].any()
+        finally:
+            ctx.enable_stage_timing(0)
+            prob.free()
+
+
 def test_f32_and_f64_storage_agree(ctx):
     """X / W2 handed over as float32 (exactly representable) or float64 give bit-identical results."""
     import cp_oracle
@@ -554,6 +584,27 @@ def test_svd_rows_matches_numpy(ctx):
         assert np.abs(Vt * sgn[:, None] - U[:, :r].T).max() <= 1e-9
         assert np.abs(SH * sgn[:, None] - S[:r, None] * Ht[:r]).max() <= 1e-9 * S[0]
         assert np.abs(Vt @ Vt.T - np.eye(r)).max() <= 1e-12
+
+
+def test_svd_rows_one_launch_form_matches_per_round_launches():
+    """CP_JACOBI_PERSISTENT=1 (all sweeps in one launch, device-wide barrier between the rounds) gives the bits of the
+    default per-round launches: same rotations in the same order.  Own processes: the switch is read once."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from cpmi355 import default_context; ctx = default_context(); "
+            "rs = np.random.RandomState(5); import hashlib; h = hashlib.sha1()\n"
+            "for m, n, r in ((24, 40, 24), (128, 128, 64), (97, 130, 30), (256, 256, 128)):\n"
+            "    M = rs.randn(m, n) * (0.05 + rs.rand(m, 1)); s, Vt, SH = ctx.svd_rows(M, r)\n"
+            "    U, S, Ht = np.linalg.svd(M, full_matrices=False); assert np.abs(s - S[:r]).max() <= 1e-12 * S[0]\n"
+            "    [h.update(np.ascontiguousarray(a).tobytes()) for a in (s, Vt, SH)]\n"
+            "print(h.hexdigest())") % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "channel-pruning_amd")
+    digests = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, CP_JACOBI_PERSISTENT=flag)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
 
 
 def test_vh_decompose_matches_reference_golden_svd(ctx):

@@ -536,7 +536,8 @@ def test_resident_layer_set_chunks_streams_and_latency_layers(monkeypatch):
             assert [int(W[0, 0, 0, 0]) for _, W, _, _ in out] == list(range(8))
             singles = [c for c in calls if c[0] == "single"]
             assert sorted(c[1][0] for c in singles) == [2, 5] and sorted(tuple(c[1]) for c in calls if c[0] == "batch") == [(0, 1), (3, 4), (6, 7)]
-            assert [c[2] for c in singles if c[1] == [5]] == [True] and [c[2] for c in singles if c[1] == [2]] == [False]
+            # in a job the heaviest single layer gets its normal equations precomputed ("gram"), not the factorisation too
+            assert [c[2] for c in singles if c[1] == [5]] == ["gram"] and [c[2] for c in singles if c[1] == [2]] == [False]
             for _, tags, _, draws in calls:
                 assert draws == [int(np.random.RandomState(1234 + t).randint(0, 1 << 30)) for t in tags]
         assert [(r["c"], len(r["layers"])) for r in rset.chunk_report()] == [(512, 2), (256, 2), (256, 1), (128, 1), (64, 2)]
@@ -557,3 +558,20 @@ def test_bench_vgg16_job_is_the_reference_rank_table():
         p = json.loads(str(g["params"]))
         assert (p["layer_id"], p["c"], p["n"], p["rank"], p["N"]) == (s["layer_id"], s["c"], s["n"], s["rank"], s["N"])
         assert "newW2_sketch" in g.files and g["idxs"].shape == (s["c"],)
+
+
+def test_precompute_flag_modes(monkeypatch):
+    """pruner.precompute_flag: single-layer calls (True) ask for the normal equations AND the factorisation of the full Gram
+    during the search, a resident set's heaviest layers ("gram") for the normal equations only, batches for nothing; only
+    when at least 70 % of the channels are kept; CP_REFIT_PRECOMPUTE=0/1 in the environment forces it."""
+    from cpmi355 import capi, pruner
+    monkeypatch.delenv("CP_REFIT_PRECOMPUTE", raising=False)
+    both = capi.CP_REFIT_PRECOMPUTE | capi.CP_REFIT_PREFACTOR
+    assert pruner.precompute_flag(True, 445, 512) == both
+    assert pruner.precompute_flag("gram", 445, 512) == capi.CP_REFIT_PRECOMPUTE
+    assert pruner.precompute_flag(False, 445, 512) == 0
+    assert pruner.precompute_flag(True, 256, 512) == 0 and pruner.precompute_flag(True, 512, 512) == 0
+    monkeypatch.setenv("CP_REFIT_PRECOMPUTE", "0")
+    assert pruner.precompute_flag(True, 445, 512) == 0
+    monkeypatch.setenv("CP_REFIT_PRECOMPUTE", "1")
+    assert pruner.precompute_flag("gram", 256, 512) == capi.CP_REFIT_PRECOMPUTE and pruner.precompute_flag(True, 256, 512) == both
