@@ -351,20 +351,25 @@ def bench_vgg16(args, env):
     if env.world == 1 and not args.profile_mode:
         from cpmi355.pruner import LayerProblem
         ctx0 = roots[0]
-        t1 = time.perf_counter()
-        h2d = 0
-        for j in sorted(probs):
-            spec = specs[own[j]]
-            X, W2, Y = host_data[spec["layer_id"]]
-            pr = LayerProblem(ctx0, X, W2, Y, flags=CD_FLAGS)
-            h2d += pr.h2d_bytes
-            prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
-            pr.free()
-        t_seq = time.perf_counter() - t1
-        pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "h2d_bytes": int(h2d),
+        t_pass = []
+        for _ in range(2):       # first pass: workspaces of the context grow layer by layer (cold); second: steady state
+            t1 = time.perf_counter()
+            h2d = 0
+            for j in sorted(probs):
+                spec = specs[own[j]]
+                X, W2, Y = host_data[spec["layer_id"]]
+                pr = LayerProblem(ctx0, X, W2, Y, flags=CD_FLAGS)
+                h2d += pr.h2d_bytes
+                prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
+                pr.free()
+            t_pass.append(time.perf_counter() - t1)
+        t_seq = t_pass[1]
+        pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "first_pass_ms": round(t_pass[0] * 1e3, 2),
+                "h2d_bytes": int(h2d),
                 "layers_per_s_with_h2d": round(len(specs) / t_seq, 2),
                 "note": "every layer uploaded from pageable host memory (hipMemcpy) and pruned, one after another on one "
-                        "stream: what the drop-in dictionary() does per call; never part of `value`"}
+                        "stream: what the drop-in dictionary() does per call; never part of `value`.  first_pass_ms: the "
+                        "context's workspaces still growing from layer to layer"}
 
     # ---- verification on rank 0 (outside the timed region) ----
     out = None
