@@ -343,7 +343,7 @@ def bench_vgg16(args, env):
             alone_g_ms.append(st["refit_gram_gemm"])
             alone_g_fl.append(float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
             # latency mode: the launch computed the Gram of ALL c channels during the alpha search (CP_REFIT_PRECOMPUTE)
-            alone_g_ex.append(float(N_SAMPLES) * (spec["c"] * 9) ** 2 if "refit_gather_normal_eq" in st
+            alone_g_ex.append(float(N_SAMPLES) * (spec["c"] * 9) ** 2 if ("refit_gather_normal_eq" in st or "refit_backward" in st)
                               else float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
 
     # ---- PCIe-inclusive: upload of a layer's operands from pageable host memory + its pruning, layer after layer ----
