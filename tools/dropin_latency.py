@@ -14,7 +14,7 @@ for c in widths:
     X, W2, Y = bench.synth(spec["layer_id"], spec["c"], spec["n"])[:3]
     rows = []
     ctx.enable_stage_timing(1)
-    for rep in range(8):
+    for rep in range(int(os.environ.get("REPS", "8"))):
         t0 = time.perf_counter()
         pr = LayerProblem(ctx, X, W2, Y)
         ctx.sync()
