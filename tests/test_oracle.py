@@ -240,3 +240,39 @@ def test_itq_oracle_reproduces_reference():
                                                      bias=B2.astype(np.float64))
     for a, name in ((W1, "W1"), (Wo2, "W2"), (B, "B"), (W12, "W12")):
         assert a.shape == g[name].shape and relfro(a, g[name]) <= 1e-10, name
+
+
+def test_soft_threshold_ties_separate_every_rounding_variant_and_sklearns_own_two_paths():
+    """tests/golden/t01_ties.npz (oracle/gen_golden_ties.py): a coordinate exactly on the edge of its dead zone.  The four
+    rounding variants of the Gram-form update decide its support differently, scikit-learn's Gram form differs from its data
+    form -- which is what the reference runs (Lasso(...).fit(Z, reY), precompute=False) -- and the data form agrees with
+    flags 0 on some ties and with flags 3 on others: no Gram-form variant can promise the reference's mask AT a tie.  The
+    C restatement reproduces the stored coefficients bit for bit; scikit-learn's data form (when importable) reproduces the
+    stored support."""
+    g = np.load(os.path.join(GOLDEN_DIR, "t01_ties.npz"))
+    seed = int(g["seed"])
+    agree = np.zeros(4, dtype=int)
+    for t in range(g["l1"].shape[0]):
+        Z, y, l1 = g["Z"][t], g["y"][t], float(g["l1"][t])
+        Q, q, yy = Z.T @ Z, Z.T @ y, float(y @ y)
+        sups = []
+        for k, (recip, delta) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+            w = np.zeros(2)
+            w, _, it = cp_oracle.enet_cd_gram(w, l1, 0.0, Q, q, yy, seed=seed, recip=recip, delta=delta)
+            assert np.array_equal(w, g["w"][t, k]) and it == int(g["n_iter"][t, k])
+            sups.append(tuple(w != 0))
+            agree[k] += sups[-1] == tuple(g["sk_data"][t] != 0)
+        assert len(set(sups)) > 1                                   # the variants disagree on every stored tie
+    assert 0 < agree[0] < g["l1"].shape[0] and 0 < agree[3] < g["l1"].shape[0]   # neither flags 0 nor flags 3 always sides with the data form
+    assert any(tuple(g["sk_data"][t] != 0) != tuple(g["sk_gram"][t] != 0) for t in range(g["l1"].shape[0]))
+    try:
+        from sklearn.linear_model import Lasso
+    except ImportError:
+        return
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(g["l1"].shape[0]):
+            m = Lasso(alpha=float(g["l1"][t]) / g["Z"].shape[1], fit_intercept=False, selection="random", precompute=False,
+                      random_state=np.random.RandomState(0), tol=1e-4, max_iter=1000).fit(g["Z"][t], g["y"][t])
+            assert tuple(m.coef_ != 0) == tuple(g["sk_data"][t] != 0)
