@@ -116,6 +116,63 @@ def _shard_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import hashlib
+
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = [dict(layer_id=i, N=10, c=c, n=n, k=k, rank=1) for i, (c, n, k) in enumerate([(16, 3, 3), (5, 4, 1), (9, 2, 3), (16, 1, 1)])]
+    owner = [2, 0, 2, 2]            # rank 1 owns nothing, rank 2 three layers of different shapes
+    mine = {}
+    for i, s in enumerate(specs):
+        if owner[i] == rank:
+            rs = np.random.RandomState(50 + i)
+            idxs = rs.rand(s["c"]) < 0.6
+            idxs[0] = True
+            mine[i] = (idxs, rs.randn(s["n"], int(idxs.sum()), s["k"], s["k"]), rs.randn(s["n"]))
+    res = shard.exchange_results(specs, owner, mine, dist)
+    q.put((rank, [(r[0].tolist(), r[1].shape, hashlib.sha1(np.ascontiguousarray(r[1]).tobytes()).hexdigest(),
+                   hashlib.sha1(np.ascontiguousarray(r[2]).tobytes()).hexdigest()) for r in res],
+           dict(shard.LAST_EXCHANGE_MS)))
+    dist.destroy_process_group()
+
+
+def test_exchange_results_three_ranks_one_of_them_empty():
+    """exchange_results with uneven segments: a rank that owns nothing (empty segment), one that owns three layers of
+    different shapes; every rank ends with the same bytes for every layer, and the segment lay-out is result_segments'."""
+    import hashlib
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == got[2][1]
+    for i, (m, shape, hw, hb) in enumerate(got[0][1]):      # equal to what the owner produced
+        rs = np.random.RandomState(50 + i)
+        c, n, k = [(16, 3, 3), (5, 4, 1), (9, 2, 3), (16, 1, 1)][i]
+        idxs = rs.rand(c) < 0.6
+        idxs[0] = True
+        W, b = rs.randn(n, int(idxs.sum()), k, k), rs.randn(n)
+        assert m == idxs.tolist() and tuple(shape) == W.shape
+        assert hw == hashlib.sha1(W.tobytes()).hexdigest() and hb == hashlib.sha1(b.tobytes()).hexdigest()
+    assert got[1][2]["bytes_sent"] == 0 and got[2][2]["bytes_received"] == got[0][2]["bytes_sent"]
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import shard
+    masks = [np.array(m) for m, _, _, _ in got[0][1]]
+    specs = [dict(n=n, k=k) for (c, n, k) in [(16, 3, 3), (5, 4, 1), (9, 2, 3), (16, 1, 1)]]
+    shapes, offs, seg = shard.result_segments(specs, [2, 0, 2, 2], masks, 3)
+    assert seg[1] == 0 and offs[0] == 0 and offs[2] == int(np.prod(shapes[0])) + 3 and seg[0] == int(np.prod(shapes[1])) + 4
+
+
 def test_sharded_pruning_world_size_2_gloo():
     """Two ranks split four layers, then every rank holds every layer's (mask, W, b); the union of
     the work is exactly one call per layer and the results equal a single-process run."""
