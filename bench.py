@@ -23,8 +23,8 @@ weights, bias) back on the host inside it:
 Prints ONE JSON line (rank 0).  `roofline` = the dominant MFMA kernel (the f64 Gram GEMM of the refit, symmetric half):
 algorithmic flops N p^2 per launch / the HIP-event time of that launch recorded inside libcpmi355 on its launch stream
 during the timed steps.  `cpu_baseline` = the CPU port of the reference path (oracle/cp_oracle.py driving scikit-learn's
-own Lasso / LinearRegression: the arithmetic the reference runs) on a bounded sample of the same layers on this box's
-host cores (--cpu-full: every layer of the job).
+own Lasso / LinearRegression: the arithmetic the reference runs) on a bounded sample of the same layers (the four with
+c <= 128 and one with c = 256: about 20 s) on this box's host cores (--cpu-full: every layer of the job).
 """
 import argparse
 import ctypes
@@ -436,14 +436,16 @@ def bench_vgg16(args, env):
             "upload_and_setup_s": round(t0 - t_up0, 2),
         }
         if env.world == 1 and not args.no_cpu_baseline and not args.profile_mode:
-            sample = specs if args.cpu_full else [s for s in specs if s["c"] <= 256]
+            # bounded sample (about 20 s of CPU work): every layer up to c = 128 and the first c = 256 one
+            small = [s for s in specs if s["c"] <= 128] + [s for s in specs if s["c"] == 256][:1]
+            sample = specs if args.cpu_full else small
             secs = cpu_port_seconds([(s["layer_id"], s["c"], s["n"], s["rank"]) for s in sample])
             gpu_ms_same = sum(per_layer[s["name"]]["ms_alone"] for s in sample)
             out["cpu_baseline"] = {
                 "value": round(len(sample) / sum(secs), 4), "unit": "layers/s", "cores": host_threads(), "kind": "port",
                 "sample": "%s of the job's 12 layers (%s), one pass, sklearn Lasso (single-threaded CD) + "
                           "LinearRegression/gelsd (BLAS threads = cores): %.1f s total, per layer %s s" % (
-                              "all 12" if args.cpu_full else "the 7 layers with c <= 256", ", ".join(s["name"][:3] for s in sample),
+                              "all 12" if args.cpu_full else "%d" % len(sample), ", ".join(s["name"][:3] for s in sample),
                               sum(secs), [round(x, 2) for x in secs]),
                 "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
                 "gpu_ms_same_layers_one_at_a_time": round(gpu_ms_same, 2),
