@@ -1,6 +1,6 @@
 """bench.py -- conv layers pruned per second (BASELINE.json metric) on MI355X.
 
-Two workloads, both built from SURVEY.md section 8d's synthetic generator (float32 X and W2 -- exactly what the
+Workloads, all built from SURVEY.md section 8d's synthetic generator (float32 X and W2 -- exactly what the
 reference's float64 arrays hold -- float64 Y), operands RESIDENT in HBM before the timed region, results (mask,
 weights, bias) back on the host inside it:
 
@@ -15,6 +15,15 @@ weights, bias) back on the host inside it:
     A "step" is `jobs_per_step` back-to-back jobs (chosen during warm-up so that the timed region is >= 2 s);
     value = 12 * jobs / elapsed = layers/s of a single job instance, job_ms = its wall-clock.
 
+--workload resnet50 (BASELINE.json configs[3]): the 40 selections of the released ResNet-50 2x model
+    (temp/resnet-50-cp.prototxt: channel samplers in front of branch2a with c up to 2048, 3x3 and residual-aware 1x1
+    consumers; cpmi355/jobs.py), N = 5000; same machinery, same JSON line.
+--workload vgg16_5x (BASELINE.json configs[4]): the 10 pruned pairs of the released VGG-16 5x model
+    (temp/channel_pruning.prototxt) at N = 20000 samples per layer.
+
+--gpus N > 1 without a torch.distributed environment: bench.py launches itself under torch.distributed.run with N
+ranks (one per GPU, backend "nccl" = RCCL), so `python bench.py --gpus 8` alone is a valid command.
+
 --workload block (BASELINE.json configs[1]: the VGG-16 conv3_x block, rank = c/2)
     single_instance: the three layers of ONE block instance side by side, nothing else on the chip;
     value: replica throughput -- many independent copies of the block in flight (--inflight groups x --batch copies),
@@ -24,7 +33,9 @@ Prints ONE JSON line (rank 0).  `roofline` = the dominant MFMA kernel (the f64 G
 algorithmic flops N p^2 per launch / the HIP-event time of that launch recorded inside libcpmi355 on its launch stream
 during the timed steps.  `cpu_baseline` = the CPU port of the reference path (oracle/cp_oracle.py driving scikit-learn's
 own Lasso / LinearRegression: the arithmetic the reference runs) on a bounded sample of the same layers (the four with
-c <= 128 and one with c = 256: about 20 s) on this box's host cores (--cpu-full: every layer of the job).
+c <= 128 and one with c = 256: about 20 s) on this box's host cores, at the BLAS thread count that is fastest on the
+box (swept over 1 / 8 / 32 / all on the three smallest layers first; the CD itself is single-threaded); --cpu-full:
+every layer of the job.
 """
 import argparse
 import ctypes
@@ -57,36 +68,12 @@ BLOCK_LAYERS = [  # (layer_id, c, n, rank)  -- ids match tests/golden/L0[123]_*.
 ]
 BLOCK_GOLDEN = {31: "L01_conv2_2_conv3_1", 32: "L02_conv3_1_conv3_2", 33: "L03_conv3_2_conv3_3"}
 
-# the reference's VGG-16 rank table (net.py:1309-1321) scaled by 4/3 (:1323-1326) never exceeds int(c / 1.15), so
-# d_c = int(c / 1.15) for every pair (net.py:1346-1349): 55, 55, 111, 111, 222 x3, 445 x5
-VGG16_PAIRS = [("conv1_1", "conv1_2", 64, 64), ("conv1_2", "conv2_1", 64, 128), ("conv2_1", "conv2_2", 128, 128),
-               ("conv2_2", "conv3_1", 128, 256), ("conv3_1", "conv3_2", 256, 256), ("conv3_2", "conv3_3", 256, 256),
-               ("conv3_3", "conv4_1", 256, 512), ("conv4_1", "conv4_2", 512, 512), ("conv4_2", "conv4_3", 512, 512),
-               ("conv4_3", "conv5_1", 512, 512), ("conv5_1", "conv5_2", 512, 512), ("conv5_2", "conv5_3", 512, 512)]
-VGG16_RANKDIC = {'conv1_1': 17, 'conv1_2': 17, 'conv2_1': 37, 'conv2_2': 47, 'conv3_1': 83, 'conv3_2': 89, 'conv3_3': 106,
-                 'conv4_1': 175, 'conv4_2': 192, 'conv4_3': 227, 'conv5_1': 398, 'conv5_2': 390, 'conv5_3': 379}
-
-
-def vgg16_specs():
-    specs = []
-    for i, (prod, cons, c, n) in enumerate(VGG16_PAIRS):
-        rank = VGG16_RANKDIC[prod] if 'conv5' in prod else int(VGG16_RANKDIC[prod] * 4. / 3.)
-        d_c = max(int(c / 1.15), rank)
-        specs.append(dict(layer_id=101 + i, name="V%02d_%s_%s" % (i + 1, prod, cons), N=N_SAMPLES, c=c, n=n, k=KSIZE,
-                          rank=d_c))
-    return specs
+from cpmi355 import jobs as cpjobs   # noqa: E402  (workload tables + the synthetic generator; no device code)
 
 
 def synth(layer_id, c, n):
-    """SURVEY.md section 8d generator (same code as oracle/cp_oracle.py::synth_layer, restated here so the
-    timed product path imports nothing from oracle/)."""
-    rs = np.random.RandomState(1000 + layer_id)
-    X = np.maximum(rs.randn(N_SAMPLES, c, KSIZE, KSIZE), 0.).astype(np.float32)
-    W2 = (rs.randn(n, c, KSIZE, KSIZE) * 0.05).astype(np.float32)
-    B2 = np.zeros(n, dtype=np.float32)
-    Y = X.reshape(N_SAMPLES, -1).astype(np.float64) @ W2.reshape(n, -1).T.astype(np.float64) \
-        + 0.01 * rs.randn(N_SAMPLES, n)
-    return X, W2, Y, B2
+    """SURVEY.md section 8d generator for the conv3_x block layers (k = 3, N = 5000, ReLU'd X)"""
+    return cpjobs.synth(dict(layer_id=layer_id, N=N_SAMPLES, c=c, n=n, k=KSIZE))
 
 
 def sketch_matrix(p):
@@ -147,19 +134,52 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_port_seconds(layers):
-    """CPU port of the reference path: seconds per layer.  layers: [(layer_id, c, n, rank)]"""
+def cpu_port_seconds(specs, threads=None):
+    """CPU port of the reference path: seconds per layer.  specs: cpmi355.jobs spec dicts.  threads: BLAS / OpenMP
+    thread limit (threadpoolctl) or None for the library default (all cores)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cp_oracle
+    from threadpoolctl import threadpool_limits
     secs = []
-    for layer_id, c, n, rank in layers:
-        X, W2, Y, B2 = synth(layer_id, c, n)
+    for spec in specs:
+        X, W2, Y, B2 = cpjobs.synth(spec)
         X64 = X.astype(np.float64)
-        np.random.seed(1234 + layer_id)
-        t0 = time.perf_counter()
-        cp_oracle.dictionary_oracle(X64, W2, Y, rank, B2, alpha_in=1e-3, lasso="sklearn", ls="sklearn")
-        secs.append(time.perf_counter() - t0)
+        np.random.seed(1234 + spec["layer_id"])
+        with threadpool_limits(limits=threads):
+            t0 = time.perf_counter()
+            cp_oracle.dictionary_oracle(X64, W2, Y, spec["rank"], B2, alpha_in=1e-3, lasso="sklearn", ls="sklearn")
+            secs.append(time.perf_counter() - t0)
     return secs
+
+
+def cpu_best_threads(specs):
+    """-> (thread count that minimises the port's time on `specs`, {threads: seconds})"""
+    ncpu = os.cpu_count() or 1
+    sweep = {}
+    for t in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
+        sweep[t] = round(sum(cpu_port_seconds(specs, threads=t)), 3)
+    return min(sweep, key=lambda t: sweep[t]), sweep
+
+
+def cpu_baseline_object(specs, sample, per_layer, job_ms, full):
+    """cpu_baseline of the JSON line: the port on `sample` at the best BLAS thread count of this box."""
+    best, sweep = cpu_best_threads(sample[:3])
+    secs = cpu_port_seconds(sample, threads=best)
+    gpu_ms_same = sum(per_layer[s["name"]]["ms_alone"] for s in sample if s["name"] in per_layer)
+    out = {"value": round(len(sample) / sum(secs), 4), "unit": "layers/s", "cores": int(best), "kind": "port",
+           "sample": "%s of the job's %d layers (%s), one pass, sklearn Lasso (single-threaded CD) + LinearRegression/gelsd "
+                     "with %d BLAS threads (the fastest of the sweep): %.1f s total, per layer %s s" % (
+                         "all" if full else "%d" % len(sample), len(specs), ", ".join(s["name"][:3] for s in sample), best,
+                         sum(secs), [round(x, 2) for x in secs]),
+           "blas_thread_sweep_s": {"layers": [s["name"][:3] for s in sample[:3]], "seconds_by_threads": sweep},
+           "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
+    if gpu_ms_same > 0:
+        out["gpu_ms_same_layers_one_at_a_time"] = round(gpu_ms_same, 2)
+        out["speedup_same_layers_latency"] = round(sum(secs) * 1e3 / gpu_ms_same, 1)
+    if full:
+        out["job_seconds_cpu"] = round(sum(secs), 2)
+        out["job_speedup_wall_clock"] = round(sum(secs) * 1e3 / job_ms, 1)
+    return out
 
 
 # ==================================================================================================================
@@ -247,25 +267,41 @@ def roofline_object(g_ms, g_fl, ctx0, note, traffic):
 # ==================================================================================================================
 # workload: vgg16 (the north_star job)
 # ==================================================================================================================
-def bench_vgg16(args, env):
+JOB_TEXT = {
+    "vgg16": ("vgg16: ONE instance of the whole-network job = the 12 conv->conv pairs of VGG-16, kept channels "
+              "d_c = int(c/1.15) (the reference's 3C-4x table), N=5000 samples/layer, k=3; 1 job = 12 dictionary() calls; "
+              "1 step = jobs_per_step back-to-back jobs", "conv layers pruned/sec (VGG-16 4x, 5k samples)"),
+    "resnet50": ("resnet50: ONE instance of the ResNet-50 2x job = the 40 selections of the released model "
+                 "(temp/resnet-50-cp.prototxt): 16 channel samplers in front of branch2a (c = 64..2048, 1x1), 8 branch2a->"
+                 "branch2b (3x3), 16 branch2b->branch2c (1x1, residual-aware target, no ReLU), N=5000 samples/layer; "
+                 "1 step = jobs_per_step back-to-back jobs", "conv layers pruned/sec (ResNet-50 2x, 5k samples)"),
+    "vgg16_5x": ("vgg16_5x: ONE instance of the VGG-16 5x job = the 10 pruned conv->conv pairs of the released model "
+                 "(temp/channel_pruning.prototxt kept counts 24,22,41,51,108,89,111,184,276,228), N=20000 samples/layer, "
+                 "k=3; 1 step = jobs_per_step back-to-back jobs", "conv layers pruned/sec (VGG-16 5x, 20k samples)"),
+}
+
+
+def bench_job(args, env, job):
     import cpmi355
     from cpmi355 import shard
     from cpmi355.pruner import prune_layer, rng_rewind
 
-    specs = vgg16_specs()
+    specs = cpjobs.JOBS[job]()
     for s in specs:       # measured single-layer latencies (ms, profiles/r02_*) as LPT costs; model when absent
-        s["cost"] = VGG16_COST_MS.get(s["c"], None) or shard.layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"])
+        s["cost"] = (VGG16_COST_MS.get(s["c"], None) if job == "vgg16" else None) or \
+            shard.layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"])
     owner = shard.plan_owners(specs, env.world)
     own = [i for i in range(len(specs)) if owner[i] == env.rank]
     host_data = {}
 
     def operands(spec):
-        X, W2, Y, _ = synth(spec["layer_id"], spec["c"], spec["n"])
+        X, W2, Y, _ = cpjobs.synth(spec)
         host_data[spec["layer_id"]] = (X, W2, Y)
         return X, W2, Y
 
     t_up0 = time.perf_counter()
-    rset = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in own], operands, per_stream=args.per_stream,
+    per_stream = args.per_stream or (1 if job != "resnet50" else 2)
+    rset = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in own], operands, per_stream=per_stream,
                                   flags=CD_FLAGS, borrow_results=True)
     probs = rset.problems()           # index in `own` order -> LayerProblem
     ctxs = [cx for ch in rset.chunks for cx in ch["ctxs"]]
@@ -279,7 +315,7 @@ def bench_vgg16(args, env):
         for cx in roots:
             cx.sync()
 
-    # ---- warm-up: W jobs (>= 2), then choose jobs_per_step so that K steps take >= MIN_TIMED_SECONDS ----
+    # ---- warm-up: 1 + W jobs, then choose jobs_per_step so that K steps take >= MIN_TIMED_SECONDS ----
     one_job()
     sync_all()
     env.barrier()
@@ -307,7 +343,7 @@ def bench_vgg16(args, env):
                 for name, ms in pr.ctx.last_stage_times():
                     if name == "refit_gram_gemm":
                         g_ms.append(ms)
-                        g_fl.append(float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
+                        g_fl.append(float(pr.N) * int(pr.refit_info.p) ** 2)
     sync_all()
     env.barrier()
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
@@ -323,6 +359,7 @@ def bench_vgg16(args, env):
     stage_by_c = {}
     for j, pr in ([] if args.profile_mode else probs.items()):
         spec = specs[own[j]]
+        kk = spec["k"] ** 2
         pr.ctx.enable_stage_timing(1)
         ch = [c_ for c_ in rset.chunks if j in c_["members"]][0]
         rng, mark = ch["rngs"][ch["members"].index(j)], ch["marks"][ch["members"].index(j)]
@@ -334,83 +371,98 @@ def bench_vgg16(args, env):
             ts.append((time.perf_counter() - t1) * 1e3)
         st = dict(pr.ctx.last_stage_times())
         steps_cd = sum(f[2] for f in pr.fits) * spec["c"]
-        per_layer[spec["name"]] = {"ms_alone": round(min(ts), 3), "kept": int(pr.refit_info.p) // 9, "fits": len(pr.fits),
+        per_layer[spec["name"]] = {"ms_alone": round(min(ts), 3), "kept": int(pr.refit_info.p) // kk, "fits": len(pr.fits),
                                    "cd_steps": int(steps_cd), "alpha_search_ms": round(st.get("cd_alpha_search", 0.0), 3),
                                    "cd_us_per_step": round(st.get("cd_alpha_search", 0.0) * 1e3 / max(1, steps_cd), 4),
                                    "refit_ms": round(sum(v for k_, v in st.items() if k_.startswith("refit")), 3)}
-        stage_by_c.setdefault(spec["c"], st)
+        stage_by_c.setdefault("c%d_k%d_n%d" % (spec["c"], spec["k"], spec["n"]), st)
         if "refit_gram_gemm" in st:
             alone_g_ms.append(st["refit_gram_gemm"])
-            alone_g_fl.append(float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
+            alone_g_fl.append(float(spec["N"]) * int(pr.refit_info.p) ** 2)
             # latency mode: the launch computed the Gram of ALL c channels during the alpha search (CP_REFIT_PRECOMPUTE)
-            alone_g_ex.append(float(N_SAMPLES) * (spec["c"] * 9) ** 2 if ("refit_gather_normal_eq" in st or "refit_backward" in st)
-                              else float(N_SAMPLES) * int(pr.refit_info.p) ** 2)
+            alone_g_ex.append(float(spec["N"]) * (spec["c"] * kk) ** 2 if ("refit_gather_normal_eq" in st or "refit_backward" in st)
+                              else float(spec["N"]) * int(pr.refit_info.p) ** 2)
 
     # ---- PCIe-inclusive: upload of a layer's operands from pageable host memory + its pruning, layer after layer ----
     pcie = None
     if env.world == 1 and not args.profile_mode:
         from cpmi355.pruner import LayerProblem
         ctx0 = roots[0]
-        t_pass = []
-        for _ in range(2):       # first pass: workspaces of the context grow layer by layer (cold); second: steady state
+
+        def sequential_pass(x_dtype):
             t1 = time.perf_counter()
             h2d = 0
             for j in sorted(probs):
                 spec = specs[own[j]]
                 X, W2, Y = host_data[spec["layer_id"]]
-                pr = LayerProblem(ctx0, X, W2, Y, flags=CD_FLAGS)
+                pr = LayerProblem(ctx0, X.astype(x_dtype, copy=False), W2, Y, flags=CD_FLAGS)
                 h2d += pr.h2d_bytes
                 prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
                 pr.free()
-            t_pass.append(time.perf_counter() - t1)
-        t_seq = t_pass[1]
-        pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "first_pass_ms": round(t_pass[0] * 1e3, 2),
-                "h2d_bytes": int(h2d),
-                "layers_per_s_with_h2d": round(len(specs) / t_seq, 2),
+            return time.perf_counter() - t1, h2d
+
+        first, _ = sequential_pass(np.float32)     # first pass: workspaces of the context grow layer by layer (cold)
+        t_seq, h2d = sequential_pass(np.float32)   # steady state
+        pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "first_pass_ms": round(first * 1e3, 2),
+                "h2d_bytes": int(h2d), "layers_per_s_with_h2d": round(len(specs) / t_seq, 2),
                 "note": "every layer uploaded from pageable host memory (hipMemcpy) and pruned, one after another on one "
                         "stream: what the drop-in dictionary() does per call; never part of `value`.  first_pass_ms: the "
-                        "context's workspaces still growing from layer to layer"}
+                        "context's workspaces still growing from layer to layer.  X as float32 (the bytes the reference's "
+                        "float64 arrays hold: Caffe blobs); x_float64 = the same pass with X uploaded as the float64 array "
+                        "the reference hands to dictionary() (2x the bytes, the astype() excluded)"}
+        if not args.no_pcie_f64:
+            x64 = {lid: v[0].astype(np.float64) for lid, v in host_data.items()}
+            saved = dict(host_data)
+            for lid in x64:
+                host_data[lid] = (x64[lid],) + saved[lid][1:]
+            t64, h64 = sequential_pass(np.float64)
+            host_data.update(saved)
+            del x64
+            pcie["x_float64"] = {"job_ms_sequential_with_h2d": round(t64 * 1e3, 2), "h2d_bytes": int(h64),
+                                 "layers_per_s_with_h2d": round(len(specs) / t64, 2)}
 
     # ---- verification on rank 0 (outside the timed region) ----
     out = None
     if env.rank == 0:
-        parity, werrs, recon = True, {}, {}
+        parity, werrs, recon, no_golden = True, {}, {}, []
         for spec, (idxs, newW2, newB2) in zip(specs, results):
             same, werr = golden_check(spec["name"], idxs, newW2)
             werrs[spec["name"]] = werr
             if same is not None:
                 parity = parity and same and werr is not None and werr <= 1e-5
+            else:
+                no_golden.append(spec["name"])
             if spec["layer_id"] in host_data:
                 X, _, Y = host_data[spec["layer_id"]]
-                Xs = X[:, idxs].reshape(N_SAMPLES, -1).astype(np.float64)
+                Xs = X[:, idxs].reshape(spec["N"], -1).astype(np.float64)
                 res = Xs @ newW2.reshape(spec["n"], -1).T + newB2 - Y
                 recon[spec["name"]] = round(float(np.linalg.norm(res) / np.linalg.norm(Y)), 6)
         layers_per_s = len(specs) * jobs / elapsed
-        fl = [layer_flops(s["c"], s["n"], int(r[0].sum()) * 9) for s, r in zip(specs, results)]
-        by = [algorithmic_bytes(s["c"], s["n"], int(r[0].sum()) * 9) for s, r in zip(specs, results)]
+        fl = [layer_flops(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
+        by = [algorithmic_bytes(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
         roof = roofline_object(g_ms, g_fl, roots[0],
                                "launch duration over the timed region, i.e. while the other layers of the job share the "
                                "CUs; alone = the same kernel of every layer with the chip to itself; job_mfma = the "
-                               "whole job against the same peak", pmc_traffic("k_gemm_tn_f64<1, 2,", "r02"))
+                               "whole job against the same peak",
+                               pmc_traffic("k_gemm_tn_f64<1, 2,", PROFILE_TAG) if job == "vgg16" else None)
         if roof is not None and alone_g_ms:
             a1 = sum(alone_g_fl) / (sum(alone_g_ms) * 1e-3) / 1e12
             roof["alone"] = {"achieved": round(a1, 3), "frac": round(a1 / F64_MFMA_PEAK_TFLOPS, 4),
                              "avg_launch_ms": round(sum(alone_g_ms) / len(alone_g_ms), 4),
                              "executed_tflops": round(sum(alone_g_ex) / (sum(alone_g_ms) * 1e-3) / 1e12, 3),
                              "note": "one layer at a time = latency mode: the launch computes the Gram of ALL c channels on the "
-                                     "side stream during the alpha search (executed N (9c)^2); achieved counts only the "
+                                     "side stream during the alpha search (executed N (c k^2)^2); achieved counts only the "
                                      "algorithmic N p^2 of the kept channels"}
         out = {
-            "metric": "conv layers pruned/sec (VGG-16 4x, 5k samples)",
+            "metric": JOB_TEXT[job][1],
             "value": round(layers_per_s, 3), "unit": "layers/s", "n_gpus": env.world, "steps": args.steps,
-            "warmup": max(1, args.warmup) + 1, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "vgg16: ONE instance of the whole-network job = the 12 conv->conv pairs of VGG-16, "
-                                   "kept channels d_c = int(c/1.15) (the reference's 3C-4x table), N=5000 samples/layer, "
-                                   "k=3; 1 job = 12 dictionary() calls; 1 step = jobs_per_step back-to-back jobs",
+            "config": {"workload": JOB_TEXT[job][0],
                        "layers_per_job": len(specs), "jobs_per_step": reps, "jobs_timed": jobs,
-                       "timed_region_s": round(elapsed, 3),
+                       "untimed_jobs_before": 1 + max(1, args.warmup),
+                       "timed_region_s": round(elapsed, 3), "world_size": env.world, "backend": env.backend if env.dist else None,
                        "streams_per_gpu": len(rset.chunks), "layers_in_flight_per_gpu": len(own),
                        "layers_per_call": sorted({len(ch["members"]) for ch in rset.chunks}),
                        "owner_rank_of_layer": owner, "parallelism": "layers sharded x%d (LPT), masks all_gather + "
@@ -420,44 +472,37 @@ def bench_vgg16(args, env):
                 {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard.LAST_EXCHANGE_MS.items()},
                 avg_total_ms=round(float(np.mean(exch_ms)), 3),
                 note="host wall time of cpmi355.shard.exchange_results on rank 0 (includes waiting for the slowest rank)"),
-            "mask_parity_vs_reference_golden": parity,
+            "mask_parity_vs_reference_golden": parity if len(no_golden) < len(specs) else None,
+            "layers_without_golden": no_golden,
             "weights_rel_frobenius_vs_reference_golden": werrs,
             "reconstruction_rel_frobenius_err": recon,
             "roofline": roof,
             "job_mfma": {"gflop_per_job_algorithmic": round(alg_job / 1e9, 1), "gflop_per_job_executed_model": round(exe_job / 1e9, 1),
-                         "sustained_tflops_algorithmic": round(alg_job / (job_ms * 1e-3) / 1e12, 2),
-                         "frac_of_peak_algorithmic": round(alg_job / (job_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS / env.world, 4),
+                         "sustained_tflops_executed": round(exe_job / (job_ms * 1e-3) / 1e12, 2),
+                         "frac_of_peak_executed": round(exe_job / (job_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS / env.world, 4),
+                         "sustained_tflops_algorithmic_full_matrix_count": round(alg_job / (job_ms * 1e-3) / 1e12, 2),
                          "algorithmic_bytes_per_job": int(sum(by)),
-                         "note": "SURVEY.md 8d flop / byte formulas summed over the 12 layers (full-matrix counts)"},
+                         "note": "executed = what the launches compute (symmetric halves of the Grams, 128-padded tiles): the "
+                                 "figure to hold against the MFMA peak; algorithmic = SURVEY.md 8d's full-matrix flop count "
+                                 "(2 N p^2 for a Gram whose launch executes N p^2), kept for reference only"},
             "per_layer_rank0": per_layer,
             "chunks_rank0_last_job": chunk_report,
-            "stage_ms_alone_by_width_rank0": {str(c): {k_: round(v, 4) for k_, v in st.items()} for c, st in stage_by_c.items()},
+            "stage_ms_alone_by_shape_rank0": {c: {k_: round(v, 4) for k_, v in st.items()} for c, st in stage_by_c.items()},
             "pcie_inclusive": pcie,
             "upload_and_setup_s": round(t0 - t_up0, 2),
         }
         if env.world == 1 and not args.no_cpu_baseline and not args.profile_mode:
-            # bounded sample (about 20 s of CPU work): every layer up to c = 128 and the first c = 256 one
-            small = [s for s in specs if s["c"] <= 128] + [s for s in specs if s["c"] == 256][:1]
-            sample = specs if args.cpu_full else small
-            secs = cpu_port_seconds([(s["layer_id"], s["c"], s["n"], s["rank"]) for s in sample])
-            gpu_ms_same = sum(per_layer[s["name"]]["ms_alone"] for s in sample)
-            out["cpu_baseline"] = {
-                "value": round(len(sample) / sum(secs), 4), "unit": "layers/s", "cores": host_threads(), "kind": "port",
-                "sample": "%s of the job's 12 layers (%s), one pass, sklearn Lasso (single-threaded CD) + "
-                          "LinearRegression/gelsd (BLAS threads = cores): %.1f s total, per layer %s s" % (
-                              "all 12" if args.cpu_full else "%d" % len(sample), ", ".join(s["name"][:3] for s in sample),
-                              sum(secs), [round(x, 2) for x in secs]),
-                "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
-                "gpu_ms_same_layers_one_at_a_time": round(gpu_ms_same, 2),
-                "speedup_same_layers_latency": round(sum(secs) * 1e3 / gpu_ms_same, 1)}
-            if args.cpu_full:
-                out["cpu_baseline"]["job_speedup_wall_clock"] = round(sum(secs) * 1e3 / job_ms, 1)
+            # bounded sample (about 20 s of CPU work): the cheapest layers of the job by the cost model
+            order = sorted(specs, key=lambda s: shard.layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"]))
+            small = [s for s in specs if s["c"] <= 128] + [s for s in specs if s["c"] == 256][:1] if job == "vgg16" else order[:6]
+            out["cpu_baseline"] = cpu_baseline_object(specs, specs if args.cpu_full else small, per_layer, job_ms, args.cpu_full)
     rset.close()
     return out
 
 
 # measured ms of one layer alone by channel count (profiles/r02_*): the LPT costs of the vgg16 job
 VGG16_COST_MS = {64: 1.5, 128: 3.0, 256: 6.8, 512: 15.5}
+PROFILE_TAG = "r03"      # profiles/<tag>_pmc_{fetch,write}_size_kb.md feed roofline.traffic
 
 
 # ==================================================================================================================
@@ -680,7 +725,7 @@ def bench_block(args, env):
         g_fl = [f for w in workers for f in w.gram_flops]
         roof = roofline_object(g_ms, g_fl, workers[0].ctx,
                                "launch duration over the timed region, i.e. while the other layers in flight share the CUs",
-                               pmc_traffic("k_gemm_tn_f64<1, 2,", "r02"))
+                               pmc_traffic("k_gemm_tn_f64<1, 2,", PROFILE_TAG))
         fl = [layer_flops(w.c, w.n, int(w.prob.refit_info.p)) for w in groups[0]]
         alg_l = sum(f[0] for f in fl) / len(fl)
         calls = sum(w.calls for w in workers)
@@ -709,14 +754,81 @@ def bench_block(args, env):
         out["single_instance"] = single
         out["single_instance_layers_per_s"] = single["layers_per_s"]
         if world == 1 and not args.no_cpu_baseline:
-            secs = cpu_port_seconds(BLOCK_LAYERS)
-            out["cpu_baseline"] = {"value": round(len(BLOCK_LAYERS) / sum(secs), 4), "unit": "layers/s", "cores": host_threads(),
+            bspecs = [dict(layer_id=lid, name="L%02d" % (lid - 30), N=N_SAMPLES, c=c, n=n, k=KSIZE, rank=r) for lid, c, n, r in BLOCK_LAYERS]
+            best, sweep = cpu_best_threads(bspecs[:1])
+            secs = cpu_port_seconds(bspecs, threads=best)
+            out["cpu_baseline"] = {"value": round(len(BLOCK_LAYERS) / sum(secs), 4), "unit": "layers/s", "cores": int(best),
+                                   "blas_thread_sweep_s": sweep,
                                    "kind": "port", "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
                                    "sample": "one pass over the 3 conv3_x layers (N=5000), sklearn Lasso (single-threaded CD) "
-                                             "+ LinearRegression/gelsd (BLAS threads = cores); %.1f s total, per layer %s s" % (
+                                             "+ LinearRegression/gelsd (BLAS threads = cores, the fastest of the sweep); %.1f s total, per layer %s s" % (
                                                  sum(secs), [round(s, 2) for s in secs]),
                                    "speedup_single_instance_latency": round(sum(secs) * 1e3 / single["ms_per_pass"], 1)}
     return out
+
+
+def bench_patch_gather(device, C=256, H=56, W=56, B=10, P=10, nb=50, k=3, pad=1, reps=20):
+    """a1 (Net.extract_XY, lib/net.py:534-684): the sampled-point im2col of SURVEY.md 8d's gather workload -- B = 10 images,
+    C = 256 channels of 56 x 56, 10 sampled points per batch, 50 batches => N = 5000 rows of C*k*k floats (ReLU fused).
+    The feature maps of all batches are resident in HBM ([nb, B, C, H, W] float32 = 1.6 GB); timed: (a) ONE launch over
+    all batches (cp_patch_gather_batches), (b) one cp_patch_gather call per batch as the facade issues them while the
+    provider's forward passes run.  Algorithmic bytes = the rows written + the same bytes read (8 N C k^2)."""
+    import cpmi355
+    ctx = cpmi355.Context(device)
+    try:
+        rs = np.random.RandomState(7)
+        one = rs.randn(B, C, H, W).astype(np.float32)
+        fm = ctx.empty(nb * one.nbytes)
+        for b in range(nb):           # the same batch image nb times: contents are irrelevant to a gather's speed
+            ctx._check(ctx.lib.cp_memcpy_h2d(ctx.h, fm.ptr + b * one.nbytes, one.ctypes.data, one.nbytes), "cp_memcpy_h2d")
+        xs = rs.randint(0, H, nb * P).astype(np.int32)
+        ys = rs.randint(0, W, nb * P).astype(np.int32)
+        N = nb * P * B
+        out = ctx.empty(N * C * k * k * 4)
+        alg = 8.0 * N * C * k * k
+        res = {}
+        for name in ("one_launch", "per_batch_calls"):
+            def run():
+                if name == "one_launch":
+                    ctx.patch_gather_batches(fm, nb, B, C, H, W, xs, ys, P, k, pad, 1, True, out)
+                else:
+                    for b in range(nb):
+                        ctx.patch_gather(fm.ptr + b * one.nbytes, B, C, H, W, xs[b * P:(b + 1) * P],
+                                         ys[b * P:(b + 1) * P], k, pad, 1, True, out, b * P * B)
+            run()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            ctx.sync()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            res[name] = {"ms": round(ms, 4), "GBps_algorithmic": round(alg / ms / 1e6, 1),
+                         "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 8.0e12, 4)}
+        res["workload"] = "B=%d C=%d %dx%d k=%d pad=%d, %d points x %d batches: N=%d rows, %.1f MB written" % (
+            B, C, H, W, k, pad, P, nb, N, alg / 2e6)
+        res["note"] = ("HBM-bound gather: every sampled k-wide run of a channel row costs a whole 64-byte fabric request "
+                       "(3 x 64 B fetched per 36 B used at k = 3), so the algorithmic rate is bounded near "
+                       "8 TB/s x 72 / (192 + 36) = 2.5 TB/s; see DESIGN.md")
+        return res
+    finally:
+        ctx.close()
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no torch.distributed environment: run this same command under
+    torch.distributed.run, one rank per GPU on this node (rendezvous on 127.0.0.1)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -724,27 +836,37 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("vgg16", "block"), default=os.environ.get("CP_BENCH_WORKLOAD", "vgg16"))
+    ap.add_argument("--workload", choices=("vgg16", "resnet50", "vgg16_5x", "block"),
+                    default=os.environ.get("CP_BENCH_WORKLOAD", "vgg16"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-full", action="store_true", help="vgg16: time the CPU port on all 12 layers (about 2-3 min)")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU port on every layer of the job (vgg16: about 2-3 min)")
     ap.add_argument("--no-block", action="store_true", help="vgg16: skip the conv3_x single-instance figures")
+    ap.add_argument("--no-gather", action="store_true", help="skip the sampled-point im2col (extract_XY) measurement")
+    ap.add_argument("--no-pcie-f64", action="store_true", help="skip the float64-X variant of the PCIe-inclusive pass")
     ap.add_argument("--profile-mode", action="store_true",
-                    help="vgg16: only whole jobs (1 + warmup + steps x jobs_per_step of them), nothing else on the GPU: for rocprofv3")
-    ap.add_argument("--per-stream", type=int, default=int(os.environ.get("CP_BENCH_PER_STREAM", "1")),
-                    help="vgg16: equal-width layers per stream / cp_prune_layers call")
-    ap.add_argument("--jobs-per-step", type=int, default=0, help="vgg16: fixed jobs per step (0 = fill >= 2 s)")
+                    help="only whole jobs (1 + warmup + steps x jobs_per_step of them), nothing else on the GPU: for rocprofv3")
+    ap.add_argument("--per-stream", type=int, default=int(os.environ.get("CP_BENCH_PER_STREAM", "0")),
+                    help="equal-width layers per stream / cp_prune_layers call (0: 1, resnet50: 2)")
+    ap.add_argument("--jobs-per-step", type=int, default=0, help="fixed jobs per step (0 = fill >= 2 s)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("CP_BENCH_INFLIGHT", "6")),
                     help="block: worker groups (3 HIP streams each) running passes over the block concurrently")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("CP_BENCH_BATCH", "8")),
                     help="block: block copies a worker group prunes per cp_prune_layers call")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     env = Env()
-    if args.workload == "vgg16":
-        out = bench_vgg16(args, env)
-        if out is not None and not args.no_block and not args.profile_mode and env.world == 1:
-            single, group = block_single_instance(env.local_rank)
-            close_workers(group)
-            out["conv3_block_single_instance"] = single
+    if env.world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the torch.distributed environment has WORLD_SIZE=%d" % (args.gpus, env.world))
+    if args.workload != "block":
+        out = bench_job(args, env, args.workload)
+        if out is not None and not args.profile_mode and env.world == 1:
+            if args.workload == "vgg16" and not args.no_block:
+                single, group = block_single_instance(env.local_rank)
+                close_workers(group)
+                out["conv3_block_single_instance"] = single
+            if not args.no_gather:
+                out["patch_gather"] = bench_patch_gather(env.local_rank)
     else:
         out = bench_block(args, env)
     if env.rank == 0 and out is not None:

@@ -77,6 +77,8 @@ SIGNATURES = {
     "cp_memset": (_c_int, [_vp, _vp, _c_int, ctypes.c_size_t]),
     "cp_patch_gather": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int,
                                  _c_int, _c_int, _vp, _c_i64]),
+    "cp_patch_gather_batches": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int,
+                                         _c_int, _c_int, _vp]),
     "cp_assemble_y": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _vp]),
     "cp_lasso_gram": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
                                _vp, _vp, _vp]),
@@ -289,6 +291,15 @@ class Context:
         self._check(self.lib.cp_patch_gather(self.h, _ptr(fmap), B, C, H, W, xs.ctypes.data, ys.ctypes.data,
                                              xs.shape[0], k, pad, stride, int(bool(relu)), _ptr(X_out),
                                              int(row0)), "cp_patch_gather")
+
+    def patch_gather_batches(self, fmap, nb, B, C, H, W, xs, ys, P, k, pad, stride, relu, X_out):
+        """all nb batches in one launch: fmap [nb,B,C,H,W] f32 on the device, xs / ys int32 [nb * P] batch-major"""
+        xs = np.ascontiguousarray(xs, dtype=np.int32)
+        ys = np.ascontiguousarray(ys, dtype=np.int32)
+        assert xs.shape[0] == nb * P and ys.shape[0] == nb * P
+        self._check(self.lib.cp_patch_gather_batches(self.h, _ptr(fmap), int(nb), B, C, H, W, xs.ctypes.data, ys.ctypes.data,
+                                                     int(P), k, pad, stride, int(bool(relu)), _ptr(X_out)),
+                    "cp_patch_gather_batches")
 
     def assemble_y(self, feats, bias, resY, N, n, Y):
         self._check(self.lib.cp_assemble_y(self.h, _ptr(feats), _ptr(bias), _ptr(resY), int(N), int(n), _ptr(Y)),

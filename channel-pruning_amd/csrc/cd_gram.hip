@@ -1592,14 +1592,24 @@ __global__ void __launch_bounds__(2 * WAVE) k_cd_search_duo_batch(CdSearchBatch 
 
 }  // namespace
 
+// More than 64 KB of dynamic LDS (c > 1228: w, the per-feature scalars and the H image are 5c + 64R doubles) needs an
+// explicit opt-in per kernel: per device, idempotent, a few microseconds -- done on every such launch.  A workgroup may
+// take the CU's whole 160 KB (MI355X_MICROARCH.md, LDS), which covers c = 2048 (96 KB): ResNet-50's shortcut blobs.
+constexpr size_t CD_LDS_DEFAULT = 64 * 1024, CD_LDS_MAX = 160 * 1024;
+template <typename K>
+static hipError_t cd_lds_optin(K kernel, size_t lds) {
+    if (lds <= CD_LDS_DEFAULT) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+}
+
 #define CP_CD_DISPATCH(KERNEL, R_, ...)                                      \
     switch (R_) {                                                            \
         case 1: KERNEL<1><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;   \
         case 2: KERNEL<2><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;   \
         case 4: KERNEL<4><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;   \
         case 8: KERNEL<8><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break;   \
-        case 16: KERNEL<16><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break; \
-        default: KERNEL<32><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break; \
+        case 16: CP_HIP(ctx, cd_lds_optin(KERNEL<16>, lds)); KERNEL<16><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break; \
+        default: CP_HIP(ctx, cd_lds_optin(KERNEL<32>, lds)); KERNEL<32><<<1, WAVE, lds, ctx->stream>>>(__VA_ARGS__); break; \
     }
 
 static int pick_R(int c) {
@@ -1636,8 +1646,7 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     DevResult *dres = reinterpret_cast<DevResult *>(cp_arena_take(ctx, sizeof(DevResult)));
     const bool duo = use_duo(c);
     const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
-    if (lds > 64 * 1024)   // no opt-in above the default dynamic-LDS limit is requested for these kernels
-        return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit 65536: c <= 1228)", c, lds);
+    if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     if (duo) {
@@ -1686,8 +1695,7 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     memcpy(h + off_seed, seeds, size_t(max_fits) * sizeof(uint32_t));
     const bool duo = use_duo(c);
     const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
-    if (lds > 64 * 1024)   // no opt-in above the default dynamic-LDS limit is requested for these kernels
-        return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit 65536: c <= 1228)", c, lds);
+    if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     if (duo) {
@@ -1762,8 +1770,7 @@ int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_sear
     }
     const bool duo = use_duo(c);
     const size_t lds = duo ? duo_lds_bytes(c) : (size_t(5) * c + size_t(WAVE) * pick_R(c)) * sizeof(double);
-    if (lds > 64 * 1024)   // no opt-in above the default dynamic-LDS limit is requested for these kernels
-        return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit 65536: c <= 1228)", c, lds);
+    if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
     if (duo) {
@@ -1779,8 +1786,14 @@ int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_sear
             case 2: k_cd_search_batch<2><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
             case 4: k_cd_search_batch<4><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
             case 8: k_cd_search_batch<8><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
-            case 16: k_cd_search_batch<16><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
-            default: k_cd_search_batch<32><<<n_jobs, WAVE, lds, ctx->stream>>>(batch); break;
+            case 16:
+                CP_HIP(ctx, cd_lds_optin(k_cd_search_batch<16>, lds));
+                k_cd_search_batch<16><<<n_jobs, WAVE, lds, ctx->stream>>>(batch);
+                break;
+            default:
+                CP_HIP(ctx, cd_lds_optin(k_cd_search_batch<32>, lds));
+                k_cd_search_batch<32><<<n_jobs, WAVE, lds, ctx->stream>>>(batch);
+                break;
         }
     }
     CP_LAUNCH_CHECK(ctx);

@@ -28,7 +28,8 @@ struct cp_refit_deferred {
 // columns (cp_refit_precompute_enqueue, refit.hip).
 struct cp_ctx;
 struct cp_precompute {
-    bool ready = false;            // set by enqueue, consumed (one shot) by the next matching cp_lstsq_refit_impl
+    bool ready = false;            // set by enqueue, consumed (one shot) by the refit cp_prune_layer(s) issues next
+    bool armed = false;            // only while cp_prune_layer(s) is inside that refit: no other call may consume `ready`
     const void *X = nullptr;
     const double *Y = nullptr;
     int64_t N = 0;
@@ -115,6 +116,9 @@ int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
 // one-workgroup helper or a Cholesky diagonal block of another layer otherwise waits for such a workgroup to retire.
 hipStream_t cp_wide_stream(cp_ctx *ctx);
 hipStream_t cp_side_stream(cp_ctx *ctx);   // the device's shared stream for work that overlaps a context's own chain (never null)
+// A pending precompute that nobody will consume (error exit, an unrelated refit, new contents in its buffers): wait for the
+// side / chain stream work that still reads X / Y, then forget it.
+void cp_precompute_void(cp_ctx *ctx);
 int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n,
                                 double rank_hint = 0.0);
 void cp_precompute_release(cp_ctx *ctx);

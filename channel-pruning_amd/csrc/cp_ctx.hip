@@ -178,12 +178,7 @@ extern "C" int cp_free(cp_ctx *ctx, void *dptr) {
 extern "C" int cp_memcpy_h2d(cp_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx || (bytes && (!dst || !src))) return CP_ERR_ARG;
     CP_HIP(ctx, hipSetDevice(ctx->device));  // the calling thread may never have selected this device
-    if (ctx->pre.ready && (dst == ctx->pre.X || dst == ctx->pre.Y)) {   // new contents: a pending precompute of the old ones is void
-        if (ctx->pre.worker) CP_HIP(ctx, hipStreamSynchronize(ctx->pre.worker->stream));
-        if (ctx->pre.chain_stream) CP_HIP(ctx, hipStreamSynchronize(ctx->pre.chain_stream));
-        ctx->pre.ready = false;
-        ctx->pre.factored = false;
-    }
+    if (ctx->pre.ready && (dst == ctx->pre.X || dst == ctx->pre.Y)) cp_precompute_void(ctx);   // new contents
     // pageable source: hipMemcpyAsync stages it before returning, so the caller may reuse src.
     CP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return CP_OK;

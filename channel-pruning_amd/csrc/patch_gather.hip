@@ -7,24 +7,39 @@
 
 namespace {
 
-// One workgroup per (point, image) output row; threads sweep the C*k*k patch elements, which are
-// contiguous in the output (coalesced stores); reads walk k-wide runs of the feature map.
+// One workgroup per (batch, point, image) output row; threads sweep the C*k*k patch elements, which are
+// contiguous in the output (coalesced stores); reads walk k-wide runs of the feature map: every run of a
+// channel row costs one 64-byte fabric request whatever k is, so the kernel is bound by requests in flight --
+// four independent loads per thread are issued before the first store.  K > 0: compile-time kernel size
+// (the channel / tap split of the element index becomes multiplications); K = 0: any k.
+template <int K>
 __global__ void __launch_bounds__(256) k_patch_gather(const float *__restrict__ fmap, int B, int C, int H, int W,
-                                                      const int *__restrict__ xs, const int *__restrict__ ys, int k,
+                                                      const int *__restrict__ xs, const int *__restrict__ ys, int P, int k_rt,
                                                       int pad, int stride, int relu, float *__restrict__ out) {
-    const int row = blockIdx.x;  // = p * B + b
-    const int p = row / B, b = row - p * B;
-    const int h0 = xs[p] * stride - pad, w0 = ys[p] * stride - pad;
+    const int k = K > 0 ? K : k_rt;
+    const int row = blockIdx.x;  // = (batch * P + p) * B + b
+    const int bp = row / B, b = row - bp * B;      // bp = batch * P + p: index into xs / ys
+    const int batch = bp / P;
+    const int h0 = xs[bp] * stride - pad, w0 = ys[bp] * stride - pad;
     const int kk = k * k, total = C * kk;
-    const float *src = fmap + size_t(b) * C * H * W;
+    const float *src = fmap + (size_t(batch) * B + b) * C * H * W;
     float *dst = out + size_t(row) * total;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int ch = e / kk, t = e - ch * kk, dh = t / k, dw = t - dh * k;
-        const int hh = h0 + dh, ww = w0 + dw;
-        float v = 0.f;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = src[(size_t(ch) * H + hh) * W + ww];
-        if (relu && v < 0.f) v = 0.f;
-        dst[e] = v;
+    constexpr int U = 4;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            const int ch = e / kk, t = e - ch * kk, dh = t / k, dw = t - dh * k;
+            const int hh = h0 + dh, ww = w0 + dw;
+            v[u] = 0.f;
+            if (e < total && hh >= 0 && hh < H && ww >= 0 && ww < W) v[u] = src[(size_t(ch) * H + hh) * W + ww];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < total) dst[e] = (relu && v[u] < 0.f) ? 0.f : v[u];
+        }
     }
 }
 
@@ -42,6 +57,24 @@ __global__ void __launch_bounds__(256) k_assemble_y(const float *__restrict__ fe
 
 }  // namespace
 
+static int patch_gather_launch(cp_ctx *ctx, const float *fmap, int nb, int B, int C, int H, int W, const int32_t *xs,
+                               const int32_t *ys, int P, int k, int pad, int stride, int relu, float *dst) {
+    const size_t np = size_t(nb) * P;
+    CP_TRY(cp_arena_reserve(ctx, np * 8 + 4096));
+    int *dx = cp_arena_take_t<int>(ctx, np), *dy = cp_arena_take_t<int>(ctx, np);
+    CP_HIP(ctx, hipMemcpyAsync(dx, xs, np * 4, hipMemcpyHostToDevice, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(dy, ys, np * 4, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned grid = unsigned(np * B);
+    if (k == 3)
+        k_patch_gather<3><<<grid, 256, 0, ctx->stream>>>(fmap, B, C, H, W, dx, dy, P, k, pad, stride, relu, dst);
+    else if (k == 1)
+        k_patch_gather<1><<<grid, 256, 0, ctx->stream>>>(fmap, B, C, H, W, dx, dy, P, k, pad, stride, relu, dst);
+    else
+        k_patch_gather<0><<<grid, 256, 0, ctx->stream>>>(fmap, B, C, H, W, dx, dy, P, k, pad, stride, relu, dst);
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}
+
 extern "C" int cp_patch_gather(cp_ctx *ctx, const float *fmap, int B, int C, int H, int W, const int32_t *xs,
                                const int32_t *ys, int P, int k, int pad, int stride, int relu, float *X_out,
                                int64_t row0) {
@@ -49,14 +82,20 @@ extern "C" int cp_patch_gather(cp_ctx *ctx, const float *fmap, int B, int C, int
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0 || k <= 0 || pad < 0 || stride <= 0 || row0 < 0)
         return cp_set_error(ctx, CP_ERR_ARG, "patch_gather: bad sizes");
     CP_HIP(ctx, hipSetDevice(ctx->device));
-    CP_TRY(cp_arena_reserve(ctx, size_t(P) * 8 + 4096));
-    int *dx = cp_arena_take_t<int>(ctx, P), *dy = cp_arena_take_t<int>(ctx, P);
-    CP_HIP(ctx, hipMemcpyAsync(dx, xs, size_t(P) * 4, hipMemcpyHostToDevice, ctx->stream));
-    CP_HIP(ctx, hipMemcpyAsync(dy, ys, size_t(P) * 4, hipMemcpyHostToDevice, ctx->stream));
-    float *dst = X_out + size_t(row0) * C * k * k;
-    k_patch_gather<<<P * B, 256, 0, ctx->stream>>>(fmap, B, C, H, W, dx, dy, k, pad, stride, relu, dst);
-    CP_LAUNCH_CHECK(ctx);
-    return CP_OK;
+    return patch_gather_launch(ctx, fmap, 1, B, C, H, W, xs, ys, P, k, pad, stride, relu, X_out + size_t(row0) * C * k * k);
+}
+
+// All batches of a layer in ONE launch: fmap DEVICE [nb, B, C, H, W], xs / ys HOST [nb * P] (batch-major); rows
+// [(batch * P + p) * B + b] of X_out -- the reference's row order over the batches (lib/net.py:642-657).
+extern "C" int cp_patch_gather_batches(cp_ctx *ctx, const float *fmap, int nb, int B, int C, int H, int W,
+                                       const int32_t *xs, const int32_t *ys, int P, int k, int pad, int stride, int relu,
+                                       float *X_out) {
+    if (!ctx || !fmap || !xs || !ys || !X_out) return CP_ERR_ARG;
+    if (nb <= 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || P <= 0 || k <= 0 || pad < 0 || stride <= 0 ||
+        int64_t(nb) * P * B > int64_t(0x7fffffff))
+        return cp_set_error(ctx, CP_ERR_ARG, "patch_gather_batches: bad sizes");
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    return patch_gather_launch(ctx, fmap, nb, B, C, H, W, xs, ys, P, k, pad, stride, relu, X_out);
 }
 
 extern "C" int cp_assemble_y(cp_ctx *ctx, const float *feats, const float *bias, const double *resY, int64_t N, int n,

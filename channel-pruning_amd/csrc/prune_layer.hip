@@ -5,6 +5,8 @@
 #include "cp_common.h"
 
 #include <chrono>
+#include <memory>
+#include <vector>
 
 namespace {
 
@@ -23,6 +25,21 @@ int layer_ws_reserve(cp_ctx *ctx, size_t bytes) {
     ctx->layer_ws_bytes = bytes;
     return CP_OK;
 }
+
+// The overlapped normal equations (cp_refit_precompute_enqueue) belong to ONE cp_prune_layer(s) call: only the refit that call
+// issues may consume them, and whatever way the call ends nothing of them stays pending -- a later refit on pooled buffers
+// with the same addresses must never pick up a stale Gram.
+struct PrecomputeScope {
+    cp_ctx *ctx;
+    explicit PrecomputeScope(cp_ctx *c) : ctx(c) {
+        cp_precompute_void(ctx);      // left over from a call that failed midway
+        ctx->pre.armed = true;
+    }
+    ~PrecomputeScope() {
+        ctx->pre.armed = false;
+        cp_precompute_void(ctx);      // no-op after a refit that consumed it
+    }
+};
 
 double now_ms() {
     using namespace std::chrono;
@@ -64,6 +81,7 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
         return cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer: bad size (c=%d n=%d kk=%d N=%lld max_fits=%d)", c, n, kk,
                             (long long)N, max_fits);
     CP_HIP(ctx, hipSetDevice(ctx->device));
+    PrecomputeScope pre_scope(ctx);
     memset(res, 0, sizeof(*res));
     ctx->result_n = 0;
     const size_t cc = size_t(c);
@@ -148,6 +166,8 @@ extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_j
             return cp_set_error(ctx0, CP_ERR_ARG, "cp_prune_layers: job %d: bad size or channel count differs from job 0", l);
     }
     CP_HIP(ctx0, hipSetDevice(ctx0->device));
+    std::vector<std::unique_ptr<PrecomputeScope>> pre_scopes;
+    for (int l = 0; l < n_jobs; ++l) pre_scopes.emplace_back(new PrecomputeScope(ctxs[l]));
     for (int l = 0; l < n_jobs; ++l) ctxs[l]->refit_pending = false;  // nothing left over from a call that failed midway
     const int c = jobs[0].c;
     const size_t cc = size_t(c);

@@ -1749,6 +1749,16 @@ __global__ void __launch_bounds__(RT) k_gather_normal_eq(const double *__restric
 
 }  // namespace
 
+void cp_precompute_void(cp_ctx *ctx) {
+    cp_precompute &pc = ctx->pre;
+    if (pc.ready || pc.factored) {
+        if (pc.worker) hipStreamSynchronize(pc.worker->stream);
+        if (pc.chain_stream) hipStreamSynchronize(pc.chain_stream);
+    }
+    pc.ready = false;
+    pc.factored = false;
+}
+
 void cp_precompute_release(cp_ctx *ctx) {
     cp_precompute &pc = ctx->pre;
     if (pc.worker) {
@@ -2080,7 +2090,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     const int rows_per_block = int((N + RB - 1) / RB);
     {   // the full Gram was factored during the alpha search: constrained solve, no factorisation of the kept sub-matrix
         cp_precompute &pf = ctx->pre;
-        if (pf.ready && pf.factored && !ctx->defer_refit_wait && pf.X == X && pf.Y == Y && pf.N == N && pf.c == c && pf.kk == kk &&
+        if (pf.armed && pf.ready && pf.factored && !ctx->defer_refit_wait && pf.X == X && pf.Y == Y && pf.N == N && pf.c == c && pf.kk == kk &&
             pf.n == n && pf.x_dtype == x_dtype && pf.n_pad == n_pad && ridge == 0.0) {
             bool done = false;
             pf.factored = false;
@@ -2135,8 +2145,9 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
     // full normal equations already under way on the side stream (cp_refit_precompute_enqueue): one shot
     cp_precompute &pc = ctx->pre;
-    const bool from_pre = pc.ready && pc.X == X && pc.Y == Y && pc.N == N && pc.c == c && pc.kk == kk && pc.n == n &&
+    const bool from_pre = pc.armed && pc.ready && pc.X == X && pc.Y == Y && pc.N == N && pc.c == c && pc.kk == kk && pc.n == n &&
                           pc.x_dtype == x_dtype && pc.n_pad == n_pad && ridge == 0.0;
+    if (!from_pre) cp_precompute_void(ctx);   // a leftover nobody may consume: its side-stream work still reads its X / Y
     pc.ready = false;
     if (from_pre) {
         CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, pc.done, 0));

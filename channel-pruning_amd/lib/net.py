@@ -185,9 +185,13 @@ class Net(object):
         idx = 0
         for batch in range(nB):
             blobs = self.forward(batch)
-            if save and not frozen:
+            if save and not frozen and blobs.get("data") is not None:
+                # a provider that exposes its input blob: the images and labels of every batch are frozen with the points
+                # (net.py:431-433).  One that does not (batch -> {blob: array} is the whole contract) freezes features
+                # and points only; load_frozen() then leaves the provider's batches alone.
                 data = np.asarray(blobs["data"])
-                label = np.asarray(blobs["label"]) if "label" in blobs else np.zeros((data.shape[0], 1, 1, 1), dtype=np.float32)
+                label = np.asarray(blobs["label"]) if blobs.get("label") is not None else \
+                    np.zeros((data.shape[0], 1, 1, 1), dtype=np.float32)
                 if batch == 0:
                     points_dict["data"] = tuple(data.shape)
                     points_dict["label"] = tuple(label.shape)

@@ -76,6 +76,11 @@ int cp_memset(cp_ctx *ctx, void *dst_dev, int value, size_t bytes);
 int cp_patch_gather(cp_ctx *ctx, const float *fmap, int B, int C, int H, int W, const int32_t *xs,
                     const int32_t *ys, int P, int k, int pad, int stride, int relu, float *X_out,
                     int64_t row0);
+/* The same for ALL nb batches of a layer in one launch (the loop over batches of lib/net.py:622-657):
+ * fmap DEVICE [nb,B,C,H,W] f32, xs/ys HOST int32[nb*P] batch-major; writes the nb*P*B rows of X_out. */
+int cp_patch_gather_batches(cp_ctx *ctx, const float *fmap, int nb, int B, int C, int H, int W,
+                            const int32_t *xs, const int32_t *ys, int P, int k, int pad, int stride, int relu,
+                            float *X_out);
 
 /* ---- a2: target assembly -------------------------------------------------------- */
 /* Y = feats - bias (+ resY): lib/net.py:1707,1716-1722.  feats DEVICE [N,n] f32,

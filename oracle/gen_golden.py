@@ -106,6 +106,23 @@ CASES = {
 }
 
 
+def _job_cases():
+    """---- round 3: every layer of the two other whole-network jobs of bench.py (cpmi355/jobs.py) ----
+    W01..W10: BASELINE.json configs[4], VGG-16 5x at N = 20000 (kept counts: temp/channel_pruning.prototxt);
+    R01..R48: configs[3], ResNet-50 2x (temp/resnet-50-cp.prototxt): channel samplers with c up to 2048, 3x3 and
+    residual-aware 1x1 consumers."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "channel-pruning_amd"))
+    from cpmi355 import jobs
+    out = {}
+    for spec in jobs.vgg16_5x() + jobs.resnet50_2x():
+        out[spec["name"]] = dict(layer_id=spec["layer_id"], N=spec["N"], c=spec["c"], n=spec["n"], k=spec["k"],
+                                 rank=spec["rank"], residual=spec["residual"], large=True, sketch=True)
+    return out
+
+
+CASES.update(_job_cases())
+
+
 def versions():
     import scipy
     import sklearn

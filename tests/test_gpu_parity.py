@@ -283,6 +283,17 @@ def test_patch_gather_and_assemble_y(ctx):
         got = ctx.to_host(od, (P * B + 3, C, k, k), np.float32)
         assert np.array_equal(got[3:], ref) and np.all(got[:3] == 0)
         out_rows += P * B
+    # all batches of a layer in one launch (cp_patch_gather_batches) = the per-batch calls, for k = 1, 3 and the generic kernel
+    for k, pad, stride, relu in ((3, 1, 1, 1), (1, 0, 1, 0), (1, 0, 2, 1), (5, 2, 1, 1)):
+        nb = 3
+        fm = rs.randn(nb, B, C, H, W).astype(np.float32)
+        top = (H + 2 * pad - k) // stride + 1
+        xs, ys = rs.randint(0, top, nb * P), rs.randint(0, top, nb * P)
+        ref = np.concatenate([cp_oracle.patch_gather(fm[b], xs[b * P:(b + 1) * P], ys[b * P:(b + 1) * P], k, pad, stride, relu)
+                              for b in range(nb)])
+        od = ctx.zeros(nb * P * B * C * k * k * 4)
+        ctx.patch_gather_batches(ctx.to_device(fm), nb, B, C, H, W, xs, ys, P, k, pad, stride, relu, od)
+        assert np.array_equal(ctx.to_host(od, (nb * P * B, C, k, k), np.float32), ref)
     feats = rs.randn(300, 40).astype(np.float32)
     bias = rs.randn(40).astype(np.float32)
     res = rs.randn(300, 40)
@@ -369,6 +380,15 @@ def test_dictionary_matches_reference_golden_full_size(ctx, name):
     assert np.abs(res.mean(0)).max() <= 1e-9
     naive = Xs @ W2[:, idxs].reshape(W2.shape[0], -1).T.astype(np.float64) - Y
     assert np.linalg.norm(res) < np.linalg.norm(naive)
+
+
+@pytest.mark.parametrize("name", golden_cases("WR"))
+def test_dictionary_matches_reference_golden_resnet50_and_vgg16_5x_jobs(ctx, name):
+    """Every layer of the two other whole-network jobs of bench.py (cpmi355/jobs.py), pinned to the unmodified reference:
+    W* = BASELINE.json configs[4], VGG-16 5x at N = 20000; R* = configs[3], ResNet-50 2x -- channel samplers with
+    c = 1024 / 2048 (the wide single-workgroup CD kernels, > 64 KB of LDS), 3x3 and residual-aware 1x1 consumers."""
+    g, p, X, W2, Y, B2 = load_case(name)
+    _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "device", exact_ops=True))
 
 
 def test_refit_with_the_prefactored_full_gram_matches_the_kept_submatrix_route(ctx):

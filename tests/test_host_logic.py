@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import GOLDEN_DIR as _GOLDEN, ROOT
 
 
 def test_cfgs_mirror_has_the_keys_the_path_reads():
@@ -632,3 +632,64 @@ def test_precompute_flag_modes(monkeypatch):
     assert pruner.precompute_flag(True, 445, 512) == 0
     monkeypatch.setenv("CP_REFIT_PRECOMPUTE", "1")
     assert pruner.precompute_flag("gram", 256, 512) == capi.CP_REFIT_PRECOMPUTE and pruner.precompute_flag(True, 256, 512) == both
+
+
+
+def test_job_tables_match_the_goldens():
+    """bench.py's synthetic operands (cpmi355.jobs.synth) are the arrays the goldens were generated from"""
+    import cp_oracle
+    from cpmi355 import jobs
+    for spec in (jobs.vgg16_4x()[0], jobs.vgg16_5x()[1], jobs.resnet50_2x()[0], jobs.resnet50_2x()[2]):
+        g = np.load(os.path.join(_GOLDEN, spec["name"] + ".npz"))
+        p = json.loads(str(g["params"]))
+        assert all(p[k] == spec[k] for k in ("layer_id", "N", "c", "n", "k", "rank"))
+        small = dict(spec, N=200)
+        a = jobs.synth(small)
+        b = cp_oracle.synth_layer(p["layer_id"], 200, p["c"], p["n"], p["k"], residual=p.get("residual", False))
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_job_tables_follow_the_reference_fixtures():
+    """kept counts of the released models: VGG-16 5x (temp/channel_pruning.prototxt) and ResNet-50 2x
+    (temp/resnet-50-cp.prototxt); every layer of the three jobs has a reference golden"""
+    from cpmi355 import jobs
+    assert [s["rank"] for s in jobs.vgg16_4x()] == [55, 55, 111, 111, 222, 222, 222, 445, 445, 445, 445, 445]
+    assert [s["rank"] for s in jobs.vgg16_5x()] == [24, 22, 41, 51, 108, 89, 111, 184, 276, 228]
+    assert all(s["N"] == 20000 for s in jobs.vgg16_5x())
+    r = jobs.resnet50_2x()
+    assert len(r) == 40 and max(s["c"] for s in r) == 2048
+    sel = [s for s in r if s["name"].endswith("_sel")]
+    assert [s["rank"] for s in sel] == [35, 101, 97, 144, 205, 198, 288, 278, 418, 407, 423, 412, 595, 606, 1222, 1147]
+    assert all(s["k"] == 1 and not s["residual"] for s in sel)
+    assert all(s["residual"] and s["k"] == 1 and s["n"] == 4 * s["c"] for s in r if s["name"].endswith("_b2b"))
+    assert all(s["k"] == 3 and s["n"] == s["c"] for s in r if s["name"].endswith("_b2a"))
+    assert len({s["layer_id"] for s in r + jobs.vgg16_5x() + jobs.vgg16_4x()}) == 62
+    for s in r + jobs.vgg16_5x() + jobs.vgg16_4x():
+        assert os.path.isfile(os.path.join(_GOLDEN, s["name"] + ".npz")), s["name"]
+
+
+def test_bench_gpus_n_launches_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run
+    with N ranks on 127.0.0.1; with one, a WORLD_SIZE that differs from --gpus is refused."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--workload", "resnet50"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--workload", "resnet50"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # inside a 2-rank environment --gpus 4 is an error, not a silent world of 2
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(bench.Env, "__init__", lambda self: setattr(self, "world", 2))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)

@@ -127,3 +127,34 @@ def test_w1keep_w2keep_select_combinehp_bookkeeping():
     assert net.combineHP() == ["convA_H"]
     assert np.allclose(net.WPQ[("convA_H", 0)], ref_w) and np.allclose(net.WPQ[("convA_H", 1)], ref_b)
     assert ("convA_P", 0) not in net.WPQ and ("convB_P", 0) in net.WPQ and net.removed == ["convA_P"]
+
+
+def test_provider_without_data_blob_freezes_features_and_points_only(tmp_path):
+    """The provider contract is batch -> {blob name: array}; the input images are optional.  Without a "data" blob
+    freeze_images() / dictionary_kernel()'s non-frozen path store no (batch, 0) / (batch, 1) / "data" / "label" entries
+    (same features, same sample points, same RNG consumption) and load_frozen() leaves the provider's batches alone."""
+    g = np.load(os.path.join(GOLDEN_DIR, "n01_vgg_pruning.npz"))
+    p = json.loads(str(g["params"]))
+    net, _, _ = _vgg(p)
+    inner = net.provider
+
+    class NoData:
+        batches = inner.batches
+
+        def __call__(self, batch, *a):
+            return {k: v for k, v in inner(batch, *a).items() if k not in ("data", "label")}
+
+    net.provider = NoData()
+    net._blob_cache = (None, None)
+    np.random.seed(3)
+    path = net.freeze_images(path=str(tmp_path / "frozen.pickle"), convs=net.convs)
+    assert int(np.random.randint(0, 2147483647)) == int(g["rng_after_freeze"])
+    feats, points = pickle.load(open(path, "rb"))
+    rfeats, rpoints = pickle.load(open(os.path.join(GOLDEN_DIR, "n01_frozen.pickle"), "rb"))
+    dropped = {"data", "label"} | {(b, i) for b in range(p["nBatches"]) for i in (0, 1)}
+    assert set(points.keys()) == set(rpoints.keys()) - dropped
+    for k in points:
+        assert np.array_equal(np.asarray(points[k]), np.asarray(rpoints[k])), k
+    for k in rfeats:
+        assert np.array_equal(feats[k], rfeats[k]), k
+    assert net._mem
