@@ -92,8 +92,9 @@ JOBS = {"vgg16": vgg16_4x, "vgg16_5x": vgg16_5x, "resnet50": resnet50_2x}
 
 
 def synth(spec):
-    """SURVEY.md section 8d generator (the same arithmetic as oracle/cp_oracle.py::synth_layer, which the goldens were
-    generated with; restated here so that the product path imports nothing from oracle/):
+    """SURVEY.md section 8d generator (the arithmetic the reference goldens under tests/golden/ were generated from; the
+    equality is pinned by tests/test_host_logic.py; restated here so that the product path imports nothing from the test
+    infrastructure):
     -> X[N,c,k,k] float32, W2[n,c,k,k] float32, Y[N,n] float64, B2[n] float32"""
     N, c, n, k = spec["N"], spec["c"], spec["n"], spec["k"]
     residual = bool(spec.get("residual", False))

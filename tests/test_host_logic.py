@@ -606,7 +606,7 @@ def test_bench_vgg16_job_is_the_reference_rank_table():
     """bench.py's whole-network job: d_c = max(int(c / 1.15), rank) with the reference's rank table x 4/3 (net.py:1309-1327,
     1346-1349) for the 12 conv -> conv pairs; golden names V01..V12 exist for every layer."""
     import bench
-    specs = bench.vgg16_specs()
+    specs = bench.cpjobs.JOBS["vgg16"]()
     assert [(s["c"], s["n"], s["rank"]) for s in specs] == [
         (64, 64, 55), (64, 128, 55), (128, 128, 111), (128, 256, 111), (256, 256, 222), (256, 256, 222), (256, 512, 222),
         (512, 512, 445), (512, 512, 445), (512, 512, 445), (512, 512, 445), (512, 512, 445)]
