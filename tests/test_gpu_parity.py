@@ -826,8 +826,8 @@ def test_resident_layer_set_vgg16_job_matches_reference_goldens(flags):
     goldens V01..V12: masks and per-fit logs identical, weights <= 1e-5 (sketch estimate), twice (runs are repeatable)."""
     import bench
     from cpmi355 import shard
-    specs = bench.vgg16_specs()
-    rset = shard.ResidentLayerSet(0, specs, lambda s: bench.synth(s["layer_id"], s["c"], s["n"])[:3], per_stream=2, flags=flags)
+    specs = bench.cpjobs.JOBS["vgg16"]()
+    rset = shard.ResidentLayerSet(0, specs, lambda s: bench.cpjobs.synth(s)[:3], per_stream=2, flags=flags)
     try:
         first = None
         for _ in range(2):
