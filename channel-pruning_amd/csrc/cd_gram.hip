@@ -21,6 +21,7 @@
 //     reductions are tree-ordered and only feed the stopping test).
 #include "cp_common.h"
 #include "xorshift_jump.h"
+#include "cd_shared.h"
 
 // tuning switches (tools/cd_bench.py builds variants with -D...)
 #ifndef CD_UNCOND_R
@@ -35,95 +36,7 @@
 
 namespace {
 
-constexpr int WAVE = 64;
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double u = __shfl_xor(v, o, WAVE);
-        v = u > v ? u : v;
-    }
-    return v;
-}
-
-// uniform-lane read of a double held in `v` (lane index is wave-uniform)
-__device__ __forceinline__ double read_lane(double v, int lane) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
-
-// 8-byte row-element load: SGPR descriptor + SGPR row offset + per-lane column offset.  No
-// address arithmetic on the vector unit, and the load stays on the vector-memory path (an
-// s_load would share lgkmcnt with the LDS reads and force full drains).
-__device__ __forceinline__ double load_q(__amdgpu_buffer_rsrc_t rsrc, uint32_t col_bytes, uint32_t row_bytes) {
-    const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col_bytes, row_bytes, 0);
-    return __hiloint2double(int(v[1]), int(v[0]));
-}
-
-typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-// 16-byte variant: two consecutive row elements per lane (one vector-memory issue instead of two)
-__device__ __forceinline__ void load_q2(__amdgpu_buffer_rsrc_t rsrc, uint32_t col_bytes, uint32_t row_bytes, double &a,
-                                        double &b) {
-    const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col_bytes, row_bytes, 0);
-    a = __hiloint2double(int(v[1]), int(v[0]));
-    b = __hiloint2double(int(v[3]), int(v[2]));
-}
-
-#ifndef CP_CD_PACKED
-#define CP_CD_PACKED 1
-#endif
-
-// Coordinate stream rand_int(c) of _cd_fast.pyx:30-32, produced 64 values at a time
-// (xorshift_jump.h): lane l of `idx`/`off` holds the coordinate / row byte offset of value
-// 64*batch + l; `pos` (wave-uniform) is the next lane to hand out.
-struct IdxStream {
-    uint32_t st, idx, off;
-    uint32_t n, row_stride_bytes;
-    uint64_t magic;
-    __device__ __forceinline__ void derive() {
-        idx = cpx::fastmod(st & 0x7fffffffu, magic, n);
-        off = idx * row_stride_bytes;
-    }
-    __device__ __forceinline__ void init(uint32_t seed, uint32_t n_, uint32_t row_stride_bytes_, int lane) {
-        n = n_;
-        row_stride_bytes = row_stride_bytes_;
-        magic = cpx::fastmod_magic(n_);
-        uint32_t s = seed == 0 ? 1u : seed;  // _random.pxd:24-25
-        for (int i = 0; i <= lane; ++i) s = cpx::xs_step(s);
-        st = s;
-        derive();
-    }
-    // value number `pos` (wave-uniform, < 64) of the current batch
-    __device__ __forceinline__ void take(int pos, int &ii, uint32_t &row_off) const {
-        ii = __builtin_amdgcn_readlane(int(idx), pos);
-        row_off = uint32_t(__builtin_amdgcn_readlane(int(off), pos));
-    }
-    __device__ __forceinline__ void next_batch() {
-        st = cpx::xs_jump64(st);
-        derive();
-    }
-    // drop the first k (< 64) values of the batch: lane l takes over value l + k
-    __device__ __forceinline__ void realign(int k, int lane) {
-        const uint32_t rot = uint32_t(__shfl(int(st), (lane + k) & 63, WAVE));
-        const uint32_t adv = cpx::xs_jump64(rot);
-        st = lane + k >= 64 ? adv : rot;
-        derive();
-    }
-};
-
-struct FitOut {
-    double gap;
-    int n_iter;
-    int nnz;
-};
+using namespace cdk;
 
 template <int R>
 struct Ring {
@@ -383,22 +296,6 @@ struct DuoCtl {
     double gap;
 };
 
-// Flags and payloads all live in LDS, and the LDS executes one wave's instructions in program order:
-// a flag written after its payload lands after it, a payload read after the flag read sees what the
-// flag announced.  So the hand-offs need no s_waitcnt of their own (an acquire / release atomic would
-// also drain the outstanding vector-memory prefetches) -- only the compiler must keep the order.
-// (explicit LDS address space: a volatile access through a generic pointer stays a FLAT instruction
-// with a full vmcnt(0) drain around it)
-typedef __attribute__((address_space(3))) volatile int duo_lds_vint;
-__device__ __forceinline__ int duo_load(int *p) {
-    const int v = *(duo_lds_vint *)p;
-    asm volatile("" ::: "memory");
-    return v;
-}
-__device__ __forceinline__ void duo_store(int *p, int v) {
-    asm volatile("" ::: "memory");
-    *(duo_lds_vint *)p = v;
-}
 // wait until *p >= need (returns false if `stop` was raised or the bound ran out)
 __device__ __forceinline__ bool duo_wait(int *p, int need, DuoCtl *ctl, bool watch_stop) {
     for (int spin = 0;; ++spin) {
@@ -1329,13 +1226,6 @@ __device__ __forceinline__ void load_features(const double *__restrict__ Q, int 
 }
 
 
-struct DevResult {  // mirrors cp_cd_result
-    double gap;
-    double tol_scaled;
-    int32_t n_iter;
-    int32_t nnz;
-};
-
 template <int R>
 __global__ void __launch_bounds__(WAVE) k_cd_fit(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
                                                  const double *__restrict__ stats, int c, double l1, double l2,
@@ -1540,27 +1430,6 @@ cd_search_duo_body(const double *__restrict__ Q, int ldq, const double *__restri
 // One alpha search per workgroup.  k_cd_search / k_cd_search_duo: one layer per launch; the _batch forms take up
 // to CP_CD_MAX_BATCH layers of the same width (blockIdx.x picks the argument block): independent layers that share a
 // stream then run their searches side by side instead of one after the other.
-struct CdSearchArgs {
-    const double *Q;
-    int ldq;
-    const double *q, *stats;
-    int c;
-    double M, right0, rank, lbound, rbound;
-    const uint32_t *seeds;
-    int max_fits, max_iter;
-    double tol;
-    int flags;
-    double *w, *w_host;
-    DevResult *log;
-    double *log_alpha;
-    int *fits_used;
-    double *alpha_out;
-};
-constexpr int CP_CD_MAX_BATCH = 16;
-struct CdSearchBatch {
-    CdSearchArgs a[CP_CD_MAX_BATCH];
-};
-
 template <int R>
 __global__ void __launch_bounds__(WAVE)
 k_cd_search(const double *__restrict__ Q, int ldq, const double *__restrict__ q, const double *__restrict__ stats,
@@ -1601,6 +1470,14 @@ static hipError_t cd_lds_optin(K kernel, size_t lds) {
     if (lds <= CD_LDS_DEFAULT) return hipSuccess;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
 }
+
+// team form (cd_team.hip): chain wave + K keeper waves; c % 8 == 0, c <= 2048, flags 0 or 3
+bool cp_cd_team_wanted(int c, int flags);
+int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c, double l1_reg,
+                          double l2_reg, uint32_t seed, int max_iter, double tol, int flags, double *w, void *dres);
+int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c);
+extern "C" int cp_debug_cd_team_cycles(cp_ctx *ctx, unsigned long long *out8);
+static bool g_last_cd_was_team = false;
 
 #define CP_CD_DISPATCH(KERNEL, R_, ...)                                      \
     switch (R_) {                                                            \
@@ -1649,7 +1526,10 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    if (duo) {
+    g_last_cd_was_team = cp_cd_team_wanted(c, flags);
+    if (g_last_cd_was_team) {
+        CP_TRY(cp_cd_team_fit_launch(ctx, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres));
+    } else if (duo) {
         CP_CD_DISPATCH_DUO(k_cd_fit_duo, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
     } else {
         CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
@@ -1666,6 +1546,7 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
 
 extern "C" int cp_debug_cd_cycles(cp_ctx *ctx, unsigned long long *out2) {
     if (!ctx || !out2) return CP_ERR_ARG;
+    if (g_last_cd_was_team) return cp_debug_cd_team_cycles(ctx, out2);
     CP_HIP(ctx, cp_stream_wait(ctx));
     CP_HIP(ctx, hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_cd_debug), 8 * sizeof(unsigned long long)));
     return CP_OK;
@@ -1698,7 +1579,18 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    if (duo) {
+    g_last_cd_was_team = cp_cd_team_wanted(c, flags);
+    if (g_last_cd_was_team) {
+        CdSearchBatch batch;
+        memset(&batch, 0, sizeof(batch));
+        CdSearchArgs &a = batch.a[0];
+        a.Q = Q; a.ldq = ldq; a.q = q; a.stats = stats; a.c = c; a.M = M; a.right0 = alpha_right0; a.rank = rank;
+        a.lbound = lbound; a.rbound = rbound; a.seeds = reinterpret_cast<const uint32_t *>(h + off_seed);
+        a.max_fits = max_fits; a.max_iter = max_iter; a.tol = tol; a.flags = flags; a.w = w;
+        a.w_host = reinterpret_cast<double *>(h + off_w); a.log = reinterpret_cast<DevResult *>(h + off_log);
+        a.log_alpha = reinterpret_cast<double *>(h + off_al); a.fits_used = hfits; a.alpha_out = halpha;
+        CP_TRY(cp_cd_team_search_launch(ctx, &batch, 1, c));
+    } else if (duo) {
         CP_CD_DISPATCH_DUO(k_cd_search_duo, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
                            reinterpret_cast<const uint32_t *>(h + off_seed), max_fits, max_iter, tol, flags, w,
                            reinterpret_cast<double *>(h + off_w), reinterpret_cast<DevResult *>(h + off_log),
@@ -1773,7 +1665,11 @@ int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_sear
     if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    if (duo) {
+    g_last_cd_was_team = cp_cd_team_wanted(c, jobs[0].flags);
+    for (int l = 1; l < n_jobs; ++l) g_last_cd_was_team = g_last_cd_was_team && jobs[l].flags == jobs[0].flags;
+    if (g_last_cd_was_team) {
+        CP_TRY(cp_cd_team_search_launch(ctx, &batch, n_jobs, c));
+    } else if (duo) {
         switch (R) {
             case 1: k_cd_search_duo_batch<1><<<n_jobs, 2 * WAVE, lds, ctx->stream>>>(batch); break;
             case 2: k_cd_search_duo_batch<2><<<n_jobs, 2 * WAVE, lds, ctx->stream>>>(batch); break;

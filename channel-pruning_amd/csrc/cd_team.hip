@@ -1,0 +1,789 @@
+// Coordinate-descent LASSO on the Gram matrix, team form: ONE chain wave + K keeper waves in one workgroup.
+//
+// Same recurrence, same visit order, same fma sequence per H entry as cd_gram.hip (sklearn's
+// enet_coordinate_descent_gram, _cd_fast.pyx:564-737; coordinate stream our_rand_r, _random.pxd:20-35), so w, n_iter and
+// the zero pattern are bit-identical to oracle/cd_oracle.c::cpo_enet_cd_gram in sklearn's own operation order (flags 0).
+//
+// Why a team.  A single wavefront issues one instruction every ~5-6.5 cycles whatever the dependencies, so a coordinate
+// step costs what its instruction count costs, and the step is a serial chain.  cd_gram.hip splits the count over two
+// waves (chain + keeper) for 256 < c <= 512 and runs everything in one wave otherwise; its keeper applies 2 c / 64 fma per
+// lane and step and is the bottleneck at c = 512 (331 cycles per step measured), and the one-wave forms for c > 512 are
+// bound by the row traffic one wave can keep in flight (0.41 us per step at c = 1024, 0.69 at c = 2048).  Here
+//   chain wave  (wave 0)      the scalar recurrence only: per step the soft-threshold chain, one readlane pair per published
+//                              value and the fma pair on the lanes' private H[ii]; never touches the full H;
+//   keeper k    (wave 1 + k)   owns H[:, 64 R k .. 64 R (k + 1)) in registers (R <= 4 doubles per lane), fetches its slice of
+//                              the rows Q[ii, :] sixteen steps ahead, applies a block's 8 updates with what the chain wave
+//                              published and exposes its slice of H as an LDS image after every block;
+// K = ceil(c / 256) <= 8 keepers: the fma work per wave and step is 2 R <= 8 whatever c is, and K waves keep K times the
+// row bytes in flight.  Hand-offs are sequence counters in LDS, one writer each (the LDS executes a wave's instructions in
+// program order, so a counter written after its payload lands after it); no barrier inside a fit.
+//
+// The division of the soft-threshold step.  sklearn divides by Q_ii (+ beta); an IEEE f64 division is ~11 dependent
+// instructions on the chain.  With r = RN(1 / d) computed once per feature by a true division (load time, off the chain):
+//     q0 = RN(m r);  rem = RN(m - d q0) (exact: fma);  q1 = RN(q0 + rem r)          (Markstein 1990)
+// q1 is the correctly rounded quotient m / d for every finite m >= 0, d > 0 away from over / underflow (three operations;
+// checked against the hardware division on 8e8 random and adversarial operand pairs by tests/host/test_markstein.c, and
+// by every bit-exactness test of the CD kernels).  Features or l1 weights outside [2^-400, 2^400] take the IEEE division.
+#include "cp_common.h"
+#include "xorshift_jump.h"
+#include "cd_shared.h"
+
+namespace {
+using namespace cdk;
+
+constexpr int B = 8;        // coordinate steps per block (= per hand-off)
+constexpr int KMAX = 8;     // keeper waves at most (c <= 2048)
+
+struct TeamCtl {
+    int seqA;          // blocks published by the chain wave
+    int batB;          // index batches published by keeper 0
+    int stop;          // chain -> keepers: the fit is over
+    int err;           // a bounded wait ran out (never in a correct run)
+    int n_iter, nnz;
+    int mk_ok;         // every feature's denominator is inside the range the three-operation division is exact on
+    int pad;
+    int seqB[KMAX];    // images published by keeper k (image t = H after the first t blocks; count = t + 1)
+    double gap;
+};
+
+template <int R, int K>
+struct TeamLds {
+    static constexpr int IMG = 64 * R * K;
+    double *img;       // [2][IMG]
+    double *pub;       // [4][2 * B]
+    uint32_t *ii;      // [3][64]
+    uint64_t *dup;     // [4] lanes whose coordinate repeats inside their block
+    uint64_t *xdup;    // [4] lanes whose coordinate also occurs in the block before theirs
+    TeamCtl *ctl;
+    static __host__ __device__ constexpr int doubles() { return 2 * IMG + 4 * 2 * B + 3 * 32 + 8 + int(sizeof(TeamCtl) / 8) + 2; }
+    __device__ void bind(double *base) {
+        img = base;
+        pub = img + 2 * IMG;
+        ii = reinterpret_cast<uint32_t *>(pub + 4 * 2 * B);
+        dup = reinterpret_cast<uint64_t *>(ii + 3 * 64);
+        xdup = dup + 4;
+        ctl = reinterpret_cast<TeamCtl *>(xdup + 4);
+    }
+};
+
+// wait until *p >= need (false if `stop` was raised or the bound ran out)
+__device__ __forceinline__ bool team_wait(int *p, int need, TeamCtl *ctl, bool watch_stop) {
+    for (int spin = 0;; ++spin) {
+        if (duo_load(p) >= need) return true;
+        if (watch_stop && duo_load(&ctl->stop)) return false;
+        if (spin > (1 << 22)) {
+            duo_store(&ctl->err, 1);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// every keeper has published image `need - 1`
+template <int K>
+__device__ __forceinline__ bool images_ready(TeamCtl *ctl, int need, int lane) {
+    return __ballot(duo_load(&ctl->seqB[lane & (K - 1)]) >= need) == ~uint64_t(0);
+}
+template <int K>
+__device__ __forceinline__ bool team_wait_images(TeamCtl *ctl, int need, int lane) {
+    for (int spin = 0;; ++spin) {
+        if (images_ready<K>(ctl, need, lane)) return true;
+        if (spin > (1 << 22)) {
+            duo_store(&ctl->err, 1);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__device__ unsigned long long g_team_debug[8];
+
+// ---------------------------------------------------------------------------------------------------------------------
+// keeper wave k: columns [64 R k, 64 R (k + 1)) of H
+// ---------------------------------------------------------------------------------------------------------------------
+template <int R, int K, bool DELTA>
+__device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ldq, int c, uint32_t seed, const double *w_lds,
+                                            TeamLds<R, K> &L, int k) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    // register r of lane l holds column colof(r): packed (R even) 128 (r/2) + 2 l + (r&1), so that one 16-byte load
+    // fetches two of a lane's row elements; columns past c re-read the last pair: their H entries are never consumed
+    constexpr bool PK = CP_CD_PACKED && (R % 2 == 0);
+    const int col0 = k * 64 * R;
+    auto colof = [&](int r) -> int { return col0 + (PK ? (r >> 1) * 2 * WAVE + 2 * lane + (r & 1) : r * WAVE + lane); };
+    uint32_t colb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int col = colof(r);
+        colb[r] = uint32_t(col < c ? col : (PK ? c - 2 + (r & 1) : c - 1)) * 8u;
+    }
+    auto load_row = [&](double (&dst)[R], uint32_t roff) {
+        if (PK) {
+#pragma unroll
+            for (int r = 0; r < R; r += 2) load_q2(rsrc, colb[r], roff, dst[r], dst[r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = load_q(rsrc, colb[r], roff);
+        }
+    };
+    double H[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) H[r] = 0.0;
+    constexpr int U = 8;
+    for (int j0 = 0; j0 < c; j0 += U) {  // H = Q w in index order (as the oracle)
+        double row[U][R];
+        double wj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u;
+            wj[u] = j < c ? w_lds[j] : 0.0;
+            load_row(row[u], uint32_t(j < c ? j : c - 1) * row_stride_bytes);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (wj[u] != 0.0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(wj[u], row[u][r], H[r]);
+            }
+    }
+    int *my_seq = &L.ctl->seqB[k];
+    auto write_image = [&](int t) {
+        double *im = L.img + (t & 1) * TeamLds<R, K>::IMG + col0;
+        if (PK) {
+#pragma unroll
+            for (int r = 0; r < R; r += 2) *reinterpret_cast<double2 *>(im + r * WAVE + 2 * lane) = make_double2(H[r], H[r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) im[r * WAVE + lane] = H[r];
+        }
+        duo_store(my_seq, t + 1);
+    };
+    write_image(0);
+
+    // every keeper runs the index stream itself (no hand-off on the rows' critical path); keeper 0 also publishes the
+    // batches, with their duplicate scans, for the chain wave
+    IdxStream rng;
+    rng.init(seed, uint32_t(c), row_stride_bytes, lane);
+    uint32_t prev_idx = 0xffffffffu;  // coordinates of the batch published before (none yet)
+    auto publish_batch = [&](int kb) {
+        if (k != 0) return;
+        L.ii[(kb % 3) * 64 + lane] = rng.idx;
+        bool dup = false, xd = false;
+        const int bs = lane & ~(B - 1);
+#pragma unroll
+        for (int sft = 1; sft < B; ++sft) {
+            const int other = __shfl(int(rng.idx), bs | ((lane + sft) & (B - 1)), WAVE);
+            dup |= (uint32_t(other) == rng.idx);
+        }
+#pragma unroll
+        for (int sft = 0; sft < B; ++sft) {  // the block before: lanes bs-8.. of this batch, or 56.. of the previous one
+            const int src = ((bs - B) & 63) + sft;
+            const int o_same = __shfl(int(rng.idx), src, WAVE), o_prev = __shfl(int(prev_idx), src, WAVE);
+            xd |= uint32_t(bs == 0 ? o_prev : o_same) == rng.idx;
+        }
+        const uint64_t m = __ballot(dup), mx = __ballot(xd);
+        if (lane == 0) {
+            L.dup[kb & 3] = m;
+            L.xdup[kb & 3] = mx;
+        }
+        prev_idx = rng.idx;
+        duo_store(&L.ctl->batB, kb + 1);
+    };
+    publish_batch(0);  // the ring runs two batches ahead of the one being applied
+    uint32_t off_cur = rng.off;
+    rng.next_batch();
+    publish_batch(1);
+    uint32_t off_nxt = rng.off;
+    rng.next_batch();
+    publish_batch(2);
+    uint32_t off_n2 = rng.off;
+    int batch = 0;
+
+    double rowA[B][R], rowB[B][R];
+    auto fill = [&](double (&S)[B][R], uint32_t off_vec, int base) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) load_row(S[a], uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a)));
+    };
+    auto settle = [&](double (&S)[B][R]) {
+#pragma unroll
+        for (int a = 0; a < B; ++a)
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(S[a][r]));
+    };
+    unsigned long long waitB = 0, blocksB = 0;
+    // apply block t with the rows in S; false when the fit is over
+    auto apply = [&](const double (&S)[B][R], int t) -> bool {
+        const unsigned long long w0 = __builtin_readcyclecounter();
+        const bool okw = team_wait(&L.ctl->seqA, t + 1, L.ctl, true);
+        waitB += __builtin_readcyclecounter() - w0;
+        ++blocksB;
+        if (!okw) {
+            if (lane == 0 && k == 0) {
+                g_team_debug[4] = waitB;
+                g_team_debug[5] = blocksB;
+            }
+            return false;
+        }
+        const double *pb = L.pub + (t & 3) * 2 * B;
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            if (DELTA) {
+                const double d_a = pb[a];  // same address in every lane: LDS broadcast
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(d_a, S[a][r], H[r]);
+            } else {
+                const double wo_a = pb[2 * a], wn_a = pb[2 * a + 1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S[a][r], fma(-wo_a, S[a][r], H[r]));
+            }
+        }
+        write_image(t + 1);
+        return true;
+    };
+    fill(rowA, off_cur, 0);
+    for (int t = 0;; t += 2) {  // two blocks per iteration (register sets A / B); 8 blocks per batch
+        const int g = t & 7;
+        fill(rowB, off_cur, (g + 1) * B);
+        if (!apply(rowA, t)) break;
+        if (g + 2 < 8) {
+            fill(rowA, off_cur, (g + 2) * B);
+        } else {
+            fill(rowA, off_nxt, 0);
+        }
+        if (!apply(rowB, t + 1)) break;
+        settle(rowA);
+        if (g + 2 >= 8) {  // batch roll-over
+            off_cur = off_nxt;
+            off_nxt = off_n2;
+            rng.next_batch();
+            ++batch;
+            publish_batch(batch + 2);
+            off_n2 = rng.off;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// chain wave
+// ---------------------------------------------------------------------------------------------------------------------
+// MK: three-operation correctly rounded division (see the header); RECIP: multiply by the reciprocal (CP_CD_RECIPROCAL,
+// not bit-identical to sklearn's division)
+template <int R, int K, bool RECIP, bool DELTA, bool MK>
+__device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
+                                           int max_iter, double tol_scaled, double d_w_tol, double y_norm2, double *w_lds,
+                                           const double *feat, TeamLds<R, K> &L) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    const uint32_t rel = uint32_t(lane) & uint32_t(B - 1);
+    constexpr uint32_t OOB = 0x80000000u;  // beyond num_records with or without the row offset, no 32-bit wrap
+    constexpr int IMG = TeamLds<R, K>::IMG;
+    TeamCtl *ctl = L.ctl;
+
+    struct Batch {
+        uint32_t ii, off, voff;
+        uint32_t vm[B];  // coupling column offsets, out of range for lanes at or before position a of their block
+        double q, Qd, den, rden;
+        uint64_t dupmask, xdupmask;
+    };
+    auto load_batch = [&](Batch &bt, int kb) -> bool {
+        if (!team_wait(&ctl->batB, kb + 1, ctl, false)) return false;
+        bt.ii = L.ii[(kb % 3) * 64 + lane];
+        bt.dupmask = L.dup[kb & 3];
+        bt.xdupmask = L.xdup[kb & 3];
+        bt.off = bt.ii * row_stride_bytes;
+        bt.voff = bt.ii * 8u;
+#pragma unroll
+        for (int a = 0; a < B; ++a) bt.vm[a] = rel > uint32_t(a) ? bt.voff : OOB;
+        const double2 qQ = *reinterpret_cast<const double2 *>(feat + 4 * bt.ii);
+        const double2 dr = *reinterpret_cast<const double2 *>(feat + 4 * bt.ii + 2);
+        bt.q = qQ.x;
+        bt.Qd = qQ.y;
+        bt.den = dr.x;
+        bt.rden = dr.y;
+        return true;
+    };
+    struct CSet {
+        double qc[B];  // Q[ii_a, ii_lane] within the block (0 for finished lanes)
+        double qx[B];  // Q[ii_a(previous block), ii_lane]
+    };
+    auto fill = [&](CSet &S, const Batch &bt, int base, const Batch &pb, int prev_base, bool has_prev) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(bt.off), base + a));
+            S.qc[a] = load_q(rsrc, bt.vm[a], roff);
+        }
+        if (has_prev) {
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(pb.off), prev_base + a));
+                S.qx[a] = load_q(rsrc, bt.voff, roff);
+            }
+        }
+    };
+    auto settle = [&](CSet &S) {
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+            asm volatile("" : "+v"(S.qc[a]));
+            asm volatile("" : "+v"(S.qx[a]));
+        }
+    };
+    // w_new of one lane from its private H: _cd_fast.pyx:662-667
+    auto soft_step = [&](const Batch &bt, double wo_v, double Hs_v) -> double {
+        const double Hp = fma(-wo_v, bt.Qd, Hs_v);
+        const double tmp = bt.q - Hp;
+        if (MK) {
+            const double m = fmax(fabs(tmp) - alpha, 0.0);   // >= +0
+            const double q0 = m * bt.rden;
+            const double rem = fma(-bt.den, q0, m);
+            return copysign(fma(rem, bt.rden, q0), tmp);     // den > 0: the quotient carries tmp's sign, zeros included
+        }
+        const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+        return RECIP ? thr * bt.den : thr / bt.den;
+    };
+
+    Batch cur, nxt;
+    if (!load_batch(cur, 0) || !load_batch(nxt, 1)) return;
+    int batch = 0;
+    int n_iter = 0, f = 0;
+    double wmax_v = 0.0, dmax_v = 0.0;
+    double gap_out = tol_scaled + 1.0;
+    double dp0[B], dp1[B];  // what the previous block published (DELTA: dp0 = differences; else dp0 = w_old, dp1 = w_new)
+#pragma unroll
+    for (int a = 0; a < B; ++a) dp0[a] = dp1[a] = 0.0;
+
+    // the image after t_done blocks is complete: dual gap from it (same arithmetic as the one-wave form)
+    auto epoch_end = [&](int t_done) -> bool {
+        const double w_max = wave_max(wmax_v), d_w_max = wave_max(dmax_v);
+        bool done = false;
+        if (w_max == 0.0 || d_w_max / w_max < d_w_tol || n_iter == max_iter - 1) {
+            if (!team_wait_images<K>(ctl, t_done + 1, lane)) return true;
+            const double *im = L.img + (t_done & 1) * IMG;
+            double s_qw = 0, s_wh = 0, s_ww = 0, s_l1 = 0, m_xta = 0;
+#pragma unroll 4
+            for (int r = 0; r < R * K; ++r) {
+                const int col = r * WAVE + lane;
+                if (col < c) {
+                    const double wv = w_lds[col], qv = feat[4 * col], hv = im[col];
+                    const double xta = qv - hv - beta * wv;
+                    s_qw += wv * qv;
+                    s_wh += wv * hv;
+                    s_ww += wv * wv;
+                    s_l1 += fabs(wv);
+                    m_xta = fmax(m_xta, fabs(xta));
+                }
+            }
+            const double q_dot_w = wave_sum(s_qw), wh = wave_sum(s_wh), w_norm2 = wave_sum(s_ww),
+                         l1 = wave_sum(s_l1), dual_norm = wave_max(m_xta);
+            const double R_norm2 = y_norm2 + wh - 2.0 * q_dot_w;
+            double const_, gap;
+            if (dual_norm > alpha) {
+                const_ = alpha / dual_norm;
+                const double A_norm2 = R_norm2 * (const_ * const_);
+                gap = 0.5 * (R_norm2 + A_norm2);
+            } else {
+                const_ = 1.0;
+                gap = R_norm2;
+            }
+            gap += alpha * l1 - const_ * y_norm2 + const_ * q_dot_w + 0.5 * beta * (1.0 + const_ * const_) * w_norm2;
+            gap_out = gap;
+            if (gap < tol_scaled) done = true;
+        }
+        ++n_iter;
+        wmax_v = 0.0;
+        dmax_v = 0.0;
+        f = 0;
+        return done || n_iter == max_iter;
+    };
+
+    unsigned long long waitA = 0, repairs = 0;
+    // per-lane inputs of a block, fetched while the block before it is still running
+    struct Pre {
+        double Hn;   // image part of H[ii] (the previous block's 8 updates are added through qx)
+        double wo;   // w[ii]
+        bool fresh;  // every keeper had published the image when Hn was read
+    };
+    auto prefetch = [&](Pre &pr, const Batch &nb, int t_next) {  // for block t_next: image t_next - 1
+        pr.fresh = images_ready<K>(ctl, t_next, lane);
+        pr.Hn = (L.img + ((t_next - 1) & 1) * IMG)[nb.ii];
+        pr.wo = w_lds[nb.ii];
+    };
+
+    // one block: lanes base..base+7 of `bt`; after step PF the inputs of the next block (lanes nbase.. of `nb`)
+    // are requested into `pn`
+    constexpr int PF = 5;
+    auto compute = [&](const CSet &S, const Batch &bt, int base, int t, const Pre &pc, bool has_prev, const Batch &nb,
+                       int nbase, Pre &pn) {
+        double Hs_v = pc.Hn;
+        if (has_prev) {
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                if (DELTA)
+                    Hs_v = fma(dp0[a], S.qx[a], Hs_v);
+                else
+                    Hs_v = fma(dp1[a], S.qx[a], fma(-dp0[a], S.qx[a], Hs_v));
+            }
+        }
+        double wo_v = pc.wo;
+        const uint64_t blockmask = ((uint64_t(1) << B) - 1) << base;
+        uint64_t wmask = blockmask;
+        const bool has_dup = (bt.dupmask & blockmask) != 0;
+        double wn_keep = 0.0, p0_v = 0.0, p1_v = 0.0;  // what this lane publishes for its own step
+        if (!has_dup) {
+            double wn_v = 0.0;
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const int la = base + a;
+                // every lane evaluates "its" update against its private H; lane la's is the one that counts now, lanes
+                // before it reproduce their final value (their couplings to this and later steps read 0)
+                wn_v = soft_step(bt, wo_v, Hs_v);
+                if (DELTA) {
+                    const double d_a = read_lane(wn_v - wo_v, la);
+                    dp0[a] = d_a;
+                    Hs_v = fma(d_a, S.qc[a], Hs_v);
+                } else {
+                    const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
+                    dp0[a] = wo_a;
+                    dp1[a] = wn_a;
+                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+                }
+                if (a == PF) prefetch(pn, nb, t + 1);
+            }
+            wn_keep = wn_v;
+            p0_v = DELTA ? wn_v - wo_v : wo_v;
+            p1_v = wn_v;
+        } else {  // a coordinate repeats inside the block: later visits must see the earlier result
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const int la = base + a;
+                const double wn_v = soft_step(bt, wo_v, Hs_v);
+                const bool mine = lane == la;
+                wn_keep = mine ? wn_v : wn_keep;
+                const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
+                if (DELTA) {
+                    const double dv = wn_v - wo_v;
+                    const double d_a = read_lane(dv, la);
+                    p0_v = mine ? dv : p0_v;
+                    dp0[a] = d_a;
+                    Hs_v = fma(d_a, S.qc[a], Hs_v);
+                } else {
+                    p0_v = mine ? wo_v : p0_v;
+                    p1_v = mine ? wn_v : p1_v;
+                    dp0[a] = wo_a;
+                    dp1[a] = wn_a;
+                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+                }
+                const uint32_t ii_a = uint32_t(__builtin_amdgcn_readlane(int(bt.ii), la));
+                const bool later_same = bt.ii == ii_a && lane > la && lane < base + B;
+                wo_v = later_same ? wn_a : wo_v;
+                if (__ballot(later_same) != 0) wmask &= ~(uint64_t(1) << la);
+                if (a == PF) prefetch(pn, nb, t + 1);
+            }
+        }
+        if ((blockmask >> lane) & 1) {
+            double *pb = L.pub + (t & 3) * 2 * B;
+            if (DELTA) {
+                pb[rel] = p0_v;
+            } else {
+                pb[2 * rel] = p0_v;
+                pb[2 * rel + 1] = p1_v;
+            }
+            dmax_v = fmax(dmax_v, fabs(wn_keep - wo_v));
+            wmax_v = fmax(wmax_v, fabs(wn_keep));
+        }
+        if ((wmask >> lane) & 1) w_lds[bt.ii] = wn_keep;
+        duo_store(&ctl->seqA, t + 1);
+        // rare repairs of the prefetch: a keeper had not published image t yet, or the next block revisits a coordinate
+        // this block just changed
+        if (!pn.fresh) {
+            const unsigned long long w0 = __builtin_readcyclecounter();
+            team_wait_images<K>(ctl, t + 1, lane);
+            pn.Hn = (L.img + (t & 1) * IMG)[nb.ii];
+            waitA += __builtin_readcyclecounter() - w0;
+            ++repairs;
+        }
+        if ((nb.xdupmask >> nbase) & ((uint64_t(1) << B) - 1)) pn.wo = w_lds[nb.ii];
+    };
+
+    CSet SA, SB;
+    Pre pa, pb2;
+    fill(SA, cur, 0, cur, 0, false);
+    team_wait_images<K>(ctl, 1, lane);
+    pa.Hn = L.img[cur.ii];
+    pa.wo = w_lds[cur.ii];
+    pa.fresh = true;
+    for (int t = 0;; t += 2) {  // blocks t (set A) and t+1 (set B); 8 blocks per batch
+        const int g = t & 7;
+        // ---- block t ----
+        fill(SB, cur, (g + 1) * B, cur, g * B, true);
+        compute(SA, cur, g * B, t, pa, t > 0, cur, (g + 1) * B, pb2);
+        f += B;
+        if (f == c && epoch_end(t + 1)) break;
+        // ---- block t+1 ----
+        const bool roll = g + 2 >= 8;
+        if (!roll) {
+            fill(SA, cur, (g + 2) * B, cur, (g + 1) * B, true);
+            compute(SB, cur, (g + 1) * B, t + 1, pb2, true, cur, (g + 2) * B, pa);
+        } else {
+            fill(SA, nxt, 0, cur, (g + 1) * B, true);
+            compute(SB, cur, (g + 1) * B, t + 1, pb2, true, nxt, 0, pa);
+        }
+        f += B;
+        if (f == c && epoch_end(t + 2)) break;
+        settle(SA);
+        if (roll) {
+            cur = nxt;
+            ++batch;
+            if (!load_batch(nxt, batch + 1)) break;
+        }
+    }
+    duo_store(&ctl->stop, 1);
+    int cnt = 0;
+#pragma unroll 4
+    for (int r = 0; r < R * K; ++r) {
+        const int col = r * WAVE + lane;
+        cnt += (col < c && w_lds[col] != 0.0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+    if (lane == 0) {
+        g_team_debug[2] = waitA;
+        g_team_debug[3] = repairs;
+        ctl->gap = gap_out;
+        ctl->n_iter = duo_load(&ctl->err) ? -1 : n_iter;
+        ctl->nnz = cnt;
+    }
+}
+
+// all K + 1 waves of the workgroup call this; returns the same FitOut in all threads.  flags: CP_CD_RECIPROCAL | CP_CD_DELTA
+// (0: sklearn's operation order with the three-operation division where it is exact; 3: both rounding variants)
+template <int R, int K>
+__device__ __forceinline__ FitOut team_fit(int flags, int exact_div, const double *__restrict__ Q, int ldq, int c, double alpha,
+                                           double beta, uint32_t seed, int max_iter, double tol_scaled, double d_w_tol,
+                                           double y_norm2, double *w_lds, const double *feat, double *team_base) {
+    TeamLds<R, K> L;
+    L.bind(team_base);
+    if (threadIdx.x == 0) {
+        L.ctl->seqA = 0;
+        L.ctl->batB = 0;
+        L.ctl->stop = 0;
+        L.ctl->err = 0;
+        for (int k = 0; k < KMAX; ++k) L.ctl->seqB[k] = 0;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    const bool fast = (flags & (CP_CD_RECIPROCAL | CP_CD_DELTA)) == (CP_CD_RECIPROCAL | CP_CD_DELTA);
+    if (wave > 0) {
+        if (fast)
+            team_keeper<R, K, true>(Q, ldq, c, seed, w_lds, L, wave - 1);
+        else
+            team_keeper<R, K, false>(Q, ldq, c, seed, w_lds, L, wave - 1);
+    } else {
+#define CP_CHAIN_ARGS Q, ldq, c, alpha, beta, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds, feat, L
+        const bool mk = !exact_div && L.ctl->mk_ok && alpha >= 0x1p-400 && alpha <= 0x1p400;
+        if (fast)
+            team_chain<R, K, true, true, false>(CP_CHAIN_ARGS);
+        else if (mk)
+            team_chain<R, K, false, false, true>(CP_CHAIN_ARGS);
+        else
+            team_chain<R, K, false, false, false>(CP_CHAIN_ARGS);
+#undef CP_CHAIN_ARGS
+    }
+    __syncthreads();
+    FitOut out;
+    out.gap = L.ctl->gap;
+    out.n_iter = L.ctl->n_iter;
+    out.nnz = L.ctl->nnz;
+    __syncthreads();
+    return out;
+}
+
+// LDS image: feat[4 c] | w[c] | team area.  feat[4 j + {0,1,2,3}] = { q[j], Q[j,j], d = Q[j,j] + beta (its reciprocal with
+// CP_CD_RECIPROCAL), RN(1 / d) }; zero-diagonal features are skipped by sklearn (_cd_fast.pyx:651): here their update is a
+// no-op through d = 1 (their row of Q, q and H entry are all zero).
+template <int R, int K>
+__device__ __forceinline__ void team_load_features(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
+                                                   const double *__restrict__ w_in, int c, double l2, int flags,
+                                                   double *w_lds, double *feat, double *team_base) {
+    TeamLds<R, K> L;
+    L.bind(team_base);
+    if (threadIdx.x == 0) L.ctl->mk_ok = 1;
+    __syncthreads();
+    bool ok = true;
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        const double dj = Q[size_t(j) * ldq + j];
+        w_lds[j] = w_in ? w_in[j] : 0.0;
+        const double d = dj == 0.0 ? 1.0 : dj + l2;
+        feat[4 * j + 0] = q[j];
+        feat[4 * j + 1] = dj;
+        feat[4 * j + 2] = (flags & CP_CD_RECIPROCAL) ? (dj == 0.0 ? 0.0 : 1.0 / d) : d;
+        feat[4 * j + 3] = 1.0 / d;
+        ok = ok && d >= 0x1p-400 && d <= 0x1p400;
+    }
+    if (!ok) L.ctl->mk_ok = 0;
+    __syncthreads();
+}
+
+template <int R, int K>
+__global__ void __launch_bounds__(64 * (K + 1)) k_cd_fit_team(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
+                                                              const double *__restrict__ stats, int c, double l1, double l2,
+                                                              uint32_t seed, int max_iter, double tol, int flags, int exact_div,
+                                                              double *__restrict__ w, DevResult *__restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *feat = smem, *w_lds = smem + 4 * c, *team = smem + 5 * c;
+    team_load_features<R, K>(Q, ldq, q, w, c, l2, flags, w_lds, feat, team);
+    const double y_norm2 = stats[0];
+    const double tol_scaled = tol * y_norm2;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    FitOut o = team_fit<R, K>(flags, exact_div, Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, w_lds, feat, team);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        g_team_debug[0] = t1 - t0;
+        g_team_debug[1] = (unsigned long long)o.n_iter * (unsigned long long)c;
+    }
+    for (int j = threadIdx.x; j < c; j += blockDim.x) w[j] = w_lds[j];
+    if (threadIdx.x == 0) {
+        res->gap = o.gap;
+        res->tol_scaled = tol_scaled;
+        res->n_iter = o.n_iter;
+        res->nnz = o.nnz;
+    }
+}
+
+// Whole alpha search of lib/decompose.py:490-525, one search per workgroup (blockIdx.x picks the argument block)
+template <int R, int K>
+__global__ void __launch_bounds__(64 * (K + 1)) k_cd_search_team(CdSearchBatch b, int exact_div) {
+    const CdSearchArgs &a = b.a[blockIdx.x];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int c = a.c;
+    double *feat = smem, *w_lds = smem + 4 * c, *team = smem + 5 * c;
+    team_load_features<R, K>(a.Q, a.ldq, a.q, nullptr, c, 0.0, a.flags, w_lds, feat, team);
+    const double y_norm2 = a.stats[0];
+    const double tol_scaled = a.tol * y_norm2;
+    int fit = 0;
+    double left = 0.0, right = a.right0, alpha = a.right0;
+    bool bracketing = true, ok = false;
+    while (fit < a.max_fits) {
+        alpha = bracketing ? right : (left + right) / 2;
+        FitOut o = team_fit<R, K>(a.flags, exact_div, a.Q, a.ldq, c, alpha * a.M, 0.0, a.seeds[fit], a.max_iter, tol_scaled,
+                                  a.tol, y_norm2, w_lds, feat, team);
+        if (threadIdx.x == 0) {
+            a.log[fit].gap = o.gap;
+            a.log[fit].tol_scaled = tol_scaled;
+            a.log[fit].n_iter = o.n_iter;
+            a.log[fit].nnz = o.nnz;
+            a.log_alpha[fit] = alpha;
+        }
+        ++fit;
+        const double tmp = double(o.nnz);
+        if (bracketing) {  // decompose.py:502-515
+            if (tmp < a.rank)
+                bracketing = false;
+            else
+                right *= 2;
+        } else {  // decompose.py:516-525
+            if (tmp > a.rbound)
+                left = alpha;
+            else if (tmp < a.lbound)
+                right = alpha;
+            else {
+                ok = true;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        a.w[j] = w_lds[j];
+        a.w_host[j] = w_lds[j];
+    }
+    if (threadIdx.x == 0) {
+        *a.fits_used = ok ? fit : -fit;  // negative: ran out of pre-drawn seeds
+        *a.alpha_out = alpha;
+    }
+}
+
+struct TeamShape {
+    int R, K;
+};
+TeamShape team_shape(int c) {
+    if (c <= 64) return {1, 1};
+    if (c <= 128) return {2, 1};
+    if (c <= 256) return {4, 1};
+    if (c <= 512) return {4, 2};
+    if (c <= 1024) return {4, 4};
+    return {4, 8};
+}
+size_t team_lds_bytes(int c) {
+    const TeamShape s = team_shape(c);
+    const size_t img = size_t(64) * s.R * s.K;
+    return (size_t(5) * c + 2 * img + 4 * 2 * B + 3 * 32 + 8 + sizeof(TeamCtl) / 8 + 2) * sizeof(double);
+}
+
+template <typename Kern>
+hipError_t team_optin(Kern kernel, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+}
+
+#define CP_TEAM_SWITCH(c_, CALL)                               \
+    do {                                                       \
+        const TeamShape ts_ = team_shape(c_);                  \
+        if (ts_.K == 1 && ts_.R == 1) { CALL(1, 1); }          \
+        else if (ts_.K == 1 && ts_.R == 2) { CALL(2, 1); }     \
+        else if (ts_.K == 1) { CALL(4, 1); }                   \
+        else if (ts_.K == 2) { CALL(4, 2); }                   \
+        else if (ts_.K == 4) { CALL(4, 4); }                   \
+        else { CALL(4, 8); }                                   \
+    } while (0)
+
+}  // namespace
+
+// ---- entry points used by cd_gram.hip's dispatch ------------------------------------------------------------------
+// The team kernels take: c a multiple of 8 (block size), c <= 2048, flags 0 (sklearn's operation order) or 3.
+// CP_CD_TEAM=0 keeps the kernels of cd_gram.hip; CP_CD_EXACT_DIV=1 keeps the IEEE division on the chain.
+bool cp_cd_team_wanted(int c, int flags) {
+    static const bool on = !(getenv("CP_CD_TEAM") && atoi(getenv("CP_CD_TEAM")) == 0);
+    const int f = flags & (CP_CD_RECIPROCAL | CP_CD_DELTA);
+    return on && c % B == 0 && c >= B && c <= 64 * 4 * KMAX && (f == 0 || f == (CP_CD_RECIPROCAL | CP_CD_DELTA));
+}
+static int team_exact_div() {
+    static const int v = (getenv("CP_CD_EXACT_DIV") && atoi(getenv("CP_CD_EXACT_DIV")) != 0) ? 1 : 0;
+    return v;
+}
+
+int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c, double l1_reg,
+                          double l2_reg, uint32_t seed, int max_iter, double tol, int flags, double *w, void *dres) {
+    const size_t lds = team_lds_bytes(c);
+    const int ex = team_exact_div();
+#define CP_CALL(R_, K_)                                                                                              \
+    CP_HIP(ctx, team_optin(k_cd_fit_team<R_, K_>, lds));                                                             \
+    k_cd_fit_team<R_, K_><<<1, 64 * (K_ + 1), lds, ctx->stream>>>(Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, \
+                                                                  ex, w, static_cast<DevResult *>(dres))
+    CP_TEAM_SWITCH(c, CP_CALL);
+#undef CP_CALL
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}
+
+int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) {
+    const size_t lds = team_lds_bytes(c);
+    const int ex = team_exact_div();
+    const CdSearchBatch &b = *static_cast<const CdSearchBatch *>(batch);
+#define CP_CALL(R_, K_)                                                  \
+    CP_HIP(ctx, team_optin(k_cd_search_team<R_, K_>, lds));              \
+    k_cd_search_team<R_, K_><<<n_jobs, 64 * (K_ + 1), lds, ctx->stream>>>(b, ex)
+    CP_TEAM_SWITCH(c, CP_CALL);
+#undef CP_CALL
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}
+
+extern "C" int cp_debug_cd_team_cycles(cp_ctx *ctx, unsigned long long *out8) {
+    if (!ctx || !out8) return CP_ERR_ARG;
+    CP_HIP(ctx, cp_stream_wait(ctx));
+    CP_HIP(ctx, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_team_debug), 8 * sizeof(unsigned long long)));
+    return CP_OK;
+}

@@ -11,8 +11,11 @@ import numpy as np  # noqa: E402
 import cpmi355  # noqa: E402
 from cpmi355 import capi  # noqa: E402
 
+CS = tuple(int(v) for v in os.environ.get("CD_BENCH_C", "64,128,256,512,1024,2048").split(","))
+FLAGS = tuple(int(v) for v in os.environ.get("CD_BENCH_FLAGS", "0,3").split(","))
 if len(sys.argv) > 1:
     capi.LIB_PATH = sys.argv[1]
+print("CP_CD_TEAM=%s CP_CD_EXACT_DIV=%s" % (os.environ.get("CP_CD_TEAM", "(default 1)"), os.environ.get("CP_CD_EXACT_DIV", "(default 0)")))
 ctx = cpmi355.Context(0)
 lib = ctx.lib
 lib.cp_debug_cd_cycles.restype = ctypes.c_int
@@ -29,11 +32,11 @@ def problem(c, M=20000, seed=3):
     return np.ascontiguousarray(Zc.T @ Zc), Zc.T @ yc, float(yc @ yc), M
 
 
-for c in (64, 128, 256, 512):
+for c in CS:
     Q, q, yty, M = problem(c)
     Qd, qd = ctx.to_device(Q), ctx.to_device(q)
     sd = ctx.to_device(np.array([yty, 0, M, 0], dtype=np.float64))
-    for flags in (0, 1, 2, 3):
+    for flags in FLAGS:
         wd = ctx.zeros(c * 8)
         l1 = 0.05 * np.abs(q).max()
         ctx.enet_cd_gram(Qd, c, qd, sd, c, l1, 0.0, 7, wd, flags=flags)  # warm
