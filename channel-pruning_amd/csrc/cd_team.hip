@@ -28,6 +28,9 @@
 #include "xorshift_jump.h"
 #include "cd_shared.h"
 
+#include <algorithm>
+#include <atomic>
+
 namespace {
 using namespace cdk;
 
@@ -653,9 +656,19 @@ __global__ void __launch_bounds__(64 * (K + 1)) k_cd_fit_team(const double *__re
 }
 
 // Whole alpha search of lib/decompose.py:490-525, one search per workgroup (blockIdx.x picks the argument block)
+// spread >= 0: the launch has 8 workgroups per search and only workgroup (spread + job) % 8 of a search's group works --
+// workgroup L of a launch is placed on XCD L % 8 (observed, not promised: nothing but speed depends on it), so concurrent
+// searches, each a single workgroup whose Gram wants to stay in ONE XCD's L2, land on different XCDs instead of all on
+// XCD 0.  prio: the waves raise their issue priority over co-resident throughput kernels.
 template <int R, int K>
-__global__ void __launch_bounds__(64 * (K + 1)) k_cd_search_team(CdSearchBatch b, int exact_div) {
-    const CdSearchArgs &a = b.a[blockIdx.x];
+__global__ void __launch_bounds__(64 * (K + 1)) k_cd_search_team(CdSearchBatch b, int exact_div, int spread, int prio) {
+    int job = blockIdx.x;
+    if (spread >= 0) {
+        job = blockIdx.x >> 3;
+        if (int(blockIdx.x & 7) != ((spread + job) & 7)) return;
+    }
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    const CdSearchArgs &a = b.a[job];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int c = a.c;
     double *feat = smem, *w_lds = smem + 4 * c, *team = smem + 5 * c;
@@ -768,13 +781,26 @@ int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q
     return CP_OK;
 }
 
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) {
-    const size_t lds = team_lds_bytes(c);
+    // CP_CD_SPREAD=1: searches of concurrent launches rotate over the XCDs; CP_CD_PRIO=1: raised wave priority;
+    // CP_CD_EXCLUSIVE=1: the workgroup asks for (almost) a whole CU's LDS, so that no other workgroup shares its CU
+    static const int spread_on = env_int("CP_CD_SPREAD", 0), prio = env_int("CP_CD_PRIO", 0),
+                     exclusive = env_int("CP_CD_EXCLUSIVE", 0);
+    static std::atomic<unsigned> next_xcd{0};
+    size_t lds = team_lds_bytes(c);
+    if (exclusive && !spread_on) lds = std::max(lds, size_t(150) * 1024);
     const int ex = team_exact_div();
+    const int spread = spread_on ? int(next_xcd.fetch_add(unsigned(n_jobs)) & 7u) : -1;
+    const int grid = spread_on ? 8 * n_jobs : n_jobs;
     const CdSearchBatch &b = *static_cast<const CdSearchBatch *>(batch);
 #define CP_CALL(R_, K_)                                                  \
     CP_HIP(ctx, team_optin(k_cd_search_team<R_, K_>, lds));              \
-    k_cd_search_team<R_, K_><<<n_jobs, 64 * (K_ + 1), lds, ctx->stream>>>(b, ex)
+    k_cd_search_team<R_, K_><<<grid, 64 * (K_ + 1), lds, ctx->stream>>>(b, ex, spread, prio)
     CP_TEAM_SWITCH(c, CP_CALL);
 #undef CP_CALL
     CP_LAUNCH_CHECK(ctx);

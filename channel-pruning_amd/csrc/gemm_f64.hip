@@ -44,6 +44,58 @@ __device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int 
     }
 }
 
+// Super-tile enumeration for launches with many tiles: the tile list is ordered super-block by super-block (SB x SB tiles,
+// row-major inside a block; lower / upper triangle: the blocks on and below the diagonal, a diagonal block holding only its
+// own triangle).  An XCD works on a contiguous range of this list and keeps 2 x 32 workgroups resident, i.e. about one
+// 8 x 8 super-block: its tiles share 8 + 8 operand panels in the XCD's L2 instead of the 2-3 + tiles_n panels of a band of
+// tile rows.  tiles_m = tile rows (TRI_NONE), tiles_n = tile columns (= tiles per side for the triangles).
+constexpr int SB = 8;
+__device__ __forceinline__ void decode_tile_blocked(int tri, int idx, int tiles_m, int tiles_n, int &ti, int &tj) {
+    if (tri == CP_TRI_NONE) {
+        const int per_row = SB * tiles_n;                      // tiles of a full block row
+        int I = idx / per_row;
+        const int nbr = (tiles_m + SB - 1) / SB;
+        if (I > nbr - 1) I = nbr - 1;
+        const int rem = idx - I * per_row;
+        const int h = min(SB, tiles_m - I * SB);
+        const int J = rem / (h * SB);
+        const int r2 = rem - J * h * SB;
+        const int w = min(SB, tiles_n - J * SB);
+        ti = I * SB + r2 / w;
+        tj = J * SB + r2 % w;
+        return;
+    }
+    const int T = tiles_n;
+    int I = 0, before = 0;                                     // block row I holds h S I + h (h + 1) / 2 tiles
+    for (;; ++I) {
+        const int h = min(SB, T - I * SB);
+        const int cnt = h * SB * I + h * (h + 1) / 2;
+        if (idx < before + cnt) break;
+        before += cnt;
+    }
+    const int h = min(SB, T - I * SB);
+    const int rem = idx - before;
+    int a, b;
+    if (rem < h * SB * I) {                                    // a full block left of the diagonal
+        const int J = rem / (h * SB), r2 = rem - J * h * SB;
+        a = I * SB + r2 / SB;
+        b = J * SB + r2 % SB;
+    } else {                                                   // the diagonal block: row r of it has r + 1 tiles
+        const int r3 = rem - h * SB * I;
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= r3) ++r;
+        a = I * SB + r;
+        b = I * SB + r3 - r * (r + 1) / 2;
+    }
+    if (tri == CP_TRI_LOWER_MIRROR) {
+        ti = a;
+        tj = b;
+    } else {
+        ti = b;
+        tj = a;
+    }
+}
+
 // WT = per-wave output tile (64 -> 128x128 workgroup tile, 32 -> 64x64).  The small tile is
 // used for the skinny K = 128 products of the blocked Cholesky / substitutions, where the
 // large one would leave most CUs idle and make every call as long as one 128^3 tile.
@@ -95,8 +147,9 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         tile = slot % n_tiles;
     } else if (n_tiles >= 64) {
         // XCD-aware: workgroup L runs on XCD L % 8 (each XCD has its own L2).  Give every XCD a CONTIGUOUS range of the
-        // row-major tile list -- a band of tile rows -- so that the row panel of a band is read from HBM by one L2 instead
-        // of by all eight (PMC: the p = 4250 refit Gram fetched 2.8 GB for 0.31 GB of operands with the plain order).
+        // super-tile ordered list (decode_tile_blocked): the workgroups resident on an XCD at any time then cover about one
+        // 8 x 8 block of tiles and share its 16 operand panels in that L2 (PMC: the p = 4250 refit Gram fetched 2.8 GB for
+        // 0.31 GB of operands with the plain order, 2.4 GB with bands of tile rows per XCD).
         const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
         const int base = n_tiles >> 3, rem = n_tiles & 7;
         tile = xcd * base + (xcd < rem ? xcd : rem) + slot;
@@ -106,7 +159,10 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         z = 0;
     }
     int ti, tj;
-    decode_tile(TRI, tile, tiles_n, ti, tj);
+    if (splits == 1 && n_tiles >= 64)
+        decode_tile_blocked(TRI, tile, M / TM, tiles_n, ti, tj);
+    else
+        decode_tile(TRI, tile, tiles_n, ti, tj);
     const int m0 = ti * TM, n0 = tj * TM;
     const int k0 = z * kchunk;
     int k1 = k0 + kchunk;

@@ -13,7 +13,7 @@
 // i.e. (S + n) P^2 / 2 MFMA flops instead of S n c^2 (1.6x fewer at k = 3, S n / (S + n) ~ 126x fewer
 // at k = 1) and 2 x 21 MB of Gram tiles instead of the 131 MB of Z written and read back.
 // Launches: k_lasso_prep (sampled rows of X, W2 and Y^T widened to f64 + target statistics), one paired
-// MFMA launch for GX and GW, one for T, k_q_finish, k_hadamard_q.
+// MFMA launch for GX and GW, one for T, k_q_cols + k_q_finish, k_hadamard_q.
 // All float64, deterministic reductions (fixed order, no atomics).
 #include "cp_common.h"
 
@@ -102,55 +102,96 @@ __global__ void __launch_bounds__(ZT) k_lasso_prep(const TX *__restrict__ X, con
     }
 }
 
-// One workgroup per channel i: column sums of Xs and Wf over its kk columns, the products with T,
-// then zmean[i] and q[i].  Thread = row (sample s, then filter j), kk consecutive doubles each.
-__global__ void __launch_bounds__(ZT) k_q_finish(const double *__restrict__ Xs, const double *__restrict__ Tm,
-                                                 const double *__restrict__ Wf, int S_pad, int n_pad, int ldp, int kk,
+// Column pass of q / zmean: workgroup = 64 consecutive columns (i,t) x 4 row lanes, so every row is read as one
+// 512-byte run (the first form walked kk-double segments with a row stride between threads: 15x the operand bytes
+// fetched at c = 512).  Per column: colX = sum_s Xs, colD = sum_s Xs T, colW = sum_j Wf; rows s = lane, lane + 4, ...
+// with four loads in flight, the four row lanes combined in fixed order.
+constexpr int QC = 64, QR = ZT / QC;
+__global__ void __launch_bounds__(ZT) k_q_cols(const double *__restrict__ Xs, const double *__restrict__ Tm,
+                                               const double *__restrict__ Wf, int S_pad, int n_pad, int ldp,
+                                               double *__restrict__ colX, double *__restrict__ colD,
+                                               double *__restrict__ colW) {
+    __shared__ double red[3][QR][QC];
+    const int cl = threadIdx.x & (QC - 1), rl = threadIdx.x / QC;
+    const size_t col = size_t(blockIdx.x) * QC + cl;
+    double xs = 0.0, dot = 0.0, ws = 0.0;
+    int s = rl;
+    for (; s + 3 * QR < S_pad; s += 4 * QR) {
+        double x[4], t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x[u] = Xs[size_t(s + u * QR) * ldp + col];
+            t[u] = Tm[size_t(s + u * QR) * ldp + col];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xs += x[u];
+            dot = fma(x[u], t[u], dot);
+        }
+    }
+    for (; s < S_pad; s += QR) {
+        const double x = Xs[size_t(s) * ldp + col];
+        xs += x;
+        dot = fma(x, Tm[size_t(s) * ldp + col], dot);
+    }
+    int j = rl;
+    for (; j + 3 * QR < n_pad; j += 4 * QR) {
+        double w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = Wf[size_t(j + u * QR) * ldp + col];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ws += w[u];
+    }
+    for (; j < n_pad; j += QR) ws += Wf[size_t(j) * ldp + col];
+    red[0][rl][cl] = xs;
+    red[1][rl][cl] = dot;
+    red[2][rl][cl] = ws;
+    __syncthreads();
+    if (rl == 0) {
+        double a = 0.0, d = 0.0, w = 0.0;
+#pragma unroll
+        for (int r = 0; r < QR; ++r) {
+            a += red[0][r][cl];
+            d += red[1][r][cl];
+            w += red[2][r][cl];
+        }
+        colX[col] = a;
+        colD[col] = d;
+        colW[col] = w;
+    }
+}
+
+// Per channel i (one thread): zmean[i] = sum_t colX colW / M,  q[i] = sum_t colD - M zmean[i] ybar; target statistics
+// from the YB partials (fixed order).
+__global__ void __launch_bounds__(ZT) k_q_finish(const double *__restrict__ colX, const double *__restrict__ colD,
+                                                 const double *__restrict__ colW, int c, int kk,
                                                  const double *__restrict__ ypart, const double *__restrict__ Y,
                                                  const int64_t *__restrict__ samples, int n, double M,
                                                  double *__restrict__ stats, double *__restrict__ zmean,
                                                  double *__restrict__ q) {
-    __shared__ double red[ZT / 64];
-    __shared__ double cx[64], cw[64];
-    const int i = blockIdx.x;
-    // target statistics from the YB partials (every block recombines them in the same fixed order)
+    const int i = blockIdx.x * ZT + threadIdx.x;
     double S1 = 0.0, S2 = 0.0;
     for (int k = 0; k < YB; ++k) {
         S1 += ypart[2 * k];
         S2 += ypart[2 * k + 1];
     }
     const double ymean = Y[samples[0] * n] + S1 / M;
-    if (i == 0 && threadIdx.x == 0) {
+    if (i == 0) {
         stats[0] = S2 - S1 * (S1 / M);
         stats[1] = ymean;
         stats[2] = M;
         stats[3] = 0.0;
     }
+    if (i >= c) return;
     const size_t c0 = size_t(i) * kk;
-    double dot = 0.0;
+    double acc = 0.0, dot = 0.0;
     for (int t = 0; t < kk; ++t) {
-        double xs = 0.0, ws = 0.0;
-        for (int s = threadIdx.x; s < S_pad; s += ZT) {
-            const double x = Xs[size_t(s) * ldp + c0 + t];
-            xs += x;
-            dot = fma(x, Tm[size_t(s) * ldp + c0 + t], dot);
-        }
-        for (int j = threadIdx.x; j < n_pad; j += ZT) ws += Wf[size_t(j) * ldp + c0 + t];
-        xs = block_sum(xs, red);
-        ws = block_sum(ws, red);
-        if (threadIdx.x == 0) {
-            cx[t] = xs;
-            cw[t] = ws;
-        }
+        acc = fma(colX[c0 + t], colW[c0 + t], acc);
+        dot += colD[c0 + t];
     }
-    dot = block_sum(dot, red);
-    if (threadIdx.x == 0) {
-        double acc = 0.0;
-        for (int t = 0; t < kk; ++t) acc = fma(cx[t], cw[t], acc);
-        const double zm = acc / M;
-        zmean[i] = zm;
-        q[i] = dot - M * zm * ymean;
-    }
+    const double zm = acc / M;
+    zmean[i] = zm;
+    q[i] = dot - M * zm * ymean;
 }
 
 // Q[i,i'] = sum_{t,t'} GX[(i,t),(i',t')] GW[(i,t),(i',t')] - M zbar_i zbar_i'  for i <= i', mirrored.
@@ -197,7 +238,7 @@ extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N,
     size_t ws = std::max(cp_gemm_tn_workspace(ctx, P_pad, P_pad, S_pad, CP_TRI_UPPER),
                          cp_gemm_tn_workspace(ctx, P_pad, P_pad, n_pad, CP_TRI_UPPER));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, S_pad, P_pad, n_pad, CP_TRI_NONE));
-    const size_t need = (2 * g_cnt + (2 * size_t(S_pad) + n_pad) * P_pad + size_t(n_pad) * S_pad + size_t(c) + 64) * 8 +
+    const size_t need = (2 * g_cnt + (2 * size_t(S_pad) + n_pad + 3) * P_pad + size_t(n_pad) * S_pad + size_t(c) + 64) * 8 +
                         size_t(S) * 8 + ws + (1 << 16);
     CP_TRY(cp_arena_reserve(ctx, need));
     double *GX = cp_arena_take_t<double>(ctx, g_cnt);
@@ -207,9 +248,11 @@ extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N,
     double *Wf = cp_arena_take_t<double>(ctx, size_t(n_pad) * P_pad);
     double *Yst = cp_arena_take_t<double>(ctx, size_t(n_pad) * S_pad);
     double *zmean = cp_arena_take_t<double>(ctx, c);
+    double *colX = cp_arena_take_t<double>(ctx, 3 * size_t(P_pad)), *colD = colX ? colX + P_pad : nullptr,
+           *colW = colX ? colX + 2 * size_t(P_pad) : nullptr;
     double *ypart = cp_arena_take_t<double>(ctx, 2 * YB);
     int64_t *dsamples = cp_arena_take_t<int64_t>(ctx, S);
-    if (!GX || !GW || !Xs || !Tm || !Wf || !Yst || !zmean || !ypart || !dsamples)
+    if (!GX || !GW || !Xs || !Tm || !Wf || !Yst || !zmean || !colX || !ypart || !dsamples)
         return cp_set_error(ctx, CP_ERR_NOMEM, "lasso_gram: arena");
 
     cp_stage_begin(ctx);
@@ -238,8 +281,10 @@ extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N,
                                CP_TRI_UPPER));
     CP_TRY(cp_gemm_tn_f64(ctx, S_pad, P_pad, n_pad, 1.0, Yst, S_pad, Wf, P_pad, 0.0, Tm, P_pad, CP_TRI_NONE));
     cp_stage_mark(ctx, "lasso_gram_gemms");
-    k_q_finish<<<c, ZT, 0, ctx->stream>>>(Xs, Tm, Wf, S_pad, n_pad, P_pad, kk, ypart, Y, dsamples, n,
-                                          double(S) * double(n), stats, zmean, q);
+    k_q_cols<<<P_pad / QC, ZT, 0, ctx->stream>>>(Xs, Tm, Wf, S_pad, n_pad, P_pad, colX, colD, colW);
+    CP_LAUNCH_CHECK(ctx);
+    k_q_finish<<<(c + ZT - 1) / ZT, ZT, 0, ctx->stream>>>(colX, colD, colW, c, kk, ypart, Y, dsamples, n,
+                                                          double(S) * double(n), stats, zmean, q);
     CP_LAUNCH_CHECK(ctx);
     k_hadamard_q<<<dim3(c, (c + ZT - 1) / ZT), ZT, 0, ctx->stream>>>(GX, GW, P_pad, c, kk, zmean, stats, Q, c);
     CP_LAUNCH_CHECK(ctx);

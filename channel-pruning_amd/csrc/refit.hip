@@ -42,6 +42,7 @@ __device__ __forceinline__ double ldv(const T *p, size_t i) {
 // ---- column means, gather + centre -------------------------------------------------------
 // Column sums of the kept X columns (gathered through chan[]) and of Y in one launch:
 // blockIdx.x < gx covers 256 X columns, the rest 256 Y columns; blockIdx.y = row block.
+constexpr int CSU = 8;
 template <typename TX>
 __global__ void __launch_bounds__(RT) k_colsum_xy(const TX *__restrict__ X, const double *__restrict__ Y, int64_t N,
                                                   int c, int kk, int n, const int *__restrict__ chan, int p, int gx,
@@ -54,12 +55,30 @@ __global__ void __launch_bounds__(RT) k_colsum_xy(const TX *__restrict__ X, cons
         if (col >= p) return;
         const int a = col / kk, t = col - a * kk;
         const size_t src = size_t(chan[a]) * kk + t, stride = size_t(c) * kk;
-        for (int64_t r = r0; r < r1; ++r) s += ldv(X, size_t(r) * stride + src);
+        // eight independent row loads in flight per thread, summed in row order (one dependent load per iteration left the
+        // pass at 6 % of the HBM rate)
+        int64_t r = r0;
+        for (; r + CSU <= r1; r += CSU) {
+            double v[CSU];
+#pragma unroll
+            for (int u = 0; u < CSU; ++u) v[u] = ldv(X, size_t(r + u) * stride + src);
+#pragma unroll
+            for (int u = 0; u < CSU; ++u) s += v[u];
+        }
+        for (; r < r1; ++r) s += ldv(X, size_t(r) * stride + src);
         part_x[size_t(blockIdx.y) * ldx + col] = s;
     } else {
         const int col = (blockIdx.x - gx) * RT + threadIdx.x;
         if (col >= n) return;
-        for (int64_t r = r0; r < r1; ++r) s += Y[size_t(r) * n + col];
+        int64_t r = r0;
+        for (; r + CSU <= r1; r += CSU) {
+            double v[CSU];
+#pragma unroll
+            for (int u = 0; u < CSU; ++u) v[u] = Y[size_t(r + u) * n + col];
+#pragma unroll
+            for (int u = 0; u < CSU; ++u) s += v[u];
+        }
+        for (; r < r1; ++r) s += Y[size_t(r) * n + col];
         part_y[size_t(blockIdx.y) * ldy + col] = s;
     }
 }

@@ -276,3 +276,17 @@ def test_soft_threshold_ties_separate_every_rounding_variant_and_sklearns_own_tw
             m = Lasso(alpha=float(g["l1"][t]) / g["Z"].shape[1], fit_intercept=False, selection="random", precompute=False,
                       random_state=np.random.RandomState(0), tol=1e-4, max_iter=1000).fit(g["Z"][t], g["y"][t])
             assert tuple(m.coef_ != 0) == tuple(g["sk_data"][t] != 0)
+
+
+def test_three_operation_division_is_correctly_rounded():
+    """tests/host/test_markstein.c: q1 = fma(fma(-b, a r, a), r, a r) with r = RN(1 / b) equals a / b on 1e8 random,
+    adversarial and structured operand pairs (the chain wave of csrc/cd_team.hip divides this way)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = "/tmp/cp_test_markstein"
+    subprocess.check_call(["gcc", "-O2", "-mfma", os.path.join(ROOT, "tests", "host", "test_markstein.c"), "-lm", "-o", exe])
+    out = subprocess.run([exe, "20000000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "random: 0 mismatches" in out.stdout and "adversarial: 0 mismatches" in out.stdout \
+        and "structured: 0 mismatches" in out.stdout, out.stdout
