@@ -24,7 +24,8 @@ _vp = ctypes.c_void_p
 
 
 class CdResult(ctypes.Structure):
-    _fields_ = [("gap", _c_dbl), ("tol_scaled", _c_dbl), ("n_iter", ctypes.c_int32), ("nnz", ctypes.c_int32)]
+    _fields_ = [("gap", _c_dbl), ("tol_scaled", _c_dbl), ("n_iter", ctypes.c_int32), ("nnz", ctypes.c_int32),
+                ("edge_margin", _c_dbl), ("gap_margin", _c_dbl)]
 
 
 class RefitInfo(ctypes.Structure):
@@ -333,7 +334,8 @@ class Context:
                                                    ctypes.byref(alpha_out), ctypes.cast(log, _vp),
                                                    alphas.ctypes.data), "cp_lasso_alpha_search")
         nf = fits_used.value
-        fits = [(float(alphas[i]), int(log[i].nnz), int(log[i].n_iter)) for i in range(nf)]
+        fits = [(float(alphas[i]), int(log[i].nnz), int(log[i].n_iter), float(log[i].edge_margin), float(log[i].gap_margin))
+                for i in range(max(nf, 0))]
         return nf, alpha_out.value, fits
 
     def lstsq_refit(self, X, x_dtype, N, c, kk, mask, Y, n, ridge, W_out, b_out):

@@ -125,6 +125,7 @@ class LayerProblem:
         self.flags = flags
         self.S = 0
         self.fits = []          # [(alpha, nnz, n_iter)] of the last search
+        self.margins = []       # [(edge_margin, gap_margin)] per fit: cp_cd_result's tie sentinels (-1 = not tracked)
         self.refit_info = None
 
     def __init__(self, ctx, X, W2, Y, flags=0):
@@ -168,6 +169,7 @@ class LayerProblem:
         r = self.ctx.enet_cd_gram(self.Qd, self.c, self.qd, self.statsd, self.c, alpha * self.M, 0.0, seed,
                                   self.wd, flags=self.flags)
         self.fits.append((float(alpha), int(r.nnz), int(r.n_iter)))
+        self.margins.append((float(r.edge_margin), float(r.gap_margin)))
         return int(r.nnz)
 
     def mask(self):
@@ -205,6 +207,7 @@ class LayerProblem:
         draw_seeds(rng, res.fits_used)     # consume exactly what the reference would have
         self.fits = [(float(res.fit_alpha[i]), int(res.fit_log[i].nnz), int(res.fit_log[i].n_iter))
                      for i in range(res.fits_used)]
+        self.margins = [(float(res.fit_log[i].edge_margin), float(res.fit_log[i].gap_margin)) for i in range(res.fits_used)]
         info = capi.RefitInfo()
         info.p, info.rank, info.fallback = res.p, res.refit_rank, res.fallback
         self.refit_info = info
@@ -214,6 +217,7 @@ class LayerProblem:
     def alpha_search(self, rank, alpha_right0, rank_tol, rng, mode="device"):
         lbound, rbound = self.rank_bounds(rank, rank_tol)
         self.fits = []
+        self.margins = []
         self.reset_w()
         if mode == "device":
             mark = rng_mark(rng)
@@ -229,7 +233,8 @@ class LayerProblem:
             rng_rewind(rng, mark)
             if nf > 0:
                 draw_seeds(rng, nf)        # consume exactly what the reference would have
-                self.fits = fits
+                self.fits = [f[:3] for f in fits]
+                self.margins = [f[3:] for f in fits]
                 return alpha
             self.reset_w()                 # did not settle within MAX_FITS: replay fit by fit
         left, right = 0, alpha_right0
@@ -278,6 +283,25 @@ class LayerProblem:
 
 GLOBAL_RNG = np.random  # module-level legacy RandomState: randint / get_state / set_state
 
+TIE_ULPS = 64.0          # a decision within this many float64 ulp of its threshold is reported (tie_report)
+
+
+def tie_report(prob):
+    """The tie sentinels of the last search on `prob` (cp_cd_result.edge_margin / gap_margin per fit) -> dict
+        edge_margin   smallest relative distance of a coefficient from the edge of its dead zone in the last epoch of a fit
+        gap_margin    smallest relative distance of a duality gap from its stopping threshold
+        suspect       True when either is within TIE_ULPS ulp: the reference (scikit-learn's DATA form of the recurrence,
+                      lib/decompose.py:449, 456) may have decided that coefficient / that stop the other way, so the mask
+                      is not pinned by rounding-level agreement alone
+        tracked       False when the kernel form does not report the sentinels (-1)."""
+    eps = np.finfo(np.float64).eps
+    edges = [m[0] for m in prob.margins if m[0] >= 0]
+    gaps = [m[1] for m in prob.margins if m[1] >= 0]
+    edge = min(edges) if edges else None
+    gap = min(gaps) if gaps else None
+    return dict(edge_margin=edge, gap_margin=gap, tracked=bool(edges or gaps),
+                suspect=bool((edge is not None and edge <= TIE_ULPS * eps) or (gap is not None and gap <= TIE_ULPS * eps)))
+
 
 def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="device", alpha_arg=1e-4,
                 refit="linear", W2_host=None, latency_mode=True, fixed_alpha=None):
@@ -296,6 +320,7 @@ def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="de
     if fixed_alpha is not None:                                   # decompose.py:582-585: idxs, rank = solve(alpha)
         prob.lasso_gram(samples)
         prob.fits = []
+        prob.margins = []
         prob.reset_w()
         prob.solve(fixed_alpha, rng.randint(0, RAND_R_MAX))
         idxs = prob.mask()
@@ -304,6 +329,7 @@ def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="de
         idxs = np.array([True] * rank)
         alpha = alpha_arg
         prob.fits = []
+        prob.margins = []
     else:
         if mode == "device" and refit == "linear":
             fused = prob.prune_fused(rank, alpha_in, rank_tol, rng, samples, ridge, latency_mode=latency_mode)
@@ -359,6 +385,7 @@ def prune_layers_batched(probs, ranks, alpha_ins, rngs, rank_tol=.1, ridge=0.0, 
         draw_seeds(rng, res.fits_used)             # consume exactly what the reference would have
         prob.fits = [(float(res.fit_alpha[j]), int(res.fit_log[j].nnz), int(res.fit_log[j].n_iter))
                      for j in range(res.fits_used)]
+        prob.margins = [(float(res.fit_log[j].edge_margin), float(res.fit_log[j].gap_margin)) for j in range(res.fits_used)]
         info = capi.RefitInfo()
         info.p, info.rank, info.fallback = res.p, res.refit_rank, res.fallback
         prob.refit_info = info

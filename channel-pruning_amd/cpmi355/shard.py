@@ -128,7 +128,14 @@ class ResidentLayerSet:
             per = max(1, min(int(per_stream), capi_max_jobs()))
             for g0 in range(0, len(members), per):
                 group = members[g0:g0 + per]
-                root = capi.Context(device)
+                # critical-path-first: the streams of the widest layers get the higher HIP priority (CP_JOB_PRIORITY=1)
+                import os
+                if os.environ.get("CP_JOB_PRIORITY", "0") == "1" and c == max(by_width):
+                    os.environ["CP_CTX_PRIORITY"] = "-1"
+                try:
+                    root = capi.Context(device)
+                finally:
+                    os.environ.pop("CP_CTX_PRIORITY", None)
                 ctxs = [root] + [root.sibling() for _ in group[1:]]
                 probs, rngs = [], []
                 for cx, i in zip(ctxs, group):

@@ -1250,6 +1250,8 @@ __global__ void __launch_bounds__(WAVE) k_cd_fit(const double *__restrict__ Q, i
         res->tol_scaled = tol_scaled;
         res->n_iter = o.n_iter;
         res->nnz = o.nnz;
+        res->edge_margin = -1.0;
+        res->gap_margin = -1.0;
     }
 }
 
@@ -1278,6 +1280,8 @@ cd_search_body(const double *__restrict__ Q, int ldq, const double *__restrict__
             log[fit].tol_scaled = tol_scaled;
             log[fit].n_iter = o.n_iter;
             log[fit].nnz = o.nnz;
+            log[fit].edge_margin = -1.0;
+            log[fit].gap_margin = -1.0;
             log_alpha[fit] = alpha;
         }
         ++fit;
@@ -1369,6 +1373,8 @@ __global__ void __launch_bounds__(2 * WAVE) k_cd_fit_duo(const double *__restric
         res->tol_scaled = tol_scaled;
         res->n_iter = o.n_iter;
         res->nnz = o.nnz;
+        res->edge_margin = -1.0;
+        res->gap_margin = -1.0;
     }
 }
 
@@ -1396,6 +1402,8 @@ cd_search_duo_body(const double *__restrict__ Q, int ldq, const double *__restri
             log[fit].tol_scaled = tol_scaled;
             log[fit].n_iter = o.n_iter;
             log[fit].nnz = o.nnz;
+            log[fit].edge_margin = -1.0;
+            log[fit].gap_margin = -1.0;
             log_alpha[fit] = alpha;
         }
         ++fit;

@@ -96,6 +96,7 @@ struct FitOut {
     double gap;
     int n_iter;
     int nnz;
+    double edge_margin = -1.0, gap_margin = -1.0;
 };
 
 // Flags and payloads all live in LDS, and the LDS executes one wave's instructions in program order:
@@ -119,6 +120,8 @@ struct DevResult {  // mirrors cp_cd_result
     double tol_scaled;
     int32_t n_iter;
     int32_t nnz;
+    double edge_margin;  // tie sentinels (-1: not tracked by this kernel form)
+    double gap_margin;
 };
 
 struct CdSearchArgs {

@@ -47,6 +47,7 @@ struct TeamCtl {
     int pad;
     int seqB[KMAX];    // images published by keeper k (image t = H after the first t blocks; count = t + 1)
     double gap;
+    double edge_margin, gap_margin;   // tie sentinels of the fit (cp_cd_result)
 };
 
 template <int R, int K>
@@ -334,16 +335,18 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         }
     };
     // w_new of one lane from its private H: _cd_fast.pyx:662-667
-    auto soft_step = [&](const Batch &bt, double wo_v, double Hs_v) -> double {
+    // d_out: |tmp| - alpha before the clamp -- its magnitude is how far the coefficient is from the edge of its dead zone
+    auto soft_step = [&](const Batch &bt, double wo_v, double Hs_v, double &d_out) -> double {
         const double Hp = fma(-wo_v, bt.Qd, Hs_v);
         const double tmp = bt.q - Hp;
+        d_out = fabs(tmp) - alpha;
         if (MK) {
-            const double m = fmax(fabs(tmp) - alpha, 0.0);   // >= +0
+            const double m = fmax(d_out, 0.0);               // >= +0
             const double q0 = m * bt.rden;
             const double rem = fma(-bt.den, q0, m);
             return copysign(fma(rem, bt.rden, q0), tmp);     // den > 0: the quotient carries tmp's sign, zeros included
         }
-        const double thr = copysign(fmax(fabs(tmp) - alpha, 0.0), tmp);
+        const double thr = copysign(fmax(d_out, 0.0), tmp);
         return RECIP ? thr * bt.den : thr / bt.den;
     };
 
@@ -353,6 +356,11 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     int n_iter = 0, f = 0;
     double wmax_v = 0.0, dmax_v = 0.0;
     double gap_out = tol_scaled + 1.0;
+    // tie sentinels: per-lane minimum of | |tmp| - alpha | over the current epoch (every lane's LAST evaluation in a block is
+    // its own final update: lanes past their step reproduce it), the value of the last finished epoch, and the closest the
+    // duality gap came to its threshold
+    const double big = __builtin_huge_val();
+    double edge_v = big, edge_last = big, gap_margin = big;
     double dp0[B], dp1[B];  // what the previous block published (DELTA: dp0 = differences; else dp0 = w_old, dp1 = w_new)
 #pragma unroll
     for (int a = 0; a < B; ++a) dp0[a] = dp1[a] = 0.0;
@@ -392,12 +400,18 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
             }
             gap += alpha * l1 - const_ * y_norm2 + const_ * q_dot_w + 0.5 * beta * (1.0 + const_ * const_) * w_norm2;
             gap_out = gap;
+            gap_margin = fmin(gap_margin, fabs(gap - tol_scaled));
             if (gap < tol_scaled) done = true;
         }
         ++n_iter;
         wmax_v = 0.0;
         dmax_v = 0.0;
         f = 0;
+        double e = edge_v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e = fmin(e, __shfl_xor(e, o, WAVE));
+        edge_last = e;
+        edge_v = big;
         return done || n_iter == max_iter;
     };
 
@@ -434,6 +448,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         uint64_t wmask = blockmask;
         const bool has_dup = (bt.dupmask & blockmask) != 0;
         double wn_keep = 0.0, p0_v = 0.0, p1_v = 0.0;  // what this lane publishes for its own step
+        double d_v = big;                              // |tmp| - alpha of this lane's last evaluation
         if (!has_dup) {
             double wn_v = 0.0;
 #pragma unroll
@@ -441,7 +456,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
                 const int la = base + a;
                 // every lane evaluates "its" update against its private H; lane la's is the one that counts now, lanes
                 // before it reproduce their final value (their couplings to this and later steps read 0)
-                wn_v = soft_step(bt, wo_v, Hs_v);
+                wn_v = soft_step(bt, wo_v, Hs_v, d_v);
                 if (DELTA) {
                     const double d_a = read_lane(wn_v - wo_v, la);
                     dp0[a] = d_a;
@@ -461,8 +476,10 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
 #pragma unroll
             for (int a = 0; a < B; ++a) {
                 const int la = base + a;
-                const double wn_v = soft_step(bt, wo_v, Hs_v);
+                double d_a;
+                const double wn_v = soft_step(bt, wo_v, Hs_v, d_a);
                 const bool mine = lane == la;
+                d_v = mine ? d_a : d_v;
                 wn_keep = mine ? wn_v : wn_keep;
                 const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
                 if (DELTA) {
@@ -495,6 +512,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
             }
             dmax_v = fmax(dmax_v, fabs(wn_keep - wo_v));
             wmax_v = fmax(wmax_v, fabs(wn_keep));
+            edge_v = fmin(edge_v, fabs(d_v));
         }
         if ((wmask >> lane) & 1) w_lds[bt.ii] = wn_keep;
         duo_store(&ctl->seqA, t + 1);
@@ -557,6 +575,8 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         ctl->gap = gap_out;
         ctl->n_iter = duo_load(&ctl->err) ? -1 : n_iter;
         ctl->nnz = cnt;
+        ctl->edge_margin = edge_last == big ? -1.0 : edge_last / alpha;
+        ctl->gap_margin = gap_margin == big ? -1.0 : gap_margin / tol_scaled;
     }
 }
 
@@ -599,6 +619,8 @@ __device__ __forceinline__ FitOut team_fit(int flags, int exact_div, const doubl
     out.gap = L.ctl->gap;
     out.n_iter = L.ctl->n_iter;
     out.nnz = L.ctl->nnz;
+    out.edge_margin = L.ctl->edge_margin;
+    out.gap_margin = L.ctl->gap_margin;
     __syncthreads();
     return out;
 }
@@ -652,6 +674,8 @@ __global__ void __launch_bounds__(64 * (K + 1)) k_cd_fit_team(const double *__re
         res->tol_scaled = tol_scaled;
         res->n_iter = o.n_iter;
         res->nnz = o.nnz;
+        res->edge_margin = o.edge_margin;
+        res->gap_margin = o.gap_margin;
     }
 }
 
@@ -687,6 +711,8 @@ __global__ void __launch_bounds__(64 * (K + 1)) k_cd_search_team(CdSearchBatch b
             a.log[fit].tol_scaled = tol_scaled;
             a.log[fit].n_iter = o.n_iter;
             a.log[fit].nnz = o.nnz;
+            a.log[fit].edge_margin = o.edge_margin;
+            a.log[fit].gap_margin = o.gap_margin;
             a.log_alpha[fit] = alpha;
         }
         ++fit;
@@ -787,10 +813,13 @@ static int env_int(const char *name, int dflt) {
 }
 
 int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) {
-    // CP_CD_SPREAD=1: searches of concurrent launches rotate over the XCDs; CP_CD_PRIO=1: raised wave priority;
-    // CP_CD_EXCLUSIVE=1: the workgroup asks for (almost) a whole CU's LDS, so that no other workgroup shares its CU
+    // CP_CD_EXCLUSIVE (default 1): the workgroup asks for (almost) a whole CU's LDS, so that no other workgroup shares its
+    // CU -- next to the products of other layers (or of its own layer's side stream) the chain and keeper waves otherwise
+    // share their SIMDs' issue slots with MFMA-heavy waves: c = 512 search 10.5 -> 8.9 ms in a single-layer call, vgg16
+    // job 33.4 -> 31.1 ms.  CP_CD_SPREAD=1: searches of concurrent launches rotate over the XCDs; CP_CD_PRIO=1: raised
+    // wave priority (both measured without effect on the job: 33.6 / 33.7 ms; left as switches).
     static const int spread_on = env_int("CP_CD_SPREAD", 0), prio = env_int("CP_CD_PRIO", 0),
-                     exclusive = env_int("CP_CD_EXCLUSIVE", 0);
+                     exclusive = env_int("CP_CD_EXCLUSIVE", 1);
     static std::atomic<unsigned> next_xcd{0};
     size_t lds = team_lds_bytes(c);
     if (exclusive && !spread_on) lds = std::max(lds, size_t(150) * 1024);

@@ -2,6 +2,8 @@
 // micro-probes of libcpmi355.so.
 #include "cp_common.h"
 
+#include <algorithm>
+
 #include <chrono>
 
 int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...) {
@@ -103,7 +105,21 @@ extern "C" int cp_ctx_create(int device, cp_ctx **out) {
             return CP_ERR_NODEVICE;
         }
     }
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    // CP_CTX_PRIORITY (read at every creation; < 0 = higher): the HIP priority of this context's stream.  A resident layer
+    // set raises it for the layers on the job's critical path (cpmi355.shard.ResidentLayerSet), whose short dependent
+    // kernels (factorisation steps) then do not queue behind the long products of layers with slack.
+    int prio = 0;
+    if (const char *pv = getenv("CP_CTX_PRIORITY")) prio = atoi(pv);
+    hipError_t se;
+    if (prio != 0) {
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);   // numerically lower = higher priority
+        prio = std::max(greatest, std::min(least, prio));
+        se = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, prio);
+    } else {
+        se = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    }
+    if (se != hipSuccess) {
         delete ctx;
         return CP_ERR_HIP;
     }

@@ -16,8 +16,11 @@ theanols, GDsolver; decompose.py:12-20, 641-660) raise NotImplementedError here.
 """
 import numpy as np
 
+import warnings
+
 from cpmi355 import LayerProblem, default_context, prune_layer
 from cpmi355 import capi as _capi
+from cpmi355.pruner import tie_report
 
 from . import cfgs
 from .cfgs import c as dcfgs
@@ -61,10 +64,18 @@ def prune_resident(prob, rank, W2_host, alpha=1e-4):
                                                 alpha_arg=alpha, refit=refit, W2_host=W2_host, fixed_alpha=fixed)
     last_call_info.clear()
     ri = prob.refit_info
+    ties = tie_report(prob)
     last_call_info.update(fits=list(prob.fits), samples=prob.samples,
                           fallback=int(ri.fallback) if ri is not None else 0,
                           rank=int(ri.rank) if ri is not None else -1,
-                          p=int(ri.p) if ri is not None else int(idxs.sum()) * prob.kk)
+                          p=int(ri.p) if ri is not None else int(idxs.sum()) * prob.kk, ties=ties)
+    if ties["suspect"]:
+        # the device solves the LASSO on Z^T Z, the reference on Z itself (Lasso.fit(Z, reY), decompose.py:449, 456): the two
+        # agree to rounding, so a coefficient this close to the edge of its dead zone (or a stop this close to its
+        # threshold) may have gone the other way there -- the mask is then not guaranteed identical
+        warnings.warn("dictionary(): a LASSO decision was taken within %g ulp of its threshold (edge margin %s, duality-gap "
+                      "margin %s): the selected channels may differ from the CPU reference's at this tie"
+                      % (64, ties["edge_margin"], ties["gap_margin"]), RuntimeWarning, stacklevel=2)
     if not dcfgs.autodet:
         cfgs.alpha = alpha_out                           # decompose.py:626-627 (`if not norank`)
     return idxs, newW2, newB2

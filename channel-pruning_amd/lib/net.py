@@ -13,6 +13,7 @@ names, argument meaning and return contracts:
     Net.R3()                           the VGG "3C" driver loop, pruning step  net.py:1292-1471
     Net.appresb / invBN / getBNaff     ResNet residual-aware target             net.py:1641-1683, 1200-1217, 1106-1112
     Net.W1keep / W2keep / select / combineHP   write-back bookkeeping           net.py:1521-1630, 1473-1504
+    Net.prune_resnet(keep)             the bottleneck-by-bottleneck ResNet loop those helpers serve (not in the release)
     Net.pruning_kernel / param accessors used by the above
 
 Networks with more than a plain conv stack (BatchNorm / Scale / Eltwise shortcuts: ResNet) pass ``graph`` -- the
@@ -474,7 +475,7 @@ class Net(object):
     def select(self, name, nextname, idxs):
         """A channel-selection ("Filter") layer between blob `name` and its consumer `nextname` (net.py:1627-1630; the
         reference inserts it into the prototxt, lib/builder.py:666-672): remembered in nonWPQ under the filter's name."""
-        fname = underline(name, 'filter')
+        fname = name + '_Filter'                          # builder.py:315-319, 659-661: <bottom>_Filter (e.g. res2a_Filter)
         self.nonWPQ[fname] = np.asarray(idxs).astype(int)
         self._layer_bottom[nextname] = fname
         return fname
@@ -502,6 +503,64 @@ class Net(object):
                 self.removed.append(pname)
                 merged.append(h)
         return merged
+
+    # ---- ResNet driver (reconstructed: the reference ships the helpers, not the loop) ------------------------------
+    def resnet_blocks(self):
+        """[(block, branch2a, branch2b, branch2c)] of the bottlenecks in network order (blocks = the Eltwise sums)"""
+        out = []
+        for blk in self.sums:
+            names = [blk + '_branch2' + t for t in 'abc']
+            if all(n in self.convs for n in names):
+                out.append((blk,) + tuple(names))
+        return out
+
+    def _producer_handle(self, blob):
+        """What W1keep() is called with for the producer of `blob`: the BatchNorm behind it when there is one (W1keep
+        then finds the conv and the Scale: net.py:1547-1569), else the conv itself; ReLU layers are looked through."""
+        name = blob
+        while name in self.relus or (name not in self.convs and name not in self.bns and name in self._layer_bottom
+                                     and not isinstance(self._layer_bottom[name], list)
+                                     and name not in self.sums and name not in self.pools):
+            name = self._layer_bottom[name]
+        return name
+
+    def prune_resnet(self, keep, layerbylayer=False):
+        """Layer-by-layer channel pruning of a bottleneck ResNet -- the loop the reference's helpers W1keep / W2keep /
+        select / appresb / invBN (net.py:1521-1683, 1200-1217) were written for and its release leaves out (SURVEY.md
+        section 2, component 12), reconstructed from them and from the released ResNet-50 2x model
+        (temp/resnet-50-cp.prototxt: a Filter layer in front of every branch2a, pruned branch2a / branch2b outputs).
+
+        keep: {consumer conv: number of its INPUT channels to keep}.  Per bottleneck, in network order:
+          branch2a  reads the block input, which the shortcut shares: its producer keeps all filters and a channel
+                    sampler is put in front of branch2a (select), whose weights are refitted on the sampled channels;
+          branch2b  prunes branch2a's filters (W1keep on its BatchNorm / Scale / conv) and refits branch2b (W2keep);
+          branch2c  prunes branch2b's filters against the residual-aware target Y + (frozen - current shortcut)
+                    (appresb + invBN inside dictionary_kernel; dcfgs.res.short = 1, dic.option = resnet).
+        Needs frozen features (freeze_images / load_frozen) and, for the residual term to see the pruned earlier layers,
+        a live provider.  Returns (WPQ, nonWPQ): WPQ as W1keep / W2keep fill it, nonWPQ the samplers' index masks."""
+        if not self._mem:
+            raise ValueError("prune_resnet needs the frozen features of the original network: call freeze_images() first")
+        saved = (dcfgs.model, dcfgs.res.short, dcfgs.dic.option)
+        dcfgs.model, dcfgs.res.short, dcfgs.dic.option = cfgs.Models.resnet, 1, cfgs.pruning_options.resnet
+        t = Timer()
+        try:
+            for blk, b2a, b2b, b2c in self.resnet_blocks():
+                for consumer in (b2a, b2b, b2c):
+                    if consumer not in keep:
+                        continue
+                    t.tic()
+                    X_name = self.bottom_names[consumer][0]
+                    idxs, W2, B2 = self.dictionary_kernel(X_name, None, int(keep[consumer]), consumer, None)
+                    if consumer == b2a:
+                        self.select(X_name, consumer, idxs)
+                    else:
+                        self.W1keep(self._producer_handle(X_name), idxs)
+                    self.W2keep(consumer, idxs, W2, B2, layerbylayer=layerbylayer)
+                    self.selection[consumer] = idxs
+                    t.toc('channel_pruning')
+        finally:
+            dcfgs.model, dcfgs.res.short, dcfgs.dic.option = saved
+        return self.WPQ, self.nonWPQ
 
     # ---- baseline pruner (net.py:1632-1639) -------------------------------------------------------
     def pruning_kernel(self, X_name, d_prime, Y_name):

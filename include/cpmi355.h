@@ -106,6 +106,13 @@ typedef struct cp_cd_result {
     double tol_scaled; /* tol * yc^T yc */
     int32_t n_iter;    /* epochs run (sklearn's n_iter_) */
     int32_t nnz;       /* count of w != 0 (the reference's sum(idxs), decompose.py:465) */
+    /* Tie sentinels: how close the fit's discrete decisions came to flipping.  The reference runs scikit-learn's DATA
+     * form of the recurrence; any Gram form agrees with it to rounding only, so a decision taken within a few ulp of its
+     * threshold is one the reference may have taken the other way.  -1 = not tracked (kernel forms
+     * of cd_gram.hip; the team kernels of cd_team.hip track both). */
+    double edge_margin; /* min over the LAST epoch's coordinate updates of | |q_i - H_i| - l1 | / l1: distance of a
+                           coefficient from the edge of its dead zone (zero <-> non-zero), relative to l1 */
+    double gap_margin;  /* min over the fit's duality-gap tests of |gap - tol_scaled| / tol_scaled (stop <-> one more epoch) */
 } cp_cd_result;
 
 #define CP_CD_RECIPROCAL 1 /* multiply by 1/(Qii+l2) instead of dividing (<=1 ulp/step) */

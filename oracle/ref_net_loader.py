@@ -226,6 +226,18 @@ class FakeNetParam(object):
         b = self.layer[name][0].bottom
         return b[0] if len(b) == 1 else b
 
+    def selector(self, bottom, top, shape, num_output):
+        """lib/builder.py:666-672 inserts a Filter layer named <bottom>_Filter (builder.py:315-319, 659-661) between `bottom`
+        and its consumer `top`; here only the name and the re-wiring of `top` are kept (Net.select stores the mask)."""
+        fname = bottom + "_Filter"
+        self.layer[top][0].bottom = [fname]
+        self.filters = getattr(self, "filters", []) + [(fname, bottom, top, int(num_output))]
+        return fname
+
+    def rm_layer(self, name, inplace=False):
+        """lib/builder.py: drop a layer from the prototxt (Net.remove -> combineHP); remembered only"""
+        self.removed = getattr(self, "removed", []) + [name]
+
 
 def make_reference_net(layers, batches):
     """A reference ``Net`` (unmodified class) around the fake pycaffe net; __init__ is bypassed (it parses a prototxt)."""

@@ -156,6 +156,34 @@ def test_cd_follows_its_oracle_bit_for_bit_at_soft_threshold_ties(ctx, pad):
     assert differing >= (g["l1"].shape[0] if pad == 0 else 1)
 
 
+def test_tie_sentinels_fire_at_constructed_ties_and_only_there(ctx):
+    """cp_cd_result.edge_margin / gap_margin (team kernels): on the constructed soft-threshold ties of t01 (padded to a
+    block of 8 features) the last epoch contains an update within 64 ulp of the edge of its dead zone; on a generic problem
+    and on every dictionary() golden (checked in _check_against_golden) the margins stay orders of magnitude away."""
+    import cp_oracle
+    from cpmi355.pruner import TIE_ULPS
+    eps = np.finfo(np.float64).eps
+    g = np.load(os.path.join(GOLDEN_DIR, "t01_ties.npz"))
+    seed = int(g["seed"])
+    for t in range(g["l1"].shape[0]):
+        Z, y, l1 = g["Z"][t], g["y"][t], float(g["l1"][t])
+        c = 8
+        Q, q = np.zeros((c, c)), np.zeros(c)
+        Q[:2, :2], q[:2], yy = Z.T @ Z, Z.T @ y, float(y @ y)
+        wd = ctx.zeros(c * 8)
+        r = ctx.enet_cd_gram(ctx.to_device(Q), c, ctx.to_device(q), ctx.to_device(np.array([yy, 0, Z.shape[0], 0.])), c, l1, 0.0,
+                             seed, wd, flags=0)
+        w_ref = np.zeros(c)
+        cp_oracle.enet_cd_gram(w_ref, l1, 0.0, Q, q, yy, seed=seed)
+        assert np.array_equal(ctx.to_host(wd, (c,), np.float64), w_ref)
+        assert 0.0 <= r.edge_margin <= TIE_ULPS * eps, (t, r.edge_margin)
+    Q, q, yty, M = _cd_problem(64)
+    wd = ctx.zeros(64 * 8)
+    r = ctx.enet_cd_gram(ctx.to_device(Q), 64, ctx.to_device(q), ctx.to_device(np.array([yty, 0, M, 0.])), 64, 0.05 * np.abs(q).max(),
+                         0.0, 11, wd, flags=0)
+    assert r.edge_margin > 1e-9 and r.gap_margin > 1e-9
+
+
 def test_cd_zero_diagonal_and_zero_seed(ctx):
     """Q[ii,ii] == 0 features are skipped but still consume a draw (_cd_fast.pyx:651); seed 0 -> 1."""
     import cp_oracle
@@ -341,6 +369,9 @@ def _check_against_golden(g, p, got):
     assert np.array_equal(info["samples"], g["samples"])
     assert alpha_out == float(g["alpha_out"])
     assert rng_next == int(g["rng_next"]), "numpy global RNG stream consumed differently"
+    ties = info.get("ties")
+    if ties is not None and ties["tracked"]:      # no decision of a golden's search sits within 64 ulp of its threshold
+        assert not ties["suspect"] and (ties["edge_margin"] is None or ties["edge_margin"] > 1e-12), ties
     assert weights_err(newW2, g) <= REL_W
     assert relfro(newB2, g["newB2"]) <= REL_W
 

@@ -435,6 +435,52 @@ def test_resnet_residual_target_matches_reference_net_py(ctx):
         dcfgs.model, dcfgs.res.short, dcfgs.dic.option = '', 0, cfgs.pruning_options.prb
 
 
+def test_prune_resnet_loop_matches_the_reference_helpers_driven_the_same_way(ctx):
+    """f4: Net.prune_resnet() -- every bottleneck: channel sampler in front of branch2a, branch2a -> branch2b, branch2b ->
+    branch2c with the residual-aware target -- against golden n04, the same loop composed of the REFERENCE's own
+    dictionary_kernel / appresb / invBN / W1keep / W2keep / select on the bit-portable ResNet: every selection identical,
+    alpha carry and RNG stream identical, refitted weights <= 1e-5, WPQ / nonWPQ keys and shapes identical, values <= 1e-5."""
+    import lib.cfgs as cfgs
+    import portable_net
+    from lib.net import Net
+    from portable_provider import PortableProvider
+    g = np.load(os.path.join(GOLDEN_DIR, "n04_resnet_loop.npz"))
+    p = json.loads(str(g["params"]))
+    layers, batches = portable_net.resnet_like(seed=p["seed"], B=p["B"], HW=p["HW"], nBatches=p["nBatches"], width=p["width"],
+                                               mid=p["mid"])
+    net = Net(None, PortableProvider(layers, batches), nBatches=p["nBatches"], nPointsPerLayer=p["nPoints"], graph=layers,
+              model=cfgs.Models.resnet)
+    saved = (cfgs.c.model, cfgs.c.res.short, cfgs.c.dic.option)
+    cfgs.c.model, cfgs.c.res.short, cfgs.c.dic.option = cfgs.Models.resnet, 1, cfgs.pruning_options.resnet
+    try:
+        np.random.seed(9)
+        feats, points = net.extract_features(names=json.loads(str(g["names"])), save=1)   # shared shortcut points (net.py:466-487)
+    finally:
+        cfgs.c.model, cfgs.c.res.short, cfgs.c.dic.option = saved
+    net.load_frozen(feats_dict=feats, points_dict=points)
+    cfgs.alpha = 1e-3
+    np.random.seed(80)
+    WPQ, nonWPQ = net.prune_resnet(json.loads(str(g["keep"])))
+    steps = json.loads(str(g["steps"]))
+    assert [s[1] for s in steps] == list(net.selection.keys())
+    for i, (X_name, consumer, d_prime) in enumerate(steps):
+        assert np.array_equal(net.selection[consumer], g["idxs%d" % i]), consumer
+        assert _rel(WPQ[(consumer, 0)], g["W%d" % i]) <= 1e-5, consumer
+    assert cfgs.alpha == float(g["alpha%d" % (len(steps) - 1)])
+    assert int(np.random.randint(0, 2147483647)) == int(g["rng_next"])
+    keys = json.loads(str(g["wpq_keys"]))
+    assert ["%s|%d" % k for k in WPQ.keys()] == keys
+    for tag in keys:
+        name, idx = tag.split("|")
+        got, ref = np.asarray(WPQ[(name, int(idx))]), g["WPQ:" + tag]
+        assert got.shape == ref.shape and _rel(got, ref) <= 1e-5, tag
+    assert list(nonWPQ.keys()) == json.loads(str(g["nonwpq_keys"]))
+    for k in nonWPQ:
+        assert np.array_equal(nonWPQ[k], g["nonWPQ:" + k])
+    for name in net.convs + net.bns + net.affines:
+        assert _rel(net.param_data(name), g["finalW:" + name]) <= 1e-5 and _rel(net.param_b_data(name), g["finalb:" + name]) <= 1e-5
+
+
 def test_dictionary_kernel_honours_the_refit_flags_of_dictionary(ctx):
     """Net.dictionary_kernel goes through the body of lib.decompose.dictionary(): dcfgs.nonlinear_fc / nofc give the same
     result on the Net path as calling dictionary() on the same operands (the reference routes both through dictionary(),

@@ -158,3 +158,80 @@ def test_provider_without_data_blob_freezes_features_and_points_only(tmp_path):
     for k in rfeats:
         assert np.array_equal(feats[k], rfeats[k]), k
     assert net._mem
+
+
+def _resnet(p, model=None):
+    import lib.cfgs as cfgs
+    import portable_net
+    from lib.net import Net
+    from portable_provider import PortableProvider
+    layers, batches = portable_net.resnet_like(seed=p["seed"], B=p["B"], HW=p["HW"], nBatches=p["nBatches"], width=p["width"],
+                                               mid=p["mid"])
+    return Net(None, PortableProvider(layers, batches), nBatches=p["nBatches"], nPointsPerLayer=p["nPoints"], graph=layers,
+               model=cfgs.Models.resnet)
+
+
+def test_write_back_helpers_match_the_reference_on_the_resnet_loop():
+    """W1keep / W2keep / select (lib/net.py:1521-1630) against the REFERENCE's own methods: golden n04 ran them through
+    oracle/ref_net_loader.py on the portable ResNet, step by step; fed with the same (idxs, W2, B2) per step the facade must
+    leave the same WPQ (keys, order, values), nonWPQ, bottoms2ch and live parameters -- bit for bit."""
+    import lib.cfgs as cfgs
+    from lib.cfgs import c as dcfgs
+    g = np.load(os.path.join(GOLDEN_DIR, "n04_resnet_loop.npz"))
+    p = json.loads(str(g["params"]))
+    net = _resnet(p)
+    net._mem = True
+    saved = (dcfgs.model, dcfgs.res.short, dcfgs.dic.option)
+    dcfgs.model, dcfgs.res.short, dcfgs.dic.option = cfgs.Models.resnet, 1, cfgs.pruning_options.resnet
+    try:
+        for i, (X_name, consumer, d_prime) in enumerate(json.loads(str(g["steps"]))):
+            assert X_name == net.bottom_names[consumer][0]
+            idxs, W2, B2 = g["idxs%d" % i], g["W%d" % i], g["B%d" % i]
+            if consumer.endswith("_branch2a"):
+                net.select(X_name, consumer, idxs)
+            else:
+                net.W1keep(net._producer_handle(X_name), idxs)
+            net.W2keep(consumer, idxs, W2, B2)
+    finally:
+        dcfgs.model, dcfgs.res.short, dcfgs.dic.option = saved
+    keys = json.loads(str(g["wpq_keys"]))
+    assert ["%s|%d" % k for k in net.WPQ.keys()] == keys
+    for tag in keys:
+        name, idx = tag.split("|")
+        got, ref = np.asarray(net.WPQ[(name, int(idx))]), g["WPQ:" + tag]
+        assert got.shape == ref.shape and np.array_equal(got, ref), tag
+    assert list(net.nonWPQ.keys()) == json.loads(str(g["nonwpq_keys"]))
+    for k in net.nonWPQ:
+        assert np.array_equal(net.nonWPQ[k], g["nonWPQ:" + k])
+    assert [[a, b] for a, b, _ in net.bottoms2ch] == json.loads(str(g["bottoms2ch"]))
+    for name in net.convs + net.bns + net.affines:
+        assert np.array_equal(net.param_data(name), g["finalW:" + name]), name
+        assert np.array_equal(net.param_b_data(name), g["finalb:" + name]), name
+    # the samplers re-wire their consumers (lib/builder.py:666-672)
+    for fname, bottom, top, kept in json.loads(str(g["filters"])):
+        assert net.layer_bottom(top) == fname and int(net.nonWPQ[fname].sum()) == kept
+
+
+def test_combine_hp_matches_the_reference():
+    """combineHP (lib/net.py:1473-1504) against the reference's own method (golden n05): conv_P folded into conv_H where
+    3 m >= 2 o, left alone otherwise; merged weights, bias and the list of removed layers identical."""
+    from lib.net import ConvSpec, Net
+    g = np.load(os.path.join(GOLDEN_DIR, "n05_combine_hp.npz"))
+    shapes = json.loads(str(g["shapes"]))
+    convs = [ConvSpec(n, np.zeros((2, 3, 3, 3), np.float32), np.zeros(2, np.float32), "data") for n in shapes]
+    net = Net(convs, lambda b: {}, nBatches=1, nPointsPerLayer=1)
+    for n in shapes:
+        for suf in ("_H", "_P"):
+            net.WPQ[(n + suf, 0)] = g["W:" + n + suf].copy()
+            net.WPQ[(n + suf, 1)] = g["b:" + n + suf].copy()
+        net.WPQ[n + "_V"] = g["W:" + n + "_V"].copy()
+    merged = net.combineHP()
+    removed = json.loads(str(g["removed"]))
+    assert net.removed == removed and merged == [r[:-2] + "_H" for r in removed]
+    for n in shapes:
+        h = n + "_H"
+        assert np.array_equal(np.asarray(net.WPQ[(h, 0)]), g["newW:" + h]) and np.array_equal(np.asarray(net.WPQ[(h, 1)]), g["newb:" + h])
+        if n + "_P" in removed:
+            assert (n + "_P", 0) not in net.WPQ and net.num_output[h] == g["newW:" + h].shape[0]
+        else:
+            assert np.array_equal(net.WPQ[(n + "_P", 0)], g["W:" + n + "_P"])
