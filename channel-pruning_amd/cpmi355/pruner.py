@@ -288,7 +288,7 @@ TIE_ULPS = 64.0          # a decision within this many float64 ulp of its thresh
 
 def tie_report(prob):
     """The tie sentinels of the last search on `prob` (cp_cd_result.edge_margin / gap_margin per fit) -> dict
-        edge_margin   smallest relative distance of a coefficient from the edge of its dead zone in the last epoch of a fit
+        edge_margin   smallest relative distance of a coefficient, at its last update of a fit, from the edge of its dead zone
         gap_margin    smallest relative distance of a duality gap from its stopping threshold
         suspect       True when either is within TIE_ULPS ulp: the reference (scikit-learn's DATA form of the recurrence,
                       lib/decompose.py:449, 456) may have decided that coefficient / that stop the other way, so the mask

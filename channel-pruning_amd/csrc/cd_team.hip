@@ -14,8 +14,9 @@
 //   keeper k    (wave 1 + k)   owns H[:, 64 R k .. 64 R (k + 1)) in registers (R <= 4 doubles per lane), fetches its slice of
 //                              the rows Q[ii, :] sixteen steps ahead, applies a block's 8 updates with what the chain wave
 //                              published and exposes its slice of H as an LDS image after every block;
-// K = ceil(c / 256) <= 8 keepers: the fma work per wave and step is 2 R <= 8 whatever c is, and K waves keep K times the
-// row bytes in flight.  Hand-offs are sequence counters in LDS, one writer each (the LDS executes a wave's instructions in
+// K = ceil(c / 256) keepers up to c = 1024 (R <= 4: 2 R <= 8 fma per wave and step whatever c is), six keepers of 384 columns
+// for c <= 2304 (seven waves: at most two per SIMD, so every wave keeps 256 registers); K waves keep K times the row bytes
+// in flight.  Hand-offs are sequence counters in LDS, one writer each (the LDS executes a wave's instructions in
 // program order, so a counter written after its payload lands after it); no barrier inside a fit.
 //
 // The division of the soft-threshold step.  sklearn divides by Q_ii (+ beta); an IEEE f64 division is ~11 dependent
@@ -35,7 +36,7 @@ namespace {
 using namespace cdk;
 
 constexpr int B = 8;        // coordinate steps per block (= per hand-off)
-constexpr int KMAX = 8;     // keeper waves at most (c <= 2048)
+constexpr int KMAX = 8;     // keeper waves at most
 
 struct TeamCtl {
     int seqA;          // blocks published by the chain wave
@@ -54,15 +55,17 @@ template <int R, int K>
 struct TeamLds {
     static constexpr int IMG = 64 * R * K;
     double *img;       // [2][IMG]
+    double *edge;      // [IMG] | |tmp| - alpha | of every coordinate's LAST update in the fit (tie sentinel)
     double *pub;       // [4][2 * B]
     uint32_t *ii;      // [3][64]
     uint64_t *dup;     // [4] lanes whose coordinate repeats inside their block
     uint64_t *xdup;    // [4] lanes whose coordinate also occurs in the block before theirs
     TeamCtl *ctl;
-    static __host__ __device__ constexpr int doubles() { return 2 * IMG + 4 * 2 * B + 3 * 32 + 8 + int(sizeof(TeamCtl) / 8) + 2; }
+    static __host__ __device__ constexpr int doubles() { return 3 * IMG + 4 * 2 * B + 3 * 32 + 8 + int(sizeof(TeamCtl) / 8) + 2; }
     __device__ void bind(double *base) {
         img = base;
-        pub = img + 2 * IMG;
+        edge = img + 2 * IMG;
+        pub = edge + IMG;
         ii = reinterpret_cast<uint32_t *>(pub + 4 * 2 * B);
         dup = reinterpret_cast<uint64_t *>(ii + 3 * 64);
         xdup = dup + 4;
@@ -85,7 +88,7 @@ __device__ __forceinline__ bool team_wait(int *p, int need, TeamCtl *ctl, bool w
 // every keeper has published image `need - 1`
 template <int K>
 __device__ __forceinline__ bool images_ready(TeamCtl *ctl, int need, int lane) {
-    return __ballot(duo_load(&ctl->seqB[lane & (K - 1)]) >= need) == ~uint64_t(0);
+    return __ballot(duo_load(&ctl->seqB[lane % K]) >= need) == ~uint64_t(0);
 }
 template <int K>
 __device__ __forceinline__ bool team_wait_images(TeamCtl *ctl, int need, int lane) {
@@ -356,11 +359,10 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     int n_iter = 0, f = 0;
     double wmax_v = 0.0, dmax_v = 0.0;
     double gap_out = tol_scaled + 1.0;
-    // tie sentinels: per-lane minimum of | |tmp| - alpha | over the current epoch (every lane's LAST evaluation in a block is
-    // its own final update: lanes past their step reproduce it), the value of the last finished epoch, and the closest the
-    // duality gap came to its threshold
+    // tie sentinels: L.edge[i] = | |tmp| - alpha | of coordinate i's latest update (every lane's LAST evaluation in a block is
+    // its own final update: lanes past their step reproduce it); gap_margin = the closest the duality gap came to its threshold
     const double big = __builtin_huge_val();
-    double edge_v = big, edge_last = big, gap_margin = big;
+    double gap_margin = big;
     double dp0[B], dp1[B];  // what the previous block published (DELTA: dp0 = differences; else dp0 = w_old, dp1 = w_new)
 #pragma unroll
     for (int a = 0; a < B; ++a) dp0[a] = dp1[a] = 0.0;
@@ -407,11 +409,6 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         wmax_v = 0.0;
         dmax_v = 0.0;
         f = 0;
-        double e = edge_v;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) e = fmin(e, __shfl_xor(e, o, WAVE));
-        edge_last = e;
-        edge_v = big;
         return done || n_iter == max_iter;
     };
 
@@ -512,9 +509,11 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
             }
             dmax_v = fmax(dmax_v, fabs(wn_keep - wo_v));
             wmax_v = fmax(wmax_v, fabs(wn_keep));
-            edge_v = fmin(edge_v, fabs(d_v));
         }
-        if ((wmask >> lane) & 1) w_lds[bt.ii] = wn_keep;
+        if ((wmask >> lane) & 1) {
+            w_lds[bt.ii] = wn_keep;
+            L.edge[bt.ii] = fabs(d_v);
+        }
         duo_store(&ctl->seqA, t + 1);
         // rare repairs of the prefetch: a keeper had not published image t yet, or the next block revisits a coordinate
         // this block just changed
@@ -562,20 +561,25 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     }
     duo_store(&ctl->stop, 1);
     int cnt = 0;
+    double edge_min = big;
 #pragma unroll 4
     for (int r = 0; r < R * K; ++r) {
         const int col = r * WAVE + lane;
         cnt += (col < c && w_lds[col] != 0.0) ? 1 : 0;
+        if (col < c) edge_min = fmin(edge_min, L.edge[col]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o, WAVE);
+        edge_min = fmin(edge_min, __shfl_xor(edge_min, o, WAVE));
+    }
     if (lane == 0) {
         g_team_debug[2] = waitA;
         g_team_debug[3] = repairs;
         ctl->gap = gap_out;
         ctl->n_iter = duo_load(&ctl->err) ? -1 : n_iter;
         ctl->nnz = cnt;
-        ctl->edge_margin = edge_last == big ? -1.0 : edge_last / alpha;
+        ctl->edge_margin = edge_min == big ? -1.0 : edge_min / alpha;
         ctl->gap_margin = gap_margin == big ? -1.0 : gap_margin / tol_scaled;
     }
 }
@@ -595,6 +599,7 @@ __device__ __forceinline__ FitOut team_fit(int flags, int exact_div, const doubl
         L.ctl->err = 0;
         for (int k = 0; k < KMAX; ++k) L.ctl->seqB[k] = 0;
     }
+    for (int j = threadIdx.x; j < TeamLds<R, K>::IMG; j += blockDim.x) L.edge[j] = __builtin_huge_val();
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     const bool fast = (flags & (CP_CD_RECIPROCAL | CP_CD_DELTA)) == (CP_CD_RECIPROCAL | CP_CD_DELTA);
@@ -753,12 +758,13 @@ TeamShape team_shape(int c) {
     if (c <= 256) return {4, 1};
     if (c <= 512) return {4, 2};
     if (c <= 1024) return {4, 4};
-    return {4, 8};
+    return {6, 6};   // c <= 2304: 7 waves = at most two per SIMD, i.e. 256 registers per lane (nine waves of a (4, 8) team
+                     // would share SIMDs three by three: 168 registers, and the keepers' row ring spills)
 }
 size_t team_lds_bytes(int c) {
     const TeamShape s = team_shape(c);
     const size_t img = size_t(64) * s.R * s.K;
-    return (size_t(5) * c + 2 * img + 4 * 2 * B + 3 * 32 + 8 + sizeof(TeamCtl) / 8 + 2) * sizeof(double);
+    return (size_t(5) * c + 3 * img + 4 * 2 * B + 3 * 32 + 8 + sizeof(TeamCtl) / 8 + 2) * sizeof(double);
 }
 
 template <typename Kern>
@@ -775,7 +781,7 @@ hipError_t team_optin(Kern kernel, size_t lds) {
         else if (ts_.K == 1) { CALL(4, 1); }                   \
         else if (ts_.K == 2) { CALL(4, 2); }                   \
         else if (ts_.K == 4) { CALL(4, 4); }                   \
-        else { CALL(4, 8); }                                   \
+        else { CALL(6, 6); }                                   \
     } while (0)
 
 }  // namespace
@@ -786,7 +792,7 @@ hipError_t team_optin(Kern kernel, size_t lds) {
 bool cp_cd_team_wanted(int c, int flags) {
     static const bool on = !(getenv("CP_CD_TEAM") && atoi(getenv("CP_CD_TEAM")) == 0);
     const int f = flags & (CP_CD_RECIPROCAL | CP_CD_DELTA);
-    return on && c % B == 0 && c >= B && c <= 64 * 4 * KMAX && (f == 0 || f == (CP_CD_RECIPROCAL | CP_CD_DELTA));
+    return on && c % B == 0 && c >= B && c <= 64 * 6 * 6 && (f == 0 || f == (CP_CD_RECIPROCAL | CP_CD_DELTA));
 }
 static int team_exact_div() {
     static const int v = (getenv("CP_CD_EXACT_DIV") && atoi(getenv("CP_CD_EXACT_DIV")) != 0) ? 1 : 0;

@@ -110,8 +110,8 @@ typedef struct cp_cd_result {
      * form of the recurrence; any Gram form agrees with it to rounding only, so a decision taken within a few ulp of its
      * threshold is one the reference may have taken the other way.  -1 = not tracked (kernel forms
      * of cd_gram.hip; the team kernels of cd_team.hip track both). */
-    double edge_margin; /* min over the LAST epoch's coordinate updates of | |q_i - H_i| - l1 | / l1: distance of a
-                           coefficient from the edge of its dead zone (zero <-> non-zero), relative to l1 */
+    double edge_margin; /* min over the coordinates, each at its LAST update of the fit, of | |q_i - H_i| - l1 | / l1: distance
+                           of a coefficient from the edge of its dead zone (zero <-> non-zero), relative to l1 */
     double gap_margin;  /* min over the fit's duality-gap tests of |gap - tol_scaled| / tol_scaled (stop <-> one more epoch) */
 } cp_cd_result;
 

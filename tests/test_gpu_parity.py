@@ -157,26 +157,38 @@ def test_cd_follows_its_oracle_bit_for_bit_at_soft_threshold_ties(ctx, pad):
 
 
 def test_tie_sentinels_fire_at_constructed_ties_and_only_there(ctx):
-    """cp_cd_result.edge_margin / gap_margin (team kernels): on the constructed soft-threshold ties of t01 (padded to a
-    block of 8 features) the last epoch contains an update within 64 ulp of the edge of its dead zone; on a generic problem
+    """cp_cd_result.edge_margin / gap_margin (team kernels).  The constructed soft-threshold ties of t01, padded to a block of
+    8 features (the padding changes the visit order, so not every case still ends ON its tie): wherever the four rounding
+    variants of the recurrence end with different supports, i.e. wherever rounding decides the mask, the sentinel of the
+    default variant fires (a coefficient's last update within 64 ulp of the edge of its dead zone).  On a generic problem
     and on every dictionary() golden (checked in _check_against_golden) the margins stay orders of magnitude away."""
     import cp_oracle
     from cpmi355.pruner import TIE_ULPS
     eps = np.finfo(np.float64).eps
     g = np.load(os.path.join(GOLDEN_DIR, "t01_ties.npz"))
     seed = int(g["seed"])
+    fired = 0
     for t in range(g["l1"].shape[0]):
         Z, y, l1 = g["Z"][t], g["y"][t], float(g["l1"][t])
         c = 8
         Q, q = np.zeros((c, c)), np.zeros(c)
         Q[:2, :2], q[:2], yy = Z.T @ Z, Z.T @ y, float(y @ y)
+        sups = []
+        for flags in range(4):
+            w_ref = np.zeros(c)
+            cp_oracle.enet_cd_gram(w_ref, l1, 0.0, Q, q, yy, seed=seed, recip=bool(flags & 1), delta=bool(flags & 2))
+            sups.append(tuple(w_ref != 0))
+            if flags == 0:
+                w0 = w_ref
         wd = ctx.zeros(c * 8)
         r = ctx.enet_cd_gram(ctx.to_device(Q), c, ctx.to_device(q), ctx.to_device(np.array([yy, 0, Z.shape[0], 0.])), c, l1, 0.0,
                              seed, wd, flags=0)
-        w_ref = np.zeros(c)
-        cp_oracle.enet_cd_gram(w_ref, l1, 0.0, Q, q, yy, seed=seed)
-        assert np.array_equal(ctx.to_host(wd, (c,), np.float64), w_ref)
-        assert 0.0 <= r.edge_margin <= TIE_ULPS * eps, (t, r.edge_margin)
+        assert np.array_equal(ctx.to_host(wd, (c,), np.float64), w0)
+        assert r.edge_margin >= 0.0 and r.gap_margin >= 0.0
+        if len(set(sups)) > 1:
+            assert r.edge_margin <= TIE_ULPS * eps, (t, r.edge_margin, sups)
+            fired += 1
+    assert fired >= 1
     Q, q, yty, M = _cd_problem(64)
     wd = ctx.zeros(64 * 8)
     r = ctx.enet_cd_gram(ctx.to_device(Q), 64, ctx.to_device(q), ctx.to_device(np.array([yty, 0, M, 0.])), 64, 0.05 * np.abs(q).max(),
