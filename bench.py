@@ -301,6 +301,11 @@ def bench_job(args, env, job):
 
     t_up0 = time.perf_counter()
     per_stream = args.per_stream or (1 if job != "resnet50" else 2)
+    if os.environ.get("CP_BENCH_PER_STREAM_BY_WIDTH"):      # e.g. "512:5,256:3": layers per chunk by channel count
+        per_stream = {"default": per_stream}
+        for item in os.environ["CP_BENCH_PER_STREAM_BY_WIDTH"].split(","):
+            k_, v_ = item.split(":")
+            per_stream[int(k_)] = int(v_)
     rset = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in own], operands, per_stream=per_stream,
                                   flags=CD_FLAGS, borrow_results=True)
     probs = rset.problems()           # index in `own` order -> LayerProblem

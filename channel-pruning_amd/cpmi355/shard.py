@@ -125,7 +125,9 @@ class ResidentLayerSet:
             by_width.setdefault(int(s["c"]), []).append(i)
         self.chunks = []                 # dicts: members, ctxs, probs, rngs, marks, thread plumbing
         for c, members in sorted(by_width.items(), key=lambda kv: -kv[0]):     # widest (slowest) first
-            per = max(1, min(int(per_stream), capi_max_jobs()))
+            # per_stream: layers per chunk -- one number, or {channel count: number} (default 1 for the counts not named)
+            per = per_stream.get(c, per_stream.get("default", 1)) if isinstance(per_stream, dict) else per_stream
+            per = max(1, min(int(per), capi_max_jobs()))
             for g0 in range(0, len(members), per):
                 group = members[g0:g0 + per]
                 # critical-path-first: the streams of the widest layers get the higher HIP priority (CP_JOB_PRIORITY=1)
