@@ -260,7 +260,7 @@ def roofline_object(g_ms, g_fl, ctx0, note, traffic):
             "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + "
                             "WRITE_SIZE passes committed under profiles/",
             "avg_launch_ms": round(sum(g_ms) / len(g_ms), 4), "launches": len(g_ms),
-            "flops_per_launch": "N*p^2 (symmetric half of 2*N*p^2), p = kept*9",
+            "flops_per_launch": "N*p^2 (symmetric half of 2*N*p^2), p = kept*k*k",
             "peak_measured_probe": round(ctx0.probe_mfma_f64(), 2), "note": note}
 
 
@@ -290,7 +290,11 @@ def bench_job(args, env, job):
     for s in specs:       # measured single-layer latencies (ms, profiles/r02_*) as LPT costs; model when absent
         s["cost"] = (VGG16_COST_MS.get(s["c"], None) if job == "vgg16" else None) or \
             shard.layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"])
-    owner = shard.plan_owners(specs, env.world)
+    # --scaling weak (default): every rank prunes its OWN instance of the whole job (per-GPU work fixed; the only
+    # collective is the uint8 all_gather of the channel masks); strong: the layers of ONE instance are sharded over the ranks
+    # (LPT) and every rank ends with every layer's (mask, W, b) (one mask all_gather + one all_gather of the packed results)
+    weak = args.scaling == "weak"
+    owner = [env.rank] * len(specs) if weak else shard.plan_owners(specs, env.world)
     own = [i for i in range(len(specs)) if owner[i] == env.rank]
     host_data = {}
 
@@ -312,7 +316,19 @@ def bench_job(args, env, job):
     ctxs = [cx for ch in rset.chunks for cx in ch["ctxs"]]
     roots = [ch["ctxs"][0] for ch in rset.chunks]
 
+    masks_equal = [True]
+
     def one_job():
+        if weak:
+            res = rset()
+            if env.dist is not None:          # the trivial gather of the selected-channel masks (one uint8 all_gather)
+                t_x = time.perf_counter()
+                every = shard.gather_masks(specs, res, env.dist)
+                masks_equal[0] = masks_equal[0] and all(np.array_equal(every[r][i], res[i][0])
+                                                        for r in range(env.world) for i in range(len(specs)))
+                shard.LAST_EXCHANGE_MS.clear()
+                shard.LAST_EXCHANGE_MS.update(total=(time.perf_counter() - t_x) * 1e3, bytes_sent=sum(s["c"] for s in specs))
+            return res
         return shard.prune_sharded(specs, compute_many=rset, dist=env.dist, owner=owner,
                                    staging="device" if env.dist is not None else None)
 
@@ -442,7 +458,8 @@ def bench_job(args, env, job):
                 Xs = X[:, idxs].reshape(spec["N"], -1).astype(np.float64)
                 res = Xs @ newW2.reshape(spec["n"], -1).T + newB2 - Y
                 recon[spec["name"]] = round(float(np.linalg.norm(res) / np.linalg.norm(Y)), 6)
-        layers_per_s = len(specs) * jobs / elapsed
+        instances = env.world if weak else 1
+        layers_per_s = len(specs) * instances * jobs / elapsed
         fl = [layer_flops(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         by = [algorithmic_bytes(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
@@ -463,28 +480,34 @@ def bench_job(args, env, job):
             "metric": JOB_TEXT[job][1],
             "value": round(layers_per_s, 3), "unit": "layers/s", "n_gpus": env.world, "steps": args.steps,
             "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
             "config": {"workload": JOB_TEXT[job][0],
+                       "job_instances": instances,
                        "layers_per_job": len(specs), "jobs_per_step": reps, "jobs_timed": jobs,
                        "untimed_jobs_before": 1 + max(1, args.warmup),
                        "timed_region_s": round(elapsed, 3), "world_size": env.world, "backend": env.backend if env.dist else None,
                        "streams_per_gpu": len(rset.chunks), "layers_in_flight_per_gpu": len(own),
                        "layers_per_call": sorted({len(ch["members"]) for ch in rset.chunks}),
-                       "owner_rank_of_layer": owner, "parallelism": "layers sharded x%d (LPT), masks all_gather + "
-                                                                    "ONE all_gather of the packed (W,b)" % env.world},
+                       "owner_rank_of_layer": None if weak else owner,
+                       "parallelism": ("one job instance per GPU x%d, uint8 all_gather of the channel masks per job" % env.world)
+                       if weak else ("layers of one instance sharded x%d (LPT), masks all_gather + ONE all_gather of the "
+                                     "packed (W,b)" % env.world)},
             "job_ms": round(job_ms, 3),
             "exchange_rank0": None if not exch_ms else dict(
                 {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard.LAST_EXCHANGE_MS.items()},
                 avg_total_ms=round(float(np.mean(exch_ms)), 3),
                 note="host wall time of cpmi355.shard.exchange_results on rank 0 (includes waiting for the slowest rank)"),
             "mask_parity_vs_reference_golden": parity if len(no_golden) < len(specs) else None,
+            "masks_identical_on_every_rank": (bool(masks_equal[0]) if (weak and env.dist is not None) else None),
             "layers_without_golden": no_golden,
             "weights_rel_frobenius_vs_reference_golden": werrs,
             "reconstruction_rel_frobenius_err": recon,
             "roofline": roof,
             "job_mfma": {"gflop_per_job_algorithmic": round(alg_job / 1e9, 1), "gflop_per_job_executed_model": round(exe_job / 1e9, 1),
                          "sustained_tflops_executed": round(exe_job / (job_ms * 1e-3) / 1e12, 2),
-                         "frac_of_peak_executed": round(exe_job / (job_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS / env.world, 4),
+                         "frac_of_peak_executed": round(exe_job / (job_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS /
+                                                        (1 if weak else env.world), 4),
                          "sustained_tflops_algorithmic_full_matrix_count": round(alg_job / (job_ms * 1e-3) / 1e12, 2),
                          "algorithmic_bytes_per_job": int(sum(by)),
                          "note": "executed = what the launches compute (symmetric halves of the Grams, 128-padded tiles): the "
@@ -843,6 +866,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=("vgg16", "resnet50", "vgg16_5x", "block"),
                     default=os.environ.get("CP_BENCH_WORKLOAD", "vgg16"))
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("CP_BENCH_SCALING", "weak"),
+                    help="N > 1: weak = one instance of the job per GPU (default); strong = ONE instance, layers sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU port on every layer of the job (vgg16: about 2-3 min)")
     ap.add_argument("--no-block", action="store_true", help="vgg16: skip the conv3_x single-instance figures")

@@ -274,6 +274,21 @@ def result_segments(specs, owner, masks, world):
 LAST_EXCHANGE_MS = {}      # wall time of the phases of this process's last exchange_results (host clock)
 
 
+def gather_masks(specs, results, dist, device=None):
+    """The "trivial gather of selected-channel masks" alone: ONE fixed-size uint8 all_gather of every rank's masks of the
+    layers in `specs` (results[i][0] = idxs of layer i on this rank) -> masks[rank][layer] (bool).  Used when every rank
+    prunes its own instance of the job (weak scaling): the weights stay with the instance that produced them."""
+    import torch
+    cmax = max(s["c"] for s in specs)
+    local = np.zeros((len(specs), cmax), dtype=np.uint8)
+    for i, r in enumerate(results):
+        local[i, : specs[i]["c"]] = np.asarray(r[0], dtype=np.uint8)
+    on_gpu = dist.get_backend() == "nccl"
+    dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
+    g = _all_gather_rows(dist, torch.from_numpy(local).to(dev)).cpu().numpy()
+    return [[g[r, i, : specs[i]["c"]].astype(bool) for i in range(len(specs))] for r in range(g.shape[0])]
+
+
 def exchange_results(specs, owner, mine, dist, device=None, staging=None):
     """Every rank ends with every layer's (mask, W, b) on the host.  Two collectives on the data the job produces:
     (1) ONE fixed-size uint8 all_gather of the channel masks (the "trivial gather of selected-channel masks"); the

@@ -693,3 +693,35 @@ def test_bench_gpus_n_launches_n_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def _mask_gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = [dict(c=c) for c in (16, 5, 9)]
+    res = [(np.random.RandomState(10 * rank + i).rand(s["c"]) < 0.5, None, None) for i, s in enumerate(specs)]
+    every = shard.gather_masks(specs, res, dist)
+    q.put((rank, [[m.tolist() for m in per_rank] for per_rank in every]))
+    dist.destroy_process_group()
+
+
+def test_gather_masks_world_size_2_gloo():
+    """weak scaling's only collective: one uint8 all_gather of the channel masks -> masks[rank][layer] on every rank"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_mask_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1]
+    for r in range(2):
+        for i, c in enumerate((16, 5, 9)):
+            assert got[0][1][r][i] == (np.random.RandomState(10 * r + i).rand(c) < 0.5).tolist()
