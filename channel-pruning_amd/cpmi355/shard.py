@@ -160,6 +160,9 @@ class ResidentLayerSet:
             set(id(ch) for ch in single)
         # a set of one or two layers has the chip to itself: the full treatment (pruner.precompute_flag)
         self._latency_kind = "gram" if len(self.chunks) > 2 else True
+        import os
+        if os.environ.get("CP_JOB_LATENCY_KIND") == "full":       # experiment: prefactored full Gram inside a job too
+            self._latency_kind = True
         self._stop = False
         self._threads = []
         for ch in self.chunks:
