@@ -45,7 +45,7 @@ struct TeamCtl {
     int err;           // a bounded wait ran out (never in a correct run)
     int n_iter, nnz;
     int mk_ok;         // every feature's denominator is inside the range the three-operation division is exact on
-    int pad;
+    int cplSeq;        // blocks whose couplings keeper 0 has staged in LDS
     int seqB[KMAX];    // images published by keeper k (image t = H after the first t blocks; count = t + 1)
     double gap;
     double edge_margin, gap_margin;   // tie sentinels of the fit (cp_cd_result)
@@ -57,16 +57,21 @@ struct TeamLds {
     double *img;       // [2][IMG]
     double *edge;      // [IMG] | |tmp| - alpha | of every coordinate's LAST update in the fit (tie sentinel)
     double *pub;       // [4][2 * B]
+    double *cpl;       // [4][B][2 * B] couplings of a block, staged by keeper 0: [j][a] = Q[ii_a, ii_j] (0 for j <= a),
+                       //               [j][B + a] = Q[ii_a(previous block), ii_j]
     uint32_t *ii;      // [3][64]
     uint64_t *dup;     // [4] lanes whose coordinate repeats inside their block
     uint64_t *xdup;    // [4] lanes whose coordinate also occurs in the block before theirs
     TeamCtl *ctl;
-    static __host__ __device__ constexpr int doubles() { return 3 * IMG + 4 * 2 * B + 3 * 32 + 8 + int(sizeof(TeamCtl) / 8) + 2; }
+    static __host__ __device__ constexpr int doubles() {
+        return 3 * IMG + 4 * 2 * B + 4 * B * 2 * B + 3 * 32 + 8 + int(sizeof(TeamCtl) / 8) + 2;
+    }
     __device__ void bind(double *base) {
         img = base;
         edge = img + 2 * IMG;
         pub = edge + IMG;
-        ii = reinterpret_cast<uint32_t *>(pub + 4 * 2 * B);
+        cpl = pub + 4 * 2 * B;
+        ii = reinterpret_cast<uint32_t *>(cpl + 4 * B * 2 * B);
         dup = reinterpret_cast<uint64_t *>(ii + 3 * 64);
         xdup = dup + 4;
         ctl = reinterpret_cast<TeamCtl *>(xdup + 4);
@@ -207,6 +212,38 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
     uint32_t off_n2 = rng.off;
     int batch = 0;
 
+    // Keeper 0 also stages the couplings the chain wave needs per block -- Q[ii_a, ii_j] for the 8 x 8 pairs inside block
+    // blk and for (a in block blk - 1, j in block blk) -- as TWO 64-lane gathers (lane = 8 a + j) written to LDS in the
+    // lay-out the chain wave reads with four 16-byte loads per lane; the chain wave used to fetch them itself with 16
+    // loads + 16 readlanes per block.  Three blocks ahead of the block this wave applies (the index batches are published
+    // two batches ahead), so the chain wave never waits for them.
+    constexpr uint32_t OOB = 0x80000000u;
+    auto idx_of = [&](int v) -> uint32_t { return L.ii[((v >> 6) % 3) * 64 + (v & 63)]; };
+    auto cpl_request = [&](int blk, double &qc, double &qx) {
+        const int a = lane >> 3, j = lane & 7;
+        const uint32_t col = idx_of(8 * blk + j) * 8u;
+        const uint32_t row = idx_of(8 * blk + a) * row_stride_bytes;
+        qc = load_q(rsrc, j > a ? row + col : OOB, 0u);      // out of range -> 0.0: finished lanes stop changing
+        const uint32_t prow = idx_of(blk > 0 ? 8 * (blk - 1) + a : 0) * row_stride_bytes;
+        qx = load_q(rsrc, blk > 0 ? prow + col : OOB, 0u);
+    };
+    auto cpl_store = [&](int blk, double qc, double qx) {
+        const int a = lane >> 3, j = lane & 7;
+        double *dst = L.cpl + (blk & 3) * (B * 2 * B) + j * (2 * B);
+        dst[a] = qc;
+        dst[B + a] = qx;
+        duo_store(&L.ctl->cplSeq, blk + 1);
+    };
+    if (k == 0) {
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk) {
+            double qc, qx;
+            cpl_request(blk, qc, qx);
+            cpl_store(blk, qc, qx);
+        }
+    }
+    double cqc = 0.0, cqx = 0.0;
+
     double rowA[B][R], rowB[B][R];
     auto fill = [&](double (&S)[B][R], uint32_t off_vec, int base) {
 #pragma unroll
@@ -251,14 +288,20 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
     fill(rowA, off_cur, 0);
     for (int t = 0;; t += 2) {  // two blocks per iteration (register sets A / B); 8 blocks per batch
         const int g = t & 7;
+        if (k == 0) cpl_request(t + 3, cqc, cqx);
         fill(rowB, off_cur, (g + 1) * B);
         if (!apply(rowA, t)) break;
+        if (k == 0) {
+            cpl_store(t + 3, cqc, cqx);
+            cpl_request(t + 4, cqc, cqx);
+        }
         if (g + 2 < 8) {
             fill(rowA, off_cur, (g + 2) * B);
         } else {
             fill(rowA, off_nxt, 0);
         }
         if (!apply(rowB, t + 1)) break;
+        if (k == 0) cpl_store(t + 4, cqc, cqx);
         settle(rowA);
         if (g + 2 >= 8) {  // batch roll-over
             off_cur = off_nxt;
@@ -290,8 +333,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     TeamCtl *ctl = L.ctl;
 
     struct Batch {
-        uint32_t ii, off, voff;
-        uint32_t vm[B];  // coupling column offsets, out of range for lanes at or before position a of their block
+        uint32_t ii;
         double q, Qd, den, rden;
         uint64_t dupmask, xdupmask;
     };
@@ -300,10 +342,6 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         bt.ii = L.ii[(kb % 3) * 64 + lane];
         bt.dupmask = L.dup[kb & 3];
         bt.xdupmask = L.xdup[kb & 3];
-        bt.off = bt.ii * row_stride_bytes;
-        bt.voff = bt.ii * 8u;
-#pragma unroll
-        for (int a = 0; a < B; ++a) bt.vm[a] = rel > uint32_t(a) ? bt.voff : OOB;
         const double2 qQ = *reinterpret_cast<const double2 *>(feat + 4 * bt.ii);
         const double2 dr = *reinterpret_cast<const double2 *>(feat + 4 * bt.ii + 2);
         bt.q = qQ.x;
@@ -316,28 +354,30 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         double qc[B];  // Q[ii_a, ii_lane] within the block (0 for finished lanes)
         double qx[B];  // Q[ii_a(previous block), ii_lane]
     };
-    auto fill = [&](CSet &S, const Batch &bt, int base, const Batch &pb, int prev_base, bool has_prev) {
+    // the couplings of block blk, staged by keeper 0 (lane l reads the record of position l & 7: eight distinct addresses
+    // per instruction, broadcast within each group of eight lanes)
+    auto fill = [&](CSet &S, int blk) {
+        const double *src = L.cpl + (blk & 3) * (B * 2 * B) + rel * (2 * B);
+        auto read = [&]() {
 #pragma unroll
-        for (int a = 0; a < B; ++a) {
-            const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(bt.off), base + a));
-            S.qc[a] = load_q(rsrc, bt.vm[a], roff);
-        }
-        if (has_prev) {
-#pragma unroll
-            for (int a = 0; a < B; ++a) {
-                const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(pb.off), prev_base + a));
-                S.qx[a] = load_q(rsrc, bt.voff, roff);
+            for (int a = 0; a < B; a += 2) {
+                const double2 v = *reinterpret_cast<const double2 *>(src + a);
+                const double2 x = *reinterpret_cast<const double2 *>(src + B + a);
+                S.qc[a] = v.x;
+                S.qc[a + 1] = v.y;
+                S.qx[a] = x.x;
+                S.qx[a + 1] = x.y;
             }
+        };
+        // the flag read and the data reads go out back to back (the LDS executes them in order, so data read behind a flag
+        // that says "staged" is the staged data): one LDS round trip instead of two; not staged yet (rare) -> wait, re-read
+        const int staged = duo_load(&ctl->cplSeq);
+        read();
+        if (__builtin_expect(staged < blk + 1, 0)) {
+            team_wait(&ctl->cplSeq, blk + 1, ctl, false);
+            read();
         }
     };
-    auto settle = [&](CSet &S) {
-#pragma unroll
-        for (int a = 0; a < B; ++a) {
-            asm volatile("" : "+v"(S.qc[a]));
-            asm volatile("" : "+v"(S.qx[a]));
-        }
-    };
-    // w_new of one lane from its private H: _cd_fast.pyx:662-667
     // d_out: |tmp| - alpha before the clamp -- its magnitude is how far the coefficient is from the edge of its dead zone
     auto soft_step = [&](const Batch &bt, double wo_v, double Hs_v, double &d_out) -> double {
         const double Hp = fma(-wo_v, bt.Qd, Hs_v);
@@ -417,10 +457,11 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     struct Pre {
         double Hn;   // image part of H[ii] (the previous block's 8 updates are added through qx)
         double wo;   // w[ii]
-        bool fresh;  // every keeper had published the image when Hn was read
+        int seq;     // lane l: keeper (l % K)'s image counter as read just before Hn (evaluated when the block ends, so that
+                     // the three reads go out back to back)
     };
     auto prefetch = [&](Pre &pr, const Batch &nb, int t_next) {  // for block t_next: image t_next - 1
-        pr.fresh = images_ready<K>(ctl, t_next, lane);
+        pr.seq = duo_load(&ctl->seqB[lane % K]);
         pr.Hn = (L.img + ((t_next - 1) & 1) * IMG)[nb.ii];
         pr.wo = w_lds[nb.ii];
     };
@@ -517,7 +558,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         duo_store(&ctl->seqA, t + 1);
         // rare repairs of the prefetch: a keeper had not published image t yet, or the next block revisits a coordinate
         // this block just changed
-        if (!pn.fresh) {
+        if (__ballot(pn.seq >= t + 1) != ~uint64_t(0)) {   // a keeper had not published image t when Hn was read
             const unsigned long long w0 = __builtin_readcyclecounter();
             team_wait_images<K>(ctl, t + 1, lane);
             pn.Hn = (L.img + (t & 1) * IMG)[nb.ii];
@@ -529,30 +570,28 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
 
     CSet SA, SB;
     Pre pa, pb2;
-    fill(SA, cur, 0, cur, 0, false);
+    fill(SA, 0);
     team_wait_images<K>(ctl, 1, lane);
     pa.Hn = L.img[cur.ii];
     pa.wo = w_lds[cur.ii];
-    pa.fresh = true;
+    pa.seq = 1;
     for (int t = 0;; t += 2) {  // blocks t (set A) and t+1 (set B); 8 blocks per batch
         const int g = t & 7;
         // ---- block t ----
-        fill(SB, cur, (g + 1) * B, cur, g * B, true);
+        fill(SB, t + 1);
         compute(SA, cur, g * B, t, pa, t > 0, cur, (g + 1) * B, pb2);
         f += B;
         if (f == c && epoch_end(t + 1)) break;
         // ---- block t+1 ----
         const bool roll = g + 2 >= 8;
+        fill(SA, t + 2);
         if (!roll) {
-            fill(SA, cur, (g + 2) * B, cur, (g + 1) * B, true);
             compute(SB, cur, (g + 1) * B, t + 1, pb2, true, cur, (g + 2) * B, pa);
         } else {
-            fill(SA, nxt, 0, cur, (g + 1) * B, true);
             compute(SB, cur, (g + 1) * B, t + 1, pb2, true, nxt, 0, pa);
         }
         f += B;
         if (f == c && epoch_end(t + 2)) break;
-        settle(SA);
         if (roll) {
             cur = nxt;
             ++batch;
@@ -597,6 +636,7 @@ __device__ __forceinline__ FitOut team_fit(int flags, int exact_div, const doubl
         L.ctl->batB = 0;
         L.ctl->stop = 0;
         L.ctl->err = 0;
+        L.ctl->cplSeq = 0;
         for (int k = 0; k < KMAX; ++k) L.ctl->seqB[k] = 0;
     }
     for (int j = threadIdx.x; j < TeamLds<R, K>::IMG; j += blockDim.x) L.edge[j] = __builtin_huge_val();
@@ -753,6 +793,8 @@ struct TeamShape {
     int R, K;
 };
 TeamShape team_shape(int c) {
+    // (twice the keepers with half the columns each -- (1,2) / (2,2) / (2,4) for c <= 128 / 256 / 512 -- measured equal: 276 /
+    //  246 / 262 cycles per step against 251 / 255 / 253; the chain wave's dependent latency is the floor)
     if (c <= 64) return {1, 1};
     if (c <= 128) return {2, 1};
     if (c <= 256) return {4, 1};
@@ -764,7 +806,7 @@ TeamShape team_shape(int c) {
 size_t team_lds_bytes(int c) {
     const TeamShape s = team_shape(c);
     const size_t img = size_t(64) * s.R * s.K;
-    return (size_t(5) * c + 3 * img + 4 * 2 * B + 3 * 32 + 8 + sizeof(TeamCtl) / 8 + 2) * sizeof(double);
+    return (size_t(5) * c + 3 * img + 4 * 2 * B + 4 * B * 2 * B + 3 * 32 + 8 + sizeof(TeamCtl) / 8 + 2) * sizeof(double);
 }
 
 template <typename Kern>
