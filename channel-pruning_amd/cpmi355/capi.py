@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpmi355.so")
 
+CP_ERR_NOMEM = -3          # include/cpmi355.h
 CP_F32, CP_F64 = 0, 1
 CP_CD_RECIPROCAL = 1
 CP_CD_DELTA = 2
@@ -224,7 +225,7 @@ class Context:
         self.h = None
 
     # -- pool of freed device blocks (exact-size reuse; see DevBuf) ---------------------------
-    POOL_LIMIT = int(os.environ.get("CP_POOL_BYTES", str(8 << 30)))
+    POOL_LIMIT = int(os.environ.get("CP_POOL_BYTES", str(4 << 30)))
 
     def _pool_take(self, nbytes):
         blocks = self.__dict__.setdefault("_pool", {}).get(nbytes)
@@ -255,7 +256,10 @@ class Context:
 
     def _check(self, rc, what):
         if rc != 0:
-            raise CpError(rc, what, self.lib.cp_last_error(self.h).decode() if self.h else "")
+            err = CpError(rc, what, self.lib.cp_last_error(self.h).decode() if self.h else "")
+            if rc == CP_ERR_NOMEM:      # an allocation inside the library failed: give the pooled blocks back, so that a
+                self._pool_drain()      # retry by the caller does not fail next to gigabytes of idle blocks
+            raise err
 
     # -- memory ---------------------------------------------------------------------
     def empty(self, nbytes):

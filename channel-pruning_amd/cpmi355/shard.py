@@ -208,8 +208,9 @@ class ResidentLayerSet:
             ch["error"] = None
             ch["go"].set()
         out = [None] * len(self.specs)
+        for ch in self.chunks:          # every chunk finishes before anything is raised: a chunk still inside its foreign
+            ch["done"].wait()           # call must not see its events re-armed or its contexts freed
         for ch in self.chunks:
-            ch["done"].wait()
             if ch["error"] is not None:
                 raise ch["error"]
             for i, r in zip(ch["members"], ch["out"]):
@@ -233,8 +234,10 @@ class ResidentLayerSet:
         for ch in self.chunks:
             ch["go"].set()
         for t in self._threads:
-            t.join(timeout=10)
-        for ch in self.chunks:
+            t.join(timeout=60)
+        for ch, t in zip(self.chunks, self._threads):
+            if t.is_alive():            # still inside a foreign call: leave its device memory and contexts alone (leaked, not
+                continue                # freed under a running kernel)
             for pr in ch["probs"]:
                 pr.free()
             for cx in reversed(ch["ctxs"]):
@@ -327,8 +330,6 @@ def exchange_results(specs, owner, mine, dist, device=None, staging=None):
             send[offs[i]:offs[i] + nw].copy_(torch.from_numpy(np.ascontiguousarray(W).reshape(-1)), non_blocking=True)
             send[offs[i] + nw:offs[i] + nw + specs[i]["n"]].copy_(torch.from_numpy(np.ascontiguousarray(b)), non_blocking=True)
         every = _all_gather_rows(dist, send)
-        if LAST_EXCHANGE_MS.get("split"):
-            torch.cuda.current_stream(dev).synchronize()
         t_gather = time.perf_counter()
         starts, total = {}, 0
         for r in range(world):

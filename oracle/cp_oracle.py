@@ -459,7 +459,9 @@ def mix_channels(X, rs, mix):
     """Ill-conditioned channel structure for the q* goldens (float64 in, float64 out; X[N,c,k,k]):
        kappa   : channels mixed by a c x c matrix with log-spaced singular values 1 .. 1/kappa
        dup     : three channels are copies of three others + eps * noise (eps = 0: exact copies, rank-deficient)
-       relumix : relu of a rank-r mixture of latent maps + delta of its own full-rank remainder"""
+       relumix : relu of a rank-r mixture of latent maps + delta of its own full-rank remainder
+       powerlaw: relu of a full-rank mixture of latent maps whose singular values fall off like i^-p -- strongly
+                 correlated channels with a long spectrum, the shape of real post-ReLU activations (unlike i.i.d. columns)"""
     N, c = X.shape[0], X.shape[1]
     kind = mix["kind"]
     if kind == "kappa":
@@ -467,6 +469,13 @@ def mix_channels(X, rs, mix):
         V, _ = np.linalg.qr(rs.randn(c, c))
         T = (U * np.logspace(0, -np.log10(mix["kappa"]), c)) @ V.T
         return np.einsum("nikl,ij->njkl", X, T) * np.sqrt(c)
+    if kind == "powerlaw":
+        U, _ = np.linalg.qr(rs.randn(c, c))
+        V, _ = np.linalg.qr(rs.randn(c, c))
+        T = (U * np.arange(1, c + 1, dtype=np.float64) ** -mix["p"]) @ V.T
+        G = rs.randn(*X.shape)
+        Z = np.einsum("nikl,ij->njkl", G, T)
+        return np.maximum(Z / Z.std(), 0.)
     if kind == "dup":
         X = X.copy()
         for (i, j) in ((1, 9), (4, 5), (20, 2)):

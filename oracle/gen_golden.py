@@ -89,6 +89,12 @@ CASES = {
     "q04_dup_1e-7": dict(layer_id=54, N=1200, c=32, n=24, k=3, rank=20, mix=dict(kind="dup", eps=1e-7)),
     "q05_dup_exact": dict(layer_id=55, N=1200, c=32, n=24, k=3, rank=20, mix=dict(kind="dup", eps=0.0)),
     "q06_relumix": dict(layer_id=56, N=1500, c=48, n=32, k=3, rank=30, mix=dict(kind="relumix", r=12, delta=1e-5)),
+    # ---- round 3: strongly correlated channels (power-law spectrum) at full size, through the whole dictionary() call ----
+    "q07_powerlaw_small": dict(layer_id=57, N=1500, c=64, n=48, k=3, rank=32, mix=dict(kind="powerlaw", p=0.75)),
+    "L16_conv3_powerlaw": dict(layer_id=58, N=5000, c=256, n=256, k=3, rank=128, large=True,
+                               mix=dict(kind="powerlaw", p=0.75)),
+    "L17_conv4_powerlaw": dict(layer_id=59, N=2400, c=512, n=512, k=3, rank=445, large=True, sketch=True,
+                               mix=dict(kind="powerlaw", p=0.5)),
     # the whole-network job of bench.py --workload vgg16: the 12 conv -> conv pairs of VGG-16 with the reference's
     # 3C-4x kept-channel count d_c = max(int(c / 1.15), rank) (net.py:1309-1327, 1346-1349), N = 5000
     "V01_conv1_1_conv1_2": dict(layer_id=101, N=5000, c=64, n=64, k=3, rank=55, large=True, sketch=True),
