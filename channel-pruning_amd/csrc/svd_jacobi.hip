@@ -4,7 +4,11 @@
 // orthogonal:  R M = Sigma H  with R = J^T orthogonal, so
 //   singular values  sigma_k = |row k of R M|,   V = R^T (column k = row k of R),   diag(sigma) H = R M
 // -- the reference needs exactly V[:, :rank] and diag(sigma) H[:rank] (decompose.py:105-112), so the rows are
-// never normalised.  High relative accuracy (no Gram squaring).
+// never normalised.  The scalar form (one pair of rows per workgroup, dot products taken from the rows themselves) has
+// one-sided Jacobi's high relative accuracy; the block form below decides its rotations from a 16 x 16 Gram that it
+// updates in place, whose off-diagonals carry noise of about eps * |largest row| * |row| -- for strongly graded rows
+// (condition beyond ~1e10) that can keep it rotating, so after BLOCK_SWEEP_BOUND sweeps without convergence the remaining
+// sweeps run in the scalar form.
 // BLOCK form: rows in blocks of 8, one launch per round of the round-robin ordering over the blocks, one workgroup per
 // block pair.  The workgroup forms the 16 x 16 Gram of its 16 rows on MFMA, diagonalises it in LDS (two-sided cyclic
 // Jacobi with the same rotation formula, 8 disjoint pairs at a time), and applies the accumulated 16 x 16 rotation to the
@@ -20,6 +24,7 @@
 namespace {
 
 constexpr int JT = 256;
+constexpr int BLOCK_SWEEP_BOUND = 20;   // block-form sweeps before the scalar form takes over (typical: 6-15 sweeps in all)
 
 __device__ __forceinline__ double jblock_sum(double v, double *red) {
 #pragma unroll
@@ -396,9 +401,11 @@ int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r,
         if (head[2] != 0) return cp_set_error(ctx, CP_ERR_NUMERIC, "svd_rows: device barrier timed out");
         sweeps = head[1];
     } else {
+        bool use_scalar = scalar;
         for (; sweeps < MAX_SWEEPS; ++sweeps) {
             CP_HIP(ctx, hipMemsetAsync(rotated, 0, sizeof(int), ctx->stream));
-            if (scalar) {
+            if (!use_scalar && sweeps >= BLOCK_SWEEP_BOUND) use_scalar = true;   // graded rows: see the file header
+            if (use_scalar) {
                 for (int round = 0; round < me - 1; ++round) {
                     k_jacobi_round<<<me / 2, JT, 0, ctx->stream>>>(Wk, n, R, me, round, tol, rotated, floor2);
                     CP_LAUNCH_CHECK(ctx);

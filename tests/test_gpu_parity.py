@@ -681,6 +681,28 @@ def test_svd_rows_matches_numpy(ctx):
         assert np.abs(Vt @ Vt.T - np.eye(r)).max() <= 1e-12
 
 
+def test_svd_rows_strongly_graded_rows(ctx):
+    """cp_svd_rows on rows graded over 12 orders of magnitude (the block form's in-place 16 x 16 Gram carries noise of
+    eps * |largest row| * |row| there; after BLOCK_SWEEP_BOUND sweeps the scalar form, which takes its dot products from the
+    rows, finishes): converges, the leading singular values to 1e-10 relative, the reconstruction of the leading part
+    to 1e-10 of the matrix norm."""
+    rs = np.random.RandomState(3)
+    m, n, r = 64, 96, 40
+    U, _ = np.linalg.qr(rs.randn(m, m))
+    V, _ = np.linalg.qr(rs.randn(n, m))
+    sv = np.logspace(0, -12, m)
+    M = (U * sv) @ V.T
+    sig, Vt, SH = ctx.svd_rows(M, r)
+    ref = np.linalg.svd(M, compute_uv=False)[:r]
+    big = ref > 1e-6
+    assert np.all(np.abs(sig[big] - ref[big]) <= 1e-10 * ref[big])
+    assert np.all(np.abs(sig - ref) <= 1e-13)                       # absolute accuracy for the small ones
+    Mr = Vt.T @ SH
+    Ur, sr, Vr = np.linalg.svd(M)
+    lead = (Ur[:, :r] * sr[:r]) @ Vr[:r]
+    assert np.linalg.norm(Mr - lead) <= 1e-10 * np.linalg.norm(M)
+
+
 def test_svd_rows_one_launch_form_matches_per_round_launches():
     """CP_JACOBI_PERSISTENT=1 (all sweeps in one launch, device-wide barrier between the rounds) gives the bits of the
     default per-round launches: same rotations in the same order.  Own processes: the switch is read once."""
