@@ -96,13 +96,14 @@ def _cd_problem(c, M=4000, seed=3):
     return np.ascontiguousarray(Zc.T @ Zc), Zc.T @ yc, float(yc @ yc), M
 
 
-@pytest.mark.parametrize("c", [8, 16, 55, 64, 96, 128, 222, 256, 264, 512, 1024])
+@pytest.mark.parametrize("c", [8, 16, 55, 64, 96, 128, 222, 256, 264, 512, 1024, 1224, 1536, 2048])
 @pytest.mark.parametrize("recip", [0, 1, 2, 3])
 def test_cd_fit_bit_exact_vs_oracle(ctx, c, recip):
     """cp_enet_cd_gram vs cpo_enet_cd_gram on the same Q, q, seed: identical n_iter and
     bit-identical w (same fma sequence), for cold and warm starts, in all four rounding variants
-    (flags: 1 = CP_CD_RECIPROCAL, 2 = CP_CD_DELTA).  c covers the blocked kernel (c % 8 == 0,
-    c <= 512), the generic one (55, 222, 1024) and several register widths R = ceil(c/64)."""
+    (flags: 1 = CP_CD_RECIPROCAL, 2 = CP_CD_DELTA).  c covers every team shape (flags 0 and 3, c % 8 == 0: (1,1) ... (4,4) up
+    to 1024, (6,6) with a ragged last keeper at 1224 / 1536 and full at 2048; the three-operation division), the two-wave
+    and one-wave kernels of cd_gram.hip (flags 1 and 2; 55, 222) and several register widths."""
     import cp_oracle
     from cpmi355 import capi
     Q, q, yty, M = _cd_problem(c)
