@@ -1103,6 +1103,10 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     // CP_CHOL_PANEL_SPLIT=1: the panel as its own LDS-free launch.  Measured neutral (4.30 vs 4.29 ms alone at p = 4250, vgg16
     // job 32.7 vs 32.8 ms), so the one-launch form stays.
     static const bool split_panel = getenv("CP_CHOL_PANEL_SPLIT") && getenv("CP_CHOL_PANEL_SPLIT")[0] == '1';
+    // (Look-ahead -- step b's update cut into the block row the next panel needs, on this stream, and the rows below it on a
+    //  side stream behind an event, so that potrf(b + 1) overlaps them -- was built and measured in round 3: same numbers, but
+    //  two cross-stream event hand-offs per step cost more than the overlap gives: refit of a c = 512 layer alone 7.0 -> 16.1 ms,
+    //  vgg16 job 31.1 -> 32.9 ms.  Removed.)
     for (int b = 0; b < ch.nblk; ++b) {
         if (split_panel) {   // diagonal block (one workgroup), then its panel U12 = U11^-T G12 as a light launch of its own
             k_potrf<false><<<1, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
