@@ -600,6 +600,15 @@ def test_resident_layer_set_chunks_streams_and_latency_layers(monkeypatch):
         assert [(r["c"], len(r["layers"])) for r in rset.chunk_report()] == [(512, 2), (256, 2), (256, 1), (128, 1), (64, 2)]
     finally:
         rset.close()
+    # per_stream by width: {c: layers per stream, "default": ...} -- wide layers alone, narrow ones batched
+    rset = shard.ResidentLayerSet(0, specs, lambda s: (s["layer_id"], None, None), per_stream={512: 1, 64: 2, "default": 3},
+                                  precompute_heaviest=0)
+    try:
+        assert [(r["c"], len(r["layers"])) for r in rset.chunk_report()] == [(512, 1), (512, 1), (256, 3), (128, 1), (64, 2)]
+        out = rset.run()
+        assert [int(W[0, 0, 0, 0]) for _, W, _, _ in out] == list(range(8))
+    finally:
+        rset.close()
 
 
 def test_bench_vgg16_job_is_the_reference_rank_table():
