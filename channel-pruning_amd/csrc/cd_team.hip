@@ -45,16 +45,18 @@ struct TeamCtl {
     int err;           // a bounded wait ran out (never in a correct run)
     int n_iter, nnz;
     int mk_ok;         // every feature's denominator is inside the range the three-operation division is exact on
-    int cplSeq;        // blocks whose couplings keeper 0 has staged in LDS
+    int cplSeq;        // blocks whose couplings keeper 0 (multi-CU team: the stager wave) has staged in LDS
+    int hnSlot[4];     // multi-CU team: hnSlot[v & 3] = v + 1 once a gatherer wave has published block v's starting H values
     int seqB[KMAX];    // images published by keeper k (image t = H after the first t blocks; count = t + 1)
     double gap;
     double edge_margin, gap_margin;   // tie sentinels of the fit (cp_cd_result)
 };
 
-template <int R, int K>
+template <int R, int K, int NI = 2>
 struct TeamLds {
     static constexpr int IMG = 64 * R * K;
-    double *img;       // [2][IMG]
+    static constexpr int PUB_RING = NI > 2 ? 8 : 4, II_RING = 3, CPL_REC = 2 * B;
+    double *img;       // [NI][IMG]
     double *edge;      // [IMG] | |tmp| - alpha | of every coordinate's LAST update in the fit (tie sentinel)
     double *pub;       // [4][2 * B]
     double *cpl;       // [4][B][2 * B] couplings of a block, staged by keeper 0: [j][a] = Q[ii_a, ii_j] (0 for j <= a),
@@ -64,13 +66,13 @@ struct TeamLds {
     uint64_t *xdup;    // [4] lanes whose coordinate also occurs in the block before theirs
     TeamCtl *ctl;
     static __host__ __device__ constexpr int doubles() {
-        return 3 * IMG + 4 * 2 * B + 4 * B * 2 * B + 3 * 32 + 8 + int(sizeof(TeamCtl) / 8) + 2;
+        return (NI + 1) * IMG + PUB_RING * 2 * B + 4 * B * 2 * B + 3 * 32 + 8 + int(sizeof(TeamCtl) / 8) + 2;
     }
     __device__ void bind(double *base) {
         img = base;
-        edge = img + 2 * IMG;
+        edge = img + NI * IMG;
         pub = edge + IMG;
-        cpl = pub + 4 * 2 * B;
+        cpl = pub + PUB_RING * 2 * B;
         ii = reinterpret_cast<uint32_t *>(cpl + 4 * B * 2 * B);
         dup = reinterpret_cast<uint64_t *>(ii + 3 * 64);
         xdup = dup + 4;
@@ -108,13 +110,113 @@ __device__ __forceinline__ bool team_wait_images(TeamCtl *ctl, int need, int lan
 }
 
 __device__ unsigned long long g_team_debug[8];
+#ifdef CP_CD_MULTI_TRACE   // timing experiment: wall-clock stamps (10 ns units) of one block's trip through the multi-CU team
+__device__ unsigned long long g_multi_trace[16];
+#define CP_TRACE(slot, cond)                                                             \
+    do {                                                                                 \
+        if ((cond) && (threadIdx.x & 63) == 0) g_multi_trace[slot] = wall_clock64();     \
+    } while (0)
+constexpr int TRACE_BLOCK = 2000;
+#else
+#define CP_TRACE(slot, cond) do { } while (0)
+#endif
+
+// ---- cross-workgroup mailbox of the multi-CU team (see the section "multi-CU team" below) --------------------------------
+// Every word is read and written with relaxed agent-scope atomics only (sc1 loads / stores: coherent across the XCDs' L2s)
+// and carries its own validity: a slot holds SENT until its one writer stores the value, and its one reader puts SENT back.
+#ifndef CP_CD_MULTI_LAG
+#define CP_CD_MULTI_LAG 5
+#endif
+constexpr int XLAG = CP_CD_MULTI_LAG;      // blocks the remotes run behind the chain wave (2 <= XLAG <= 5)
+constexpr unsigned long long SENT = 0x7FF8C0DEC0DEC0DEull;   // a quiet NaN no arithmetic produces
+constexpr int RING = 8;                                      // blocks of slots per ring
+struct MultiBox {
+    unsigned long long *dl;     // [G][RING][2 B]  home -> remote g: what the chain wave published for a block
+    unsigned long long *hv;     // [G][RING][B]    remote g -> home: H[ii_j] of a block's coordinates, LAG blocks stale
+    unsigned long long *fitw;   // [c]             home -> remotes: w at the start of a fit
+    unsigned long long *himg;   // [G * slice]     remotes -> home: H at the end of an epoch
+    unsigned long long *ctl;    // [0,G) fit posted | [G,2G) fit stopped | [2G,3G) stop acknowledged | [3G,4G) epoch image | [4G] abort
+    int G, slice;
+};
+__device__ __forceinline__ unsigned long long xld(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xst(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double xld_d(const unsigned long long *p) { return __longlong_as_double((long long)xld(p)); }
+__device__ __forceinline__ void xst_d(unsigned long long *p, double v) { xst(p, (unsigned long long)__double_as_longlong(v)); }
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr int XSPIN = 1 << 21;   // bound of a wait on another workgroup (~1 s; never reached in a correct run)
+__device__ __forceinline__ bool multi_aborted(const MultiBox *box) { return xld(box->ctl + 4 * box->G) != 0; }
+__device__ __forceinline__ void multi_abort(const MultiBox *box, TeamCtl *ctl) {
+    xst(box->ctl + 4 * box->G, 1);
+    duo_store(&ctl->err, 1);
+    duo_store(&ctl->stop, 1);
+}
+// Poll one mailbox word per lane until no lane of `want` reads SENT any more (returns 1, the words in `out`), `over(word)`
+// holds in some lane (returns 0) or the bound runs out (returns -1).  An sc1 load takes ~0.4 us here, so LOOKS of them are
+// kept in flight, issued from inline assembly and collected with an explicit vmcnt: a new look every ~0.1 us instead of one
+// per round trip.  The looks still in flight when the call returns keep writing into lk.r: the caller owns those registers
+// and hands them back with poll_settle() once its urgent work is done (a destination the compiler had re-used for something
+// else in the meantime would be overwritten under its feet).
+template <int LOOKS>
+struct Looks {
+    unsigned long long r[LOOKS];
+};
+template <int LOOKS>
+__device__ __forceinline__ void poll_settle(Looks<LOOKS> &lk) {
+    vm_drain();
+#pragma unroll
+    for (int i = 0; i < LOOKS; ++i) asm volatile("" : "+v"(lk.r[i]));
+}
+template <int LOOKS, class Over>
+__device__ __forceinline__ int poll_words(Looks<LOOKS> &lk, const unsigned long long *addr, bool want, unsigned long long &out,
+                                          Over over) {
+    unsigned long long(&r)[LOOKS] = lk.r;
+#pragma unroll
+    for (int i = 0; i < LOOKS; ++i) {
+        r[i] = SENT;   // whatever the register allocator does with a look's destination before it lands, it reads "not yet"
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(r[i]) : "v"(addr) : "memory");
+    }
+    for (int spin = 0; spin < XSPIN; ++spin) {
+#pragma unroll
+        for (int i = 0; i < LOOKS; ++i) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[i]) : "n"(LOOKS - 1) : "memory");   // the oldest look has landed
+            const unsigned long long v = r[i];
+            if (__ballot(want && v == SENT) == 0) {
+                out = v;
+                return 1;
+            }
+            if (over(v)) return 0;
+            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(r[i]) : "v"(addr) : "memory");
+        }
+    }
+    return -1;
+}
+
+// chain wave: every remote workgroup has posted its slice of H after `epoch` epochs of fit `fit`
+__device__ __forceinline__ bool multi_wait_epoch_image(const MultiBox *box, int fit, int epoch, int lane, TeamCtl *ctl) {
+    const unsigned long long need = ((unsigned long long)(fit + 1) << 24) | (unsigned long long)epoch;
+    for (int spin = 0;; ++spin) {
+        const unsigned long long v = lane < box->G ? xld(box->ctl + 3 * box->G + lane) : ~0ull;
+        if (__ballot(v >= need) == ~uint64_t(0)) return true;
+        if (spin > XSPIN || (spin % 64 == 63 && multi_aborted(box))) {
+            multi_abort(box, ctl);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // keeper wave k: columns [64 R k, 64 R (k + 1)) of H
 // ---------------------------------------------------------------------------------------------------------------------
-template <int R, int K, bool DELTA>
+// NI: images kept in LDS (the multi-CU team's extractor reads them NI - 2 blocks late); STAGE: keeper 0 stages the chain
+// wave's couplings; slice0: first column of this workgroup's slice of H (images are indexed relative to it)
+template <int R, int K, bool DELTA, int NI = 2, bool STAGE = true>
 __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ldq, int c, uint32_t seed, const double *w_lds,
-                                            TeamLds<R, K> &L, int k) {
+                                            TeamLds<R, K, NI> &L, int k, int slice0 = 0) {
     const int lane = threadIdx.x & 63;
     const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -122,7 +224,7 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
     // register r of lane l holds column colof(r): packed (R even) 128 (r/2) + 2 l + (r&1), so that one 16-byte load
     // fetches two of a lane's row elements; columns past c re-read the last pair: their H entries are never consumed
     constexpr bool PK = CP_CD_PACKED && (R % 2 == 0);
-    const int col0 = k * 64 * R;
+    const int rel0 = k * 64 * R, col0 = slice0 + rel0;
     auto colof = [&](int r) -> int { return col0 + (PK ? (r >> 1) * 2 * WAVE + 2 * lane + (r & 1) : r * WAVE + lane); };
     uint32_t colb[R];
 #pragma unroll
@@ -161,7 +263,7 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
     }
     int *my_seq = &L.ctl->seqB[k];
     auto write_image = [&](int t) {
-        double *im = L.img + (t & 1) * TeamLds<R, K>::IMG + col0;
+        double *im = L.img + (t % NI) * TeamLds<R, K, NI>::IMG + rel0;
         if (PK) {
 #pragma unroll
             for (int r = 0; r < R; r += 2) *reinterpret_cast<double2 *>(im + r * WAVE + 2 * lane) = make_double2(H[r], H[r + 1]);
@@ -170,6 +272,7 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
             for (int r = 0; r < R; ++r) im[r * WAVE + lane] = H[r];
         }
         duo_store(my_seq, t + 1);
+        CP_TRACE(3, NI > 2 && k == 0 && slice0 == 0 && t == TRACE_BLOCK + 1);
     };
     write_image(0);
 
@@ -234,7 +337,7 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
         dst[B + a] = qx;
         duo_store(&L.ctl->cplSeq, blk + 1);
     };
-    if (k == 0) {
+    if (STAGE && k == 0) {
 #pragma unroll
         for (int blk = 0; blk < 3; ++blk) {
             double qc, qx;
@@ -251,7 +354,13 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
     double rowA[B][R], rowB[B][R];
     auto fill = [&](double (&S)[B][R], uint32_t off_vec, int base) {
 #pragma unroll
-        for (int a = 0; a < B; ++a) load_row(S[a], uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a)));
+        for (int a = 0; a < B; ++a) {
+            uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a));
+#ifdef CP_CD_DEBUG_ALIAS  // timing experiment only (results are garbage): every row request aliases onto the first few rows
+            roff %= uint32_t(CP_CD_DEBUG_ALIAS) * row_stride_bytes;
+#endif
+            load_row(S[a], roff);
+        }
     };
     auto settle = [&](double (&S)[B][R]) {
 #pragma unroll
@@ -273,7 +382,7 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
             }
             return false;
         }
-        const double *pb = L.pub + (t & 3) * 2 * B;
+        const double *pb = L.pub + (t & (TeamLds<R, K, NI>::PUB_RING - 1)) * 2 * B;
 #pragma unroll
         for (int a = 0; a < B; ++a) {
             if (DELTA) {
@@ -289,13 +398,86 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
         write_image(t + 1);
         return true;
     };
+    if constexpr (NI > 2 && PK) {
+        // Remote keeper of the multi-CU team: the same two-set ring, but the row loads are issued from inline assembly and
+        // waited for with an explicit vmcnt.  The compiler's own wait insertion drains loop-carried loads completely
+        // (settle() below exists to give that drain a harmless place), which makes every second block wait for the rows
+        // requested just before it -- fine while Q sits in L2, a microsecond per block when the rows come from HBM.  Here a
+        // set is waited for with vmcnt(loads of the other, younger set): two blocks of prefetch distance, never a drain.
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const uint64_t qa = reinterpret_cast<uint64_t>(Q);
+        u32x4 rw;
+        rw.x = __builtin_amdgcn_readfirstlane(uint32_t(qa));
+        rw.y = __builtin_amdgcn_readfirstlane(uint32_t(qa >> 32) & 0xffffu);
+        rw.z = __builtin_amdgcn_readfirstlane(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u);
+        rw.w = 0x00020000u;
+        constexpr int NL = B * (R / 2);   // loads per set
+        d2v A2[B][R / 2], B2[B][R / 2];
+        auto fill2 = [&](d2v (&S)[B][R / 2], uint32_t off_vec, int base) {
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                const uint32_t roff = uint32_t(__builtin_amdgcn_readlane(int(off_vec), base + a));
+                // (the row offset comes out of a v_readlane: a VALU-written SGPR needs five wait states before a vector-memory
+                //  instruction reads it, and the compiler's hazard recognizer does not look into inline assembly)
+                asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(S[a][0]) : "v"(colb[0]), "s"(rw), "s"(roff) : "memory");
+#pragma unroll
+                for (int r2 = 1; r2 < R / 2; ++r2)
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(S[a][r2]) : "v"(colb[2 * r2]), "s"(rw), "s"(roff) : "memory");
+            }
+        };
+        auto apply2 = [&](d2v (&S)[B][R / 2], int t) -> bool {
+            if (!team_wait(&L.ctl->seqA, t + 1, L.ctl, true)) return false;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // everything but the other set's loads has landed
+#pragma unroll
+            for (int a = 0; a < B; ++a)
+#pragma unroll
+                for (int r2 = 0; r2 < R / 2; ++r2) asm volatile("" : "+v"(S[a][r2]));
+            const double *pb = L.pub + (t & (TeamLds<R, K, NI>::PUB_RING - 1)) * 2 * B;
+#pragma unroll
+            for (int a = 0; a < B; ++a) {
+                if (DELTA) {
+                    const double d_a = pb[a];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(d_a, S[a][r >> 1][r & 1], H[r]);
+                } else {
+                    const double wo_a = pb[2 * a], wn_a = pb[2 * a + 1];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S[a][r >> 1][r & 1], fma(-wo_a, S[a][r >> 1][r & 1], H[r]));
+                }
+            }
+            write_image(t + 1);
+            return true;
+        };
+        fill2(A2, off_cur, 0);
+        for (int t = 0;; t += 2) {
+            const int g = t & 7;
+            fill2(B2, off_cur, (g + 1) * B);
+            if (!apply2(A2, t)) break;
+            if (g + 2 < 8)
+                fill2(A2, off_cur, (g + 2) * B);
+            else
+                fill2(A2, off_nxt, 0);
+            if (!apply2(B2, t + 1)) break;
+            if (g + 2 >= 8) {  // batch roll-over
+                off_cur = off_nxt;
+                off_nxt = off_n2;
+                rng.next_batch();
+                ++batch;
+                publish_batch(batch + 2);
+                off_n2 = rng.off;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     fill(rowA, off_cur, 0);
     for (int t = 0;; t += 2) {  // two blocks per iteration (register sets A / B); 8 blocks per batch
         const int g = t & 7;
-        if (k == 0) cpl_request(t + 3, cqc, cqx);
+        if (STAGE && k == 0) cpl_request(t + 3, cqc, cqx);
         fill(rowB, off_cur, (g + 1) * B);
         if (!apply(rowA, t)) break;
-        if (k == 0) {
+        if (STAGE && k == 0) {
             cpl_store(t + 3, cqc, cqx);
             cpl_request(t + 4, cqc, cqx);
         }
@@ -305,7 +487,7 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
             fill(rowA, off_nxt, 0);
         }
         if (!apply(rowB, t + 1)) break;
-        if (k == 0) cpl_store(t + 4, cqc, cqx);
+        if (STAGE && k == 0) cpl_store(t + 4, cqc, cqx);
         settle(rowA);
         if (g + 2 >= 8) {  // batch roll-over
             off_cur = off_nxt;
@@ -323,17 +505,21 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
 // ---------------------------------------------------------------------------------------------------------------------
 // MK: three-operation correctly rounded division (see the header); RECIP: multiply by the reciprocal (CP_CD_RECIPROCAL,
 // not bit-identical to sklearn's division)
-template <int R, int K, bool RECIP, bool DELTA, bool MK>
+// MULTI (multi-CU team, below): the block's starting H values come from the gatherer wave's ring (L.hn) instead of the
+// keepers' LDS images, the epoch-end image from the remote workgroups through global memory (box, fit)
+template <class LDS, int R, int K, bool RECIP, bool DELTA, bool MK, bool MULTI = false>
 __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq, int c, double alpha, double beta,
                                            int max_iter, double tol_scaled, double d_w_tol, double y_norm2, double *w_lds,
-                                           const double *feat, TeamLds<R, K> &L) {
+                                           const double *feat, LDS &L, const MultiBox *box = nullptr, int fit = 0) {
     const int lane = threadIdx.x & 63;
     const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
     const uint32_t rel = uint32_t(lane) & uint32_t(B - 1);
     constexpr uint32_t OOB = 0x80000000u;  // beyond num_records with or without the row offset, no 32-bit wrap
-    constexpr int IMG = TeamLds<R, K>::IMG;
+    constexpr int IMG = 64 * R * K;
+    constexpr int PUBM = LDS::PUB_RING - 1;
+    const int ncol64 = MULTI ? (c + WAVE - 1) / WAVE : R * K;
     TeamCtl *ctl = L.ctl;
 
     struct Batch {
@@ -343,7 +529,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     };
     auto load_batch = [&](Batch &bt, int kb) -> bool {
         if (!team_wait(&ctl->batB, kb + 1, ctl, false)) return false;
-        bt.ii = L.ii[(kb % 3) * 64 + lane];
+        bt.ii = L.ii[(kb % LDS::II_RING) * 64 + lane];
         bt.dupmask = L.dup[kb & 3];
         bt.xdupmask = L.xdup[kb & 3];
         const double2 qQ = *reinterpret_cast<const double2 *>(feat + 4 * bt.ii);
@@ -361,7 +547,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     // the couplings of block blk, staged by keeper 0 (lane l reads the record of position l & 7: eight distinct addresses
     // per instruction, broadcast within each group of eight lanes)
     auto fill = [&](CSet &S, int blk) {
-        const double *src = L.cpl + (blk & 3) * (B * 2 * B) + rel * (2 * B);
+        const double *src = L.cpl + (blk & 3) * (B * LDS::CPL_REC) + rel * LDS::CPL_REC;
         auto read = [&]() {
 #pragma unroll
             for (int a = 0; a < B; a += 2) {
@@ -416,14 +602,19 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         const double w_max = wave_max(wmax_v), d_w_max = wave_max(dmax_v);
         bool done = false;
         if (w_max == 0.0 || d_w_max / w_max < d_w_tol || n_iter == max_iter - 1) {
-            if (!team_wait_images<K>(ctl, t_done + 1, lane)) return true;
-            const double *im = L.img + (t_done & 1) * IMG;
+            const double *im = nullptr;
+            if constexpr (MULTI) {
+                if (!multi_wait_epoch_image(box, fit, n_iter + 1, lane, ctl)) return true;
+            } else {
+                if (!team_wait_images<K>(ctl, t_done + 1, lane)) return true;
+                im = L.img + (t_done & 1) * IMG;
+            }
             double s_qw = 0, s_wh = 0, s_ww = 0, s_l1 = 0, m_xta = 0;
 #pragma unroll 4
-            for (int r = 0; r < R * K; ++r) {
+            for (int r = 0; r < ncol64; ++r) {
                 const int col = r * WAVE + lane;
                 if (col < c) {
-                    const double wv = w_lds[col], qv = feat[4 * col], hv = im[col];
+                    const double wv = w_lds[col], qv = feat[4 * col], hv = MULTI ? xld_d(box->himg + col) : im[col];
                     const double xta = qv - hv - beta * wv;
                     s_qw += wv * qv;
                     s_wh += wv * hv;
@@ -457,6 +648,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     };
 
     unsigned long long waitA = 0, repairs = 0;
+    bool dead = false;   // MULTI: a wait on the other waves / workgroups ran out
     // per-lane inputs of a block, fetched while the block before it is still running
     struct Pre {
         double Hn;   // image part of H[ii] (the previous block's 8 updates are added through qx)
@@ -465,8 +657,13 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
                      // the three reads go out back to back)
     };
     auto prefetch = [&](Pre &pr, const Batch &nb, int t_next) {  // for block t_next: image t_next - 1
-        pr.seq = duo_load(&ctl->seqB[lane % K]);
-        pr.Hn = (L.img + ((t_next - 1) & 1) * IMG)[nb.ii];
+        if constexpr (MULTI) {
+            pr.seq = duo_load(&ctl->hnSlot[t_next & 3]);
+            pr.Hn = L.hn[(t_next & 3) * B + rel];
+        } else {
+            pr.seq = duo_load(&ctl->seqB[lane % K]);
+            pr.Hn = (L.img + ((t_next - 1) & 1) * IMG)[nb.ii];
+        }
         pr.wo = w_lds[nb.ii];
     };
 
@@ -545,7 +742,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
             }
         }
         if ((blockmask >> lane) & 1) {
-            double *pb = L.pub + (t & 3) * 2 * B;
+            double *pb = L.pub + (t & PUBM) * 2 * B;
             if (DELTA) {
                 pb[rel] = p0_v;
             } else {
@@ -560,12 +757,19 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
             L.edge[bt.ii] = fabs(d_v);
         }
         duo_store(&ctl->seqA, t + 1);
+        CP_TRACE(0, MULTI && t == TRACE_BLOCK);
+        CP_TRACE(7, MULTI && t == TRACE_BLOCK + XLAG);   // the block before the one the traced values feed
         // rare repairs of the prefetch: a keeper had not published image t yet, or the next block revisits a coordinate
         // this block just changed
-        if (__ballot(pn.seq >= t + 1) != ~uint64_t(0)) {   // a keeper had not published image t when Hn was read
-            const unsigned long long w0 = __builtin_readcyclecounter();
-            team_wait_images<K>(ctl, t + 1, lane);
-            pn.Hn = (L.img + (t & 1) * IMG)[nb.ii];
+        if (__ballot(pn.seq >= t + (MULTI ? 2 : 1)) != ~uint64_t(0)) {   // image t (MULTI: the values of block t + 1) had not
+            const unsigned long long w0 = __builtin_readcyclecounter();  // been published when Hn was read
+            if constexpr (MULTI) {
+                dead = !team_wait(&ctl->hnSlot[(t + 1) & 3], t + 2, ctl, true);
+                pn.Hn = L.hn[((t + 1) & 3) * B + rel];
+            } else {
+                team_wait_images<K>(ctl, t + 1, lane);
+                pn.Hn = (L.img + (t & 1) * IMG)[nb.ii];
+            }
             waitA += __builtin_readcyclecounter() - w0;
             ++repairs;
         }
@@ -575,8 +779,13 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     CSet SA, SB;
     Pre pa, pb2;
     fill(SA, 0);
-    team_wait_images<K>(ctl, 1, lane);
-    pa.Hn = L.img[cur.ii];
+    if constexpr (MULTI) {
+        dead = !team_wait(&ctl->hnSlot[0], 1, ctl, true);
+        pa.Hn = L.hn[rel];
+    } else {
+        team_wait_images<K>(ctl, 1, lane);
+        pa.Hn = L.img[cur.ii];
+    }
     pa.wo = w_lds[cur.ii];
     pa.seq = 1;
     for (int t = 0;; t += 2) {  // blocks t (set A) and t+1 (set B); 8 blocks per batch
@@ -585,6 +794,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         fill(SB, t + 1);
         compute(SA, cur, g * B, t, pa, t > 0, cur, (g + 1) * B, pb2);
         f += B;
+        if (MULTI && dead) break;
         if (f == c && epoch_end(t + 1)) break;
         // ---- block t+1 ----
         const bool roll = g + 2 >= 8;
@@ -595,6 +805,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
             compute(SB, cur, (g + 1) * B, t + 1, pb2, true, nxt, 0, pa);
         }
         f += B;
+        if (MULTI && dead) break;
         if (f == c && epoch_end(t + 2)) break;
         if (roll) {
             cur = nxt;
@@ -606,7 +817,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     int cnt = 0;
     double edge_min = big;
 #pragma unroll 4
-    for (int r = 0; r < R * K; ++r) {
+    for (int r = 0; r < ncol64; ++r) {
         const int col = r * WAVE + lane;
         cnt += (col < c && w_lds[col] != 0.0) ? 1 : 0;
         if (col < c) edge_min = fmin(edge_min, L.edge[col]);
@@ -656,11 +867,11 @@ __device__ __forceinline__ FitOut team_fit(int flags, int exact_div, const doubl
 #define CP_CHAIN_ARGS Q, ldq, c, alpha, beta, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds, feat, L
         const bool mk = !exact_div && L.ctl->mk_ok && alpha >= 0x1p-400 && alpha <= 0x1p400;
         if (fast)
-            team_chain<R, K, true, true, false>(CP_CHAIN_ARGS);
+            team_chain<TeamLds<R, K>, R, K, true, true, false>(CP_CHAIN_ARGS);
         else if (mk)
-            team_chain<R, K, false, false, true>(CP_CHAIN_ARGS);
+            team_chain<TeamLds<R, K>, R, K, false, false, true>(CP_CHAIN_ARGS);
         else
-            team_chain<R, K, false, false, false>(CP_CHAIN_ARGS);
+            team_chain<TeamLds<R, K>, R, K, false, false, false>(CP_CHAIN_ARGS);
 #undef CP_CHAIN_ARGS
     }
     __syncthreads();
@@ -677,12 +888,10 @@ __device__ __forceinline__ FitOut team_fit(int flags, int exact_div, const doubl
 // LDS image: feat[4 c] | w[c] | team area.  feat[4 j + {0,1,2,3}] = { q[j], Q[j,j], d = Q[j,j] + beta (its reciprocal with
 // CP_CD_RECIPROCAL), RN(1 / d) }; zero-diagonal features are skipped by sklearn (_cd_fast.pyx:651): here their update is a
 // no-op through d = 1 (their row of Q, q and H entry are all zero).
-template <int R, int K>
+template <class LDS>
 __device__ __forceinline__ void team_load_features(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
                                                    const double *__restrict__ w_in, int c, double l2, int flags,
-                                                   double *w_lds, double *feat, double *team_base) {
-    TeamLds<R, K> L;
-    L.bind(team_base);
+                                                   double *w_lds, double *feat, LDS &L) {
     if (threadIdx.x == 0) L.ctl->mk_ok = 1;
     __syncthreads();
     bool ok = true;
@@ -707,7 +916,9 @@ __global__ void __launch_bounds__(64 * (K + 1)) k_cd_fit_team(const double *__re
                                                               double *__restrict__ w, DevResult *__restrict__ res) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *feat = smem, *w_lds = smem + 4 * c, *team = smem + 5 * c;
-    team_load_features<R, K>(Q, ldq, q, w, c, l2, flags, w_lds, feat, team);
+    TeamLds<R, K> L0;
+    L0.bind(team);
+    team_load_features(Q, ldq, q, w, c, l2, flags, w_lds, feat, L0);
     const double y_norm2 = stats[0];
     const double tol_scaled = tol * y_norm2;
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -745,7 +956,9 @@ __global__ void __launch_bounds__(64 * (K + 1)) k_cd_search_team(CdSearchBatch b
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int c = a.c;
     double *feat = smem, *w_lds = smem + 4 * c, *team = smem + 5 * c;
-    team_load_features<R, K>(a.Q, a.ldq, a.q, nullptr, c, 0.0, a.flags, w_lds, feat, team);
+    TeamLds<R, K> L0;
+    L0.bind(team);
+    team_load_features(a.Q, a.ldq, a.q, nullptr, c, 0.0, a.flags, w_lds, feat, L0);
     const double y_norm2 = a.stats[0];
     const double tol_scaled = a.tol * y_norm2;
     int fit = 0;
@@ -782,6 +995,649 @@ __global__ void __launch_bounds__(64 * (K + 1)) k_cd_search_team(CdSearchBatch b
             }
         }
     }
+    __syncthreads();
+    for (int j = threadIdx.x; j < c; j += blockDim.x) {
+        a.w[j] = w_lds[j];
+        a.w_host[j] = w_lds[j];
+    }
+    if (threadIdx.x == 0) {
+        *a.fits_used = ok ? fit : -fit;  // negative: ran out of pre-drawn seeds
+        *a.alpha_out = alpha;
+    }
+}
+
+// =====================================================================================================================
+// multi-CU team: the keepers of a WIDE layer spread over several workgroups (= CUs)
+// =====================================================================================================================
+// Above c = 512 the one-workgroup team is bound by what ONE CU can pull through its vector L1: a step moves a whole row of Q
+// (8 c bytes) and the L1 delivers <= 64 B / cycle -- 288 cycles per step at c = 2048 whatever the keepers do (measured 470,
+// 428 with every row resident in L2).  Here the columns of H are cut in slices of 512, one REMOTE workgroup (receiver wave,
+// extractor wave, two keeper waves) per slice, each on its own CU, and the HOME workgroup keeps only the serial part:
+//   chain wave     team_chain<MULTI>: as in the one-workgroup team, but a block's starting H values come from L.hn;
+//   stager wave    the index stream, the batches and the couplings Q[ii_a, ii_j] of a block with itself and with the XLAG
+//                  blocks before it (keeper 0's side duties in the one-workgroup team);
+//   forwarder wave copies what the chain wave publishes per block into the remotes' delta rings;
+//   gatherer wave  collects the remotes' H values of a block's eight coordinates and brings them up to date with the blocks
+//                  the remotes had not seen.
+// The workgroups talk through global memory (MultiBox; ~630 ns per round trip inside an XCD, 850-1100 ns across XCDs:
+// tools/probes/xwg_pingpong.hip), far more than the ~0.9 us a block takes.  So the remotes run XLAG blocks behind: the value
+// a remote posts for block v is H[ii_j(v)] after blocks < v - XLAG (image v - XLAG), the gatherer applies blocks
+// v - XLAG .. v - 2 and the chain wave block v - 1 -- each H entry still sees the same fma sequence in the same order as in the
+// oracle (keeper for the old blocks, then gatherer, then chain wave), so w, n_iter and the zero pattern stay bit-identical.
+// Flow control: every remote posts a (possibly empty) record for EVERY block and the gatherer waits for all G of them, so
+// nobody can be more than XLAG + 1 blocks ahead of anybody else and the rings of RING = 8 slots are never overrun.
+constexpr int XR = 4, XK = 2;              // a remote workgroup: two keeper waves of 256 columns each
+constexpr int XSLICE = 64 * XR * XK;       // columns of H per remote workgroup
+constexpr int XNI = XLAG + 2;              // images a remote keeps: the extractor reads image i while the keepers may be at i + XLAG + 1
+constexpr int XMAXG = 4;                   // remote workgroups at most (c <= 2048)
+constexpr int XGW = 3;                     // gatherer waves of the home workgroup (wave w takes the blocks v = w mod XGW)
+constexpr int XWAVES = 3 + XGW;            // waves per workgroup: home = chain, stager, forwarder, gatherers; remote = 2 + XK
+constexpr unsigned long long EXITV = ~0ull;
+static_assert(XLAG >= 2 && XLAG <= 5 && RING >= XLAG + 3 && XWAVES >= 2 + XK, "ring depth");
+typedef TeamLds<XR, XK, XNI> RemoteLds;
+
+struct HomeLds {
+    static constexpr int PUB_RING = 8, II_RING = 4, CPL_REC = (XLAG + 1) * B;
+    double *edge;      // [cpad]
+    double *pub;       // [8][2 B]
+    double *cpl;       // [4][B][CPL_REC]: record of position j = { Q[ii_a(blk - l), ii_j(blk)] : l = 0 .. XLAG, a = 0 .. 7 } (l = 0: 0 for j <= a)
+    double *hn;        // [4][B] starting H values of a block's coordinates (everything but the block before it applied)
+    uint32_t *ii;      // [4][64]
+    uint64_t *dup, *xdup;
+    TeamCtl *ctl;
+    static __host__ __device__ constexpr int doubles(int cpad) {
+        return cpad + PUB_RING * 2 * B + 4 * B * CPL_REC + 4 * B + II_RING * 32 + 8 + int(sizeof(TeamCtl) / 8) + 2;
+    }
+    __device__ void bind(double *base, int cpad) {
+        edge = base;
+        pub = edge + cpad;
+        cpl = pub + PUB_RING * 2 * B;
+        hn = cpl + 4 * B * CPL_REC;
+        ii = reinterpret_cast<uint32_t *>(hn + 4 * B);
+        dup = reinterpret_cast<uint64_t *>(ii + II_RING * 64);
+        xdup = dup + 4;
+        ctl = reinterpret_cast<TeamCtl *>(xdup + 4);
+    }
+};
+
+__device__ __forceinline__ void team_ctl_reset(TeamCtl *ctl) {
+    ctl->seqA = 0;
+    ctl->batB = 0;
+    ctl->stop = 0;
+    ctl->err = 0;
+    ctl->cplSeq = 0;
+    for (int k = 0; k < 4; ++k) ctl->hnSlot[k] = 0;
+    for (int k = 0; k < KMAX; ++k) ctl->seqB[k] = 0;
+}
+
+// ---- home workgroup, stager wave -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void multi_stager(const double *__restrict__ Q, int ldq, int c, uint32_t seed, HomeLds &L) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;
+    TeamCtl *ctl = L.ctl;
+    IdxStream rng;
+    rng.init(seed, uint32_t(c), row_stride_bytes, lane);
+    uint32_t prev_idx = 0xffffffffu;
+    auto publish_batch = [&](int kb) {   // as keeper 0 of the one-workgroup team; four batches stay readable
+        L.ii[(kb & 3) * 64 + lane] = rng.idx;
+        bool dup = false, xd = false;
+        const int bs = lane & ~(B - 1);
+#pragma unroll
+        for (int sft = 1; sft < B; ++sft) {
+            const int other = __shfl(int(rng.idx), bs | ((lane + sft) & (B - 1)), WAVE);
+            dup |= (uint32_t(other) == rng.idx);
+        }
+#pragma unroll
+        for (int sft = 0; sft < B; ++sft) {
+            const int src = ((bs - B) & 63) + sft;
+            const int o_same = __shfl(int(rng.idx), src, WAVE), o_prev = __shfl(int(prev_idx), src, WAVE);
+            xd |= uint32_t(bs == 0 ? o_prev : o_same) == rng.idx;
+        }
+        const uint64_t m = __ballot(dup), mx = __ballot(xd);
+        if (lane == 0) {
+            L.dup[kb & 3] = m;
+            L.xdup[kb & 3] = mx;
+        }
+        prev_idx = rng.idx;
+        duo_store(&ctl->batB, kb + 1);
+    };
+    publish_batch(0);
+    rng.next_batch();
+    publish_batch(1);
+    rng.next_batch();
+    publish_batch(2);
+    int published = 3;
+    auto idx_of = [&](int v) -> uint32_t { return L.ii[((v >> 6) & 3) * 64 + (v & 63)]; };
+    const int a = lane >> 3, j = lane & 7;
+    auto request = [&](int blk, double (&qv)[XLAG + 1]) {
+        const uint32_t col = idx_of(8 * blk + j) * 8u;
+        qv[0] = load_q(rsrc, j > a ? idx_of(8 * blk + a) * row_stride_bytes + col : OOB, 0u);
+#pragma unroll
+        for (int l = 1; l <= XLAG; ++l)
+            qv[l] = load_q(rsrc, blk >= l ? idx_of(8 * (blk - l) + a) * row_stride_bytes + col : OOB, 0u);
+    };
+    auto store = [&](int blk, const double (&qv)[XLAG + 1]) {
+        double *dst = L.cpl + (blk & 3) * (B * HomeLds::CPL_REC) + j * HomeLds::CPL_REC + a;
+#pragma unroll
+        for (int l = 0; l <= XLAG; ++l) dst[l * B] = qv[l];
+        duo_store(&ctl->cplSeq, blk + 1);
+    };
+    double rq[3][XLAG + 1];
+    request(0, rq[0]);
+    request(1, rq[1]);
+    for (int blk = 0;; blk += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int b = blk + u;
+            request(b + 2, rq[(u + 2) % 3]);
+            // the record of block b - 4 is dead once that block is complete
+            if (!team_wait(&ctl->seqA, b - 3, ctl, true)) return;
+            store(b, rq[u]);
+            // batch kb's slot is free once batch kb - 4 is history: keep the batches of the current block + 2 published
+            const int done = duo_load(&ctl->seqA);
+            while (done >= 8 * (published - 2)) {
+                rng.next_batch();
+                publish_batch(published);
+                ++published;
+            }
+        }
+    }
+}
+
+// ---- home workgroup, forwarder wave -------------------------------------------------------------------------------------------
+// what the chain wave published for block t -> slot t % RING of every remote's delta ring (lane = 16 g + i).  A slot is
+// written only after it has been SEEN to hold SENT (its reader put that back RING blocks ago; checked while waiting for the
+// block), so the hand-off needs no ordering between different words.
+template <bool DELTA>
+__device__ __forceinline__ void multi_forwarder(HomeLds &L, const MultiBox *box) {
+    const int lane = threadIdx.x & 63, G = box->G, g = lane >> 4, i = lane & 15;
+    TeamCtl *ctl = L.ctl;
+    constexpr int NV = DELTA ? B : 2 * B;
+    const bool active = g < G && i < NV;
+    for (int t = 0;; ++t) {
+        unsigned long long *slot = box->dl + (g * RING + (t % RING)) * 2 * B + i;
+        bool free_seen = false;
+        for (int spin = 0;; ++spin) {
+            if (!free_seen) {
+                const unsigned long long raw = active ? xld(slot) : SENT;
+                free_seen = __ballot(raw != SENT) == 0;
+            }
+            if (free_seen && duo_load(&ctl->seqA) >= t + 1) break;
+            if (duo_load(&ctl->stop)) {
+                vm_drain();
+                return;
+            }
+            if (spin > XSPIN || (spin % 256 == 255 && multi_aborted(box))) {
+                multi_abort(box, ctl);
+                vm_drain();
+                return;
+            }
+            if (free_seen) __builtin_amdgcn_s_sleep(1);
+        }
+        if (active) xst_d(slot, L.pub[(t & 7) * 2 * B + i]);
+        CP_TRACE(1, t == TRACE_BLOCK);
+    }
+}
+
+// ---- home workgroup, gatherer waves ---------------------------------------------------------------------------
+// block v: collect every remote's record (lane = 8 g + j), take each coordinate's value from its owner, apply the blocks
+// v - XLAG .. v - 2 the remotes had not seen, publish.  The chain wave applies block v - 1 itself.  One pass costs more than
+// a block of the chain wave (~1000 cycles per block applied), so XGW waves take the blocks in turn; the last block applied,
+// v - 2, completes ~1.6 blocks before the values are needed, everything before it is history by then.
+template <bool DELTA>
+__device__ __forceinline__ void multi_gatherer(HomeLds &L, const MultiBox *box, int w) {
+    const int lane = threadIdx.x & 63, j = lane & 7, G = box->G;
+    TeamCtl *ctl = L.ctl;
+    const bool active = lane < 8 * G;
+    auto idx_of = [&](int v) -> uint32_t { return L.ii[((v >> 6) & 3) * 64 + (v & 63)]; };
+    auto slot_of = [&](int v) -> unsigned long long * { return box->hv + ((lane >> 3) * RING + (v % RING)) * B + j; };
+    double Hs = 0.0;
+    auto apply = [&](int u, const double (&qx)[B]) {
+        const double *pb = L.pub + (u & 7) * 2 * B;
+        if (DELTA) {
+            double d[B];
+#pragma unroll
+            for (int a = 0; a < B; a += 2) {
+                const double2 t2 = *reinterpret_cast<const double2 *>(pb + a);
+                d[a] = t2.x;
+                d[a + 1] = t2.y;
+            }
+#pragma unroll
+            for (int a = 0; a < B; ++a) Hs = fma(d[a], qx[a], Hs);
+        } else {
+            double2 p[B];
+#pragma unroll
+            for (int a = 0; a < B; ++a) p[a] = *reinterpret_cast<const double2 *>(pb + 2 * a);   // (w_old, w_new) of step a
+#pragma unroll
+            for (int a = 0; a < B; ++a) Hs = fma(p[a].y, qx[a], fma(-p[a].x, qx[a], Hs));
+        }
+    };
+    auto couplings = [&](int v, int l, double (&qx)[B]) {
+        const double *src = L.cpl + (v & 3) * (B * HomeLds::CPL_REC) + j * HomeLds::CPL_REC + l * B;
+#pragma unroll
+        for (int a = 0; a < B; a += 2) {
+            const double2 t2 = *reinterpret_cast<const double2 *>(src + a);
+            qx[a] = t2.x;
+            qx[a + 1] = t2.y;
+        }
+    };
+    for (int v = w;; v += XGW) {
+        unsigned long long *slot = active ? slot_of(v) : box->ctl;
+        CP_TRACE(8, v == TRACE_BLOCK + 1 + XLAG);
+        unsigned long long mine = 0;
+        int looks = 0;
+        Looks<4> lk;
+        const int got = poll_words(lk, slot, active, mine, [&](unsigned long long) -> bool {
+            return duo_load(&ctl->stop) != 0 || (++looks % 1024 == 0 && multi_aborted(box));
+        });
+        if (got <= 0) {
+            if (got < 0) multi_abort(box, ctl);
+            poll_settle(lk);
+            return;
+        }
+        if (active) xst(slot, SENT);
+        CP_TRACE(5, v == TRACE_BLOCK + 1 + XLAG);
+        if (!team_wait(&ctl->batB, (v >> 3) + 1, ctl, true) || !team_wait(&ctl->cplSeq, v + 1, ctl, true)) break;
+        const int owner = int(idx_of(8 * v + j)) / XSLICE;
+        Hs = __shfl(__longlong_as_double((long long)mine), owner * 8 + j, WAVE);
+        double qx[B];
+        if (!team_wait(&ctl->seqA, v - 2, ctl, true)) break;   // blocks <= v - 3: complete long ago, a formality
+        if (v >= XLAG) {   // steady state: all operands of the XLAG - 2 old blocks first, then one chain of fma
+            double qo[XLAG - 2][B];
+            double po[XLAG - 2][DELTA ? B : 2 * B];
+#pragma unroll
+            for (int l = XLAG; l >= 3; --l) {
+                couplings(v, l, qo[XLAG - l]);
+                const double *pb = L.pub + ((v - l) & 7) * 2 * B;
+#pragma unroll
+                for (int a = 0; a < (DELTA ? B : 2 * B); a += 2) {
+                    const double2 t2 = *reinterpret_cast<const double2 *>(pb + a);
+                    po[XLAG - l][a] = t2.x;
+                    po[XLAG - l][a + 1] = t2.y;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < XLAG - 2; ++o)
+#pragma unroll
+                for (int a = 0; a < B; ++a) {
+                    if (DELTA)
+                        Hs = fma(po[o][a], qo[o][a], Hs);
+                    else
+                        Hs = fma(po[o][2 * a + 1], qo[o][a], fma(-po[o][2 * a], qo[o][a], Hs));
+                }
+        } else {
+            for (int u = 0; u <= v - 3; ++u) {
+                couplings(v, v - u, qx);
+                apply(u, qx);
+            }
+        }
+        CP_TRACE(9, v == TRACE_BLOCK + 1 + XLAG);
+        if (v >= 2) {   // block v - 2 has just finished, or is about to: its couplings first, then the wait
+            couplings(v, 2, qx);
+            if (!team_wait(&ctl->seqA, v - 1, ctl, true)) break;
+            apply(v - 2, qx);
+        }
+        if (lane < B) L.hn[(v & 3) * B + j] = Hs;
+        duo_store(&ctl->hnSlot[v & 3], v + 1);
+        CP_TRACE(6, v == TRACE_BLOCK + 1 + XLAG);
+        poll_settle(lk);
+    }
+    vm_drain();
+}
+
+// ---- remote workgroup, wave 0 -------------------------------------------------------------------------------------------
+template <bool DELTA>
+__device__ __forceinline__ void multi_receiver(RemoteLds &L, const MultiBox *box, int g, int fit) {
+    const int lane = threadIdx.x & 63, G = box->G;
+    TeamCtl *ctl = L.ctl;
+    constexpr int NV = DELTA ? B : 2 * B;
+    // lanes < NV: the block's values; lane 32: "fit stopped"; lane 33: abort
+    for (int t = 0;; ++t) {
+        unsigned long long *slot = box->dl + (g * RING + (t % RING)) * 2 * B + lane;
+        const unsigned long long *addr = lane < NV ? slot : lane == 32 ? box->ctl + G + g : lane == 33 ? box->ctl + 4 * G : box->ctl;
+        unsigned long long raw = 0;
+        Looks<4> lk;
+        const int got = poll_words(lk, addr, lane < NV, raw, [&](unsigned long long v) -> bool {
+            return __ballot((lane == 32 && v >= (unsigned long long)(fit + 1)) || (lane == 33 && v != 0)) != 0;
+        });
+        if (got <= 0) {
+            if (got < 0)
+                multi_abort(box, ctl);
+            else
+                duo_store(&ctl->stop, 1);
+            poll_settle(lk);
+            return;
+        }
+        if (lane < NV) {
+            L.pub[(t & (RemoteLds::PUB_RING - 1)) * 2 * B + lane] = __longlong_as_double((long long)raw);
+            xst(slot, SENT);
+        }
+        duo_store(&ctl->seqA, t + 1);
+        CP_TRACE(2, g == 0 && t == TRACE_BLOCK);
+        poll_settle(lk);   // the keepers are at work: nothing waits for this
+    }
+}
+
+// ---- remote workgroup, wave 1 -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void multi_extractor(int c, RemoteLds &L, const MultiBox *box, int g, int fit) {
+    const int lane = threadIdx.x & 63, G = box->G, slice0 = g * XSLICE;
+    TeamCtl *ctl = L.ctl;
+    constexpr int IMG = RemoteLds::IMG;
+    const int blocks_per_epoch = c / B;
+    auto idx_of = [&](int v) -> uint32_t { return L.ii[((v >> 6) % 3) * 64 + (v & 63)]; };
+    auto slot_of = [&](int v) -> unsigned long long * { return box->hv + (g * RING + (v % RING)) * B + (lane & 7); };
+    unsigned long long chk = xld(slot_of(0));   // the slot of the next record, looked at ahead of time: it must hold SENT
+    bool ok = true;
+    auto post = [&](int i, int v) {   // this slice's part of block v's starting values, from image i
+        if (!ok || !team_wait(&ctl->batB, (v >> 3) + 1, ctl, true)) {
+            ok = false;
+            return;
+        }
+        unsigned long long *slot = slot_of(v);
+        for (int spin = 0; __ballot(chk != SENT) != 0; ++spin) {
+            if (duo_load(&ctl->stop) || spin > XSPIN) {
+                if (spin > XSPIN) multi_abort(box, ctl);
+                ok = false;
+                return;
+            }
+            chk = xld(slot);
+        }
+        if (lane < B) {
+            const int rel = int(idx_of(8 * v + lane)) - slice0;
+            const double val = (rel >= 0 && rel < XSLICE) ? L.img[(i % XNI) * IMG + rel] : 0.0;
+            xst_d(slot, val);
+        }
+        CP_TRACE(4, g == 0 && v == TRACE_BLOCK + 1 + XLAG);
+        chk = xld(slot_of(v + 1));
+    };
+    for (int i = 0; ok; ++i) {
+        for (int spin = 0;; ++spin) {   // image i of every keeper
+            if (__ballot(duo_load(&ctl->seqB[lane % XK]) >= i + 1) == ~uint64_t(0)) break;
+            if (duo_load(&ctl->stop)) {
+                ok = false;
+                break;
+            }
+            if (spin > (1 << 22)) {
+                multi_abort(box, ctl);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) break;
+        if (i == 0)
+            for (int v = 0; v < XLAG; ++v) post(0, v);
+        post(i, i + XLAG);
+        if (ok && i > 0 && i % blocks_per_epoch == 0) {   // end of an epoch: the whole slice, for the chain wave's duality gap
+            for (int col = lane; col < XSLICE; col += WAVE)
+                if (slice0 + col < c) xst_d(box->himg + slice0 + col, L.img[(i % XNI) * IMG + col]);
+            vm_drain();   // the image is in place before its announcement
+            if (lane == 0)
+                xst(box->ctl + 3 * G + g, ((unsigned long long)(fit + 1) << 24) | (unsigned long long)(i / blocks_per_epoch));
+        }
+    }
+    vm_drain();
+}
+
+// ---- remote workgroup: all its fits ------------------------------------------------------------------------------------
+__device__ __forceinline__ void multi_remote(const double *__restrict__ Q, int ldq, int c, int flags, const uint32_t *seeds,
+                                             uint32_t seed_single, const MultiBox *box, int g, double *smem) {
+    const int cpad = (c + 63) & ~63;
+    double *w_lds = smem;
+    RemoteLds L;
+    L.bind(smem + cpad);
+    const int wave = threadIdx.x >> 6, G = box->G;
+    const bool fast = (flags & (CP_CD_RECIPROCAL | CP_CD_DELTA)) == (CP_CD_RECIPROCAL | CP_CD_DELTA);
+    for (int fit = 0;; ++fit) {
+        if (threadIdx.x == 0) {
+            int go = -1;
+            for (int spin = 0; spin < XSPIN; ++spin) {
+                const unsigned long long v = xld(box->ctl + g);
+                if (v == EXITV) break;
+                if (v >= (unsigned long long)(fit + 1)) {
+                    go = 1;
+                    break;
+                }
+                if (spin % 64 == 63 && multi_aborted(box)) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            L.ctl->nnz = go;
+        }
+        __syncthreads();
+        if (L.ctl->nnz < 0) return;
+        __syncthreads();
+        for (int j = threadIdx.x; j < c; j += blockDim.x) w_lds[j] = xld_d(box->fitw + j);
+        if (threadIdx.x == 0) team_ctl_reset(L.ctl);
+        __syncthreads();
+        const uint32_t seed = seeds ? seeds[fit] : seed_single;
+        if (wave == 0) {
+            if (fast)
+                multi_receiver<true>(L, box, g, fit);
+            else
+                multi_receiver<false>(L, box, g, fit);
+        } else if (wave == 1) {
+            multi_extractor(c, L, box, g, fit);
+        } else if (wave < 2 + XK) {
+            if (fast)
+                team_keeper<XR, XK, true, XNI, false>(Q, ldq, c, seed, w_lds, L, wave - 2, g * XSLICE);
+            else
+                team_keeper<XR, XK, false, XNI, false>(Q, ldq, c, seed, w_lds, L, wave - 2, g * XSLICE);
+        }
+        __syncthreads();
+        // the fit is over: whatever is left in this workgroup's delta ring is void; tell the home workgroup
+        for (int i = threadIdx.x; i < RING * 2 * B; i += blockDim.x) xst(box->dl + g * RING * 2 * B + i, SENT);
+        vm_drain();
+        __syncthreads();
+        if (threadIdx.x == 0) xst(box->ctl + 2 * G + g, (unsigned long long)(fit + 1));
+    }
+}
+
+// ---- home workgroup: one fit (all its threads call this; same FitOut in all of them) -------------------------------------
+__device__ __forceinline__ FitOut multi_home_fit(int flags, int exact_div, const double *__restrict__ Q, int ldq, int c,
+                                                 double alpha, double beta, uint32_t seed, int max_iter, double tol_scaled,
+                                                 double d_w_tol, double y_norm2, double *w_lds, const double *feat, HomeLds &L,
+                                                 const MultiBox *box, int fit) {
+    const int cpad = (c + 63) & ~63, G = box->G, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = threadIdx.x; j < c; j += blockDim.x) xst_d(box->fitw + j, w_lds[j]);
+    if (threadIdx.x == 0) team_ctl_reset(L.ctl);
+    for (int j = threadIdx.x; j < cpad; j += blockDim.x) L.edge[j] = __builtin_huge_val();
+    vm_drain();
+    __syncthreads();
+    if (threadIdx.x < G) xst(box->ctl + threadIdx.x, (unsigned long long)(fit + 1));   // w is in place: start
+    const bool fast = (flags & (CP_CD_RECIPROCAL | CP_CD_DELTA)) == (CP_CD_RECIPROCAL | CP_CD_DELTA);
+    if (wave == 0) {
+#define CP_CHAIN_ARGS Q, ldq, c, alpha, beta, max_iter, tol_scaled, d_w_tol, y_norm2, w_lds, feat, L, box, fit
+        const bool mk = !exact_div && L.ctl->mk_ok && alpha >= 0x1p-400 && alpha <= 0x1p400;
+        if (fast)
+            team_chain<HomeLds, 1, 1, true, true, false, true>(CP_CHAIN_ARGS);
+        else if (mk)
+            team_chain<HomeLds, 1, 1, false, false, true, true>(CP_CHAIN_ARGS);
+        else
+            team_chain<HomeLds, 1, 1, false, false, false, true>(CP_CHAIN_ARGS);
+#undef CP_CHAIN_ARGS
+    } else if (wave <= XGW) {   // waves 1 .. XGW: a SIMD each as long as XGW <= 3
+        if (fast)
+            multi_gatherer<true>(L, box, wave - 1);
+        else
+            multi_gatherer<false>(L, box, wave - 1);
+    } else if (wave == XGW + 1) {   // the two light waves share SIMDs with the chain wave and the first gatherer
+        multi_stager(Q, ldq, c, seed, L);
+    } else if (wave == XGW + 2) {
+        if (fast)
+            multi_forwarder<true>(L, box);
+        else
+            multi_forwarder<false>(L, box);
+    }
+    __syncthreads();
+    // nothing of this fit is on its way any more: stop the remotes, wait until they have cleared their rings, clear ours
+    if (threadIdx.x < G) xst(box->ctl + G + threadIdx.x, (unsigned long long)(fit + 1));
+    if (wave == 0) {
+        for (int spin = 0;; ++spin) {
+            const unsigned long long v = lane < G ? xld(box->ctl + 2 * G + lane) : ~0ull;
+            if (__ballot(v >= (unsigned long long)(fit + 1)) == ~uint64_t(0)) break;
+            if (spin > XSPIN || (spin % 64 == 63 && multi_aborted(box))) {
+                multi_abort(box, L.ctl);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < G * RING * B; i += blockDim.x) xst(box->hv + i, SENT);
+    vm_drain();
+    __syncthreads();
+    FitOut out;
+    out.gap = L.ctl->gap;
+    out.n_iter = duo_load(&L.ctl->err) ? -1 : L.ctl->n_iter;
+    out.nnz = L.ctl->nnz;
+    out.edge_margin = L.ctl->edge_margin;
+    out.gap_margin = L.ctl->gap_margin;
+    __syncthreads();
+    return out;
+}
+
+// the words of a job's mailbox: [dl | hv] start as SENT, the rest as 0 (k_multi_box_init)
+__host__ __device__ inline size_t multi_box_sent_words(int G) { return size_t(G) * RING * 3 * B; }
+__host__ __device__ inline size_t multi_box_words(int c, int G) {
+    return multi_box_sent_words(G) + size_t(8 * XMAXG) + size_t((c + 63) & ~63) + size_t(G) * XSLICE;
+}
+__device__ __forceinline__ MultiBox multi_box_bind(unsigned long long *base, int c, int G) {
+    MultiBox b;
+    b.dl = base;
+    b.hv = b.dl + size_t(G) * RING * 2 * B;
+    b.ctl = b.hv + size_t(G) * RING * B;
+    b.fitw = b.ctl + 8 * XMAXG;
+    b.himg = b.fitw + ((c + 63) & ~63);
+    b.G = G;
+    b.slice = XSLICE;
+    return b;
+}
+__global__ void k_multi_box_init(unsigned long long *base, size_t words_per_job, size_t sent_words, int n_jobs) {
+    const size_t total = words_per_job * size_t(n_jobs);
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += size_t(gridDim.x) * blockDim.x)
+        base[i] = (i % words_per_job) < sent_words ? SENT : 0ull;
+}
+
+struct MultiLaunch {
+    unsigned long long *base;   // n_jobs mailboxes of `words` words each
+    size_t words;
+    int G, n_jobs, same_xcd;
+};
+// workgroup -> (job, role): role 0 = home, 1 + g = remote g.  same_xcd: workgroup L of a launch lands on XCD L % 8 (observed,
+// not promised: only the hand-off latency depends on it), so a job's 1 + G workgroups take ids that are 8 apart
+__device__ __forceinline__ bool multi_role(const MultiLaunch &ml, int &job, int &role) {
+    const int members = 1 + ml.G;
+    if (ml.same_xcd) {
+        const int x = blockIdx.x & 7, m = blockIdx.x >> 3;
+        job = (m / members) * 8 + x;
+        role = m % members;
+    } else {
+        job = blockIdx.x / members;
+        role = blockIdx.x % members;
+    }
+    return job < ml.n_jobs;
+}
+inline int multi_grid(int n_jobs, int G, int same_xcd) {
+    return same_xcd ? 8 * (1 + G) * ((n_jobs + 7) / 8) : n_jobs * (1 + G);
+}
+
+__global__ void __launch_bounds__(64 * XWAVES) k_cd_fit_multi(const double *__restrict__ Q, int ldq,
+                                                                const double *__restrict__ q, const double *__restrict__ stats,
+                                                                int c, double l1, double l2, uint32_t seed, int max_iter,
+                                                                double tol, int flags, int exact_div, double *__restrict__ w,
+                                                                DevResult *__restrict__ res, MultiLaunch ml) {
+    int job, role;
+    if (!multi_role(ml, job, role)) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const MultiBox box = multi_box_bind(ml.base, c, ml.G);
+    if (role > 0) {
+        multi_remote(Q, ldq, c, flags, nullptr, seed, &box, role - 1, smem);
+        return;
+    }
+    const int cpad = (c + 63) & ~63;
+    double *feat = smem, *w_lds = smem + 4 * c;
+    HomeLds L;
+    L.bind(smem + 5 * c, cpad);
+    team_load_features(Q, ldq, q, w, c, l2, flags, w_lds, feat, L);
+    const double y_norm2 = stats[0];
+    const double tol_scaled = tol * y_norm2;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    FitOut o = multi_home_fit(flags, exact_div, Q, ldq, c, l1, l2, seed, max_iter, tol_scaled, tol, y_norm2, w_lds, feat, L, &box, 0);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x < ml.G) xst(box.ctl + threadIdx.x, EXITV);
+    if (threadIdx.x == 0) {
+        g_team_debug[0] = t1 - t0;
+        g_team_debug[1] = (unsigned long long)(o.n_iter > 0 ? o.n_iter : 0) * (unsigned long long)c;
+    }
+    for (int j = threadIdx.x; j < c; j += blockDim.x) w[j] = w_lds[j];
+    if (threadIdx.x == 0) {
+        res->gap = o.gap;
+        res->tol_scaled = tol_scaled;
+        res->n_iter = o.n_iter;
+        res->nnz = o.nnz;
+        res->edge_margin = o.edge_margin;
+        res->gap_margin = o.gap_margin;
+    }
+}
+
+// the alpha search of lib/decompose.py:490-525 (as k_cd_search_team), one search per 1 + G workgroups
+__global__ void __launch_bounds__(64 * XWAVES) k_cd_search_multi(CdSearchBatch b, int exact_div, MultiLaunch ml) {
+    int job, role;
+    if (!multi_role(ml, job, role)) return;
+    const CdSearchArgs &a = b.a[job];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int c = a.c;
+    const MultiBox box = multi_box_bind(ml.base + size_t(job) * ml.words, c, ml.G);
+    if (role > 0) {
+        multi_remote(a.Q, a.ldq, c, a.flags, a.seeds, 0u, &box, role - 1, smem);
+        return;
+    }
+    const int cpad = (c + 63) & ~63;
+    double *feat = smem, *w_lds = smem + 4 * c;
+    HomeLds L;
+    L.bind(smem + 5 * c, cpad);
+    team_load_features(a.Q, a.ldq, a.q, nullptr, c, 0.0, a.flags, w_lds, feat, L);
+    const double y_norm2 = a.stats[0];
+    const double tol_scaled = a.tol * y_norm2;
+    int fit = 0;
+    double left = 0.0, right = a.right0, alpha = a.right0;
+    bool bracketing = true, ok = false;
+    while (fit < a.max_fits) {
+        alpha = bracketing ? right : (left + right) / 2;
+        FitOut o = multi_home_fit(a.flags, exact_div, a.Q, a.ldq, c, alpha * a.M, 0.0, a.seeds[fit], a.max_iter, tol_scaled, a.tol,
+                                  y_norm2, w_lds, feat, L, &box, fit);
+        if (threadIdx.x == 0) {
+            a.log[fit].gap = o.gap;
+            a.log[fit].tol_scaled = tol_scaled;
+            a.log[fit].n_iter = o.n_iter;
+            a.log[fit].nnz = o.nnz;
+            a.log[fit].edge_margin = o.edge_margin;
+            a.log[fit].gap_margin = o.gap_margin;
+            a.log_alpha[fit] = alpha;
+        }
+        ++fit;
+        if (o.n_iter < 0) break;   // a hand-off failed: reported through the log (n_iter = -1)
+        const double tmp = double(o.nnz);
+        if (bracketing) {  // decompose.py:502-515
+            if (tmp < a.rank)
+                bracketing = false;
+            else
+                right *= 2;
+        } else {  // decompose.py:516-525
+            if (tmp > a.rbound)
+                left = alpha;
+            else if (tmp < a.lbound)
+                right = alpha;
+            else {
+                ok = true;
+                break;
+            }
+        }
+    }
+    if (threadIdx.x < ml.G) xst(box.ctl + threadIdx.x, EXITV);
     __syncthreads();
     for (int j = threadIdx.x; j < c; j += blockDim.x) {
         a.w[j] = w_lds[j];
@@ -844,11 +1700,65 @@ static int team_exact_div() {
     static const int v = (getenv("CP_CD_EXACT_DIV") && atoi(getenv("CP_CD_EXACT_DIV")) != 0) ? 1 : 0;
     return v;
 }
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// ---- multi-CU team: host side ------------------------------------------------------------------------------------------
+// CP_CD_MULTI (default 1): layers of 512 < c <= 2048 channels run the multi-CU team (1 + ceil(c / 512) workgroups per search);
+// CP_CD_MULTI_MIN_C moves the lower limit; CP_CD_MULTI_SAME_XCD (default 1): a search's workgroups share an XCD;
+// CP_CD_MULTI_EXCLUSIVE (default 1): each of them asks for a whole CU's LDS.
+static int multi_groups(int c) { return (c + XSLICE - 1) / XSLICE; }
+static bool multi_wanted(int c) {
+    static const int on = env_int("CP_CD_MULTI", 1), min_c = env_int("CP_CD_MULTI_MIN_C", 513);
+    return on && c >= min_c && c > XSLICE / 2 && multi_groups(c) <= XMAXG && multi_groups(c) >= 1;
+}
+static size_t multi_lds_bytes(int c) {
+    const int cpad = (c + 63) & ~63;
+    const size_t home = size_t(5) * c + size_t(HomeLds::doubles(cpad)), remote = size_t(cpad) + size_t(RemoteLds::doubles());
+    size_t lds = std::max(home, remote) * sizeof(double);
+    static const int exclusive = env_int("CP_CD_MULTI_EXCLUSIVE", 1);
+    if (exclusive) lds = std::max(lds, size_t(150) * 1024);
+    return lds;
+}
+static int multi_prepare(cp_ctx *ctx, int c, int n_jobs, MultiLaunch &ml) {
+    static const int same_xcd = env_int("CP_CD_MULTI_SAME_XCD", 1);
+    ml.G = multi_groups(c);
+    ml.n_jobs = n_jobs;
+    ml.same_xcd = same_xcd;
+    ml.words = (multi_box_words(c, ml.G) + 31) & ~size_t(31);
+    const size_t bytes = ml.words * size_t(n_jobs) * sizeof(unsigned long long);
+    if (ctx->cd_box_bytes < bytes) {
+        CP_HIP(ctx, cp_stream_wait(ctx));
+        if (ctx->cd_box) CP_HIP(ctx, hipFree(ctx->cd_box));
+        ctx->cd_box = nullptr;
+        ctx->cd_box_bytes = 0;
+        CP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->cd_box), bytes));
+        ctx->cd_box_bytes = bytes;
+    }
+    ml.base = reinterpret_cast<unsigned long long *>(ctx->cd_box);
+    const size_t total = ml.words * size_t(n_jobs);
+    k_multi_box_init<<<int(std::min<size_t>((total + 255) / 256, 64)), 256, 0, ctx->stream>>>(ml.base, ml.words,
+                                                                                             multi_box_sent_words(ml.G), n_jobs);
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}
 
 int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c, double l1_reg,
                           double l2_reg, uint32_t seed, int max_iter, double tol, int flags, double *w, void *dres) {
-    const size_t lds = team_lds_bytes(c);
     const int ex = team_exact_div();
+    if (multi_wanted(c)) {
+        MultiLaunch ml;
+        CP_TRY(multi_prepare(ctx, c, 1, ml));
+        const size_t mlds = multi_lds_bytes(c);
+        CP_HIP(ctx, team_optin(k_cd_fit_multi, mlds));
+        k_cd_fit_multi<<<multi_grid(1, ml.G, ml.same_xcd), 64 * XWAVES, mlds, ctx->stream>>>(
+            Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, ex, w, static_cast<DevResult *>(dres), ml);
+        CP_LAUNCH_CHECK(ctx);
+        return CP_OK;
+    }
+    const size_t lds = team_lds_bytes(c);
 #define CP_CALL(R_, K_)                                                                                              \
     CP_HIP(ctx, team_optin(k_cd_fit_team<R_, K_>, lds));                                                             \
     k_cd_fit_team<R_, K_><<<1, 64 * (K_ + 1), lds, ctx->stream>>>(Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, \
@@ -859,11 +1769,6 @@ int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q
     return CP_OK;
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) {
     // CP_CD_EXCLUSIVE (default 1): the workgroup asks for (almost) a whole CU's LDS, so that no other workgroup shares its
     // CU -- next to the products of other layers (or of its own layer's side stream) the chain and keeper waves otherwise
@@ -872,6 +1777,16 @@ int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) 
     // wave priority (both measured without effect on the job: 33.6 / 33.7 ms; left as switches).
     static const int spread_on = env_int("CP_CD_SPREAD", 0), prio = env_int("CP_CD_PRIO", 0),
                      exclusive = env_int("CP_CD_EXCLUSIVE", 1);
+    if (multi_wanted(c)) {
+        MultiLaunch ml;
+        CP_TRY(multi_prepare(ctx, c, n_jobs, ml));
+        const size_t mlds = multi_lds_bytes(c);
+        CP_HIP(ctx, team_optin(k_cd_search_multi, mlds));
+        k_cd_search_multi<<<multi_grid(n_jobs, ml.G, ml.same_xcd), 64 * XWAVES, mlds, ctx->stream>>>(
+            *static_cast<const CdSearchBatch *>(batch), team_exact_div(), ml);
+        CP_LAUNCH_CHECK(ctx);
+        return CP_OK;
+    }
     static std::atomic<unsigned> next_xcd{0};
     size_t lds = team_lds_bytes(c);
     if (exclusive && !spread_on) lds = std::max(lds, size_t(150) * 1024);
@@ -891,6 +1806,17 @@ int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) 
 extern "C" int cp_debug_cd_team_cycles(cp_ctx *ctx, unsigned long long *out8) {
     if (!ctx || !out8) return CP_ERR_ARG;
     CP_HIP(ctx, cp_stream_wait(ctx));
+#ifdef CP_CD_MULTI_TRACE
+    {
+        unsigned long long tr[16];
+        CP_HIP(ctx, hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_multi_trace), sizeof(tr)));
+        fprintf(stderr, "multi trace (ns after the chain wave published block %d): forwarded %lld, received %lld, image %lld, posted %lld, "
+                        "collected %lld (polling since %lld), old blocks applied %lld, published %lld; chain finished block %d at %lld\n", TRACE_BLOCK, (long long)(tr[1] - tr[0]) * 10,
+                (long long)(tr[2] - tr[0]) * 10, (long long)(tr[3] - tr[0]) * 10, (long long)(tr[4] - tr[0]) * 10,
+                (long long)(tr[5] - tr[0]) * 10, (long long)(tr[8] - tr[0]) * 10, (long long)(tr[9] - tr[0]) * 10,
+                (long long)(tr[6] - tr[0]) * 10, TRACE_BLOCK + XLAG, (long long)(tr[7] - tr[0]) * 10);
+    }
+#endif
     CP_HIP(ctx, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_team_debug), 8 * sizeof(unsigned long long)));
     return CP_OK;
 }

@@ -90,6 +90,8 @@ struct cp_ctx {
     cp_precompute pre;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // hand-offs to / from the shared CU-masked stream of the long GEMMs
     int itq_sweeps = 0;               // Jacobi sweeps of the last cp_itq_iterate (all alternations)
+    char *cd_box = nullptr;           // mailboxes of the multi-CU coordinate-descent team (cd_team.hip), grow-only
+    size_t cd_box_bytes = 0;
     bool potrf_lds_opt_in = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
 

@@ -153,6 +153,7 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     cp_precompute_release(ctx);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->layer_ws) hipFree(ctx->layer_ws);
+    if (ctx->cd_box) hipFree(ctx->cd_box);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     for (int i = 0; i < 2 * CP_MAX_STAGES; ++i)
         if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
