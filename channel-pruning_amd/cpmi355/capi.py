@@ -84,6 +84,7 @@ SIGNATURES = {
     "cp_assemble_y": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _vp]),
     "cp_lasso_gram": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
                                _vp, _vp, _vp]),
+    "cp_cd_kernel_form": (_c_int, [_c_int, _c_int]),
     "cp_enet_cd_gram": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _c_int, _c_dbl, _c_dbl, _c_u32, _c_int, _c_dbl,
                                  _c_int, _vp, ctypes.POINTER(CdResult)]),
     "cp_lasso_alpha_search": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _c_int, _c_dbl, _c_dbl, _c_dbl, _c_dbl, _c_dbl,
@@ -315,6 +316,10 @@ class Context:
         self._check(self.lib.cp_lasso_gram(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), _ptr(W2), w_dtype,
                                            int(n), _ptr(Y), samples.ctypes.data, samples.shape[0], _ptr(Q),
                                            _ptr(q), _ptr(stats)), "cp_lasso_gram")
+
+    def cd_kernel_form(self, c, flags=0):
+        """0 one wavefront, 1 two waves, 2 team, 3 multi-CU team (include/cpmi355.h: CP_CD_FORM_*)."""
+        return int(self.lib.cp_cd_kernel_form(int(c), int(flags)))
 
     def enet_cd_gram(self, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, w, max_iter=1000, tol=1e-4, flags=0):
         res = CdResult()

@@ -1552,6 +1552,13 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     return CP_OK;
 }
 
+bool cp_cd_multi_wanted(int c);
+extern "C" int cp_cd_kernel_form(int c, int flags) {
+    if (c <= 0 || c > 32 * WAVE) return -1;
+    if (cp_cd_team_wanted(c, flags)) return cp_cd_multi_wanted(c) ? CP_CD_FORM_MULTI : CP_CD_FORM_TEAM;
+    return use_duo(c) ? CP_CD_FORM_DUO : CP_CD_FORM_WAVE;
+}
+
 extern "C" int cp_debug_cd_cycles(cp_ctx *ctx, unsigned long long *out2) {
     if (!ctx || !out2) return CP_ERR_ARG;
     if (g_last_cd_was_team) return cp_debug_cd_team_cycles(ctx, out2);

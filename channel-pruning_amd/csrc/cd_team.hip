@@ -55,7 +55,7 @@ struct TeamCtl {
 template <int R, int K, int NI = 2>
 struct TeamLds {
     static constexpr int IMG = 64 * R * K;
-    static constexpr int PUB_RING = NI > 2 ? 8 : 4, II_RING = 3, CPL_REC = 2 * B;
+    static constexpr int PUB_RING = NI > 2 ? 16 : 4, II_RING = 3, CPL_REC = 2 * B;
     double *img;       // [NI][IMG]
     double *edge;      // [IMG] | |tmp| - alpha | of every coordinate's LAST update in the fit (tie sentinel)
     double *pub;       // [4][2 * B]
@@ -129,7 +129,7 @@ constexpr int TRACE_BLOCK = 2000;
 #endif
 constexpr int XLAG = CP_CD_MULTI_LAG;      // blocks the remotes run behind the chain wave (2 <= XLAG <= 5)
 constexpr unsigned long long SENT = 0x7FF8C0DEC0DEC0DEull;   // a quiet NaN no arithmetic produces
-constexpr int RING = 8;                                      // blocks of slots per ring
+constexpr int RING = XLAG > 5 ? 16 : 8;                      // blocks of slots per ring (>= XLAG + 3)
 struct MultiBox {
     unsigned long long *dl;     // [G][RING][2 B]  home -> remote g: what the chain wave published for a block
     unsigned long long *hv;     // [G][RING][B]    remote g -> home: H[ii_j] of a block's coordinates, LAG blocks stale
@@ -1031,9 +1031,12 @@ constexpr int XSLICE = 64 * XR * XK;       // columns of H per remote workgroup
 constexpr int XNI = XLAG + 2;              // images a remote keeps: the extractor reads image i while the keepers may be at i + XLAG + 1
 constexpr int XMAXG = 4;                   // remote workgroups at most (c <= 2048)
 constexpr int XGW = 3;                     // gatherer waves of the home workgroup (wave w takes the blocks v = w mod XGW)
-constexpr int XWAVES = 3 + XGW;            // waves per workgroup: home = chain, stager, forwarder, gatherers; remote = 2 + XK
+#ifndef CP_CD_MULTI_WAVES
+#define CP_CD_MULTI_WAVES (3 + XGW)
+#endif
+constexpr int XWAVES = CP_CD_MULTI_WAVES;  // waves per workgroup: home = chain, stager, forwarder, gatherers; remote = 2 + XK
 constexpr unsigned long long EXITV = ~0ull;
-static_assert(XLAG >= 2 && XLAG <= 5 && RING >= XLAG + 3 && XWAVES >= 2 + XK, "ring depth");
+static_assert(XLAG >= 2 && XLAG <= 7 && RING >= XLAG + 3 && XWAVES >= 2 + XK, "ring depth");
 typedef TeamLds<XR, XK, XNI> RemoteLds;
 
 struct HomeLds {
@@ -1245,29 +1248,37 @@ __device__ __forceinline__ void multi_gatherer(HomeLds &L, const MultiBox *box, 
         Hs = __shfl(__longlong_as_double((long long)mine), owner * 8 + j, WAVE);
         double qx[B];
         if (!team_wait(&ctl->seqA, v - 2, ctl, true)) break;   // blocks <= v - 3: complete long ago, a formality
-        if (v >= XLAG) {   // steady state: all operands of the XLAG - 2 old blocks first, then one chain of fma
-            double qo[XLAG - 2][B];
-            double po[XLAG - 2][DELTA ? B : 2 * B];
+        if (v >= XLAG) {   // steady state: the operands of (up to) three old blocks at a time, then their chain of fma
+            constexpr int CH = 3;
 #pragma unroll
-            for (int l = XLAG; l >= 3; --l) {
-                couplings(v, l, qo[XLAG - l]);
-                const double *pb = L.pub + ((v - l) & 7) * 2 * B;
+            for (int l0 = XLAG; l0 >= 3; l0 -= CH) {
+                double qo[CH][B];
+                double po[CH][DELTA ? B : 2 * B];
 #pragma unroll
-                for (int a = 0; a < (DELTA ? B : 2 * B); a += 2) {
-                    const double2 t2 = *reinterpret_cast<const double2 *>(pb + a);
-                    po[XLAG - l][a] = t2.x;
-                    po[XLAG - l][a + 1] = t2.y;
+                for (int o = 0; o < CH; ++o) {
+                    const int l = l0 - o;
+                    if (l < 3) continue;
+                    couplings(v, l, qo[o]);
+                    const double *pb = L.pub + ((v - l) & 7) * 2 * B;
+#pragma unroll
+                    for (int a = 0; a < (DELTA ? B : 2 * B); a += 2) {
+                        const double2 t2 = *reinterpret_cast<const double2 *>(pb + a);
+                        po[o][a] = t2.x;
+                        po[o][a + 1] = t2.y;
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < CH; ++o) {
+                    if (l0 - o < 3) continue;
+#pragma unroll
+                    for (int a = 0; a < B; ++a) {
+                        if (DELTA)
+                            Hs = fma(po[o][a], qo[o][a], Hs);
+                        else
+                            Hs = fma(po[o][2 * a + 1], qo[o][a], fma(-po[o][2 * a], qo[o][a], Hs));
+                    }
                 }
             }
-#pragma unroll
-            for (int o = 0; o < XLAG - 2; ++o)
-#pragma unroll
-                for (int a = 0; a < B; ++a) {
-                    if (DELTA)
-                        Hs = fma(po[o][a], qo[o][a], Hs);
-                    else
-                        Hs = fma(po[o][2 * a + 1], qo[o][a], fma(-po[o][2 * a], qo[o][a], Hs));
-                }
         } else {
             for (int u = 0; u <= v - 3; ++u) {
                 couplings(v, v - u, qx);
@@ -1525,6 +1536,7 @@ struct MultiLaunch {
     unsigned long long *base;   // n_jobs mailboxes of `words` words each
     size_t words;
     int G, n_jobs, same_xcd;
+    int xcd0;                   // same_xcd: job l lives on XCD (xcd0 + l) % 8 (rotated from launch to launch)
 };
 // workgroup -> (job, role): role 0 = home, 1 + g = remote g.  same_xcd: workgroup L of a launch lands on XCD L % 8 (observed,
 // not promised: only the hand-off latency depends on it), so a job's 1 + G workgroups take ids that are 8 apart
@@ -1532,7 +1544,7 @@ __device__ __forceinline__ bool multi_role(const MultiLaunch &ml, int &job, int 
     const int members = 1 + ml.G;
     if (ml.same_xcd) {
         const int x = blockIdx.x & 7, m = blockIdx.x >> 3;
-        job = (m / members) * 8 + x;
+        job = (m / members) * 8 + ((x - ml.xcd0) & 7);
         role = m % members;
     } else {
         job = blockIdx.x / members;
@@ -1587,6 +1599,9 @@ __global__ void __launch_bounds__(64 * XWAVES) k_cd_fit_multi(const double *__re
 __global__ void __launch_bounds__(64 * XWAVES) k_cd_search_multi(CdSearchBatch b, int exact_div, MultiLaunch ml) {
     int job, role;
     if (!multi_role(ml, job, role)) return;
+#ifdef CP_CD_MULTI_FULL_VGPR
+    asm volatile("" ::: "v255");   // experiment: the kernel claims every register of its SIMDs
+#endif
     const CdSearchArgs &a = b.a[job];
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int c = a.c;
@@ -1727,6 +1742,8 @@ static int multi_prepare(cp_ctx *ctx, int c, int n_jobs, MultiLaunch &ml) {
     ml.G = multi_groups(c);
     ml.n_jobs = n_jobs;
     ml.same_xcd = same_xcd;
+    static std::atomic<unsigned> next_xcd{0};   // concurrent searches (one launch per stream) take different XCDs
+    ml.xcd0 = int(next_xcd.fetch_add(unsigned(n_jobs)) & 7u);
     ml.words = (multi_box_words(c, ml.G) + 31) & ~size_t(31);
     const size_t bytes = ml.words * size_t(n_jobs) * sizeof(unsigned long long);
     if (ctx->cd_box_bytes < bytes) {
@@ -1744,6 +1761,8 @@ static int multi_prepare(cp_ctx *ctx, int c, int n_jobs, MultiLaunch &ml) {
     CP_LAUNCH_CHECK(ctx);
     return CP_OK;
 }
+
+bool cp_cd_multi_wanted(int c) { return multi_wanted(c); }
 
 int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c, double l1_reg,
                           double l2_reg, uint32_t seed, int max_iter, double tol, int flags, double *w, void *dres) {

@@ -136,6 +136,16 @@ int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const double *q, cons
                     double l1_reg, double l2_reg, uint32_t seed, int max_iter, double tol, int flags,
                     double *w, cp_cd_result *result);
 
+/* Which kernel form cp_enet_cd_gram / cp_lasso_alpha_search run for c channels and these flags (no GPU needed):
+ * 0 = one wavefront, 1 = chain wave + assist / keeper wave, 2 = team (chain wave + up to six keeper waves, one workgroup),
+ * 3 = multi-CU team (512 < c <= 2048: the keepers in 2-4 further workgroups, one CU each); -1 = c not supported.
+ * All forms produce the same bits; the choice follows c, the flags and the CP_CD_* environment switches. */
+#define CP_CD_FORM_WAVE 0
+#define CP_CD_FORM_DUO 1
+#define CP_CD_FORM_TEAM 2
+#define CP_CD_FORM_MULTI 3
+int cp_cd_kernel_form(int c, int flags);
+
 /* The whole alpha search of lib/decompose.py:490-525 in ONE launch (bracket doubling
  * then bisection; acceptance lbound <= nnz <= rbound), warm-starting every fit from
  * the previous one exactly as Lasso(warm_start=True) does.  seeds HOST uint32[max_fits]

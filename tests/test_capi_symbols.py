@@ -67,3 +67,17 @@ def test_header_is_valid_c99_and_links_from_plain_c(tmp_path):
                            "-L", lib_dir, "-lcpmi355", "-Wl,-rpath," + lib_dir, "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
+
+
+def test_cd_kernel_form_table():
+    """cp_cd_kernel_form (no GPU needed): which coordinate-descent kernel a width runs -- the multi-CU team takes
+    512 < c <= 2048 (c % 8 == 0) in sklearn's operation order (flags 0) and in the fast variant (flags 3), the one-workgroup
+    team c % 8 == 0 up to 512, the one- / two-wave kernels everything else; 2048 channels is the library's limit."""
+    from cpmi355 import capi
+    lib = capi.load()
+    form = lambda c, f=0: int(lib.cp_cd_kernel_form(c, f))
+    assert [form(c) for c in (64, 256, 512)] == [2, 2, 2]
+    assert [form(c) for c in (520, 1024, 1536, 2048)] == [3, 3, 3, 3] and form(2048, 3) == 3
+    assert form(2040) == 3 and form(2044) == 0          # c % 8 != 0: one wavefront, 32 doubles per lane
+    assert form(55) == 0 and form(256, 1) == 1 and form(1024, 1) == 0
+    assert form(0) == -1 and form(2056) == -1 and form(4096) == -1

@@ -101,11 +101,15 @@ def _cd_problem(c, M=4000, seed=3):
 def test_cd_fit_bit_exact_vs_oracle(ctx, c, recip):
     """cp_enet_cd_gram vs cpo_enet_cd_gram on the same Q, q, seed: identical n_iter and
     bit-identical w (same fma sequence), for cold and warm starts, in all four rounding variants
-    (flags: 1 = CP_CD_RECIPROCAL, 2 = CP_CD_DELTA).  c covers every team shape (flags 0 and 3, c % 8 == 0: (1,1) ... (4,4) up
-    to 1024, (6,6) with a ragged last keeper at 1224 / 1536 and full at 2048; the three-operation division), the two-wave
-    and one-wave kernels of cd_gram.hip (flags 1 and 2; 55, 222) and several register widths."""
+    (flags: 1 = CP_CD_RECIPROCAL, 2 = CP_CD_DELTA).  c covers every team shape (flags 0 and 3, c % 8 == 0: (1,1) ... (4,2) up
+    to 512; the three-operation division), the multi-CU team above (two remote workgroups at 1024, three with a ragged last
+    slice at 1224, three at 1536, four at 2048: keepers on other CUs, hand-offs through global memory), the two-wave and
+    one-wave kernels of cd_gram.hip (flags 1 and 2; 55, 222) and several register widths."""
     import cp_oracle
     from cpmi355 import capi
+    if os.environ.get("CP_CD_MULTI", "1") != "0" and os.environ.get("CP_CD_TEAM", "1") != "0":
+        assert ctx.cd_kernel_form(c, recip) == (3 if c > 512 and recip in (0, 3) else 2 if c % 8 == 0 and recip in (0, 3) else
+                                                ctx.cd_kernel_form(c, recip))
     Q, q, yty, M = _cd_problem(c)
     Qd, qd = ctx.to_device(Q), ctx.to_device(q)
     sd = ctx.to_device(np.array([yty, 0, M, 0], dtype=np.float64))
