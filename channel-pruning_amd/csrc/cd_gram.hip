@@ -1549,6 +1549,9 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dres, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
     CP_HIP(ctx, cp_stream_wait(ctx));
     memcpy(result, ctx->pinned, sizeof(cp_cd_result));
+    if (result->n_iter < 0)
+        return cp_set_error(ctx, CP_ERR_NUMERIC, "cd: a hand-off between the waves / workgroups of the coordinate-descent team timed out "
+                            "(CP_CD_MULTI=0 / CP_CD_TEAM=0 run the simpler kernels)");
     return CP_OK;
 }
 
@@ -1624,8 +1627,13 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     memcpy(alpha_out, halpha, sizeof(double));
     if (fit_log) memcpy(fit_log, h + off_log, log_bytes);
     if (fit_alpha) memcpy(fit_alpha, h + off_al, al_bytes);
-    if (*fits_used < 0)
+    if (*fits_used < 0) {
+        const DevResult *lg = reinterpret_cast<const DevResult *>(h + off_log);
+        if (-*fits_used <= max_fits && lg[-*fits_used - 1].n_iter < 0)
+            return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search: a hand-off between the workgroups of the coordinate-descent team "
+                                "timed out in fit %d (CP_CD_MULTI=0 runs the one-workgroup kernels)", -*fits_used - 1);
         return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search did not terminate within %d fits", max_fits);
+    }
     return CP_OK;
 }
 
@@ -1720,6 +1728,12 @@ int cp_alpha_search_collect(cp_ctx *ctx, int c, int max_fits, int *fits_used, do
     memcpy(alpha_out, h + 64, sizeof(double));
     if (fit_log) memcpy(fit_log, h + lay.off_log, size_t(max_fits) * sizeof(DevResult));
     if (fit_alpha) memcpy(fit_alpha, h + lay.off_al, size_t(max_fits) * sizeof(double));
-    if (*fits_used < 0) return CP_ERR_NUMERIC;
+    if (*fits_used < 0) {
+        const DevResult *lg = reinterpret_cast<const DevResult *>(h + lay.off_log);
+        if (-*fits_used <= max_fits && lg[-*fits_used - 1].n_iter < 0)
+            return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search: a hand-off between the workgroups of the coordinate-descent team "
+                                "timed out in fit %d (CP_CD_MULTI=0 runs the one-workgroup kernels)", -*fits_used - 1);
+        return CP_ERR_NUMERIC;
+    }
     return CP_OK;
 }

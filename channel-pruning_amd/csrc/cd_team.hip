@@ -4,6 +4,10 @@
 // enet_coordinate_descent_gram, _cd_fast.pyx:564-737; coordinate stream our_rand_r, _random.pxd:20-35), so w, n_iter and
 // the zero pattern are bit-identical to oracle/cd_oracle.c::cpo_enet_cd_gram in sklearn's own operation order (flags 0).
 //
+// Two forms live here: the ONE-WORKGROUP team (c <= 512 by default: this header and the first half of the file) and the
+// MULTI-CU team (512 < c <= 2048: its keepers in 2-4 further workgroups, one CU each, talking through global memory; see
+// the section "multi-CU team" further down).  Both run the same chain wave (team_chain) and the same keeper (team_keeper).
+//
 // Why a team.  A single wavefront issues one instruction every ~5-6.5 cycles whatever the dependencies, so a coordinate
 // step costs what its instruction count costs, and the step is a serial chain.  cd_gram.hip splits the count over two
 // waves (chain + keeper) for 256 < c <= 512 and runs everything in one wave otherwise; its keeper applies 2 c / 64 fma per
