@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 namespace {
 using namespace cdk;
@@ -123,6 +124,16 @@ __device__ unsigned long long g_multi_trace[16];
 constexpr int TRACE_BLOCK = 2000;
 #else
 #define CP_TRACE(slot, cond) do { } while (0)
+#endif
+#ifdef CP_CD_TEAM_TRACE   // timing experiment: shader-clock stamps of one block's trip chain wave -> keeper 0 -> chain wave
+__device__ unsigned long long g_team_trace[16];
+#define CP_TTRACE(slot, cond)                                                                           \
+    do {                                                                                                \
+        if ((cond) && (threadIdx.x & 63) == 0) g_team_trace[slot] = __builtin_readcyclecounter();       \
+    } while (0)
+constexpr int TTRACE_BLOCK = 1000;
+#else
+#define CP_TTRACE(slot, cond) do { } while (0)
 #endif
 
 // ---- cross-workgroup mailbox of the multi-CU team (see the section "multi-CU team" below) --------------------------------
@@ -216,9 +227,10 @@ __device__ __forceinline__ bool multi_wait_epoch_image(const MultiBox *box, int 
 // ---------------------------------------------------------------------------------------------------------------------
 // keeper wave k: columns [64 R k, 64 R (k + 1)) of H
 // ---------------------------------------------------------------------------------------------------------------------
-// NI: images kept in LDS (the multi-CU team's extractor reads them NI - 2 blocks late); STAGE: keeper 0 stages the chain
-// wave's couplings; slice0: first column of this workgroup's slice of H (images are indexed relative to it)
-template <int R, int K, bool DELTA, int NI = 2, bool STAGE = true>
+// NI: images kept in LDS (the multi-CU team's extractor reads them NI - 2 blocks late); BATCHES: keeper 0 publishes the index
+// batches in LDS (remote workgroups of the multi-CU team, for their extractor wave; elsewhere the stager wave does);
+// slice0: first column of this workgroup's slice of H (images are indexed relative to it)
+template <int R, int K, bool DELTA, int NI = 2, bool BATCHES = false>
 __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ldq, int c, uint32_t seed, const double *w_lds,
                                             TeamLds<R, K, NI> &L, int k, int slice0 = 0) {
     const int lane = threadIdx.x & 63;
@@ -286,7 +298,7 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
     rng.init(seed, uint32_t(c), row_stride_bytes, lane);
     uint32_t prev_idx = 0xffffffffu;  // coordinates of the batch published before (none yet)
     auto publish_batch = [&](int kb) {
-        if (k != 0) return;
+        if (!BATCHES || k != 0) return;
         L.ii[(kb % 3) * 64 + lane] = rng.idx;
         bool dup = false, xd = false;
         const int bs = lane & ~(B - 1);
@@ -318,38 +330,6 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
     publish_batch(2);
     uint32_t off_n2 = rng.off;
     int batch = 0;
-
-    // Keeper 0 also stages the couplings the chain wave needs per block -- Q[ii_a, ii_j] for the 8 x 8 pairs inside block
-    // blk and for (a in block blk - 1, j in block blk) -- as TWO 64-lane gathers (lane = 8 a + j) written to LDS in the
-    // lay-out the chain wave reads with four 16-byte loads per lane; the chain wave used to fetch them itself with 16
-    // loads + 16 readlanes per block.  Three blocks ahead of the block this wave applies (the index batches are published
-    // two batches ahead), so the chain wave never waits for them.
-    constexpr uint32_t OOB = 0x80000000u;
-    auto idx_of = [&](int v) -> uint32_t { return L.ii[((v >> 6) % 3) * 64 + (v & 63)]; };
-    auto cpl_request = [&](int blk, double &qc, double &qx) {
-        const int a = lane >> 3, j = lane & 7;
-        const uint32_t col = idx_of(8 * blk + j) * 8u;
-        const uint32_t row = idx_of(8 * blk + a) * row_stride_bytes;
-        qc = load_q(rsrc, j > a ? row + col : OOB, 0u);      // out of range -> 0.0: finished lanes stop changing
-        const uint32_t prow = idx_of(blk > 0 ? 8 * (blk - 1) + a : 0) * row_stride_bytes;
-        qx = load_q(rsrc, blk > 0 ? prow + col : OOB, 0u);
-    };
-    auto cpl_store = [&](int blk, double qc, double qx) {
-        const int a = lane >> 3, j = lane & 7;
-        double *dst = L.cpl + (blk & 3) * (B * 2 * B) + j * (2 * B);
-        dst[a] = qc;
-        dst[B + a] = qx;
-        duo_store(&L.ctl->cplSeq, blk + 1);
-    };
-    if (STAGE && k == 0) {
-#pragma unroll
-        for (int blk = 0; blk < 3; ++blk) {
-            double qc, qx;
-            cpl_request(blk, qc, qx);
-            cpl_store(blk, qc, qx);
-        }
-    }
-    double cqc = 0.0, cqx = 0.0;
 
     // (Measured and not kept: skipping the row of a coordinate that sits at zero inside its dead zone -- 35-45 % of the steps
     //  once the support has settled, the rows requested out of range so that the load counts stay static -- and fetching it
@@ -402,12 +382,13 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
         write_image(t + 1);
         return true;
     };
-    if constexpr (NI > 2 && PK) {
-        // Remote keeper of the multi-CU team: the same two-set ring, but the row loads are issued from inline assembly and
-        // waited for with an explicit vmcnt.  The compiler's own wait insertion drains loop-carried loads completely
-        // (settle() below exists to give that drain a harmless place), which makes every second block wait for the rows
-        // requested just before it -- fine while Q sits in L2, a microsecond per block when the rows come from HBM.  Here a
-        // set is waited for with vmcnt(loads of the other, younger set): two blocks of prefetch distance, never a drain.
+    if constexpr (PK) {
+        // The same two-set ring, but with the row loads issued from inline assembly and waited for with an explicit vmcnt.
+        // The compiler's own wait insertion drains loop-carried loads completely (settle() below exists to give that drain a
+        // harmless place), which makes every second block wait for the rows requested just before it: an L2 round trip per
+        // two blocks while Q sits in L2 (c <= 512: the chain wave waited 28 cycles per step for the images), a microsecond
+        // per block when the rows come from HBM (the remote keepers of the multi-CU team).  Here a set is waited for with
+        // vmcnt(number of younger loads): two blocks of prefetch distance, never a drain.
         typedef double d2v __attribute__((ext_vector_type(2)));
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const uint64_t qa = reinterpret_cast<uint64_t>(Q);
@@ -432,11 +413,13 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
         };
         auto apply2 = [&](d2v (&S)[B][R / 2], int t) -> bool {
             if (!team_wait(&L.ctl->seqA, t + 1, L.ctl, true)) return false;
+            CP_TTRACE(1, NI == 2 && k == 0 && t == TTRACE_BLOCK);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // everything but the other set's loads has landed
 #pragma unroll
             for (int a = 0; a < B; ++a)
 #pragma unroll
                 for (int r2 = 0; r2 < R / 2; ++r2) asm volatile("" : "+v"(S[a][r2]));
+            CP_TTRACE(2, NI == 2 && k == 0 && t == TTRACE_BLOCK);
             const double *pb = L.pub + (t & (TeamLds<R, K, NI>::PUB_RING - 1)) * 2 * B;
 #pragma unroll
             for (int a = 0; a < B; ++a) {
@@ -450,7 +433,13 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
                     for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S[a][r >> 1][r & 1], fma(-wo_a, S[a][r >> 1][r & 1], H[r]));
                 }
             }
+#ifdef CP_CD_TEAM_TRACE
+#pragma unroll
+            for (int r = 0; r < R; ++r) asm volatile("" : "+v"(H[r]));
+#endif
+            CP_TTRACE(3, NI == 2 && k == 0 && t == TTRACE_BLOCK);
             write_image(t + 1);
+            CP_TTRACE(4, NI == 2 && k == 0 && t == TTRACE_BLOCK);
             return true;
         };
         fill2(A2, off_cur, 0);
@@ -478,20 +467,14 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
     fill(rowA, off_cur, 0);
     for (int t = 0;; t += 2) {  // two blocks per iteration (register sets A / B); 8 blocks per batch
         const int g = t & 7;
-        if (STAGE && k == 0) cpl_request(t + 3, cqc, cqx);
         fill(rowB, off_cur, (g + 1) * B);
         if (!apply(rowA, t)) break;
-        if (STAGE && k == 0) {
-            cpl_store(t + 3, cqc, cqx);
-            cpl_request(t + 4, cqc, cqx);
-        }
         if (g + 2 < 8) {
             fill(rowA, off_cur, (g + 2) * B);
         } else {
             fill(rowA, off_nxt, 0);
         }
         if (!apply(rowB, t + 1)) break;
-        if (STAGE && k == 0) cpl_store(t + 4, cqc, cqx);
         settle(rowA);
         if (g + 2 >= 8) {  // batch roll-over
             off_cur = off_nxt;
@@ -500,6 +483,91 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
             ++batch;
             publish_batch(batch + 2);
             off_n2 = rng.off;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stager wave: the index stream's batches (coordinates, duplicate scans) for the chain wave, and per block the couplings
+// Q[ii_a, ii_j] the chain wave (and, in the multi-CU team, the gatherer waves) need: the 8 x 8 pairs inside the block (l = 0)
+// and between the block and each of the LAGS blocks before it, as 1 + LAGS 64-lane gathers (lane = 8 a + j) written to LDS
+// in the lay-out the chain wave reads with 16-byte loads.  Requested two blocks ahead of the store, stored up to three
+// blocks ahead of the chain wave.  (Keeper 0 used to do this next to its rows: it then needed ~2000 cycles per block and
+// the chain wave waited for its image in four blocks out of five.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <class LDS, int LAGS>
+__device__ __forceinline__ void team_stager(const double *__restrict__ Q, int ldq, int c, uint32_t seed, LDS &L) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;
+    TeamCtl *ctl = L.ctl;
+    IdxStream rng;
+    rng.init(seed, uint32_t(c), row_stride_bytes, lane);
+    uint32_t prev_idx = 0xffffffffu;
+    auto publish_batch = [&](int kb) {
+        L.ii[(kb % LDS::II_RING) * 64 + lane] = rng.idx;
+        bool dup = false, xd = false;
+        const int bs = lane & ~(B - 1);
+#pragma unroll
+        for (int sft = 1; sft < B; ++sft) {
+            const int other = __shfl(int(rng.idx), bs | ((lane + sft) & (B - 1)), WAVE);
+            dup |= (uint32_t(other) == rng.idx);
+        }
+#pragma unroll
+        for (int sft = 0; sft < B; ++sft) {
+            const int src = ((bs - B) & 63) + sft;
+            const int o_same = __shfl(int(rng.idx), src, WAVE), o_prev = __shfl(int(prev_idx), src, WAVE);
+            xd |= uint32_t(bs == 0 ? o_prev : o_same) == rng.idx;
+        }
+        const uint64_t m = __ballot(dup), mx = __ballot(xd);
+        if (lane == 0) {
+            L.dup[kb & 3] = m;
+            L.xdup[kb & 3] = mx;
+        }
+        prev_idx = rng.idx;
+        duo_store(&ctl->batB, kb + 1);
+    };
+    publish_batch(0);
+    rng.next_batch();
+    publish_batch(1);
+    rng.next_batch();
+    publish_batch(2);
+    int published = 3;
+    auto idx_of = [&](int v) -> uint32_t { return L.ii[((v >> 6) % LDS::II_RING) * 64 + (v & 63)]; };
+    const int a = lane >> 3, j = lane & 7;
+    auto request = [&](int blk, double (&qv)[LAGS + 1]) {
+        const uint32_t col = idx_of(8 * blk + j) * 8u;
+        qv[0] = load_q(rsrc, j > a ? idx_of(8 * blk + a) * row_stride_bytes + col : OOB, 0u);
+#pragma unroll
+        for (int l = 1; l <= LAGS; ++l)
+            qv[l] = load_q(rsrc, blk >= l ? idx_of(8 * (blk - l) + a) * row_stride_bytes + col : OOB, 0u);
+    };
+    auto store = [&](int blk, const double (&qv)[LAGS + 1]) {
+        double *dst = L.cpl + (blk & 3) * (B * LDS::CPL_REC) + j * LDS::CPL_REC + a;
+#pragma unroll
+        for (int l = 0; l <= LAGS; ++l) dst[l * B] = qv[l];
+        duo_store(&ctl->cplSeq, blk + 1);
+    };
+    double rq[3][LAGS + 1];
+    request(0, rq[0]);
+    request(1, rq[1]);
+    for (int blk = 0;; blk += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int b = blk + u;
+            request(b + 2, rq[(u + 2) % 3]);
+            // the record of block b - 4 is dead once that block is complete
+            if (!team_wait(&ctl->seqA, b - 3, ctl, true)) return;
+            store(b, rq[u]);
+            // batch kb's slot is free once batch kb - 4 is history: keep the batches of the current block + 2 published
+            const int done = duo_load(&ctl->seqA);
+            while (done >= 8 * (published - 2)) {
+                rng.next_batch();
+                publish_batch(published);
+                ++published;
+            }
         }
     }
 }
@@ -710,7 +778,10 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
                     dp1[a] = wn_a;
                     Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
                 }
-                if (a == PF) prefetch(pn, nb, t + 1);
+                if (a == PF) {
+                    CP_TTRACE(5, !MULTI && t == TTRACE_BLOCK + 1);
+                    prefetch(pn, nb, t + 1);
+                }
             }
             wn_keep = wn_v;
             p0_v = DELTA ? wn_v - wo_v : wo_v;
@@ -761,8 +832,10 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
             L.edge[bt.ii] = fabs(d_v);
         }
         duo_store(&ctl->seqA, t + 1);
+        CP_TTRACE(0, !MULTI && t == TTRACE_BLOCK);
         CP_TRACE(0, MULTI && t == TRACE_BLOCK);
         CP_TRACE(7, MULTI && t == TRACE_BLOCK + XLAG);   // the block before the one the traced values feed
+        CP_TTRACE(7, !MULTI && t == TTRACE_BLOCK + 1);
         // rare repairs of the prefetch: a keeper had not published image t yet, or the next block revisits a coordinate
         // this block just changed
         if (__ballot(pn.seq >= t + (MULTI ? 2 : 1)) != ~uint64_t(0)) {   // image t (MULTI: the values of block t + 1) had not
@@ -775,6 +848,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
                 pn.Hn = (L.img + (t & 1) * IMG)[nb.ii];
             }
             waitA += __builtin_readcyclecounter() - w0;
+            CP_TTRACE(6, !MULTI && t == TTRACE_BLOCK + 1);
             ++repairs;
         }
         if ((nb.xdupmask >> nbase) & ((uint64_t(1) << B) - 1)) pn.wo = w_lds[nb.ii];
@@ -842,7 +916,7 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
     }
 }
 
-// all K + 1 waves of the workgroup call this; returns the same FitOut in all threads.  flags: CP_CD_RECIPROCAL | CP_CD_DELTA
+// all K + 2 waves of the workgroup (chain, K keepers, stager) call this; returns the same FitOut in all threads.  flags: CP_CD_RECIPROCAL | CP_CD_DELTA
 // (0: sklearn's operation order with the three-operation division where it is exact; 3: both rounding variants)
 template <int R, int K>
 __device__ __forceinline__ FitOut team_fit(int flags, int exact_div, const double *__restrict__ Q, int ldq, int c, double alpha,
@@ -862,7 +936,9 @@ __device__ __forceinline__ FitOut team_fit(int flags, int exact_div, const doubl
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     const bool fast = (flags & (CP_CD_RECIPROCAL | CP_CD_DELTA)) == (CP_CD_RECIPROCAL | CP_CD_DELTA);
-    if (wave > 0) {
+    if (wave == K + 1) {
+        team_stager<TeamLds<R, K>, 1>(Q, ldq, c, seed, L);
+    } else if (wave > 0) {
         if (fast)
             team_keeper<R, K, true>(Q, ldq, c, seed, w_lds, L, wave - 1);
         else
@@ -914,7 +990,7 @@ __device__ __forceinline__ void team_load_features(const double *__restrict__ Q,
 }
 
 template <int R, int K>
-__global__ void __launch_bounds__(64 * (K + 1)) k_cd_fit_team(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
+__global__ void __launch_bounds__(64 * (K + 2)) k_cd_fit_team(const double *__restrict__ Q, int ldq, const double *__restrict__ q,
                                                               const double *__restrict__ stats, int c, double l1, double l2,
                                                               uint32_t seed, int max_iter, double tol, int flags, int exact_div,
                                                               double *__restrict__ w, DevResult *__restrict__ res) {
@@ -949,7 +1025,7 @@ __global__ void __launch_bounds__(64 * (K + 1)) k_cd_fit_team(const double *__re
 // searches, each a single workgroup whose Gram wants to stay in ONE XCD's L2, land on different XCDs instead of all on
 // XCD 0.  prio: the waves raise their issue priority over co-resident throughput kernels.
 template <int R, int K>
-__global__ void __launch_bounds__(64 * (K + 1)) k_cd_search_team(CdSearchBatch b, int exact_div, int spread, int prio) {
+__global__ void __launch_bounds__(64 * (K + 2)) k_cd_search_team(CdSearchBatch b, int exact_div, int spread, int prio) {
     int job = blockIdx.x;
     if (spread >= 0) {
         job = blockIdx.x >> 3;
@@ -1075,83 +1151,6 @@ __device__ __forceinline__ void team_ctl_reset(TeamCtl *ctl) {
     ctl->cplSeq = 0;
     for (int k = 0; k < 4; ++k) ctl->hnSlot[k] = 0;
     for (int k = 0; k < KMAX; ++k) ctl->seqB[k] = 0;
-}
-
-// ---- home workgroup, stager wave -------------------------------------------------------------------------------------------
-__device__ __forceinline__ void multi_stager(const double *__restrict__ Q, int ldq, int c, uint32_t seed, HomeLds &L) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t row_stride_bytes = uint32_t(ldq) * 8u;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(Q), 0, int(uint32_t(c - 1) * row_stride_bytes + uint32_t(c) * 8u), 0x00020000);
-    constexpr uint32_t OOB = 0x80000000u;
-    TeamCtl *ctl = L.ctl;
-    IdxStream rng;
-    rng.init(seed, uint32_t(c), row_stride_bytes, lane);
-    uint32_t prev_idx = 0xffffffffu;
-    auto publish_batch = [&](int kb) {   // as keeper 0 of the one-workgroup team; four batches stay readable
-        L.ii[(kb & 3) * 64 + lane] = rng.idx;
-        bool dup = false, xd = false;
-        const int bs = lane & ~(B - 1);
-#pragma unroll
-        for (int sft = 1; sft < B; ++sft) {
-            const int other = __shfl(int(rng.idx), bs | ((lane + sft) & (B - 1)), WAVE);
-            dup |= (uint32_t(other) == rng.idx);
-        }
-#pragma unroll
-        for (int sft = 0; sft < B; ++sft) {
-            const int src = ((bs - B) & 63) + sft;
-            const int o_same = __shfl(int(rng.idx), src, WAVE), o_prev = __shfl(int(prev_idx), src, WAVE);
-            xd |= uint32_t(bs == 0 ? o_prev : o_same) == rng.idx;
-        }
-        const uint64_t m = __ballot(dup), mx = __ballot(xd);
-        if (lane == 0) {
-            L.dup[kb & 3] = m;
-            L.xdup[kb & 3] = mx;
-        }
-        prev_idx = rng.idx;
-        duo_store(&ctl->batB, kb + 1);
-    };
-    publish_batch(0);
-    rng.next_batch();
-    publish_batch(1);
-    rng.next_batch();
-    publish_batch(2);
-    int published = 3;
-    auto idx_of = [&](int v) -> uint32_t { return L.ii[((v >> 6) & 3) * 64 + (v & 63)]; };
-    const int a = lane >> 3, j = lane & 7;
-    auto request = [&](int blk, double (&qv)[XLAG + 1]) {
-        const uint32_t col = idx_of(8 * blk + j) * 8u;
-        qv[0] = load_q(rsrc, j > a ? idx_of(8 * blk + a) * row_stride_bytes + col : OOB, 0u);
-#pragma unroll
-        for (int l = 1; l <= XLAG; ++l)
-            qv[l] = load_q(rsrc, blk >= l ? idx_of(8 * (blk - l) + a) * row_stride_bytes + col : OOB, 0u);
-    };
-    auto store = [&](int blk, const double (&qv)[XLAG + 1]) {
-        double *dst = L.cpl + (blk & 3) * (B * HomeLds::CPL_REC) + j * HomeLds::CPL_REC + a;
-#pragma unroll
-        for (int l = 0; l <= XLAG; ++l) dst[l * B] = qv[l];
-        duo_store(&ctl->cplSeq, blk + 1);
-    };
-    double rq[3][XLAG + 1];
-    request(0, rq[0]);
-    request(1, rq[1]);
-    for (int blk = 0;; blk += 3) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int b = blk + u;
-            request(b + 2, rq[(u + 2) % 3]);
-            // the record of block b - 4 is dead once that block is complete
-            if (!team_wait(&ctl->seqA, b - 3, ctl, true)) return;
-            store(b, rq[u]);
-            // batch kb's slot is free once batch kb - 4 is history: keep the batches of the current block + 2 published
-            const int done = duo_load(&ctl->seqA);
-            while (done >= 8 * (published - 2)) {
-                rng.next_batch();
-                publish_batch(published);
-                ++published;
-            }
-        }
-    }
 }
 
 // ---- home workgroup, forwarder wave -------------------------------------------------------------------------------------------
@@ -1437,9 +1436,9 @@ __device__ __forceinline__ void multi_remote(const double *__restrict__ Q, int l
             multi_extractor(c, L, box, g, fit);
         } else if (wave < 2 + XK) {
             if (fast)
-                team_keeper<XR, XK, true, XNI, false>(Q, ldq, c, seed, w_lds, L, wave - 2, g * XSLICE);
+                team_keeper<XR, XK, true, XNI, true>(Q, ldq, c, seed, w_lds, L, wave - 2, g * XSLICE);
             else
-                team_keeper<XR, XK, false, XNI, false>(Q, ldq, c, seed, w_lds, L, wave - 2, g * XSLICE);
+                team_keeper<XR, XK, false, XNI, true>(Q, ldq, c, seed, w_lds, L, wave - 2, g * XSLICE);
         }
         __syncthreads();
         // the fit is over: whatever is left in this workgroup's delta ring is void; tell the home workgroup
@@ -1479,7 +1478,7 @@ __device__ __forceinline__ FitOut multi_home_fit(int flags, int exact_div, const
         else
             multi_gatherer<false>(L, box, wave - 1);
     } else if (wave == XGW + 1) {   // the two light waves share SIMDs with the chain wave and the first gatherer
-        multi_stager(Q, ldq, c, seed, L);
+        team_stager<HomeLds, XLAG>(Q, ldq, c, seed, L);
     } else if (wave == XGW + 2) {
         if (fast)
             multi_forwarder<true>(L, box);
@@ -1784,7 +1783,7 @@ int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q
     const size_t lds = team_lds_bytes(c);
 #define CP_CALL(R_, K_)                                                                                              \
     CP_HIP(ctx, team_optin(k_cd_fit_team<R_, K_>, lds));                                                             \
-    k_cd_fit_team<R_, K_><<<1, 64 * (K_ + 1), lds, ctx->stream>>>(Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, \
+    k_cd_fit_team<R_, K_><<<1, 64 * (K_ + 2), lds, ctx->stream>>>(Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, \
                                                                   ex, w, static_cast<DevResult *>(dres))
     CP_TEAM_SWITCH(c, CP_CALL);
 #undef CP_CALL
@@ -1819,7 +1818,7 @@ int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) 
     const CdSearchBatch &b = *static_cast<const CdSearchBatch *>(batch);
 #define CP_CALL(R_, K_)                                                  \
     CP_HIP(ctx, team_optin(k_cd_search_team<R_, K_>, lds));              \
-    k_cd_search_team<R_, K_><<<grid, 64 * (K_ + 1), lds, ctx->stream>>>(b, ex, spread, prio)
+    k_cd_search_team<R_, K_><<<grid, 64 * (K_ + 2), lds, ctx->stream>>>(b, ex, spread, prio)
     CP_TEAM_SWITCH(c, CP_CALL);
 #undef CP_CALL
     CP_LAUNCH_CHECK(ctx);
@@ -1829,6 +1828,16 @@ int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) 
 extern "C" int cp_debug_cd_team_cycles(cp_ctx *ctx, unsigned long long *out8) {
     if (!ctx || !out8) return CP_ERR_ARG;
     CP_HIP(ctx, cp_stream_wait(ctx));
+#ifdef CP_CD_TEAM_TRACE
+    {
+        unsigned long long tr[16];
+        CP_HIP(ctx, hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_team_trace), sizeof(tr)));
+        fprintf(stderr, "team trace (cycles after the chain wave published block %d): keeper 0 saw it %lld, rows ready %lld, fma done %lld, "
+                        "image out %lld; chain wave: prefetch of the next-but-one block's values %lld, repair finished %lld, next block "
+                        "published %lld\n", TTRACE_BLOCK, (long long)(tr[1] - tr[0]), (long long)(tr[2] - tr[0]), (long long)(tr[3] - tr[0]),
+                (long long)(tr[4] - tr[0]), (long long)(tr[5] - tr[0]), (long long)(tr[6] - tr[0]), (long long)(tr[7] - tr[0]));
+    }
+#endif
 #ifdef CP_CD_MULTI_TRACE
     {
         unsigned long long tr[16];
