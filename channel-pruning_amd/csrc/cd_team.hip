@@ -151,6 +151,7 @@ struct MultiBox {
     unsigned long long *fitw;   // [c]             home -> remotes: w at the start of a fit
     unsigned long long *himg;   // [G * slice]     remotes -> home: H at the end of an epoch
     unsigned long long *ctl;    // [0,G) fit posted | [G,2G) fit stopped | [2G,3G) stop acknowledged | [3G,4G) epoch image | [4G] abort
+                                // | (4G, 5G] remote workgroup g is resident
     int G, slice;
 };
 __device__ __forceinline__ unsigned long long xld(const unsigned long long *p) {
@@ -412,7 +413,17 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
             }
         };
         auto apply2 = [&](d2v (&S)[B][R / 2], int t) -> bool {
-            if (!team_wait(&L.ctl->seqA, t + 1, L.ctl, true)) return false;
+            const unsigned long long w0 = __builtin_readcyclecounter();
+            const bool okw = team_wait(&L.ctl->seqA, t + 1, L.ctl, true);
+            waitB += __builtin_readcyclecounter() - w0;
+            ++blocksB;
+            if (!okw) {
+                if (lane == 0 && k == 0 && slice0 == 0) {
+                    g_team_debug[4] = waitB;
+                    g_team_debug[5] = blocksB;
+                }
+                return false;
+            }
             CP_TTRACE(1, NI == 2 && k == 0 && t == TTRACE_BLOCK);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // everything but the other set's loads has landed
 #pragma unroll
@@ -1112,7 +1123,7 @@ constexpr int XNI = XLAG + 2;              // images a remote keeps: the extract
 constexpr int XMAXG = 4;                   // remote workgroups at most (c <= 2048)
 constexpr int XGW = 3;                     // gatherer waves of the home workgroup (wave w takes the blocks v = w mod XGW)
 #ifndef CP_CD_MULTI_WAVES
-#define CP_CD_MULTI_WAVES (3 + XGW)
+#define CP_CD_MULTI_WAVES (4 + XGW)   // wave 4 idles: it would share SIMD 0 with the chain wave (waves go to SIMD index % 4)
 #endif
 constexpr int XWAVES = CP_CD_MULTI_WAVES;  // waves per workgroup: home = chain, stager, forwarder, gatherers; remote = 2 + XK
 constexpr unsigned long long EXITV = ~0ull;
@@ -1405,6 +1416,7 @@ __device__ __forceinline__ void multi_remote(const double *__restrict__ Q, int l
     L.bind(smem + cpad);
     const int wave = threadIdx.x >> 6, G = box->G;
     const bool fast = (flags & (CP_CD_RECIPROCAL | CP_CD_DELTA)) == (CP_CD_RECIPROCAL | CP_CD_DELTA);
+    if (threadIdx.x == 0) xst(box->ctl + 4 * G + 1 + g, 1ull);   // resident from here to the end of the search
     for (int fit = 0;; ++fit) {
         if (threadIdx.x == 0) {
             int go = -1;
@@ -1449,6 +1461,26 @@ __device__ __forceinline__ void multi_remote(const double *__restrict__ Q, int l
     }
 }
 
+// ---- home workgroup, once per launch: every remote workgroup is resident ----------------------------------------------------
+// The waits inside a fit are bounded at about a second -- fine between workgroups that are all running, but a remote
+// workgroup may have to wait for a free CU much longer than that on a chip full of other work.  So the home workgroup first
+// waits, patiently (~20 s), until all its remotes have reported in; from then on everybody stays resident.
+__device__ __forceinline__ void multi_wait_resident(const MultiBox *box, TeamCtl *ctl) {
+    const int lane = threadIdx.x & 63, G = box->G;
+    if (threadIdx.x < 64) {
+        for (long spin = 0;; ++spin) {
+            const unsigned long long v = lane < G ? xld(box->ctl + 4 * G + 1 + lane) : 1ull;
+            if (__ballot(v == 0) == 0) break;
+            if (spin > (10l << 20)) {
+                multi_abort(box, ctl);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    __syncthreads();
+}
+
 // ---- home workgroup: one fit (all its threads call this; same FitOut in all of them) -------------------------------------
 __device__ __forceinline__ FitOut multi_home_fit(int flags, int exact_div, const double *__restrict__ Q, int ldq, int c,
                                                  double alpha, double beta, uint32_t seed, int max_iter, double tol_scaled,
@@ -1477,9 +1509,9 @@ __device__ __forceinline__ FitOut multi_home_fit(int flags, int exact_div, const
             multi_gatherer<true>(L, box, wave - 1);
         else
             multi_gatherer<false>(L, box, wave - 1);
-    } else if (wave == XGW + 1) {   // the two light waves share SIMDs with the chain wave and the first gatherer
+    } else if (wave == XGW + 2) {   // (wave XGW + 1 = 4 idles;) the two light waves share SIMDs with the first two gatherers
         team_stager<HomeLds, XLAG>(Q, ldq, c, seed, L);
-    } else if (wave == XGW + 2) {
+    } else if (wave == XGW + 3) {
         if (fast)
             multi_forwarder<true>(L, box);
         else
@@ -1577,6 +1609,7 @@ __global__ void __launch_bounds__(64 * XWAVES) k_cd_fit_multi(const double *__re
     HomeLds L;
     L.bind(smem + 5 * c, cpad);
     team_load_features(Q, ldq, q, w, c, l2, flags, w_lds, feat, L);
+    multi_wait_resident(&box, L.ctl);
     const double y_norm2 = stats[0];
     const double tol_scaled = tol * y_norm2;
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -1618,6 +1651,7 @@ __global__ void __launch_bounds__(64 * XWAVES) k_cd_search_multi(CdSearchBatch b
     HomeLds L;
     L.bind(smem + 5 * c, cpad);
     team_load_features(a.Q, a.ldq, a.q, nullptr, c, 0.0, a.flags, w_lds, feat, L);
+    multi_wait_resident(&box, L.ctl);
     const double y_norm2 = a.stats[0];
     const double tol_scaled = a.tol * y_norm2;
     int fit = 0;

@@ -54,4 +54,4 @@ for c in CS:
             phases = [dbg[2 + i] / max(dbg[1], 1) for i in range(4)]
         best = min(rows)
         print("c=%4d flags=%d  ns/step %.1f  cycles/step %.1f  implied GHz %.2f  n_iter %d nnz %d" % (
-            (c, flags) + best), " dbg/step: %.2f %.4f %.2f %.4f" % tuple(phases), flush=True)
+            (c, flags) + best), " per step: chain wave waits %.1f cycles, %.3f repairs, keeper 0 waits %.1f cycles (%.4f blocks)" % tuple(phases), flush=True)
