@@ -1,4 +1,4 @@
-// Coordinate-descent LASSO on the Gram matrix, team form: ONE chain wave + K keeper waves in one workgroup.
+// Coordinate-descent LASSO on the Gram matrix, team form: ONE chain wave, K keeper waves and a stager wave.
 //
 // Same recurrence, same visit order, same fma sequence per H entry as cd_gram.hip (sklearn's
 // enet_coordinate_descent_gram, _cd_fast.pyx:564-737; coordinate stream our_rand_r, _random.pxd:20-35), so w, n_iter and
@@ -6,7 +6,8 @@
 //
 // Two forms live here: the ONE-WORKGROUP team (c <= 512 by default: this header and the first half of the file) and the
 // MULTI-CU team (512 < c <= 2048: its keepers in 2-4 further workgroups, one CU each, talking through global memory; see
-// the section "multi-CU team" further down).  Both run the same chain wave (team_chain) and the same keeper (team_keeper).
+// the section "multi-CU team" further down).  Both run the same chain wave (team_chain), the same keeper (team_keeper) and
+// the same stager (team_stager).
 //
 // Why a team.  A single wavefront issues one instruction every ~5-6.5 cycles whatever the dependencies, so a coordinate
 // step costs what its instruction count costs, and the step is a serial chain.  cd_gram.hip splits the count over two
@@ -18,10 +19,12 @@
 //   keeper k    (wave 1 + k)   owns H[:, 64 R k .. 64 R (k + 1)) in registers (R <= 4 doubles per lane), fetches its slice of
 //                              the rows Q[ii, :] sixteen steps ahead, applies a block's 8 updates with what the chain wave
 //                              published and exposes its slice of H as an LDS image after every block;
-// K = ceil(c / 256) keepers up to c = 1024 (R <= 4: 2 R <= 8 fma per wave and step whatever c is), six keepers of 384 columns
-// for c <= 2304 (seven waves: at most two per SIMD, so every wave keeps 256 registers); K waves keep K times the row bytes
-// in flight.  Hand-offs are sequence counters in LDS, one writer each (the LDS executes a wave's instructions in
-// program order, so a counter written after its payload lands after it); no barrier inside a fit.
+//   stager      (wave K + 1)   publishes the index stream's batches and stages the couplings Q[ii_a, ii_j] of every block
+//                              in LDS, three blocks ahead of the chain wave.
+// K = ceil(c / 256) keepers (R <= 4: 2 R <= 8 fma per wave and step whatever c is): four waves, one per SIMD, up to
+// c = 512; with CP_CD_MULTI=0 also four keepers up to c = 1024 and six keepers of 384 columns up to 2048 (eight waves: two
+// per SIMD, so every wave keeps 256 registers).  Hand-offs are sequence counters in LDS, one writer each (the LDS executes
+// a wave's instructions in program order, so a counter written after its payload lands after it); no barrier inside a fit.
 //
 // The division of the soft-threshold step.  sklearn divides by Q_ii (+ beta); an IEEE f64 division is ~11 dependent
 // instructions on the chain.  With r = RN(1 / d) computed once per feature by a true division (load time, off the chain):
