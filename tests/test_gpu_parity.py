@@ -201,12 +201,13 @@ def test_tie_sentinels_fire_at_constructed_ties_and_only_there(ctx):
     assert r.edge_margin > 1e-9 and r.gap_margin > 1e-9
 
 
-def test_cd_zero_diagonal_and_zero_seed(ctx):
-    """Q[ii,ii] == 0 features are skipped but still consume a draw (_cd_fast.pyx:651); seed 0 -> 1."""
+@pytest.mark.parametrize("c", [64, 1032])
+def test_cd_zero_diagonal_and_zero_seed(ctx, c):
+    """Q[ii,ii] == 0 features are skipped but still consume a draw (_cd_fast.pyx:651); seed 0 -> 1.  (c = 1032: the multi-CU
+    team, three remote workgroups, the last one with eight columns.)"""
     import cp_oracle
-    c = 64
     Q, q, yty, M = _cd_problem(c)
-    dead = [3, 17, 40]
+    dead = [3, 17, 40] if c == 64 else [3, 511, 512, 1031]
     for d in dead:
         Q[d, :] = 0
         Q[:, d] = 0
@@ -224,10 +225,10 @@ def test_cd_zero_diagonal_and_zero_seed(ctx):
         assert np.all(w[dead] == 0)
 
 
-def test_cd_max_iter_and_l2(ctx):
-    """max_iter cap (for/else path) and a non-zero l2 term follow the oracle."""
+@pytest.mark.parametrize("c", [96, 1536])
+def test_cd_max_iter_and_l2(ctx, c):
+    """max_iter cap (for/else path) and a non-zero l2 term follow the oracle (c = 1536: in the multi-CU team)."""
     import cp_oracle
-    c = 96
     Q, q, yty, M = _cd_problem(c)
     Qd, qd = ctx.to_device(Q), ctx.to_device(q)
     sd = ctx.to_device(np.array([yty, 0, M, 0], dtype=np.float64))
