@@ -88,6 +88,32 @@ struct TeamLds {
     }
 };
 
+// No-op updates (measured, OFF by default).  sklearn skips the axpy of a coefficient that is zero (`if w_ii != 0`,
+// _cd_fast.pyx:656 / 675), so a coordinate that is zero before AND after its step leaves H untouched -- here its fma pair adds
+// (+-0) * Q: the same bits.  Skipping the pairs of such steps in every wave that applies published steps (CP_CD_SKIP_APPLY:
+// keepers, gatherers, the chain wave's catch-up) and not re-evaluating the block's remaining lanes after one
+// (CP_CD_SKIP_CHAIN) is exact and was expected to pay on sparse searches (35-40 % of the steps of the ResNet-50 searches move
+// nothing, 70 % in tools/cd_bench.py's problem).  It does not: the compiler if-converts the pairs anyway and the branches
+// around the re-evaluation cost more than the dependent chain they skip -- c = 512 226 -> 254 cycles per step with
+// CP_CD_SKIP_CHAIN, 295 with CP_CD_SKIP_APPLY, c = 2048 253 -> 270 / 300; ResNet-50 job 35.3 -> 38.6 ms with both.
+// The step is bound by its instruction count and the readlane round trips, not by the f64 chain alone.
+#ifndef CP_CD_SKIP_CHAIN   // the chain wave's own steps (and their re-evaluation)
+#define CP_CD_SKIP_CHAIN 0
+#endif
+#ifndef CP_CD_SKIP_APPLY   // keepers, gatherers and the chain wave's catch-up of the block before
+#define CP_CD_SKIP_APPLY 0
+#endif
+template <bool ON>
+__device__ __forceinline__ bool moves_t(double a) { return !ON || (uint64_t(__double_as_longlong(a)) << 1) != 0; }
+template <bool ON>
+__device__ __forceinline__ bool moves_t(double w_old, double w_new) {
+    return !ON || ((uint64_t(__double_as_longlong(w_old)) | uint64_t(__double_as_longlong(w_new))) << 1) != 0;
+}
+__device__ __forceinline__ bool moves_h(double a) { return moves_t<CP_CD_SKIP_APPLY != 0>(a); }
+__device__ __forceinline__ bool moves_h(double w_old, double w_new) { return moves_t<CP_CD_SKIP_APPLY != 0>(w_old, w_new); }
+__device__ __forceinline__ bool moves_c(double a) { return moves_t<CP_CD_SKIP_CHAIN != 0>(a); }
+__device__ __forceinline__ bool moves_c(double w_old, double w_new) { return moves_t<CP_CD_SKIP_CHAIN != 0>(w_old, w_new); }
+
 // wait until *p >= need (false if `stop` was raised or the bound ran out)
 __device__ __forceinline__ bool team_wait(int *p, int need, TeamCtl *ctl, bool watch_stop) {
     for (int spin = 0;; ++spin) {
@@ -375,12 +401,16 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
         for (int a = 0; a < B; ++a) {
             if (DELTA) {
                 const double d_a = pb[a];  // same address in every lane: LDS broadcast
+                if (moves_h(d_a)) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) H[r] = fma(d_a, S[a][r], H[r]);
+                    for (int r = 0; r < R; ++r) H[r] = fma(d_a, S[a][r], H[r]);
+                }
             } else {
                 const double wo_a = pb[2 * a], wn_a = pb[2 * a + 1];
+                if (moves_h(wo_a, wn_a)) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S[a][r], fma(-wo_a, S[a][r], H[r]));
+                    for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S[a][r], fma(-wo_a, S[a][r], H[r]));
+                }
             }
         }
         write_image(t + 1);
@@ -439,12 +469,16 @@ __device__ __forceinline__ void team_keeper(const double *__restrict__ Q, int ld
             for (int a = 0; a < B; ++a) {
                 if (DELTA) {
                     const double d_a = pb[a];
+                    if (moves_h(d_a)) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) H[r] = fma(d_a, S[a][r >> 1][r & 1], H[r]);
+                        for (int r = 0; r < R; ++r) H[r] = fma(d_a, S[a][r >> 1][r & 1], H[r]);
+                    }
                 } else {
                     const double wo_a = pb[2 * a], wn_a = pb[2 * a + 1];
+                    if (moves_h(wo_a, wn_a)) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S[a][r >> 1][r & 1], fma(-wo_a, S[a][r >> 1][r & 1], H[r]));
+                        for (int r = 0; r < R; ++r) H[r] = fma(wn_a, S[a][r >> 1][r & 1], fma(-wo_a, S[a][r >> 1][r & 1], H[r]));
+                    }
                 }
             }
 #ifdef CP_CD_TEAM_TRACE
@@ -762,10 +796,11 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         if (has_prev) {
 #pragma unroll
             for (int a = 0; a < B; ++a) {
-                if (DELTA)
-                    Hs_v = fma(dp0[a], S.qx[a], Hs_v);
-                else
-                    Hs_v = fma(dp1[a], S.qx[a], fma(-dp0[a], S.qx[a], Hs_v));
+                if (DELTA) {
+                    if (moves_h(dp0[a])) Hs_v = fma(dp0[a], S.qx[a], Hs_v);
+                } else {
+                    if (moves_h(dp0[a], dp1[a])) Hs_v = fma(dp1[a], S.qx[a], fma(-dp0[a], S.qx[a], Hs_v));
+                }
             }
         }
         double wo_v = pc.wo;
@@ -775,23 +810,27 @@ __device__ __forceinline__ void team_chain(const double *__restrict__ Q, int ldq
         double wn_keep = 0.0, p0_v = 0.0, p1_v = 0.0;  // what this lane publishes for its own step
         double d_v = big;                              // |tmp| - alpha of this lane's last evaluation
         if (!has_dup) {
-            double wn_v = 0.0;
+            // every lane evaluates "its" update against its private H; lane la's is the one that counts at step a, lanes
+            // before it reproduce their final value (their couplings to this and later steps read 0).  (With CP_CD_SKIP_CHAIN
+            // the evaluation is repeated only after a step that moved H; by default `moved` is constant true.)
+            double wn_v = soft_step(bt, wo_v, Hs_v, d_v);
 #pragma unroll
             for (int a = 0; a < B; ++a) {
                 const int la = base + a;
-                // every lane evaluates "its" update against its private H; lane la's is the one that counts now, lanes
-                // before it reproduce their final value (their couplings to this and later steps read 0)
-                wn_v = soft_step(bt, wo_v, Hs_v, d_v);
+                bool moved;
                 if (DELTA) {
                     const double d_a = read_lane(wn_v - wo_v, la);
                     dp0[a] = d_a;
-                    Hs_v = fma(d_a, S.qc[a], Hs_v);
+                    moved = moves_c(d_a);
+                    if (moved) Hs_v = fma(d_a, S.qc[a], Hs_v);
                 } else {
                     const double wo_a = read_lane(wo_v, la), wn_a = read_lane(wn_v, la);
                     dp0[a] = wo_a;
                     dp1[a] = wn_a;
-                    Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
+                    moved = moves_c(wo_a, wn_a);
+                    if (moved) Hs_v = fma(wn_a, S.qc[a], fma(-wo_a, S.qc[a], Hs_v));
                 }
+                if (moved && a + 1 < B) wn_v = soft_step(bt, wo_v, Hs_v, d_v);
                 if (a == PF) {
                     CP_TTRACE(5, !MULTI && t == TTRACE_BLOCK + 1);
                     prefetch(pn, nb, t + 1);
@@ -1226,13 +1265,15 @@ __device__ __forceinline__ void multi_gatherer(HomeLds &L, const MultiBox *box, 
                 d[a + 1] = t2.y;
             }
 #pragma unroll
-            for (int a = 0; a < B; ++a) Hs = fma(d[a], qx[a], Hs);
+            for (int a = 0; a < B; ++a)
+                if (moves_h(d[a])) Hs = fma(d[a], qx[a], Hs);
         } else {
             double2 p[B];
 #pragma unroll
             for (int a = 0; a < B; ++a) p[a] = *reinterpret_cast<const double2 *>(pb + 2 * a);   // (w_old, w_new) of step a
 #pragma unroll
-            for (int a = 0; a < B; ++a) Hs = fma(p[a].y, qx[a], fma(-p[a].x, qx[a], Hs));
+            for (int a = 0; a < B; ++a)
+                if (moves_h(p[a].x, p[a].y)) Hs = fma(p[a].y, qx[a], fma(-p[a].x, qx[a], Hs));
         }
     };
     auto couplings = [&](int v, int l, double (&qx)[B]) {
@@ -1289,10 +1330,12 @@ __device__ __forceinline__ void multi_gatherer(HomeLds &L, const MultiBox *box, 
                     if (l0 - o < 3) continue;
 #pragma unroll
                     for (int a = 0; a < B; ++a) {
-                        if (DELTA)
-                            Hs = fma(po[o][a], qo[o][a], Hs);
-                        else
-                            Hs = fma(po[o][2 * a + 1], qo[o][a], fma(-po[o][2 * a], qo[o][a], Hs));
+                        if (DELTA) {
+                            if (moves_h(po[o][a])) Hs = fma(po[o][a], qo[o][a], Hs);
+                        } else {
+                            if (moves_h(po[o][2 * a], po[o][2 * a + 1]))
+                                Hs = fma(po[o][2 * a + 1], qo[o][a], fma(-po[o][2 * a], qo[o][a], Hs));
+                        }
                     }
                 }
             }
