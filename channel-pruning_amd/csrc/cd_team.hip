@@ -1147,11 +1147,11 @@ __global__ void __launch_bounds__(64 * (K + 2)) k_cd_search_team(CdSearchBatch b
 // 428 with every row resident in L2).  Here the columns of H are cut in slices of 512, one REMOTE workgroup (receiver wave,
 // extractor wave, two keeper waves) per slice, each on its own CU, and the HOME workgroup keeps only the serial part:
 //   chain wave     team_chain<MULTI>: as in the one-workgroup team, but a block's starting H values come from L.hn;
-//   stager wave    the index stream, the batches and the couplings Q[ii_a, ii_j] of a block with itself and with the XLAG
-//                  blocks before it (keeper 0's side duties in the one-workgroup team);
+//   stager wave    team_stager: the index stream, the batches and the couplings Q[ii_a, ii_j] of a block with itself and with
+//                  the XLAG blocks before it;
 //   forwarder wave copies what the chain wave publishes per block into the remotes' delta rings;
-//   gatherer wave  collects the remotes' H values of a block's eight coordinates and brings them up to date with the blocks
-//                  the remotes had not seen.
+//   gatherer waves (three, taking the blocks in turn) collect the remotes' H values of a block's eight coordinates and bring
+//                  them up to date with the blocks the remotes had not seen.
 // The workgroups talk through global memory (MultiBox; ~630 ns per round trip inside an XCD, 850-1100 ns across XCDs:
 // tools/probes/xwg_pingpong.hip), far more than the ~0.9 us a block takes.  So the remotes run XLAG blocks behind: the value
 // a remote posts for block v is H[ii_j(v)] after blocks < v - XLAG (image v - XLAG), the gatherer applies blocks
