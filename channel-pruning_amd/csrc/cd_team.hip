@@ -1245,7 +1245,8 @@ __device__ __forceinline__ void multi_forwarder(HomeLds &L, const MultiBox *box)
 // block v: collect every remote's record (lane = 8 g + j), take each coordinate's value from its owner, apply the blocks
 // v - XLAG .. v - 2 the remotes had not seen, publish.  The chain wave applies block v - 1 itself.  One pass costs more than
 // a block of the chain wave (~1000 cycles per block applied), so XGW waves take the blocks in turn; the last block applied,
-// v - 2, completes ~1.6 blocks before the values are needed, everything before it is history by then.
+// v - 2, completes about 0.6 of a block before the chain wave's prefetch asks for the values (1.6 before block v starts):
+// its couplings are read before the wait, its values right after.
 template <bool DELTA>
 __device__ __forceinline__ void multi_gatherer(HomeLds &L, const MultiBox *box, int w) {
     const int lane = threadIdx.x & 63, j = lane & 7, G = box->G;
@@ -1305,7 +1306,7 @@ __device__ __forceinline__ void multi_gatherer(HomeLds &L, const MultiBox *box, 
         const int owner = int(idx_of(8 * v + j)) / XSLICE;
         Hs = __shfl(__longlong_as_double((long long)mine), owner * 8 + j, WAVE);
         double qx[B];
-        if (!team_wait(&ctl->seqA, v - 2, ctl, true)) break;   // blocks <= v - 3: complete long ago, a formality
+        if (!team_wait(&ctl->seqA, v - 2, ctl, true)) break;   // blocks <= v - 3 complete (v - 3 about a block ago)
         if (v >= XLAG) {   // steady state: the operands of (up to) three old blocks at a time, then their chain of fma
             constexpr int CH = 3;
 #pragma unroll
