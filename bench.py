@@ -399,7 +399,10 @@ def bench_job(args, env, job):
         per_layer[spec["name"]] = {"ms_alone": round(min(ts), 3), "kept": int(pr.refit_info.p) // kk, "fits": len(pr.fits),
                                    "cd_steps": int(steps_cd), "alpha_search_ms": round(st.get("cd_alpha_search", 0.0), 3),
                                    "cd_us_per_step": round(st.get("cd_alpha_search", 0.0) * 1e3 / max(1, steps_cd), 4),
-                                   "refit_ms": round(sum(v for k_, v in st.items() if k_.startswith("refit")), 3)}
+                                   "refit_ms": round(sum(v for k_, v in st.items() if k_.startswith("refit")), 3),
+                                   # which coordinate-descent kernel the width runs (include/cpmi355.h: CP_CD_FORM_*)
+                                   "cd_kernel": ("one wave", "two waves", "team (one workgroup)", "multi-CU team")[
+                                       pr.ctx.cd_kernel_form(spec["c"], CD_FLAGS)]}
         stage_by_c.setdefault("c%d_k%d_n%d" % (spec["c"], spec["k"], spec["n"]), st)
         if "refit_gram_gemm" in st:
             alone_g_ms.append(st["refit_gram_gemm"])
