@@ -140,9 +140,14 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     __shared__ __attribute__((aligned(16))) double Bs2[2][BK * TLD];
 
     const int tid = threadIdx.x;
+    // Persistent form: a launch may carry fewer workgroups than tiles (gridDim.x a multiple of 8, so that a workgroup's
+    // virtual ids L keep its XCD); every workgroup then walks the tile list with stride gridDim.x.  A launch whose
+    // workgroups are all resident leaves nothing queued in the dispatcher behind which other streams' kernels would wait.
+    const int total_blocks = n_tiles * splits;
+    for (int L = blockIdx.x; L < total_blocks; L += gridDim.x) {
     int tile, z;
     if (splits > 1) {  // XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs
-        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int xcd = L & 7, slot = L >> 3;
         z = xcd + 8 * (slot / n_tiles);
         tile = slot % n_tiles;
     } else if (n_tiles >= 64) {
@@ -150,12 +155,12 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         // super-tile ordered list (decode_tile_blocked): the workgroups resident on an XCD at any time then cover about one
         // 8 x 8 block of tiles and share its 16 operand panels in that L2 (PMC: the p = 4250 refit Gram fetched 2.8 GB for
         // 0.31 GB of operands with the plain order, 2.4 GB with bands of tile rows per XCD).
-        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int xcd = L & 7, slot = L >> 3;
         const int base = n_tiles >> 3, rem = n_tiles & 7;
         tile = xcd * base + (xcd < rem ? xcd : rem) + slot;
         z = 0;
     } else {
-        tile = blockIdx.x;
+        tile = L;
         z = 0;
     }
     int ti, tj;
@@ -290,6 +295,7 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
                     *c = v;
                 }
     }
+    }   // persistent tile loop
 }
 
 // Fixed-order reduction of the split-K partials: C = alpha * sum_z P[z] + beta * C.  One
@@ -451,7 +457,12 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
         P = cp_arena_take_t<double>(ctx, size_t(p.splits) * M * N);
         if (!P) return cp_set_error(ctx, CP_ERR_NOMEM, "gemm_tn: arena exhausted (split-K partials)");
     }
-    const dim3 grid(p.n_tiles * p.splits, second ? 2 : 1);
+    // CP_GEMM_GRID_CAP (experiment; 0 = one workgroup per tile): at most that many workgroups per launch, the rest of
+    // the tile list walked by the resident ones
+    static const int grid_cap = getenv("CP_GEMM_GRID_CAP") ? atoi(getenv("CP_GEMM_GRID_CAP")) / 8 * 8 : 0;
+    int gx = p.n_tiles * p.splits;
+    if (grid_cap >= 8 && gx > grid_cap && !in_place) gx = grid_cap;
+    const dim3 grid(gx, second ? 2 : 1);
     const GemmSecond sec = second ? *second : GemmSecond{nullptr, nullptr, nullptr, 0};
 #define CP_GEMM_LAUNCH(T, G)                                                                                  \
     do {                                                                                                      \
