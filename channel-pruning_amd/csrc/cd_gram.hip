@@ -1482,10 +1482,22 @@ static hipError_t cd_lds_optin(K kernel, size_t lds) {
 // team form (cd_team.hip): chain wave + K keeper waves; c % 8 == 0, c <= 2048, flags 0 or 3
 bool cp_cd_team_wanted(int c, int flags);
 int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c, double l1_reg,
-                          double l2_reg, uint32_t seed, int max_iter, double tol, int flags, double *w, void *dres);
-int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c);
+                          double l2_reg, uint32_t seed, int max_iter, double tol, int flags, double *w, void *dres,
+                          bool allow_multi);
+int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c, bool allow_multi);
+bool cp_cd_multi_wanted(int c);
 extern "C" int cp_debug_cd_team_cycles(cp_ctx *ctx, unsigned long long *out8);
-static bool g_last_cd_was_team = false;
+// Which kernel family a context's last launch ran lives in the context (cp_ctx::last_cd_was_team): resident layer sets drive
+// these entry points from several threads at once.  The cycle counters behind cp_debug_cd_cycles are device globals shared by
+// all launches: they are only meaningful for single-stream use (tools/cd_bench.py).
+
+// a fit of the log reported a hand-off time-out between the waves / workgroups of a team (n_iter = -1)
+static int first_timed_out_fit(const DevResult *lg, int fits_used, int max_fits) {
+    const int nfit = std::min(max_fits, fits_used < 0 ? -fits_used : fits_used);
+    for (int f = 0; f < nfit; ++f)
+        if (lg[f].n_iter < 0) return f;
+    return -1;
+}
 
 #define CP_CD_DISPATCH(KERNEL, R_, ...)                                      \
     switch (R_) {                                                            \
@@ -1534,25 +1546,33 @@ extern "C" int cp_enet_cd_gram(cp_ctx *ctx, const double *Q, int ldq, const doub
     if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    g_last_cd_was_team = cp_cd_team_wanted(c, flags);
-    if (g_last_cd_was_team) {
-        CP_TRY(cp_cd_team_fit_launch(ctx, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres));
-    } else if (duo) {
-        CP_CD_DISPATCH_DUO(k_cd_fit_duo, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
-    } else {
-        CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
-    }
-    CP_LAUNCH_CHECK(ctx);
-    cp_stage_mark(ctx, "cd_fit");
+    ctx->last_cd_was_team = cp_cd_team_wanted(c, flags);
     static_assert(sizeof(DevResult) == sizeof(cp_cd_result), "layout");
     CP_TRY(cp_pinned_reserve(ctx, 4096));
-    CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dres, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
-    CP_HIP(ctx, cp_stream_wait(ctx));
-    memcpy(result, ctx->pinned, sizeof(cp_cd_result));
-    if (result->n_iter < 0)
-        return cp_set_error(ctx, CP_ERR_NUMERIC, "cd: a hand-off between the waves / workgroups of the coordinate-descent team timed out "
-                            "(CP_CD_MULTI=0 / CP_CD_TEAM=0 run the simpler kernels)");
-    return CP_OK;
+    // The multi-CU team (c > 512) depends on its 1 + G workgroups being resident together and talks through global memory
+    // with bounded waits.  Should a hand-off time out (n_iter = -1; the kernel then leaves w untouched), the fit is re-run
+    // by the one-workgroup team: the same arithmetic in the same order (bit-identical w), only slower.
+    const bool may_fall_back = ctx->last_cd_was_team && cp_cd_multi_wanted(c);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool multi = attempt == 0;
+        if (ctx->last_cd_was_team) {
+            CP_TRY(cp_cd_team_fit_launch(ctx, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres, multi));
+        } else if (duo) {
+            CP_CD_DISPATCH_DUO(k_cd_fit_duo, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
+        } else {
+            CP_CD_DISPATCH(k_cd_fit, R, Q, ldq, q, stats, c, l1_reg, l2_reg, seed, max_iter, tol, flags, w, dres);
+        }
+        CP_LAUNCH_CHECK(ctx);
+        cp_stage_mark(ctx, "cd_fit");
+        CP_HIP(ctx, hipMemcpyAsync(ctx->pinned, dres, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
+        CP_HIP(ctx, cp_stream_wait(ctx));
+        memcpy(result, ctx->pinned, sizeof(cp_cd_result));
+        if (result->n_iter >= 0) return CP_OK;
+        if (!(may_fall_back && multi)) break;
+        ++ctx->cd_fallbacks;
+    }
+    return cp_set_error(ctx, CP_ERR_NUMERIC, "cd: a hand-off between the waves of the coordinate-descent team timed out "
+                        "(CP_CD_TEAM=0 runs the one- / two-wave kernels)");
 }
 
 bool cp_cd_multi_wanted(int c);
@@ -1564,7 +1584,7 @@ extern "C" int cp_cd_kernel_form(int c, int flags) {
 
 extern "C" int cp_debug_cd_cycles(cp_ctx *ctx, unsigned long long *out2) {
     if (!ctx || !out2) return CP_ERR_ARG;
-    if (g_last_cd_was_team) return cp_debug_cd_team_cycles(ctx, out2);
+    if (ctx->last_cd_was_team) return cp_debug_cd_team_cycles(ctx, out2);
     CP_HIP(ctx, cp_stream_wait(ctx));
     CP_HIP(ctx, hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_cd_debug), 8 * sizeof(unsigned long long)));
     return CP_OK;
@@ -1597,43 +1617,53 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    g_last_cd_was_team = cp_cd_team_wanted(c, flags);
-    if (g_last_cd_was_team) {
-        CdSearchBatch batch;
-        memset(&batch, 0, sizeof(batch));
-        CdSearchArgs &a = batch.a[0];
-        a.Q = Q; a.ldq = ldq; a.q = q; a.stats = stats; a.c = c; a.M = M; a.right0 = alpha_right0; a.rank = rank;
-        a.lbound = lbound; a.rbound = rbound; a.seeds = reinterpret_cast<const uint32_t *>(h + off_seed);
-        a.max_fits = max_fits; a.max_iter = max_iter; a.tol = tol; a.flags = flags; a.w = w;
-        a.w_host = reinterpret_cast<double *>(h + off_w); a.log = reinterpret_cast<DevResult *>(h + off_log);
-        a.log_alpha = reinterpret_cast<double *>(h + off_al); a.fits_used = hfits; a.alpha_out = halpha;
-        CP_TRY(cp_cd_team_search_launch(ctx, &batch, 1, c));
-    } else if (duo) {
-        CP_CD_DISPATCH_DUO(k_cd_search_duo, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
+    ctx->last_cd_was_team = cp_cd_team_wanted(c, flags);
+    // A search always starts from w = 0 inside the kernel, so a search whose multi-CU team reported a hand-off time-out
+    // (n_iter = -1 in its log) is simply run again by the one-workgroup team: bit-identical fits, only slower.
+    const bool may_fall_back = ctx->last_cd_was_team && cp_cd_multi_wanted(c);
+    const DevResult *lg = reinterpret_cast<const DevResult *>(h + off_log);
+    int timed_out_fit = -1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        *hfits = 0;
+        if (ctx->last_cd_was_team) {
+            CdSearchBatch batch;
+            memset(&batch, 0, sizeof(batch));
+            CdSearchArgs &a = batch.a[0];
+            a.Q = Q; a.ldq = ldq; a.q = q; a.stats = stats; a.c = c; a.M = M; a.right0 = alpha_right0; a.rank = rank;
+            a.lbound = lbound; a.rbound = rbound; a.seeds = reinterpret_cast<const uint32_t *>(h + off_seed);
+            a.max_fits = max_fits; a.max_iter = max_iter; a.tol = tol; a.flags = flags; a.w = w;
+            a.w_host = reinterpret_cast<double *>(h + off_w); a.log = reinterpret_cast<DevResult *>(h + off_log);
+            a.log_alpha = reinterpret_cast<double *>(h + off_al); a.fits_used = hfits; a.alpha_out = halpha;
+            CP_TRY(cp_cd_team_search_launch(ctx, &batch, 1, c, attempt == 0));
+        } else if (duo) {
+            CP_CD_DISPATCH_DUO(k_cd_search_duo, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
+                               reinterpret_cast<const uint32_t *>(h + off_seed), max_fits, max_iter, tol, flags, w,
+                               reinterpret_cast<double *>(h + off_w), reinterpret_cast<DevResult *>(h + off_log),
+                               reinterpret_cast<double *>(h + off_al), hfits, halpha);
+        } else {
+            CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
                            reinterpret_cast<const uint32_t *>(h + off_seed), max_fits, max_iter, tol, flags, w,
                            reinterpret_cast<double *>(h + off_w), reinterpret_cast<DevResult *>(h + off_log),
                            reinterpret_cast<double *>(h + off_al), hfits, halpha);
-    } else {
-        CP_CD_DISPATCH(k_cd_search, R, Q, ldq, q, stats, c, M, alpha_right0, rank, lbound, rbound,
-                       reinterpret_cast<const uint32_t *>(h + off_seed), max_fits, max_iter, tol, flags, w,
-                       reinterpret_cast<double *>(h + off_w), reinterpret_cast<DevResult *>(h + off_log),
-                       reinterpret_cast<double *>(h + off_al), hfits, halpha);
+        }
+        CP_LAUNCH_CHECK(ctx);
+        cp_stage_mark(ctx, "cd_alpha_search");
+        CP_HIP(ctx, cp_stream_wait(ctx));
+        timed_out_fit = first_timed_out_fit(lg, *hfits, max_fits);
+        if (timed_out_fit < 0 || !(may_fall_back && attempt == 0)) break;
+        ++ctx->cd_fallbacks;
     }
-    CP_LAUNCH_CHECK(ctx);
-    cp_stage_mark(ctx, "cd_alpha_search");
-    CP_HIP(ctx, cp_stream_wait(ctx));
     ctx->pinned_w = reinterpret_cast<const double *>(h + off_w);
     memcpy(fits_used, hfits, sizeof(int));
     memcpy(alpha_out, halpha, sizeof(double));
     if (fit_log) memcpy(fit_log, h + off_log, log_bytes);
     if (fit_alpha) memcpy(fit_alpha, h + off_al, al_bytes);
-    if (*fits_used < 0) {
-        const DevResult *lg = reinterpret_cast<const DevResult *>(h + off_log);
-        if (-*fits_used <= max_fits && lg[-*fits_used - 1].n_iter < 0)
-            return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search: a hand-off between the workgroups of the coordinate-descent team "
-                                "timed out in fit %d (CP_CD_MULTI=0 runs the one-workgroup kernels)", -*fits_used - 1);
-        return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search did not terminate within %d fits", max_fits);
+    if (timed_out_fit >= 0) {   // whatever the sign of fits_used: a fit that ran on stale data voids the search
+        if (*fits_used > 0) *fits_used = -*fits_used;
+        return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search: a hand-off between the waves of the coordinate-descent team timed "
+                            "out in fit %d (CP_CD_TEAM=0 runs the one- / two-wave kernels)", timed_out_fit);
     }
+    if (*fits_used < 0) return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search did not terminate within %d fits", max_fits);
     return CP_OK;
 }
 
@@ -1653,7 +1683,7 @@ struct SearchPinned {  // lay-out of the pinned block the search kernel reads it
 };
 }  // namespace
 
-int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_search_job *jobs) {
+int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_search_job *jobs, bool allow_multi) {
     if (!ctxs || !jobs || n_jobs <= 0 || n_jobs > CP_CD_MAX_BATCH) return CP_ERR_ARG;
     cp_ctx *ctx = ctxs[0];
     const int c = jobs[0].c;
@@ -1688,10 +1718,11 @@ int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_sear
     if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
-    g_last_cd_was_team = cp_cd_team_wanted(c, jobs[0].flags);
-    for (int l = 1; l < n_jobs; ++l) g_last_cd_was_team = g_last_cd_was_team && jobs[l].flags == jobs[0].flags;
-    if (g_last_cd_was_team) {
-        CP_TRY(cp_cd_team_search_launch(ctx, &batch, n_jobs, c));
+    bool team = cp_cd_team_wanted(c, jobs[0].flags);
+    for (int l = 1; l < n_jobs; ++l) team = team && jobs[l].flags == jobs[0].flags;
+    for (int l = 0; l < n_jobs; ++l) ctxs[l]->last_cd_was_team = team;
+    if (team) {
+        CP_TRY(cp_cd_team_search_launch(ctx, &batch, n_jobs, c, allow_multi));
     } else if (duo) {
         switch (R) {
             case 1: k_cd_search_duo_batch<1><<<n_jobs, 2 * WAVE, lds, ctx->stream>>>(batch); break;
@@ -1721,19 +1752,28 @@ int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_sear
 }
 
 int cp_alpha_search_collect(cp_ctx *ctx, int c, int max_fits, int *fits_used, double *alpha_out, cp_cd_result *fit_log,
-                            double *fit_alpha) {
+                            double *fit_alpha, bool *timed_out) {
     const SearchPinned lay(max_fits, c);
     const char *h = ctx->pinned;
     memcpy(fits_used, h, sizeof(int));
     memcpy(alpha_out, h + 64, sizeof(double));
     if (fit_log) memcpy(fit_log, h + lay.off_log, size_t(max_fits) * sizeof(DevResult));
     if (fit_alpha) memcpy(fit_alpha, h + lay.off_al, size_t(max_fits) * sizeof(double));
-    if (*fits_used < 0) {
-        const DevResult *lg = reinterpret_cast<const DevResult *>(h + lay.off_log);
-        if (-*fits_used <= max_fits && lg[-*fits_used - 1].n_iter < 0)
-            return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search: a hand-off between the workgroups of the coordinate-descent team "
-                                "timed out in fit %d (CP_CD_MULTI=0 runs the one-workgroup kernels)", -*fits_used - 1);
-        return CP_ERR_NUMERIC;
+    const int bad = first_timed_out_fit(reinterpret_cast<const DevResult *>(h + lay.off_log), *fits_used, max_fits);
+    if (timed_out) *timed_out = bad >= 0;
+    if (bad >= 0) {   // whatever the sign of fits_used: a fit that ran on stale data voids the search
+        if (*fits_used > 0) *fits_used = -*fits_used;
+        return cp_set_error(ctx, CP_ERR_NUMERIC, "alpha search: a hand-off between the waves / workgroups of the coordinate-descent "
+                            "team timed out in fit %d", bad);
     }
+    if (*fits_used < 0) return CP_ERR_NUMERIC;
     return CP_OK;
 }
+
+extern "C" int cp_debug_cd_fail_multi(cp_ctx *ctx, int on) {
+    if (!ctx) return CP_ERR_ARG;
+    ctx->cd_test_fail_multi = on != 0;
+    return CP_OK;
+}
+
+extern "C" int cp_debug_cd_fallbacks(cp_ctx *ctx) { return ctx ? ctx->cd_fallbacks : -1; }

@@ -1111,6 +1111,7 @@ __global__ void __launch_bounds__(64 * (K + 2)) k_cd_search_team(CdSearchBatch b
             a.log_alpha[fit] = alpha;
         }
         ++fit;
+        if (o.n_iter < 0) break;   // a hand-off between the waves failed: w and H are stale; reported through the log (n_iter = -1)
         const double tmp = double(o.nnz);
         if (bracketing) {  // decompose.py:502-515
             if (tmp < a.rank)
@@ -1466,17 +1467,30 @@ __device__ __forceinline__ void multi_remote(const double *__restrict__ Q, int l
     if (threadIdx.x == 0) xst(box->ctl + 4 * G + 1 + g, 1ull);   // resident from here to the end of the search
     for (int fit = 0;; ++fit) {
         if (threadIdx.x == 0) {
+            // The home workgroup posts fit 0 only after EVERY remote of the search has reported in (multi_wait_resident,
+            // ~20 s of patience): a sibling may get its CU much later than this one on a busy chip.  So this wait is as
+            // patient as that one, and a remote that does give up says so (abort flag) instead of leaving silently --
+            // the home workgroup would otherwise post fits to a workgroup that is gone and burn a full time-out per wait.
             int go = -1;
-            for (int spin = 0; spin < XSPIN; ++spin) {
+            bool gave_up = true;
+            for (long spin = 0; spin < (10l << 20); ++spin) {
                 const unsigned long long v = xld(box->ctl + g);
-                if (v == EXITV) break;
-                if (v >= (unsigned long long)(fit + 1)) {
-                    go = 1;
+                if (v == EXITV) {
+                    gave_up = false;
                     break;
                 }
-                if (spin % 64 == 63 && multi_aborted(box)) break;
-                __builtin_amdgcn_s_sleep(8);
+                if (v >= (unsigned long long)(fit + 1)) {
+                    go = 1;
+                    gave_up = false;
+                    break;
+                }
+                if (spin % 64 == 63 && multi_aborted(box)) {
+                    gave_up = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(64);
             }
+            if (gave_up) multi_abort(box, L.ctl);
             L.ctl->nnz = go;
         }
         __syncthreads();
@@ -1619,6 +1633,7 @@ struct MultiLaunch {
     size_t words;
     int G, n_jobs, same_xcd;
     int xcd0;                   // same_xcd: job l lives on XCD (xcd0 + l) % 8 (rotated from launch to launch)
+    int test_abort;             // cp_debug_cd_fail_multi: the home workgroup gives up before its first fit (tests of the fallback)
 };
 // workgroup -> (job, role): role 0 = home, 1 + g = remote g.  same_xcd: workgroup L of a launch lands on XCD L % 8 (observed,
 // not promised: only the hand-off latency depends on it), so a job's 1 + G workgroups take ids that are 8 apart
@@ -1657,6 +1672,10 @@ __global__ void __launch_bounds__(64 * XWAVES) k_cd_fit_multi(const double *__re
     L.bind(smem + 5 * c, cpad);
     team_load_features(Q, ldq, q, w, c, l2, flags, w_lds, feat, L);
     multi_wait_resident(&box, L.ctl);
+    if (ml.test_abort) {
+        if (threadIdx.x == 0) multi_abort(&box, L.ctl);
+        __syncthreads();
+    }
     const double y_norm2 = stats[0];
     const double tol_scaled = tol * y_norm2;
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -1667,7 +1686,8 @@ __global__ void __launch_bounds__(64 * XWAVES) k_cd_fit_multi(const double *__re
         g_team_debug[0] = t1 - t0;
         g_team_debug[1] = (unsigned long long)(o.n_iter > 0 ? o.n_iter : 0) * (unsigned long long)c;
     }
-    for (int j = threadIdx.x; j < c; j += blockDim.x) w[j] = w_lds[j];
+    if (o.n_iter >= 0)   // a failed hand-off leaves the caller's warm start as it was: the host re-runs the fit on one workgroup
+        for (int j = threadIdx.x; j < c; j += blockDim.x) w[j] = w_lds[j];
     if (threadIdx.x == 0) {
         res->gap = o.gap;
         res->tol_scaled = tol_scaled;
@@ -1699,6 +1719,10 @@ __global__ void __launch_bounds__(64 * XWAVES) k_cd_search_multi(CdSearchBatch b
     L.bind(smem + 5 * c, cpad);
     team_load_features(a.Q, a.ldq, a.q, nullptr, c, 0.0, a.flags, w_lds, feat, L);
     multi_wait_resident(&box, L.ctl);
+    if (ml.test_abort) {
+        if (threadIdx.x == 0) multi_abort(&box, L.ctl);
+        __syncthreads();
+    }
     const double y_norm2 = a.stats[0];
     const double tol_scaled = a.tol * y_norm2;
     int fit = 0;
@@ -1823,6 +1847,7 @@ static size_t multi_lds_bytes(int c) {
 }
 static int multi_prepare(cp_ctx *ctx, int c, int n_jobs, MultiLaunch &ml) {
     static const int same_xcd = env_int("CP_CD_MULTI_SAME_XCD", 1);
+    ml.test_abort = ctx->cd_test_fail_multi ? 1 : 0;
     ml.G = multi_groups(c);
     ml.n_jobs = n_jobs;
     ml.same_xcd = same_xcd;
@@ -1849,9 +1874,10 @@ static int multi_prepare(cp_ctx *ctx, int c, int n_jobs, MultiLaunch &ml) {
 bool cp_cd_multi_wanted(int c) { return multi_wanted(c); }
 
 int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q, const double *stats, int c, double l1_reg,
-                          double l2_reg, uint32_t seed, int max_iter, double tol, int flags, double *w, void *dres) {
+                          double l2_reg, uint32_t seed, int max_iter, double tol, int flags, double *w, void *dres,
+                          bool allow_multi) {
     const int ex = team_exact_div();
-    if (multi_wanted(c)) {
+    if (allow_multi && multi_wanted(c)) {
         MultiLaunch ml;
         CP_TRY(multi_prepare(ctx, c, 1, ml));
         const size_t mlds = multi_lds_bytes(c);
@@ -1872,7 +1898,7 @@ int cp_cd_team_fit_launch(cp_ctx *ctx, const double *Q, int ldq, const double *q
     return CP_OK;
 }
 
-int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) {
+int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c, bool allow_multi) {
     // CP_CD_EXCLUSIVE (default 1): the workgroup asks for (almost) a whole CU's LDS, so that no other workgroup shares its
     // CU -- next to the products of other layers (or of its own layer's side stream) the chain and keeper waves otherwise
     // share their SIMDs' issue slots with MFMA-heavy waves: c = 512 search 10.5 -> 8.9 ms in a single-layer call, vgg16
@@ -1880,7 +1906,7 @@ int cp_cd_team_search_launch(cp_ctx *ctx, const void *batch, int n_jobs, int c) 
     // wave priority (both measured without effect on the job: 33.6 / 33.7 ms; left as switches).
     static const int spread_on = env_int("CP_CD_SPREAD", 0), prio = env_int("CP_CD_PRIO", 0),
                      exclusive = env_int("CP_CD_EXCLUSIVE", 1);
-    if (multi_wanted(c)) {
+    if (allow_multi && multi_wanted(c)) {
         MultiLaunch ml;
         CP_TRY(multi_prepare(ctx, c, n_jobs, ml));
         const size_t mlds = multi_lds_bytes(c);

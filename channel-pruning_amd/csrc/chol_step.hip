@@ -1,0 +1,465 @@
+// Blocked Cholesky G = U^T U (upper factor, 128-blocks) as ONE launch per block step, the trailing update applied lazily.
+//
+// Why one launch per step.  On a chip that is busy with other layers' products every kernel of a dependent chain waits
+// for its dispatch whatever its size: a side-car probe next to the vgg16 job (tools/ubench/sidecar.hip,
+// profiles/r04_sidecar_next_to_vgg16_job.md) times launch -> completion of a ONE-workgroup kernel at 70-100 us median and
+// 350-570 us at the 90th percentile (18 us on an idle chip) -- the same for 64 threads without LDS and for 512 threads with
+// 158 KB of it.  The chain's cost there is its launch count, so the two launches per block step of rounds 1-3 (diagonal
+// block + panel, then the trailing update as a GEMM) become one, and that launch overlaps the one serial piece of a step
+// (the 128 x 128 factorisation in one workgroup) with the chip-filling part of the previous step:
+//
+//   launch s, one workgroup per upper tile (i, j), s <= i <= j < nblk, row s first:
+//     every tile   S = G[i,j] - U[s-1,i]^T U[s-1,j]         the update of step s - 1, applied only now (K = 128, MFMA)
+//     (s, s)       S = U_ss^T U_ss in LDS, T_q = (16 x 16 diagonal blocks)^-1, flag          -> U[s,s], P[s]
+//     (s, j > s)   wait for the flag, U[s,j] = U_ss^-T S by block forward substitution          -> U[s,j], Lt[j,s]
+//     (i > s, j)   G[i,j] = S
+//
+// A workgroup of row s waits only for workgroup 0 of its own launch, which the dispatcher starts first; the tiles below row s
+// wait for nothing, so the factorisation of block s runs while the rest of the chip applies update s - 1.
+//
+// P[s] ("the operator of block s", 36 blocks of 16 x 16, row-major upper triangle of the 8 x 8 block grid): the strictly
+// upper blocks of U_ss and, in the diagonal slots, T_q = U_qq^-1.  It is what a panel workgroup needs for the substitution
+// (no 128 x 128 inverse on the chain) and what k_chol_block_inverse turns into TI_s = U_ss^-1 / TIT_s for the substitution
+// kernels of refit.hip after the last step; it lives in the first 9216 doubles of TI_s until then.
+//
+// LDS: 75,776 B per workgroup (operand chunks of the update / the packed upper triangle of the tile), 512 threads, up to 256
+// VGPRs (the in-register 16 x 16 factorisation of the diagonal role spills at 128; the chain, not the tiles below the block
+// row, bounds a step: (nblk - s)^2 / 2 tiles of 22 us each on 256 CUs against 80+ us of update + factorisation + panel).
+#include "cp_common.h"
+
+#include <mutex>
+
+typedef double v4f64s __attribute__((ext_vector_type(4)));
+typedef double v2f64s __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int NB = 128, PNB = 16, NPAN = NB / PNB, PT = 512;
+constexpr int KCH = 16;                      // k-rows of an operand chunk staged through LDS (two double2 per thread and operand)
+constexpr int SLD = NB + 16;                 // padded chunk row: the two k-rows a 32-lane half reads fall on disjoint bank halves
+constexpr int PACK = 36 * PNB * PNB;         // packed upper triangle of a 128 x 128 tile in 16 x 16 blocks
+constexpr int LDS_DOUBLES = PACK + 2 * NB;   // + dinv[128] + dref[128]
+static_assert(2 * KCH * SLD <= PACK, "the operand chunks and the packed tile share the same LDS");
+
+// slot of block (bi, bj), bi <= bj, in the packed upper triangle (row-major)
+__device__ __forceinline__ constexpr int pk(int bi, int bj) { return bi * NPAN - bi * (bi - 1) / 2 + (bj - bi); }
+// element (r, c) of the tile, block row <= block column
+#define CP_PK(r, c) sm[pk((r) >> 4, (c) >> 4) * 256 + ((r) & 15) * 16 + ((c) & 15)]
+
+template <int I>
+__device__ __forceinline__ double row_bcast(double v) {   // value of lane 16 (l / 16) + I for every lane l (DPP row broadcast)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + I, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + I, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_bcast_i(double v, int i) {  // i: constant after unrolling
+    switch (i) {
+        case 0: return row_bcast<0>(v);
+        case 1: return row_bcast<1>(v);
+        case 2: return row_bcast<2>(v);
+        case 3: return row_bcast<3>(v);
+        case 4: return row_bcast<4>(v);
+        case 5: return row_bcast<5>(v);
+        case 6: return row_bcast<6>(v);
+        case 7: return row_bcast<7>(v);
+        case 8: return row_bcast<8>(v);
+        case 9: return row_bcast<9>(v);
+        case 10: return row_bcast<10>(v);
+        case 11: return row_bcast<11>(v);
+        case 12: return row_bcast<12>(v);
+        case 13: return row_bcast<13>(v);
+        case 14: return row_bcast<14>(v);
+        default: return row_bcast<15>(v);
+    }
+}
+
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
+__device__ __forceinline__ void flag_wait(const int *flag, int *info) {
+    for (int spin = 0; spin < (1 << 26); ++spin) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    atomicCAS(info, 0, 0x7fffffff);  // never observed; the caller then reports a failed factorisation instead of hanging
+}
+
+// acc[t] (wave w: rows 16 t + fk + 4 r, column 16 w + fi of the tile) -= A^T B over K = 128, A = U[s-1, i-block], B = U[s-1, j-block]
+// (k-major 128 x 128 blocks, leading dimension ld).  Both operands go through LDS in chunks of KCH k-rows (wide coalesced
+// loads, the next chunk in flight while the current one is multiplied); SAME: A and B are the same block (diagonal tile),
+// and only the upper blocks t <= w are wanted.
+template <bool SAME>
+__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *__restrict__ Ab, const double *__restrict__ Bb,
+                                            int ld, double *sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+    double *As = sm, *Bs = SAME ? sm : sm + KCH * SLD;
+    constexpr int PER = KCH * NB / 2 / PT;   // double2 loads per thread, operand and chunk (= 2)
+    v2f64s ar[PER], br[PER];
+    // uniform base + 32-bit lane offset: the loads take the scalar-base form instead of a 64-bit address pair per load
+    const int goff = (tid >> 6) * ld + (tid & 63) * 2;   // thread's (row, column pair) inside a chunk; +8 rows per i
+    auto gload = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const double *ab = Ab + size_t(ch * KCH + (PT >> 6) * i) * ld, *bb = Bb + size_t(ch * KCH + (PT >> 6) * i) * ld;
+            ar[i] = *reinterpret_cast<const v2f64s *>(ab + goff);
+            if constexpr (!SAME) br[i] = *reinterpret_cast<const v2f64s *>(bb + goff);
+        }
+    };
+    gload(0);
+    for (int ch = 0; ch < NB / KCH; ++ch) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + PT * i, r = e >> 6, c = (e & 63) * 2;
+            *reinterpret_cast<v2f64s *>(&As[r * SLD + c]) = ar[i];
+            if constexpr (!SAME) *reinterpret_cast<v2f64s *>(&Bs[r * SLD + c]) = br[i];
+        }
+        __syncthreads();
+        if (ch + 1 < NB / KCH) gload(ch + 1);
+#pragma unroll
+        for (int kk = 0; kk < KCH / 4; ++kk) {
+            const double b = Bs[(kk * 4 + fk) * SLD + 16 * wave + fi];
+#pragma unroll
+            for (int t = 0; t < NPAN; ++t) {
+                if (SAME && t > wave) continue;   // wave-uniform
+                const double a = -As[(kk * 4 + fk) * SLD + 16 * t + fi];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// U_ss^T U_ss = S for the tile in `acc` (upper blocks t <= w valid), through the packed LDS tile.  Writes U[s,s] (upper,
+// zeros below), the operator P[s] and raises the flag.  The 16-column panel loop is the one of rounds 1-3 (wave 0 factors
+// the 16 x 16 diagonal block in registers, one thread per column solves U12, all waves apply the rank-16 update on MFMA).
+__device__ __forceinline__ void diag_factor(v4f64s (&acc)[NPAN], double *sm, double *__restrict__ Ub, int ld,
+                                            const double *__restrict__ dg0_blk, double piv_tol, double *__restrict__ P,
+                                            int *info, int blk) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+    double *dinv = sm + PACK, *dref = dinv + NB;
+#pragma unroll
+    for (int t = 0; t < NPAN; ++t) {
+        if (t > wave) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[pk(t, wave) * 256 + (fk + 4 * r) * 16 + fi] = acc[t][r];
+    }
+    if (tid < NB) dref[tid] = dg0_blk[tid];
+    __syncthreads();
+
+    for (int p = 0; p < NPAN; ++p) {
+        const int k0 = p * PNB;
+        // (1) 16 x 16 diagonal block on wave 0, in registers: lane j (< 16; the other lanes shadow them harmlessly) owns
+        // column j.  Per pivot: broadcast the pivot, scale row k, then a[i] -= U[k,i] U[k,j] for every later row i.
+        if (wave == 0) {
+            double a[PNB];
+            double *Dp = sm + pk(p, p) * 256;
+#pragma unroll
+            for (int i = 0; i < PNB; ++i) a[i] = Dp[i * 16 + fi];
+            const double refv = dref[k0 + fi];
+#pragma unroll
+            for (int k = 0; k < PNB; ++k) {
+                double piv = row_bcast_i(a[k], k);
+                const double ref = row_bcast_i(refv, k);
+                if (!(piv > piv_tol * ref)) {
+                    if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
+                    piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
+                }
+                const double inv = rsqrt_nr(piv);
+                const double u = a[k] * inv;  // U[k, j] for j > k
+                a[k] = fi == k ? piv * inv : u;
+#pragma unroll
+                for (int i = k + 1; i < PNB; ++i) a[i] = fma(-row_bcast_i(u, i), u, a[i]);
+                if (lane == 0) dinv[k0 + k] = inv;
+            }
+            if (lane < PNB) {
+#pragma unroll
+                for (int i = 0; i < PNB; ++i)
+                    if (fi >= i) Dp[i * 16 + fi] = a[i];
+            }
+        }
+        __syncthreads();
+        // (2) U12 = U11^-T A12: thread t owns column k0 + 16 + t
+        const int rest = NB - k0 - PNB;
+        if (tid < rest) {
+            const int col = k0 + PNB + tid;
+            const double *Dp = sm + pk(p, p) * 256;
+            double *Cp = sm + pk(p, col >> 4) * 256 + (col & 15);
+            double x[PNB];
+#pragma unroll
+            for (int i = 0; i < PNB; ++i) x[i] = Cp[i * 16];
+#pragma unroll
+            for (int i = 0; i < PNB; ++i) {
+                double sacc = x[i];
+#pragma unroll
+                for (int k = 0; k < i; ++k) sacc = fma(-Dp[k * 16 + i], x[k], sacc);
+                x[i] = sacc * dinv[k0 + i];
+                __builtin_amdgcn_sched_barrier(0);   // the 120 broadcast reads of U11 stay next to their uses (registers)
+            }
+#pragma unroll
+            for (int i = 0; i < PNB; ++i) Cp[i * 16] = x[i];
+        }
+        __syncthreads();
+        // (3) A22 -= U12^T U12 on the upper 16 x 16 blocks (b <= a) of the trailing grid
+        const int rt = rest / PNB, ntile = rt * (rt + 1) / 2;
+        for (int e = wave; e < ntile; e += PT / 64) {
+            int a = int((sqrtf(8.f * float(e) + 1.f) - 1.f) * 0.5f);
+            while ((a + 1) * (a + 2) / 2 <= e) ++a;
+            while (a * (a + 1) / 2 > e) --a;
+            const int b = e - a * (a + 1) / 2;  // b <= a
+            const int bi = p + 1 + b, bj = p + 1 + a;
+            double *Cij = sm + pk(bi, bj) * 256;
+            const double *Ri = sm + pk(p, bi) * 256, *Rj = sm + pk(p, bj) * 256;
+            v4f64s c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = Cij[(fk + 4 * r) * 16 + fi];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ri[(kk * 4 + fk) * 16 + fi], Rj[(kk * 4 + fk) * 16 + fi], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cij[(fk + 4 * r) * 16 + fi] = c[r];
+        }
+        __syncthreads();
+    }
+
+    // U[s,s] -> global (upper; the lower part zeroed)
+    for (int e = tid; e < NB * NB; e += PT) {
+        const int r = e >> 7, cc = e & (NB - 1);
+        Ub[size_t(r) * ld + cc] = cc >= r ? CP_PK(r, cc) : 0.0;
+    }
+    // T_p = U_pp^-1 (upper 16 x 16): thread (p, j) runs the back substitution of column j in registers
+    double tcol[PNB];
+    if (tid < NB) {
+        const int p = tid >> 4, j = tid & 15;
+        const double *Dp = sm + pk(p, p) * 256;
+#pragma unroll
+        for (int i = PNB - 1; i >= 0; --i) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = i + 1; k < PNB; ++k) sacc = fma(Dp[i * 16 + k], tcol[k], sacc);   // tcol[k] = 0 for k > j
+            tcol[i] = i <= j ? ((i == j ? 1.0 : 0.0) - sacc) * dinv[p * PNB + i] : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    if (tid < NB) {
+        const int p = tid >> 4, j = tid & 15;
+        double *Dp = sm + pk(p, p) * 256;
+#pragma unroll
+        for (int i = 0; i < PNB; ++i) Dp[i * 16 + j] = tcol[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < PACK; e += PT) P[e] = sm[e];
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// U[s,j] = U_ss^-T S for the tile in `acc`: block forward substitution over the eight 16-row blocks with the operator in
+// LDS; a wave owns 16 columns of the tile, so the eight steps are register-to-register (the D lay-out of one MFMA is the B
+// operand of the next).  Also writes the transposed tile Lt[j,s] (what the backward substitution reads).
+__device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *sm, double *__restrict__ Usj,
+                                            double *__restrict__ Ltjs, int ld) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fk = lane >> 4, fi = lane & 15;
+#pragma unroll
+    for (int q = 0; q < NPAN; ++q) {
+#pragma unroll
+        for (int k = 0; k < q; ++k) {
+            const double *Ukq = sm + pk(k, q) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ukq[(4 * r + fk) * 16 + fi], acc[k][r], acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep the 36 blocks' operand reads from being hoisted into 300 live registers
+        }
+        const double *Tq = sm + pk(q, q) * 256;
+        v4f64s y = {0., 0., 0., 0.};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
+        acc[q] = y;
+    }
+    const int uoff = fk * ld + 16 * wave + fi, loff = (16 * wave + fi) * ld + fk;
+#pragma unroll
+    for (int q = 0; q < NPAN; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            (Usj + size_t(16 * q + 4 * r) * ld)[uoff] = acc[q][r];     // row 16 q + fk + 4 r, column 16 w + fi
+            (Ltjs + (16 * q + 4 * r))[loff] = acc[q][r];               // transposed
+        }
+}
+
+// acc <- tile (i, j) of G, then the update of step s - 1 (see the head of the file)
+template <bool DIAG>
+__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const double *__restrict__ Gij, const double *__restrict__ U,
+                                                 int ld, int s, int i, int j, double *sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+    const int toff = fk * ld + 16 * wave + fi;   // lane's offset inside a (16 t + 4 r)-row band of the tile: scalar base + 32-bit offset
+#pragma unroll
+    for (int t = 0; t < NPAN; ++t) {
+        if (DIAG && t > wave) {
+            acc[t] = v4f64s{0., 0., 0., 0.};
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = (Gij + size_t(16 * t + 4 * r) * ld)[toff];
+    }
+    if (s > 0) {
+        const double *Urow = U + size_t(s - 1) * NB * ld;
+        tile_update<DIAG>(acc, Urow + size_t(i) * NB, Urow + size_t(j) * NB, ld, sm);
+    }
+}
+
+// the three roles of a workgroup of launch s; each is a function of its own (not inlined) so that the register allocation of
+// one role does not see the live ranges of the others (inlined, the kernel spilled ~100 registers even at 256), and each ends
+// the program itself (noreturn: no callee-saved registers to store and reload around it)
+__device__ __noinline__ __attribute__((noreturn)) void role_bulk(double *__restrict__ G, const double *__restrict__ U, int ld, int s, int i, int j, double *sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+    double *Gij = G + size_t(i) * NB * ld + size_t(j) * NB;
+    v4f64s acc[NPAN];
+    tile_load_update<false>(acc, Gij, U, ld, s, i, j, sm);
+    const int toff = fk * ld + 16 * wave + fi;
+#pragma unroll
+    for (int t = 0; t < NPAN; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) (Gij + size_t(16 * t + 4 * r) * ld)[toff] = acc[t][r];
+    __builtin_amdgcn_endpgm();
+}
+
+__device__ __noinline__ __attribute__((noreturn)) void role_diag(const double *__restrict__ G, double *__restrict__ U, int ld, int s,
+                                       const double *__restrict__ dg0, double piv_tol, double *__restrict__ P, int *info, double *sm) {
+    v4f64s acc[NPAN];
+    tile_load_update<true>(acc, G + size_t(s) * NB * ld + size_t(s) * NB, U, ld, s, s, s, sm);
+    diag_factor(acc, sm, U + size_t(s) * NB * ld + size_t(s) * NB, ld, dg0 + size_t(s) * NB, piv_tol, P, info, s);
+    __builtin_amdgcn_endpgm();
+}
+
+__device__ __noinline__ __attribute__((noreturn)) void role_panel(const double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int s,
+                                        int j, const double *__restrict__ P, int *info, double *sm) {
+    const int tid = threadIdx.x;
+    v4f64s acc[NPAN];
+    tile_load_update<false>(acc, G + size_t(s) * NB * ld + size_t(j) * NB, U, ld, s, s, j, sm);
+    if (tid == 0) flag_wait(info + 1 + s, info);  // bounded; running out is reported as a failed factorisation
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int e = tid; e < PACK / 2; e += PT)
+        reinterpret_cast<v2f64s *>(sm)[e] = reinterpret_cast<const v2f64s *>(P)[e];
+    __syncthreads();
+    panel_solve(acc, sm, U + size_t(s) * NB * ld + size_t(j) * NB, Lt + size_t(j) * NB * ld + size_t(s) * NB, ld);
+    __builtin_amdgcn_endpgm();
+}
+
+__global__ void __launch_bounds__(PT, 2)
+k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int s,
+            const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, int *info) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    int i = s, j;
+    {   // tile -> (i, j): row i holds nblk - i tiles, row s first
+        int t = blockIdx.x;
+        while (t >= nblk - i) {
+            t -= nblk - i;
+            ++i;
+        }
+        j = i + t;
+    }
+    double *P = TI + size_t(s) * NB * NB;
+    if (i > s)            // below the block row of this step: the updated tile goes back
+        role_bulk(G, U, ld, s, i, j, sm);
+    else if (j == s)
+        role_diag(G, U, ld, s, dg0, piv_tol, P, info, sm);
+    else
+        role_panel(G, U, Lt, ld, s, j, P, info, sm);
+}
+
+// TI_b = U_bb^-1 (upper) and TIT_b = its transpose from the operator P[b] (in the first PACK doubles of TI_b), one workgroup
+// per diagonal block, after the last step.  V = U^-1 by block back-substitution, V_ij = -T_i sum_{k=i+1..j} U_ik V_kj: wave
+// jb owns block column jb and keeps its V blocks in registers (the D lay-out of a block is the B operand of the next product).
+template <int JB>
+__device__ __forceinline__ void inverse_column(const double *sm, double *__restrict__ TIb, double *__restrict__ TITb) {
+    const int lane = threadIdx.x & 63, fk = lane >> 4, fi = lane & 15;
+    v4f64s V[JB + 1];
+    {
+        const double *Tj = sm + pk(JB, JB) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) V[JB][r] = Tj[(fk + 4 * r) * 16 + fi];
+    }
+#pragma unroll
+    for (int ib = JB - 1; ib >= 0; --ib) {
+        v4f64s S = {0., 0., 0., 0.};
+#pragma unroll
+        for (int kb = ib + 1; kb <= JB; ++kb) {
+            const double *Uik = sm + pk(ib, kb) * 256;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                S = __builtin_amdgcn_mfma_f64_16x16x4f64(Uik[fi * 16 + kk * 4 + fk], V[kb][kk], S, 0, 0, 0);
+        }
+        const double *Ti = sm + pk(ib, ib) * 256;
+        v4f64s W = {0., 0., 0., 0.};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) W = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ti[fi * 16 + kk * 4 + fk], S[kk], W, 0, 0, 0);
+        V[ib] = W;
+    }
+    // rows of block column JB: blocks ib <= JB hold V, the blocks below are zero
+#pragma unroll
+    for (int ib = 0; ib < NPAN; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ib + fk + 4 * r, col = 16 * JB + fi;
+            double v = 0.0;
+            if (ib <= JB) v = V[ib < JB + 1 ? ib : JB][r];
+            TIb[row * NB + col] = v;
+            TITb[col * NB + row] = v;
+        }
+}
+
+__global__ void __launch_bounds__(PT) k_chol_block_inverse(double *__restrict__ TI, double *__restrict__ TIT) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *TIb = TI + size_t(blockIdx.x) * NB * NB, *TITb = TIT + size_t(blockIdx.x) * NB * NB;
+    for (int e = threadIdx.x; e < PACK / 2; e += PT)
+        reinterpret_cast<v2f64s *>(sm)[e] = reinterpret_cast<const v2f64s *>(TIb)[e];
+    __syncthreads();   // the operator is in LDS: TI_b may be overwritten from here on
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+        case 0: inverse_column<0>(sm, TIb, TITb); break;
+        case 1: inverse_column<1>(sm, TIb, TITb); break;
+        case 2: inverse_column<2>(sm, TIb, TITb); break;
+        case 3: inverse_column<3>(sm, TIb, TITb); break;
+        case 4: inverse_column<4>(sm, TIb, TITb); break;
+        case 5: inverse_column<5>(sm, TIb, TITb); break;
+        case 6: inverse_column<6>(sm, TIb, TITb); break;
+        default: inverse_column<7>(sm, TIb, TITb); break;
+    }
+}
+
+hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explicit opt-in, once per device
+    static std::mutex mu;
+    static bool done[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device >= 0 && device < 64 && done[device]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_step), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       int(LDS_DOUBLES * sizeof(double)));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_block_inverse), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(PACK * sizeof(double)));
+    if (e == hipSuccess && device >= 0 && device < 64) done[device] = true;
+    return e;
+}
+
+}  // namespace
+
+// G (p_pad x p_pad, upper tiles valid, destroyed) = U^T U: U (upper, block rows), the off-diagonal blocks of Lt = U^T,
+// TI_b = U_bb^-1, TIT_b = U_bb^-T per diagonal block.  info (zeroed by the caller's k_diag_prepare): [0] 1 + the first
+// pivot <= piv_tol * its original diagonal dg0 (also NaN), [1 + b] block b factored.
+int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, int nblk, const double *dg0,
+                         double piv_tol, double *TI, double *TIT, int *info) {
+    CP_HIP(ctx, lds_opt_in(ctx->device));
+    const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
+    for (int s = 0; s < nblk; ++s) {
+        // s = 0: nothing to apply yet, only block row 0; afterwards every upper tile of the rows s .. nblk - 1
+        const int n = nblk - s, tiles = s == 0 ? n : n * (n + 1) / 2;
+        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, info);
+        CP_LAUNCH_CHECK(ctx);
+    }
+    k_chol_block_inverse<<<nblk, PT, size_t(PACK) * sizeof(double), ctx->stream>>>(TI, TIT);
+    CP_LAUNCH_CHECK(ctx);
+    return CP_OK;
+}

@@ -93,6 +93,9 @@ struct cp_ctx {
     char *cd_box = nullptr;           // mailboxes of the multi-CU coordinate-descent team (cd_team.hip), grow-only
     size_t cd_box_bytes = 0;
     bool potrf_lds_opt_in = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
+    bool last_cd_was_team = false;    // which kernel family the last coordinate-descent launch of THIS context ran (debug counters)
+    int cd_fallbacks = 0;             // searches / fits re-run on the one-workgroup team after a hand-off time-out of the multi-CU team
+    bool cd_test_fail_multi = false;  // cp_debug_cd_fail_multi: the next multi-CU launches give up at once (tests of that fallback)
 };
 
 int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
@@ -208,9 +211,14 @@ struct cp_search_job {
     int flags;
     double *w;
 };
-int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_search_job *jobs);
+// chol_step.hip: blocked Cholesky, one launch per 128-column step
+int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, int nblk, const double *dg0,
+                         double piv_tol, double *TI, double *TIT, int *info);
+int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_search_job *jobs, bool allow_multi = true);
+// timed_out (optional): a fit of the search reported a hand-off time-out of its team (n_iter = -1): run it again with
+// allow_multi = false (the one-workgroup team, bit-identical)
 int cp_alpha_search_collect(cp_ctx *ctx, int c, int max_fits, int *fits_used, double *alpha_out, cp_cd_result *fit_log,
-                            double *fit_alpha);
+                            double *fit_alpha, bool *timed_out = nullptr);
 // factor + substitute every pending deferred refit of the batch: two launches on ctxs[0]->stream (refit.hip)
 int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx);
 int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const uint8_t *mask,

@@ -215,21 +215,45 @@ extern "C" int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_j
     if (n_search > 0) {
         CP_TRY(cp_alpha_search_enqueue_batch(sctx, n_search, sj));
         CP_HIP(ctx0, cp_stream_wait(sctx[0]));   // one wait for every search of the batch
-        for (int k = 0; k < n_search; ++k) {
-            const int l = smap[k];
-            const cp_prune_job &j = jobs[l];
-            int fits_used = 0;
-            double alpha = 0.0;
-            const int rc = cp_alpha_search_collect(sctx[k], c, j.max_fits, &fits_used, &alpha, results[l].fit_log,
-                                                   results[l].fit_alpha);
-            if (rc == CP_ERR_NUMERIC) {  // did not settle within max_fits: the caller replays this layer fit by fit
-                results[l].fits_used = -1;
-                continue;
+        // a search whose multi-CU team reported a hand-off time-out runs again on the one-workgroup team (bit-identical)
+        int n_retry = 0, rmap[CP_MAX_JOBS];
+        cp_search_job rj[CP_MAX_JOBS];
+        cp_ctx *rctx[CP_MAX_JOBS];
+        for (int pass = 0; pass < 2; ++pass) {
+            const int count = pass == 0 ? n_search : n_retry;
+            int next_retry = 0;
+            for (int k = 0; k < count; ++k) {
+                const int ks = pass == 0 ? k : rmap[k];
+                const int l = smap[ks];
+                const cp_prune_job &j = jobs[l];
+                int fits_used = 0;
+                double alpha = 0.0;
+                bool timed_out = false;
+                const int rc = cp_alpha_search_collect(sctx[ks], c, j.max_fits, &fits_used, &alpha, results[l].fit_log,
+                                                       results[l].fit_alpha, &timed_out);
+                if (timed_out && pass == 0 && cp_cd_kernel_form(c, j.flags) == CP_CD_FORM_MULTI) {
+                    rj[next_retry] = sj[ks];
+                    rctx[next_retry] = sctx[ks];
+                    rmap[next_retry++] = ks;
+                    ++sctx[ks]->cd_fallbacks;
+                    continue;
+                }
+                if (rc == CP_ERR_NUMERIC) {  // did not settle within max_fits: the caller replays this layer fit by fit
+                    results[l].fits_used = -1;
+                    continue;
+                }
+                results[l].fits_used = fits_used;
+                results[l].alpha = alpha;
+                const double *wh = sctx[ks]->pinned_w;
+                for (size_t i = 0; i < cc; ++i) j.mask_out[i] = wh[i] != 0.0 ? 1 : 0;  // decompose.py:463
             }
-            results[l].fits_used = fits_used;
-            results[l].alpha = alpha;
-            const double *wh = sctx[k]->pinned_w;
-            for (size_t i = 0; i < cc; ++i) j.mask_out[i] = wh[i] != 0.0 ? 1 : 0;  // decompose.py:463
+            n_retry = next_retry;
+            if (pass == 0 && n_retry > 0) {
+                CP_TRY(cp_alpha_search_enqueue_batch(rctx, n_retry, rj, false));
+                CP_HIP(ctx0, cp_stream_wait(rctx[0]));
+            } else {
+                break;
+            }
         }
     }
     // refits: every layer's front (means, centring, Gram, X^T Y) is enqueued, then the batch factors and substitutes

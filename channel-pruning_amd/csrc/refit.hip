@@ -1092,6 +1092,9 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     // at p = 1179, 5.0 vs 4.3 ms at p = 4140 -- per 64-column step its chain is 17 us (factor) + 20 us (invert, publish) +
     // 15-20 us (panel tile: dependent loads of T_i, scattered Lt stores, agent-scope release) against 94 us per 128 columns
     // here (tests/tools/potrf64_phases.py).  Kept opt-in.
+    static const bool steps = !(getenv("CP_CHOL_STEPS") && getenv("CP_CHOL_STEPS")[0] == '0');
+    if (steps)   // one launch per block step, lazy trailing update (chol_step.hip)
+        return cp_chol_factor_steps(ctx, ch.G, ch.U, ch.Lt, ld, ch.nblk, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
     if (chol_tasks_requested()) return chol_factor_tasks(ctx, &ch, 1, piv_tol);
     static const bool fused = chol_fused_requested();
     if (fused) {  // one launch, left-looking, a workgroup per tile

@@ -616,6 +616,80 @@ def test_dictionary_replays_on_host_when_device_search_runs_out_of_seeds(ctx, na
     _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "device"))
 
 
+def _cd_debug(ctx):
+    import ctypes
+    lib = ctx.lib
+    lib.cp_debug_cd_fail_multi.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cp_debug_cd_fail_multi.restype = ctypes.c_int
+    lib.cp_debug_cd_fallbacks.argtypes = [ctypes.c_void_p]
+    lib.cp_debug_cd_fallbacks.restype = ctypes.c_int
+    return lib
+
+
+@pytest.mark.parametrize("name", ["R25_res4b_sel", "R46_res5c_sel"])
+def test_multi_cu_cd_team_falls_back_to_one_workgroup_on_a_handoff_timeout(name):
+    """A hand-off time-out of the multi-CU coordinate-descent team (512 < c <= 2048: 1 + ceil(c / 512) workgroups that talk
+    through global memory with bounded waits) must not fail the layer: the library re-runs the search on the one-workgroup
+    team, which is bit-identical.  cp_debug_cd_fail_multi makes the home workgroup raise the team's abort flag before its first
+    fit, i.e. the real abort path (every workgroup leaves, n_iter = -1 in the log); the result still equals the reference
+    golden, and so does a single fit through cp_enet_cd_gram."""
+    from cpmi355 import capi
+    ctx = capi.default_context()
+    lib = _cd_debug(ctx)
+    g, p, X, W2, Y, B2 = load_case(name)
+    assert ctx.cd_kernel_form(p["c"], 0) == 3
+    before = lib.cp_debug_cd_fallbacks(ctx.h)
+    lib.cp_debug_cd_fail_multi(ctx.h, 1)
+    try:
+        _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "device", exact_ops=True))     # fused cp_prune_layer
+        assert lib.cp_debug_cd_fallbacks(ctx.h) == before + 1
+        _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "host", exact_ops=True))       # fit by fit: cp_enet_cd_gram
+        assert lib.cp_debug_cd_fallbacks(ctx.h) >= before + 1 + len(g["fits"])
+    finally:
+        lib.cp_debug_cd_fail_multi(ctx.h, 0)
+    n0 = lib.cp_debug_cd_fallbacks(ctx.h)
+    _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "device", exact_ops=True))
+    assert lib.cp_debug_cd_fallbacks(ctx.h) == n0          # the switch is off again: the multi-CU team ran
+
+
+def test_multi_cu_cd_team_on_a_saturated_chip():
+    """The c = 2048 search (five workgroups of an ordinary launch that must be resident together) while twelve other streams
+    keep every CU busy with chip-filling f64 MFMA kernels: same result as the reference golden, no error; whether the team
+    or its one-workgroup fallback produced it is reported, not asserted."""
+    import threading
+    import cpmi355
+    from cpmi355 import capi
+    ctx = capi.default_context()
+    lib = _cd_debug(ctx)
+    g, p, X, W2, Y, B2 = load_case("R46_res5c_sel")
+    hogs = [cpmi355.Context(0) for _ in range(12)]
+    stop = threading.Event()
+    errors = []
+
+    def hog(cx):
+        try:
+            while not stop.is_set():
+                cx.probe_mfma_f64()          # 1024 workgroups x 256 threads of back-to-back MFMAs (~3 ms), then again
+        except Exception as e:                # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=hog, args=(cx,), daemon=True) for cx in hogs]
+    for t in threads:
+        t.start()
+    try:
+        before = lib.cp_debug_cd_fallbacks(ctx.h)
+        for _ in range(2):
+            _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "device", exact_ops=True))
+        print("fallbacks on the saturated chip:", lib.cp_debug_cd_fallbacks(ctx.h) - before)
+    finally:
+        stop.set()
+        for t in threads:
+            t.join(timeout=60)
+        for cx in hogs:
+            cx.close()
+    assert not errors, errors
+
+
 def test_prune_layer_rank_equal_c_skips_lasso(ctx):
     """rank == c: every channel kept, no LASSO fit, no RNG draw beyond the sample subset (decompose.py:487-488)."""
     import cp_oracle
