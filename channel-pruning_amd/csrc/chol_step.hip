@@ -13,6 +13,8 @@
 //     (s, s)       S = U_ss^T U_ss in LDS, T_q = (16 x 16 diagonal blocks)^-1, flag          -> U[s,s], P[s]
 //     (s, j > s)   wait for the flag, U[s,j] = U_ss^-T S by block forward substitution          -> U[s,j], Lt[j,s]
 //     (i > s, j)   G[i,j] = S
+//   The right-hand sides R of the solve that follows ride along as extra tile columns of every block row (B operand: block
+//   row s - 1 of Y instead of U): when the last step ends, R holds Y = U^-T R -- the forward substitution costs no launch.
 //
 // A workgroup of row s waits only for workgroup 0 of its own launch, which the dispatcher starts first; the tiles below row s
 // wait for nothing, so the factorisation of block s runs while the rest of the chip applies update s - 1.
@@ -89,24 +91,25 @@ __device__ __forceinline__ void flag_wait(const int *flag, int *info) {
 }
 
 // acc[t] (wave w: rows 16 t + fk + 4 r, column 16 w + fi of the tile) -= A^T B over K = 128, A = U[s-1, i-block], B = U[s-1, j-block]
-// (k-major 128 x 128 blocks, leading dimension ld).  Both operands go through LDS in chunks of KCH k-rows (wide coalesced
+// or, for a right-hand-side tile, Y[s-1, j-block] (k-major 128 x 128 blocks, leading dimensions ld / ldb).  Both operands go through LDS in chunks of KCH k-rows (wide coalesced
 // loads, the next chunk in flight while the current one is multiplied); SAME: A and B are the same block (diagonal tile),
 // and only the upper blocks t <= w are wanted.
 template <bool SAME>
-__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *__restrict__ Ab, const double *__restrict__ Bb,
-                                            int ld, double *sm) {
+__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *__restrict__ Ab, int ld,
+                                            const double *__restrict__ Bb, int ldb, double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     double *As = sm, *Bs = SAME ? sm : sm + KCH * SLD;
     constexpr int PER = KCH * NB / 2 / PT;   // double2 loads per thread, operand and chunk (= 2)
     v2f64s ar[PER], br[PER];
     // uniform base + 32-bit lane offset: the loads take the scalar-base form instead of a 64-bit address pair per load
     const int goff = (tid >> 6) * ld + (tid & 63) * 2;   // thread's (row, column pair) inside a chunk; +8 rows per i
+    const int goffb = (tid >> 6) * ldb + (tid & 63) * 2;
     auto gload = [&](int ch) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const double *ab = Ab + size_t(ch * KCH + (PT >> 6) * i) * ld, *bb = Bb + size_t(ch * KCH + (PT >> 6) * i) * ld;
+            const double *ab = Ab + size_t(ch * KCH + (PT >> 6) * i) * ld, *bb = Bb + size_t(ch * KCH + (PT >> 6) * i) * ldb;
             ar[i] = *reinterpret_cast<const v2f64s *>(ab + goff);
-            if constexpr (!SAME) br[i] = *reinterpret_cast<const v2f64s *>(bb + goff);
+            if constexpr (!SAME) br[i] = *reinterpret_cast<const v2f64s *>(bb + goffb);
         }
     };
     gload(0);
@@ -260,7 +263,7 @@ __device__ __forceinline__ void diag_factor(v4f64s (&acc)[NPAN], double *sm, dou
 // U[s,j] = U_ss^-T S for the tile in `acc`: block forward substitution over the eight 16-row blocks with the operator in
 // LDS; a wave owns 16 columns of the tile, so the eight steps are register-to-register (the D lay-out of one MFMA is the B
 // operand of the next).  Also writes the transposed tile Lt[j,s] (what the backward substitution reads).
-__device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *sm, double *__restrict__ Usj,
+__device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *sm, double *__restrict__ Usj, int ldu,
                                             double *__restrict__ Ltjs, int ld) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fk = lane >> 4, fi = lane & 15;
 #pragma unroll
@@ -279,22 +282,30 @@ __device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *s
         for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
         acc[q] = y;
     }
-    const int uoff = fk * ld + 16 * wave + fi, loff = (16 * wave + fi) * ld + fk;
+    const int uoff = fk * ldu + 16 * wave + fi, loff = (16 * wave + fi) * ld + fk;
 #pragma unroll
     for (int q = 0; q < NPAN; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            (Usj + size_t(16 * q + 4 * r) * ld)[uoff] = acc[q][r];     // row 16 q + fk + 4 r, column 16 w + fi
-            (Ltjs + (16 * q + 4 * r))[loff] = acc[q][r];               // transposed
+            (Usj + size_t(16 * q + 4 * r) * ldu)[uoff] = acc[q][r];    // row 16 q + fk + 4 r, column 16 w + fi
+            if (Ltjs) (Ltjs + (16 * q + 4 * r))[loff] = acc[q][r];     // transposed (factor tiles only)
         }
 }
 
-// acc <- tile (i, j) of G, then the update of step s - 1 (see the head of the file)
+// A tile of launch s: where it lives, and the B operand of its update (block row s - 1 of U, or of Y for a right-hand side)
+struct Tile {
+    double *T;          // the 128 x 128 tile (G[i,j] or R[i,jr])
+    int ldt;
+    const double *B;    // U[s-1, j-block] or Y[s-1, jr-block]
+    int ldb;
+};
+
+// acc <- the tile, then the update of step s - 1 (see the head of the file)
 template <bool DIAG>
-__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const double *__restrict__ Gij, const double *__restrict__ U,
-                                                 int ld, int s, int i, int j, double *sm) {
+__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *__restrict__ Ai, int ld, int s,
+                                                 double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
-    const int toff = fk * ld + 16 * wave + fi;   // lane's offset inside a (16 t + 4 r)-row band of the tile: scalar base + 32-bit offset
+    const int toff = fk * t_.ldt + 16 * wave + fi;   // lane's offset inside a (16 t + 4 r)-row band of the tile: scalar base + 32-bit offset
 #pragma unroll
     for (int t = 0; t < NPAN; ++t) {
         if (DIAG && t > wave) {
@@ -302,73 +313,94 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const doub
             continue;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = (Gij + size_t(16 * t + 4 * r) * ld)[toff];
+        for (int r = 0; r < 4; ++r) acc[t][r] = (t_.T + size_t(16 * t + 4 * r) * t_.ldt)[toff];
     }
-    if (s > 0) {
-        const double *Urow = U + size_t(s - 1) * NB * ld;
-        tile_update<DIAG>(acc, Urow + size_t(i) * NB, Urow + size_t(j) * NB, ld, sm);
-    }
+    if (s > 0) tile_update<DIAG>(acc, Ai, ld, t_.B, t_.ldb, sm);
 }
 
 // the three roles of a workgroup of launch s; each is a function of its own (not inlined) so that the register allocation of
 // one role does not see the live ranges of the others (inlined, the kernel spilled ~100 registers even at 256), and each ends
-// the program itself (noreturn: no callee-saved registers to store and reload around it)
-__device__ __noinline__ __attribute__((noreturn)) void role_bulk(double *__restrict__ G, const double *__restrict__ U, int ld, int s, int i, int j, double *sm) {
+// the program itself
+__device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const double *__restrict__ Ai, int ld, int s, double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
-    double *Gij = G + size_t(i) * NB * ld + size_t(j) * NB;
     v4f64s acc[NPAN];
-    tile_load_update<false>(acc, Gij, U, ld, s, i, j, sm);
-    const int toff = fk * ld + 16 * wave + fi;
+    tile_load_update<false>(acc, t_, Ai, ld, s, sm);
+    const int toff = fk * t_.ldt + 16 * wave + fi;
 #pragma unroll
     for (int t = 0; t < NPAN; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) (Gij + size_t(16 * t + 4 * r) * ld)[toff] = acc[t][r];
+        for (int r = 0; r < 4; ++r) (t_.T + size_t(16 * t + 4 * r) * t_.ldt)[toff] = acc[t][r];
     __builtin_amdgcn_endpgm();
 }
 
-__device__ __noinline__ __attribute__((noreturn)) void role_diag(const double *__restrict__ G, double *__restrict__ U, int ld, int s,
-                                       const double *__restrict__ dg0, double piv_tol, double *__restrict__ P, int *info, double *sm) {
+__device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const double *__restrict__ Ai, double *__restrict__ Uss,
+                                                                 int ld, int s, const double *__restrict__ dg0, double piv_tol,
+                                                                 double *__restrict__ P, int *info, double *sm) {
     v4f64s acc[NPAN];
-    tile_load_update<true>(acc, G + size_t(s) * NB * ld + size_t(s) * NB, U, ld, s, s, s, sm);
-    diag_factor(acc, sm, U + size_t(s) * NB * ld + size_t(s) * NB, ld, dg0 + size_t(s) * NB, piv_tol, P, info, s);
+    tile_load_update<true>(acc, t_, Ai, ld, s, sm);
+    diag_factor(acc, sm, Uss, ld, dg0 + size_t(s) * NB, piv_tol, P, info, s);
     __builtin_amdgcn_endpgm();
 }
 
-__device__ __noinline__ __attribute__((noreturn)) void role_panel(const double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int s,
-                                        int j, const double *__restrict__ P, int *info, double *sm) {
+// out / ldo: where U[s,j] (or Y[s,jr]) goes; Ltjs: the transposed copy of a factor tile, null for a right-hand side
+__device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const double *__restrict__ Ai, int ld, int s,
+                                                                  double *__restrict__ out, int ldo, double *__restrict__ Ltjs,
+                                                                  const double *__restrict__ P, int *info, double *sm) {
     const int tid = threadIdx.x;
     v4f64s acc[NPAN];
-    tile_load_update<false>(acc, G + size_t(s) * NB * ld + size_t(j) * NB, U, ld, s, s, j, sm);
+    tile_load_update<false>(acc, t_, Ai, ld, s, sm);
     if (tid == 0) flag_wait(info + 1 + s, info);  // bounded; running out is reported as a failed factorisation
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int e = tid; e < PACK / 2; e += PT)
         reinterpret_cast<v2f64s *>(sm)[e] = reinterpret_cast<const v2f64s *>(P)[e];
     __syncthreads();
-    panel_solve(acc, sm, U + size_t(s) * NB * ld + size_t(j) * NB, Lt + size_t(j) * NB * ld + size_t(s) * NB, ld);
+    panel_solve(acc, sm, out, ldo, Ltjs, ld);
     __builtin_amdgcn_endpgm();
 }
 
+// R (p_pad x ntr 128-column tiles, leading dimension ldr; null: none): right-hand sides riding along -- block row i of the
+// launch has ntr more tiles after its nblk - i factor tiles, and after the last step R holds Y = U^-T R (the forward
+// substitution of the normal-equation solve, for free in the launches of the factorisation).
 __global__ void __launch_bounds__(PT, 2)
 k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int s,
-            const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, int *info) {
+            const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, int *info, double *__restrict__ R, int ldr,
+            int ntr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    int i = s, j;
-    {   // tile -> (i, j): row i holds nblk - i tiles, row s first
+    int i = s, jt;
+    {   // tile -> (i, jt): block row i holds nblk - i factor tiles, then ntr right-hand-side tiles; row s first
         int t = blockIdx.x;
-        while (t >= nblk - i) {
-            t -= nblk - i;
+        while (t >= nblk - i + ntr) {
+            t -= nblk - i + ntr;
             ++i;
         }
-        j = i + t;
+        jt = t;
+    }
+    const bool rhs = jt >= nblk - i;
+    const int j = rhs ? jt - (nblk - i) : i + jt;     // right-hand-side tile column, or block column of the factor
+    const double *Urow = U + size_t(s > 0 ? s - 1 : 0) * NB * ld;   // block row s - 1 of U (unused at s = 0)
+    const double *Ai = Urow + size_t(i) * NB;
+    Tile t_;
+    if (rhs) {
+        t_.T = R + size_t(i) * NB * ldr + size_t(j) * NB;
+        t_.ldt = ldr;
+        t_.B = R + size_t(s > 0 ? s - 1 : 0) * NB * ldr + size_t(j) * NB;
+        t_.ldb = ldr;
+    } else {
+        t_.T = G + size_t(i) * NB * ld + size_t(j) * NB;
+        t_.ldt = ld;
+        t_.B = Urow + size_t(j) * NB;
+        t_.ldb = ld;
     }
     double *P = TI + size_t(s) * NB * NB;
     if (i > s)            // below the block row of this step: the updated tile goes back
-        role_bulk(G, U, ld, s, i, j, sm);
-    else if (j == s)
-        role_diag(G, U, ld, s, dg0, piv_tol, P, info, sm);
+        role_bulk(t_, Ai, ld, s, sm);
+    else if (!rhs && j == s)
+        role_diag(t_, Ai, U + size_t(s) * NB * ld + size_t(s) * NB, ld, s, dg0, piv_tol, P, info, sm);
+    else if (!rhs)
+        role_panel(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB, P, info, sm);
     else
-        role_panel(G, U, Lt, ld, s, j, P, info, sm);
+        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, P, info, sm);
 }
 
 // TI_b = U_bb^-1 (upper) and TIT_b = its transpose from the operator P[b] (in the first PACK doubles of TI_b), one workgroup
@@ -449,14 +481,17 @@ hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explici
 // G (p_pad x p_pad, upper tiles valid, destroyed) = U^T U: U (upper, block rows), the off-diagonal blocks of Lt = U^T,
 // TI_b = U_bb^-1, TIT_b = U_bb^-T per diagonal block.  info (zeroed by the caller's k_diag_prepare): [0] 1 + the first
 // pivot <= piv_tol * its original diagonal dg0 (also NaN), [1 + b] block b factored.
+// R (optional, p_pad x n_pad with n_pad % 128 == 0): overwritten with U^-T R, the forward substitution, in the same launches.
 int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, int nblk, const double *dg0,
-                         double piv_tol, double *TI, double *TIT, int *info) {
+                         double piv_tol, double *TI, double *TIT, int *info, double *R, int n_pad) {
+    if (R && n_pad % NB) return cp_set_error(ctx, CP_ERR_ARG, "chol: right-hand sides need n_pad %% 128 == 0 (got %d)", n_pad);
     CP_HIP(ctx, lds_opt_in(ctx->device));
     const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
+    const int ntr = R ? n_pad / NB : 0;
     for (int s = 0; s < nblk; ++s) {
         // s = 0: nothing to apply yet, only block row 0; afterwards every upper tile of the rows s .. nblk - 1
-        const int n = nblk - s, tiles = s == 0 ? n : n * (n + 1) / 2;
-        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, info);
+        const int n = nblk - s, tiles = s == 0 ? n + ntr : n * (n + 1) / 2 + n * ntr;
+        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, info, R, n_pad, ntr);
         CP_LAUNCH_CHECK(ctx);
     }
     k_chol_block_inverse<<<nblk, PT, size_t(PACK) * sizeof(double), ctx->stream>>>(TI, TIT);

@@ -213,7 +213,7 @@ struct cp_search_job {
 };
 // chol_step.hip: blocked Cholesky, one launch per 128-column step
 int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, int nblk, const double *dg0,
-                         double piv_tol, double *TI, double *TIT, int *info);
+                         double piv_tol, double *TI, double *TIT, int *info, double *R = nullptr, int n_pad = 0);
 int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_search_job *jobs, bool allow_multi = true);
 // timed_out (optional): a fit of the search reported a hand-off time-out of its team (n_iter = -1): run it again with
 // allow_multi = false (the one-workgroup team, bit-identical)

@@ -1071,8 +1071,11 @@ int chol_factor_tasks(cp_ctx *ctx, const Chol *chs, int count, double piv_tol) {
 }
 
 // G = U^T U (upper, into ch.U), TI/TIT per diagonal block, and the off-diagonal blocks of Lt = U^T.
-int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
+// fwd_R (optional, p_pad x fwd_n_pad): right-hand sides whose forward substitution U^T y = r rides in the launches of the
+// factorisation (chol_step.hip); *fwd_done tells the caller whether it did (then only the backward sweep is left).
+int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol, double *fwd_R = nullptr, int fwd_n_pad = 0, bool *fwd_done = nullptr) {
     const int ld = ch.p_pad;
+    if (fwd_done) *fwd_done = false;
     const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
     if (!ctx->potrf_lds_opt_in) {  // > 64 KB of dynamic LDS needs an explicit opt-in (per device; idempotent)
         CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf<false>),
@@ -1093,8 +1096,13 @@ int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol) {
     // 15-20 us (panel tile: dependent loads of T_i, scattered Lt stores, agent-scope release) against 94 us per 128 columns
     // here (tests/tools/potrf64_phases.py).  Kept opt-in.
     static const bool steps = !(getenv("CP_CHOL_STEPS") && getenv("CP_CHOL_STEPS")[0] == '0');
-    if (steps)   // one launch per block step, lazy trailing update (chol_step.hip)
-        return cp_chol_factor_steps(ctx, ch.G, ch.U, ch.Lt, ld, ch.nblk, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
+    if (steps) {   // one launch per block step, lazy trailing update (chol_step.hip)
+        static const bool fuse_fwd = !(getenv("CP_CHOL_FUSE_FORWARD") && getenv("CP_CHOL_FUSE_FORWARD")[0] == '0');
+        const bool fwd = fuse_fwd && fwd_R && fwd_n_pad > 0 && fwd_n_pad % NB == 0;
+        if (fwd_done) *fwd_done = fwd;
+        return cp_chol_factor_steps(ctx, ch.G, ch.U, ch.Lt, ld, ch.nblk, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info,
+                                    fwd ? fwd_R : nullptr, fwd ? fwd_n_pad : 0);
+    }
     if (chol_tasks_requested()) return chol_factor_tasks(ctx, &ch, 1, piv_tol);
     static const bool fused = chol_fused_requested();
     if (fused) {  // one launch, left-looking, a workgroup per tile
@@ -1256,10 +1264,11 @@ struct StripJob {
 struct StripBatch {
     StripJob j[CP_REFIT_MAX_BATCH];
 };
+template <int SWEEPS>
 __global__ void __launch_bounds__(512) k_solve_strips_batch(StripBatch b) {  // blockIdx.y = job
     const StripJob &a = b.j[blockIdx.y];
     if (int(blockIdx.x) * 16 >= a.n_pad) return;
-    solve_strips_body(a.U, a.Lt, a.ld, a.TI, a.TIT, a.nblk, a.R, a.n_pad, a.fin);
+    solve_strips_body<SWEEPS>(a.U, a.Lt, a.ld, a.TI, a.TIT, a.nblk, a.R, a.n_pad, a.fin);
 }
 
 int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad, const StripFinal &fin = StripFinal{},
@@ -1622,15 +1631,16 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
             info->reserved = 0;
             return CP_OK;
         }
-        CP_TRY(chol_factor(ctx, ch, PIV_TOL));
+        bool fwd = false;   // the forward substitution rode in the launches of the factorisation
+        CP_TRY(chol_factor(ctx, ch, PIV_TOL, Rm, n_pad, &fwd));
         cp_stage_mark(ctx, "refit_cholesky");
         if (nblk >= solve_blocked_min_blocks()) {   // large factor: banded substitution with GEMM updates, then the lay-out kernel
-            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad));
+            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3));
             cp_stage_mark(ctx, "refit_solve");
             CP_TRY(finalize());
         } else {
             StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
-            CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin));  // substitutions + coefficient lay-out + intercept in one launch
+            CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin, fwd ? 2 : 3));  // substitution(s) + coefficient lay-out + intercept in one launch
             cp_stage_mark(ctx, "refit_solve");
             CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything small came back with the kernel
             hinfo = *info_host;                // outputs are overwritten below if a pivot failed
@@ -1704,7 +1714,9 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
     }
     if (nj == 0) return CP_OK;
     cp_ctx *ctx = ctx0;
+    bool fwd_all = true;   // every layer's forward substitution rode in its factorisation's launches
     if (chol_fused_requested()) {  // all factorisations as one launch (see chol_factor for why this is opt-in)
+        fwd_all = false;
         const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
         // > 64 KB of dynamic LDS needs an explicit opt-in: per device, idempotent, a few microseconds -- done on every call
         CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_batch),
@@ -1717,9 +1729,12 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
             if (!c || !c->refit_pending) continue;
             const cp_refit_deferred &d = c->deferred;
             Chol ch{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
-            CP_TRY(chol_factor(c, ch, PIV_TOL));
+            bool fwd = false;
+            CP_TRY(chol_factor(c, ch, PIV_TOL, d.Rm, d.n_pad, &fwd));
+            fwd_all = fwd_all && fwd;
         }
     } else {   // every factorisation of the batch in ONE launch (grid.y = job)
+        fwd_all = false;
         Chol chs[CP_REFIT_MAX_BATCH];
         int cnt = 0;
         for (int l = 0; l < n_ctx; ++l) {
@@ -1732,7 +1747,10 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
     }
     // the substitutions of every layer of the batch: one launch (no workgroup waits for another one)
     if (max_strips > 0) {
-        k_solve_strips_batch<<<dim3(max_strips, nj), 512, 0, ctx->stream>>>(sb);
+        if (fwd_all)
+            k_solve_strips_batch<2><<<dim3(max_strips, nj), 512, 0, ctx->stream>>>(sb);
+        else
+            k_solve_strips_batch<3><<<dim3(max_strips, nj), 512, 0, ctx->stream>>>(sb);
         CP_LAUNCH_CHECK(ctx);
     }
     for (int l = 0; l < n_ctx; ++l) {   // large factors: banded substitution with GEMM updates + the lay-out kernel, layer by layer
@@ -1741,7 +1759,7 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
         const cp_refit_deferred &d = c->deferred;
         if (d.nblk < solve_blocked_min_blocks()) continue;
         Chol ch{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
-        CP_TRY(chol_solve_blocked(c, ch, d.Rm, d.n_pad));
+        CP_TRY(chol_solve_blocked(c, ch, d.Rm, d.n_pad, fwd_all ? 2 : 3));
         CP_TRY(finalize_launch(c, d.Rm, d.n_pad, d.p, d.n, d.xmean, d.ymean, d.W_out, d.b_out, d.W_host, d.b_host, d.info,
                                d.info_host, d.part));
     }
