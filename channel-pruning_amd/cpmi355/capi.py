@@ -136,7 +136,7 @@ def load():
         # bench.py --gpus > 1) has to import torch BEFORE the first Context; CP_PRELOAD_TORCH=1 does it here.
         if os.environ.get("CP_PRELOAD_TORCH", "") == "1":
             import torch  # noqa: F401
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(os.environ.get("CP_LIB_PATH") or LIB_PATH)   # CP_LIB_PATH: a variant build (kernel experiments)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
             fn.restype = res

@@ -22,11 +22,22 @@ def main():
         print("no dispatches")
         return
     t_first, t_last = rows[0][0], max(r[1] for r in rows)
+    anchor, jobs_back, njobs = None, 1, 12
+    for a in sys.argv[2:]:
+        if a.startswith("--anchor="):      # --anchor=k_lasso_prep:12 : the window is the last job = the last 12 dispatches of that kernel
+            anchor = a.split("=", 1)[1]
+            if ":" in anchor:
+                anchor, njobs = anchor.split(":")[0], int(anchor.split(":")[1])
     if len(args) >= 2:
         w0, w1 = t_first + float(args[0]) * 1e6, t_first + float(args[1]) * 1e6
+    elif anchor:
+        hits = [r for r in rows if anchor in r[2]]
+        w0 = hits[-njobs][0] - 50e3
+        later = [r for r in rows if r[0] > w0 and "k_probe" not in r[2]]
+        w1 = max(r[1] for r in later) + 50e3
     else:
         w0, w1 = t_last - 40e6, t_last
-    win = [r for r in rows if r[0] >= w0 and r[0] < w1]
+    win = [r for r in rows if r[0] >= w0 and r[0] < w1 and "k_probe" not in r[2]]
     print("window %.3f .. %.3f ms after the first dispatch, %d dispatches, %d streams" % (
         (w0 - t_first) / 1e6, (w1 - t_first) / 1e6, len(win), len({r[3] for r in win})))
     by_stream = defaultdict(list)
