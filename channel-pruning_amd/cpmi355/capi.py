@@ -110,6 +110,7 @@ SIGNATURES = {
     "cp_result_host": (_c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_c_int),
                                 ctypes.POINTER(_c_int)]),
     "cp_probe_mfma_f64": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
+    "cp_probe_mfma_f64_clock": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl)]),
     "cp_probe_hbm_copy": (_c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_c_dbl)]),
     "cp_last_stage_times": (_c_int, [_vp, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_float)]),
     "cp_stage_name": (ctypes.c_char_p, [_vp, _c_int]),
@@ -532,6 +533,13 @@ class Context:
         v = _c_dbl()
         self._check(self.lib.cp_probe_mfma_f64(self.h, ctypes.byref(v)), "cp_probe_mfma_f64")
         return v.value
+
+    def probe_mfma_f64_clock(self):
+        """-> (TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64, shader clock GHz during the launch, cycles per MFMA and SIMD)"""
+        t, g, c = _c_dbl(), _c_dbl(), _c_dbl()
+        self._check(self.lib.cp_probe_mfma_f64_clock(self.h, ctypes.byref(t), ctypes.byref(g), ctypes.byref(c)),
+                    "cp_probe_mfma_f64_clock")
+        return t.value, g.value, c.value
 
     def probe_hbm_copy(self, nbytes=1 << 30):
         v = _c_dbl()

@@ -24,9 +24,10 @@
 // (no 128 x 128 inverse on the chain) and what k_chol_block_inverse turns into TI_s = U_ss^-1 / TIT_s for the substitution
 // kernels of refit.hip after the last step; it lives in the first 9216 doubles of TI_s until then.
 //
-// LDS: 75,776 B per workgroup (operand chunks of the update / the packed upper triangle of the tile), 512 threads, up to 256
-// VGPRs (the in-register 16 x 16 factorisation of the diagonal role spills at 128; the chain, not the tiles below the block
-// row, bounds a step: (nblk - s)^2 / 2 tiles of 22 us each on 256 CUs against 80+ us of update + factorisation + panel).
+// LDS: 75,776 B per workgroup (operand chunks of the update / the packed upper triangle of the tile), 512 threads, <= 128
+// VGPRs: two workgroups per CU, or one next to a 72 KB / 128-VGPR GEMM workgroup of another layer -- a workgroup that needs
+// a CU to itself waits for one while GEMM launches with workgroups still to place keep refilling every half CU that frees up
+// (rocprof timeline of the job: the first steps of a factorisation took 1.1-1.4 ms next to other layers' Gram GEMMs).
 #include "cp_common.h"
 
 #include <cstdlib>
@@ -83,6 +84,12 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 
+__device__ __forceinline__ double read_lane(double v, int lane) {   // lane: wave-uniform (constant after unrolling) -> SGPR pair
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void flag_wait(const int *flag, int *info) {
     for (int spin = 0; spin < (1 << 26); ++spin) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
@@ -137,14 +144,15 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *_
     }
 }
 
-// U_ss^T U_ss = S for the tile in `acc` (upper blocks t <= w valid), through the packed LDS tile.  Writes U[s,s] (upper,
-// zeros below), the operator P[s] and raises the flag.  The 16-column panel loop is the one of rounds 1-3 (wave 0 factors
-// the 16 x 16 diagonal block in registers, one thread per column solves U12, all waves apply the rank-16 update on MFMA).
-__device__ __forceinline__ void diag_factor(v4f64s (&acc)[NPAN], double *sm, double *__restrict__ Ub, int ld,
-                                            const double *__restrict__ dg0_blk, double piv_tol, double *__restrict__ P,
-                                            int *info, int blk) {
+// The diagonal role in three phases, each a function of its own (not inlined: the register allocator then sees one phase at
+// a time -- as one function the 16 x 16 in-register factorisation spilled on the chain at 128 VGPRs):
+//   diag_to_lds      the tile (upper blocks t <= w of `acc`) into the packed LDS tile, pivot references
+//   diag_factor_lds  U_ss^T U_ss = S in LDS.  The 16-column panel loop is the one of rounds 1-3 (wave 0 factors the 16 x 16
+//                    diagonal block in registers, one thread per column solves U12, all waves apply the rank-16 update on MFMA)
+//   diag_output      U[s,s] (upper, zeros below), T_p = U_pp^-1 into the diagonal slots, the operator P[s], the flag
+__device__ __forceinline__ void diag_to_lds(v4f64s (&acc)[NPAN], double *sm, const double *__restrict__ dg0_blk) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
-    double *dinv = sm + PACK, *dref = dinv + NB;
+    double *dref = sm + PACK + NB;
 #pragma unroll
     for (int t = 0; t < NPAN; ++t) {
         if (t > wave) continue;
@@ -153,37 +161,47 @@ __device__ __forceinline__ void diag_factor(v4f64s (&acc)[NPAN], double *sm, dou
     }
     if (tid < NB) dref[tid] = dg0_blk[tid];
     __syncthreads();
+}
 
+__device__ __noinline__ void diag_factor_lds(double *sm, double piv_tol, int *info, int blk) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+    double *dinv = sm + PACK, *dref = dinv + NB;
+#pragma unroll 1
     for (int p = 0; p < NPAN; ++p) {
         const int k0 = p * PNB;
-        // (1) 16 x 16 diagonal block on wave 0, in registers: lane j (< 16; the other lanes shadow them harmlessly) owns
-        // column j.  Per pivot: broadcast the pivot, scale row k, then a[i] -= U[k,i] U[k,j] for every later row i.
+        // (1) 16 x 16 diagonal block on wave 0, in registers, in the D lay-out of the MFMA tiles: lane (fk, fi) holds rows
+        // fk + 4 r of column fi (4 doubles).  Per pivot: the pivot to an SGPR pair (v_readlane), 1 / sqrt on every lane, row k
+        // scaled in the lanes that hold it, then U[k, fi] and the four U[k, fk + 4 r] fetched across lanes (ds_bpermute) and
+        // a[i, j] -= U[k, i] U[k, j] on the rows below.  (The column-per-lane form of rounds 1-3 -- 16 doubles per lane and 15
+        // row broadcasts in flight per pivot -- did not fit 128 VGPRs: it spilled on the chain.)
         if (wave == 0) {
-            double a[PNB];
             double *Dp = sm + pk(p, p) * 256;
+            double v[4];
 #pragma unroll
-            for (int i = 0; i < PNB; ++i) a[i] = Dp[i * 16 + fi];
+            for (int r = 0; r < 4; ++r) v[r] = Dp[(fk + 4 * r) * 16 + fi];
             const double refv = dref[k0 + fi];
 #pragma unroll
             for (int k = 0; k < PNB; ++k) {
-                double piv = row_bcast_i(a[k], k);
-                const double ref = row_bcast_i(refv, k);
-                if (!(piv > piv_tol * ref)) {
+                const int kr = k >> 2, kq = k & 3, src = kq * 16 + k;
+                double piv = read_lane(v[kr], src);
+                const double ref = read_lane(refv, k);
+                if (!(piv > piv_tol * ref)) {   // wave-uniform
                     if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
                     piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
                 }
                 const double inv = rsqrt_nr(piv);
-                const double u = a[k] * inv;  // U[k, j] for j > k
-                a[k] = fi == k ? piv * inv : u;
+                if (fk == kq) v[kr] = fi == k ? piv * inv : v[kr] * inv;      // row k of U (columns >= k meaningful)
+                const double urow = __shfl(v[kr], kq * 16 + fi, 64);           // U[k, fi]
 #pragma unroll
-                for (int i = k + 1; i < PNB; ++i) a[i] = fma(-row_bcast_i(u, i), u, a[i]);
+                for (int r = 0; r < 4; ++r) {
+                    const double ucol = __shfl(v[kr], kq * 16 + fk + 4 * r, 64);   // U[k, fk + 4 r]
+                    if (fk + 4 * r > k) v[r] = fma(-ucol, urow, v[r]);
+                }
                 if (lane == 0) dinv[k0 + k] = inv;
             }
-            if (lane < PNB) {
 #pragma unroll
-                for (int i = 0; i < PNB; ++i)
-                    if (fi >= i) Dp[i * 16 + fi] = a[i];
-            }
+            for (int r = 0; r < 4; ++r)
+                if (fi >= fk + 4 * r) Dp[(fk + 4 * r) * 16 + fi] = v[r];
         }
         __syncthreads();
         // (2) U12 = U11^-T A12: thread t owns column k0 + 16 + t
@@ -229,6 +247,11 @@ __device__ __forceinline__ void diag_factor(v4f64s (&acc)[NPAN], double *sm, dou
         __syncthreads();
     }
 
+}
+
+__device__ __noinline__ void diag_output(double *sm, double *__restrict__ Ub, int ld, double *__restrict__ P, int *info, int blk) {
+    const int tid = threadIdx.x;
+    const double *dinv = sm + PACK;
     // U[s,s] -> global (upper; the lower part zeroed)
     for (int e = tid; e < NB * NB; e += PT) {
         const int r = e >> 7, cc = e & (NB - 1);
@@ -337,9 +360,13 @@ __device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const 
 __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const double *__restrict__ Ai, double *__restrict__ Uss,
                                                                  int ld, int s, const double *__restrict__ dg0, double piv_tol,
                                                                  double *__restrict__ P, int *info, double *sm) {
-    v4f64s acc[NPAN];
-    tile_load_update<true>(acc, t_, Ai, ld, s, sm);
-    diag_factor(acc, sm, Uss, ld, dg0 + size_t(s) * NB, piv_tol, P, info, s);
+    {
+        v4f64s acc[NPAN];
+        tile_load_update<true>(acc, t_, Ai, ld, s, sm);
+        diag_to_lds(acc, sm, dg0 + size_t(s) * NB);
+    }
+    diag_factor_lds(sm, piv_tol, info, s);
+    diag_output(sm, Uss, ld, P, info, s);
     __builtin_amdgcn_endpgm();
 }
 
@@ -363,7 +390,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
 // R (p_pad x ntr 128-column tiles, leading dimension ldr; null: none): right-hand sides riding along -- block row i of the
 // launch has ntr more tiles after its nblk - i factor tiles, and after the last step R holds Y = U^-T R (the forward
 // substitution of the normal-equation solve, for free in the launches of the factorisation).
-__global__ void __launch_bounds__(PT, 2)
+__global__ void __launch_bounds__(PT, 4)
 k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int s,
             const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, int *info, double *__restrict__ R, int ldr,
             int ntr, int panel_last) {

@@ -3,6 +3,7 @@
 #include "cp_common.h"
 
 #include <algorithm>
+#include <vector>
 
 #include <chrono>
 
@@ -276,8 +277,11 @@ void cp_stage_begin(cp_ctx *ctx) {
 
 void cp_stage_mark(cp_ctx *ctx, const char *name) {
     if (!ctx->timing || ctx->n_marks >= 2 * CP_MAX_STAGES) return;
-    // mode 2: only the two events that bracket the roofline kernel (every event is a packet in the stream)
-    if (ctx->timing_gram_only && strcmp(name, "refit_gram_begin") != 0 && strcmp(name, "refit_gram_gemm") != 0) return;
+    // mode 2: only the events that bracket the refit Gram GEMM, the factorisation chain (Cholesky steps with the forward
+    // substitution riding along) and the backward substitution (every event is a packet in the stream)
+    if (ctx->timing_gram_only && strcmp(name, "refit_gram_begin") != 0 && strcmp(name, "refit_gram_gemm") != 0 &&
+        strcmp(name, "refit_chol_begin") != 0 && strcmp(name, "refit_cholesky") != 0 && strcmp(name, "refit_solve") != 0)
+        return;
     ctx->mark_names[ctx->n_marks] = name;
     hipEventRecord(ctx->ev[ctx->n_marks], ctx->stream);
     ++ctx->n_marks;
@@ -370,6 +374,67 @@ extern "C" int cp_probe_mfma_f64(cp_ctx *ctx, double *tflops) {
     hipEventDestroy(e1);
     double flops = double(blocks) * 4 /*waves*/ * iters * 8.0 * 2048.0;
     *tflops = flops / (ms * 1e-3) / 1e12;
+    return CP_OK;
+}
+
+// the same loop with clock stamps: st[wave] = {shader cycles (s_memtime), 100 MHz ticks (s_memrealtime)} around the loop
+__global__ void __launch_bounds__(256) k_probe_mfma_f64_clock(double *out, unsigned long long *st, int iters) {
+    v4f64 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = v4f64{0., 0., 0., 0.};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (s == 12345.678) out[0] = s;  // keep the chain live
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = size_t(blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64;
+        st[2 * w] = t1 - t0;
+        st[2 * w + 1] = r1 - r0;
+    }
+}
+
+extern "C" int cp_probe_mfma_f64_clock(cp_ctx *ctx, double *tflops, double *ghz, double *cycles_per_mfma) {
+    if (!ctx || !tflops || !ghz || !cycles_per_mfma) return CP_ERR_ARG;
+    // 2 workgroups of 4 waves per CU = 2 waves per SIMD, 8 independent accumulators each: the configuration at which the
+    // pipe saturates (tools/ubench/mfma_clock.hip: 48-49 TFLOP/s at 2, 4 and 8 waves per SIMD)
+    const int iters = 20000, blocks = ctx->cu_count * 2, waves = blocks * 4;
+    CP_TRY(cp_arena_reserve(ctx, 4096 + size_t(waves) * 16));
+    double *out = cp_arena_take_t<double>(ctx, 8);
+    unsigned long long *st = cp_arena_take_t<unsigned long long>(ctx, size_t(waves) * 2);
+    if (!out || !st) return cp_set_error(ctx, CP_ERR_NOMEM, "probe arena");
+    hipEvent_t e0, e1;
+    CP_HIP(ctx, hipEventCreate(&e0));
+    CP_HIP(ctx, hipEventCreate(&e1));
+    k_probe_mfma_f64_clock<<<blocks, 256, 0, ctx->stream>>>(out, st, 100);  // warm-up
+    CP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    k_probe_mfma_f64_clock<<<blocks, 256, 0, ctx->stream>>>(out, st, iters);
+    CP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    CP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    std::vector<unsigned long long> h(size_t(waves) * 2);
+    CP_HIP(ctx, hipMemcpy(h.data(), st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> g(waves), cyc(waves);
+    for (int w = 0; w < waves; ++w) {
+        cyc[w] = double(h[2 * w]);
+        g[w] = h[2 * w + 1] ? double(h[2 * w]) / double(h[2 * w + 1]) * 0.1 : 0.0;
+    }
+    std::sort(g.begin(), g.end());
+    std::sort(cyc.begin(), cyc.end());
+    *tflops = double(waves) * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    *ghz = g[waves / 2];
+    *cycles_per_mfma = cyc[waves / 2] / (2.0 * iters * 8.0);   // a SIMD runs two of the waves
     return CP_OK;
 }
 

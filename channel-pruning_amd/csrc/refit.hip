@@ -1632,6 +1632,7 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
             return CP_OK;
         }
         bool fwd = false;   // the forward substitution rode in the launches of the factorisation
+        cp_stage_mark(ctx, "refit_chol_begin");   // opens the bracket of the factorisation chain (timing mode 2)
         CP_TRY(chol_factor(ctx, ch, PIV_TOL, Rm, n_pad, &fwd));
         cp_stage_mark(ctx, "refit_cholesky");
         if (nblk >= solve_blocked_min_blocks()) {   // large factor: banded substitution with GEMM updates, then the lay-out kernel

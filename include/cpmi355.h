@@ -316,6 +316,10 @@ int cp_prune_layers(int n_jobs, cp_ctx *const *ctxs, const cp_prune_job *jobs, c
 /* ---- micro-benchmarks used by bench.py for roofline denominators ---------------- */
 /* Sustained v_mfma_f64_16x16x4_f64 rate (TFLOP/s) and float4-copy HBM bandwidth (GB/s). */
 int cp_probe_mfma_f64(cp_ctx *ctx, double *tflops);
+/* The same probe with every wave stamping the shader-clock counter (s_memtime) and the constant 100 MHz counter
+ * (s_memrealtime) around its loop: tflops as above, ghz = the shader clock the chip held during the launch (median wave),
+ * cycles_per_mfma = shader cycles per v_mfma_f64_16x16x4_f64 and SIMD at that rate (64 would be the nominal 78.6 TFLOP/s). */
+int cp_probe_mfma_f64_clock(cp_ctx *ctx, double *tflops, double *ghz, double *cycles_per_mfma);
 int cp_probe_hbm_copy(cp_ctx *ctx, size_t bytes, double *gbps);
 
 /* Per-stage device timings (ms, HIP events on the ctx stream) of the most recent
