@@ -68,6 +68,7 @@ SIGNATURES = {
     "cp_last_error": (ctypes.c_char_p, [_vp]),
     "cp_device_count": (_c_int, [ctypes.POINTER(_c_int)]),
     "cp_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_vp)]),
+    "cp_ctx_create_priority": (_c_int, [_c_int, _c_int, ctypes.POINTER(_vp)]),
     "cp_ctx_destroy": (_c_int, [_vp]),
     "cp_ctx_create_sibling": (_c_int, [_vp, ctypes.POINTER(_vp)]),
     "cp_ctx_set_stream": (_c_int, [_vp, _vp]),
@@ -199,10 +200,14 @@ class DevBuf:
 class Context:
     """One device + one stream (cp_ctx).  Create it inside the process that uses it."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, priority=None):
+        """priority: HIP priority of the context's stream (< 0 = higher); None = the environment's CP_CTX_PRIORITY (default 0)"""
         self.lib = load()
         h = _vp()
-        rc = self.lib.cp_ctx_create(int(device), ctypes.byref(h))
+        if priority is None:
+            rc = self.lib.cp_ctx_create(int(device), ctypes.byref(h))
+        else:
+            rc = self.lib.cp_ctx_create_priority(int(device), int(priority), ctypes.byref(h))
         if rc != 0:
             raise CpError(rc, "cp_ctx_create(device=%d)" % device,
                           "a gfx950 (MI355X) device is required; there is no CPU fallback")

@@ -22,6 +22,8 @@ For the layers that dominate (conv4/conv5 sizes) the ROWS of one layer can be sp
                                        (a few MB), every rank runs the identical alpha search, the refit's column
                                        sums and Gram are summed with two all-reduces (RCCL), every rank solves
 """
+import os
+
 import numpy as np
 
 
@@ -130,14 +132,10 @@ class ResidentLayerSet:
             per = max(1, min(int(per), capi_max_jobs()))
             for g0 in range(0, len(members), per):
                 group = members[g0:g0 + per]
-                # critical-path-first: the streams of the widest layers get the higher HIP priority (CP_JOB_PRIORITY=1)
-                import os
-                if os.environ.get("CP_JOB_PRIORITY", "0") == "1" and c == max(by_width):
-                    os.environ["CP_CTX_PRIORITY"] = "-1"
-                try:
-                    root = capi.Context(device)
-                finally:
-                    os.environ.pop("CP_CTX_PRIORITY", None)
+                # critical-path-first: the streams of the widest layers get the higher HIP priority (CP_JOB_PRIORITY=1);
+                # passed explicitly -- the environment is the caller's
+                critical = os.environ.get("CP_JOB_PRIORITY", "0") == "1" and c == max(by_width)
+                root = capi.Context(device, priority=-1 if critical else None)
                 ctxs = [root] + [root.sibling() for _ in group[1:]]
                 probs, rngs = [], []
                 for cx, i in zip(ctxs, group):
@@ -152,7 +150,6 @@ class ResidentLayerSet:
         # of them get their full normal equations computed on the side stream meanwhile (pruner.precompute_flag); more
         # than the idle head can absorb only adds flops to a chip that is busy afterwards.
         if precompute_heaviest is None:
-            import os
             precompute_heaviest = int(os.environ.get("CP_JOB_PRECOMPUTE", "2"))
         single = [ch for ch in self.chunks if len(ch["members"]) == 1]
         single.sort(key=lambda ch: -layer_cost(*[self.specs[ch["members"][0]][k] for k in ("N", "c", "n", "k", "rank")]))
@@ -160,7 +157,6 @@ class ResidentLayerSet:
             set(id(ch) for ch in single)
         # a set of one or two layers has the chip to itself: the full treatment (pruner.precompute_flag)
         self._latency_kind = "gram" if len(self.chunks) > 2 else True
-        import os
         if os.environ.get("CP_JOB_LATENCY_KIND") == "full":       # experiment: prefactored full Gram inside a job too
             self._latency_kind = True
         self._stop = False

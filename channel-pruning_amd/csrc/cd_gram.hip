@@ -1617,6 +1617,7 @@ extern "C" int cp_lasso_alpha_search(cp_ctx *ctx, const double *Q, int ldq, cons
     if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
+    cp_stage_mark(ctx, "cd_search_begin");   // opens the bracket of the search (timing mode 2)
     ctx->last_cd_was_team = cp_cd_team_wanted(c, flags);
     // A search always starts from w = 0 inside the kernel, so a search whose multi-CU team reported a hand-off time-out
     // (n_iter = -1 in its log) is simply run again by the one-workgroup team: bit-identical fits, only slower.
@@ -1718,6 +1719,7 @@ int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_sear
     if (lds > CD_LDS_MAX) return cp_set_error(ctx, CP_ERR_UNSUPPORTED, "cd: c=%d needs %zu B of LDS (limit %zu)", c, lds, CD_LDS_MAX);
     const int R = pick_R(c);
     cp_stage_begin(ctx);
+    cp_stage_mark(ctx, "cd_search_begin");   // opens the bracket of the search (timing mode 2)
     bool team = cp_cd_team_wanted(c, jobs[0].flags);
     for (int l = 1; l < n_jobs; ++l) team = team && jobs[l].flags == jobs[0].flags;
     for (int l = 0; l < n_jobs; ++l) ctxs[l]->last_cd_was_team = team;

@@ -10,7 +10,7 @@
 //
 //   launch s, one workgroup per upper tile (i, j), s <= i <= j < nblk, row s first:
 //     every tile   S = G[i,j] - U[s-1,i]^T U[s-1,j]         the update of step s - 1, applied only now (K = 128, MFMA)
-//     (s, s)       S = U_ss^T U_ss in LDS, T_q = (16 x 16 diagonal blocks)^-1, flag          -> U[s,s], P[s]
+//     (s, s)       S = U_ss^T U_ss in LDS, T_q = (16 x 16 diagonal blocks)^-1, flag, U_ss^-1  -> U[s,s], operator, TI_s, TIT_s
 //     (s, j > s)   wait for the flag, U[s,j] = U_ss^-T S by block forward substitution          -> U[s,j], Lt[j,s]
 //     (i > s, j)   G[i,j] = S
 //   The right-hand sides R of the solve that follows ride along as extra tile columns of every block row (B operand: block
@@ -19,10 +19,10 @@
 // A workgroup of row s waits only for workgroup 0 of its own launch, which the dispatcher starts first; the tiles below row s
 // wait for nothing, so the factorisation of block s runs while the rest of the chip applies update s - 1.
 //
-// P[s] ("the operator of block s", 36 blocks of 16 x 16, row-major upper triangle of the 8 x 8 block grid): the strictly
-// upper blocks of U_ss and, in the diagonal slots, T_q = U_qq^-1.  It is what a panel workgroup needs for the substitution
-// (no 128 x 128 inverse on the chain) and what k_chol_block_inverse turns into TI_s = U_ss^-1 / TIT_s for the substitution
-// kernels of refit.hip after the last step; it lives in the first 9216 doubles of TI_s until then.
+// "The operator of block s" (36 blocks of 16 x 16: the upper triangle of the 8 x 8 block grid): the strictly upper blocks
+// of U_ss and, in the diagonal slots, T_q = U_qq^-1.  It is what a panel workgroup needs for the substitution (no 128 x 128
+// inverse on the chain); the diagonal role leaves it in the tile G[s,s] it came from.  TI_s = U_ss^-1 / TIT_s, which the
+// substitution kernels of refit.hip multiply with, are computed by the same workgroup AFTER it has raised the flag.
 //
 // LDS: 75,776 B per workgroup (operand chunks of the update / the packed upper triangle of the tile), 512 threads, <= 128
 // VGPRs: two workgroups per CU, or one next to a 72 KB / 128-VGPR GEMM workgroup of another layer -- a workgroup that needs
@@ -45,6 +45,9 @@ constexpr int PACK = 36 * PNB * PNB;         // packed upper triangle of a 128 x
 constexpr int LDS_DOUBLES = PACK + 2 * NB;   // + dinv[128] + dref[128]
 static_assert(2 * KCH * SLD <= PACK, "the operand chunks and the packed tile share the same LDS");
 
+// (bi, bj) of packed slot 0 .. 35
+__device__ const unsigned char PK_BI[36] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
+__device__ const unsigned char PK_BJ[36] = {0, 1, 2, 3, 4, 5, 6, 7, 1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
 // slot of block (bi, bj), bi <= bj, in the packed upper triangle (row-major)
 __device__ __forceinline__ constexpr int pk(int bi, int bj) { return bi * NPAN - bi * (bi - 1) / 2 + (bj - bi); }
 // element (r, c) of the tile, block row <= block column
@@ -249,7 +252,7 @@ __device__ __noinline__ void diag_factor_lds(double *sm, double piv_tol, int *in
 
 }
 
-__device__ __noinline__ void diag_output(double *sm, double *__restrict__ Ub, int ld, double *__restrict__ P, int *info, int blk) {
+__device__ __noinline__ void diag_output(double *sm, double *__restrict__ Ub, int ld, double *__restrict__ Gss, int *info, int blk) {
     const int tid = threadIdx.x;
     const double *dinv = sm + PACK;
     // U[s,s] -> global (upper; the lower part zeroed)
@@ -279,7 +282,11 @@ __device__ __noinline__ void diag_output(double *sm, double *__restrict__ Ub, in
         for (int i = 0; i < PNB; ++i) Dp[i * 16 + j] = tcol[i];
     }
     __syncthreads();
-    for (int e = tid; e < PACK; e += PT) P[e] = sm[e];
+    // the operator goes where the tile came from: block (bi, bj) of G[s,s] (dead from here on) -- 16 lanes per 128-byte row
+    for (int e = tid; e < PACK; e += PT) {
+        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        Gss[size_t(16 * PK_BI[b] + r) * ld + 16 * PK_BJ[b] + c] = sm[e];
+    }
     __syncthreads();
     if (tid == 0) __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -314,6 +321,61 @@ __device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *s
             (Usj + size_t(16 * q + 4 * r) * ldu)[uoff] = acc[q][r];    // row 16 q + fk + 4 r, column 16 w + fi
             if (Ltjs) (Ltjs + (16 * q + 4 * r))[loff] = acc[q][r];     // transposed (factor tiles only)
         }
+}
+
+// TI_b = U_bb^-1 (upper) and TIT_b = its transpose from the operator in LDS: what the substitution kernels of refit.hip
+// multiply with.  The diagonal role computes them AFTER it has raised the flag, i.e. off the chain, while the panel
+// workgroups substitute.  V = U^-1 by block back-substitution, V_ij = -T_i sum_{k=i+1..j} U_ik V_kj: wave jb owns block
+// column jb and keeps its V blocks in registers (the D lay-out of a block is the B operand of the next product).
+template <int JB>
+__device__ __forceinline__ void inverse_column(const double *sm, double *__restrict__ TIb, double *__restrict__ TITb) {
+    const int lane = threadIdx.x & 63, fk = lane >> 4, fi = lane & 15;
+    v4f64s V[JB + 1];
+    {
+        const double *Tj = sm + pk(JB, JB) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) V[JB][r] = Tj[(fk + 4 * r) * 16 + fi];
+    }
+#pragma unroll
+    for (int ib = JB - 1; ib >= 0; --ib) {
+        v4f64s S = {0., 0., 0., 0.};
+#pragma unroll
+        for (int kb = ib + 1; kb <= JB; ++kb) {
+            const double *Uik = sm + pk(ib, kb) * 256;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                S = __builtin_amdgcn_mfma_f64_16x16x4f64(Uik[fi * 16 + kk * 4 + fk], V[kb][kk], S, 0, 0, 0);
+        }
+        const double *Ti = sm + pk(ib, ib) * 256;
+        v4f64s W = {0., 0., 0., 0.};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) W = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ti[fi * 16 + kk * 4 + fk], S[kk], W, 0, 0, 0);
+        V[ib] = W;
+    }
+    // rows of block column JB: blocks ib <= JB hold V, the blocks below are zero
+#pragma unroll
+    for (int ib = 0; ib < NPAN; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ib + fk + 4 * r, col = 16 * JB + fi;
+            double v = 0.0;
+            if (ib <= JB) v = V[ib < JB + 1 ? ib : JB][r];
+            TIb[row * NB + col] = v;
+            TITb[col * NB + row] = v;
+        }
+}
+
+__device__ __noinline__ void diag_inverse(const double *sm, double *__restrict__ TIb, double *__restrict__ TITb) {
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+        case 0: inverse_column<0>(sm, TIb, TITb); break;
+        case 1: inverse_column<1>(sm, TIb, TITb); break;
+        case 2: inverse_column<2>(sm, TIb, TITb); break;
+        case 3: inverse_column<3>(sm, TIb, TITb); break;
+        case 4: inverse_column<4>(sm, TIb, TITb); break;
+        case 5: inverse_column<5>(sm, TIb, TITb); break;
+        case 6: inverse_column<6>(sm, TIb, TITb); break;
+        default: inverse_column<7>(sm, TIb, TITb); break;
+    }
 }
 
 // A tile of launch s: where it lives, and the B operand of its update (block row s - 1 of U, or of Y for a right-hand side)
@@ -359,29 +421,33 @@ __device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const 
 
 __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const double *__restrict__ Ai, double *__restrict__ Uss,
                                                                  int ld, int s, const double *__restrict__ dg0, double piv_tol,
-                                                                 double *__restrict__ P, int *info, double *sm) {
+                                                                 double *__restrict__ TIb, double *__restrict__ TITb, int *info,
+                                                                 double *sm) {
     {
         v4f64s acc[NPAN];
         tile_load_update<true>(acc, t_, Ai, ld, s, sm);
         diag_to_lds(acc, sm, dg0 + size_t(s) * NB);
     }
     diag_factor_lds(sm, piv_tol, info, s);
-    diag_output(sm, Uss, ld, P, info, s);
+    diag_output(sm, Uss, ld, t_.T, info, s);     // ... and the flag: the panel workgroups go on from here
+    diag_inverse(sm, TIb, TITb);
     __builtin_amdgcn_endpgm();
 }
 
 // out / ldo: where U[s,j] (or Y[s,jr]) goes; Ltjs: the transposed copy of a factor tile, null for a right-hand side
 __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const double *__restrict__ Ai, int ld, int s,
                                                                   double *__restrict__ out, int ldo, double *__restrict__ Ltjs,
-                                                                  const double *__restrict__ P, int *info, double *sm) {
+                                                                  const double *__restrict__ Gss, int *info, double *sm) {
     const int tid = threadIdx.x;
     v4f64s acc[NPAN];
     tile_load_update<false>(acc, t_, Ai, ld, s, sm);
     if (tid == 0) flag_wait(info + 1 + s, info);  // bounded; running out is reported as a failed factorisation
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int e = tid; e < PACK / 2; e += PT)
-        reinterpret_cast<v2f64s *>(sm)[e] = reinterpret_cast<const v2f64s *>(P)[e];
+    for (int e = tid; e < PACK / 2; e += PT) {   // the operator of block s, left in G[s,s] by the diagonal role
+        const int b = e >> 7, r = (e >> 3) & 15, c = (e & 7) * 2;
+        reinterpret_cast<v2f64s *>(sm)[e] = *reinterpret_cast<const v2f64s *>(Gss + size_t(16 * PK_BI[b] + r) * ld + 16 * PK_BJ[b] + c);
+    }
     __syncthreads();
     panel_solve(acc, sm, out, ldo, Ltjs, ld);
     __builtin_amdgcn_endpgm();
@@ -392,8 +458,8 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
 // substitution of the normal-equation solve, for free in the launches of the factorisation).
 __global__ void __launch_bounds__(PT, 4)
 k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int s,
-            const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, int *info, double *__restrict__ R, int ldr,
-            int ntr, int panel_last) {
+            const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, double *__restrict__ TIT, int *info,
+            double *__restrict__ R, int ldr, int ntr, int panel_last) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     int i = s, jt;
     {   // tile -> (i, jt): block row i holds nblk - i factor tiles, then ntr right-hand-side tiles; row s first --
@@ -432,74 +498,16 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
         t_.B = Urow + size_t(j) * NB;
         t_.ldb = ld;
     }
-    double *P = TI + size_t(s) * NB * NB;
+    const double *Gss = G + size_t(s) * NB * ld + size_t(s) * NB;   // where the diagonal role leaves the operator of block s
     if (i > s)            // below the block row of this step: the updated tile goes back
         role_bulk(t_, Ai, ld, s, sm);
     else if (!rhs && j == s)
-        role_diag(t_, Ai, U + size_t(s) * NB * ld + size_t(s) * NB, ld, s, dg0, piv_tol, P, info, sm);
+        role_diag(t_, Ai, U + size_t(s) * NB * ld + size_t(s) * NB, ld, s, dg0, piv_tol, TI + size_t(s) * NB * NB,
+                  TIT + size_t(s) * NB * NB, info, sm);
     else if (!rhs)
-        role_panel(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB, P, info, sm);
+        role_panel(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB, Gss, info, sm);
     else
-        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, P, info, sm);
-}
-
-// TI_b = U_bb^-1 (upper) and TIT_b = its transpose from the operator P[b] (in the first PACK doubles of TI_b), one workgroup
-// per diagonal block, after the last step.  V = U^-1 by block back-substitution, V_ij = -T_i sum_{k=i+1..j} U_ik V_kj: wave
-// jb owns block column jb and keeps its V blocks in registers (the D lay-out of a block is the B operand of the next product).
-template <int JB>
-__device__ __forceinline__ void inverse_column(const double *sm, double *__restrict__ TIb, double *__restrict__ TITb) {
-    const int lane = threadIdx.x & 63, fk = lane >> 4, fi = lane & 15;
-    v4f64s V[JB + 1];
-    {
-        const double *Tj = sm + pk(JB, JB) * 256;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) V[JB][r] = Tj[(fk + 4 * r) * 16 + fi];
-    }
-#pragma unroll
-    for (int ib = JB - 1; ib >= 0; --ib) {
-        v4f64s S = {0., 0., 0., 0.};
-#pragma unroll
-        for (int kb = ib + 1; kb <= JB; ++kb) {
-            const double *Uik = sm + pk(ib, kb) * 256;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                S = __builtin_amdgcn_mfma_f64_16x16x4f64(Uik[fi * 16 + kk * 4 + fk], V[kb][kk], S, 0, 0, 0);
-        }
-        const double *Ti = sm + pk(ib, ib) * 256;
-        v4f64s W = {0., 0., 0., 0.};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) W = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ti[fi * 16 + kk * 4 + fk], S[kk], W, 0, 0, 0);
-        V[ib] = W;
-    }
-    // rows of block column JB: blocks ib <= JB hold V, the blocks below are zero
-#pragma unroll
-    for (int ib = 0; ib < NPAN; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * ib + fk + 4 * r, col = 16 * JB + fi;
-            double v = 0.0;
-            if (ib <= JB) v = V[ib < JB + 1 ? ib : JB][r];
-            TIb[row * NB + col] = v;
-            TITb[col * NB + row] = v;
-        }
-}
-
-__global__ void __launch_bounds__(PT) k_chol_block_inverse(double *__restrict__ TI, double *__restrict__ TIT) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *TIb = TI + size_t(blockIdx.x) * NB * NB, *TITb = TIT + size_t(blockIdx.x) * NB * NB;
-    for (int e = threadIdx.x; e < PACK / 2; e += PT)
-        reinterpret_cast<v2f64s *>(sm)[e] = reinterpret_cast<const v2f64s *>(TIb)[e];
-    __syncthreads();   // the operator is in LDS: TI_b may be overwritten from here on
-    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-        case 0: inverse_column<0>(sm, TIb, TITb); break;
-        case 1: inverse_column<1>(sm, TIb, TITb); break;
-        case 2: inverse_column<2>(sm, TIb, TITb); break;
-        case 3: inverse_column<3>(sm, TIb, TITb); break;
-        case 4: inverse_column<4>(sm, TIb, TITb); break;
-        case 5: inverse_column<5>(sm, TIb, TITb); break;
-        case 6: inverse_column<6>(sm, TIb, TITb); break;
-        default: inverse_column<7>(sm, TIb, TITb); break;
-    }
+        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, sm);
 }
 
 hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explicit opt-in, once per device
@@ -510,9 +518,7 @@ hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explici
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_step), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(LDS_DOUBLES * sizeof(double)));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_block_inverse), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            int(PACK * sizeof(double)));
-    if (e == hipSuccess && device >= 0 && device < 64) done[device] = true;
+    if (device >= 0 && device < 64) done[device] = true;
     return e;
 }
 
@@ -532,10 +538,8 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     for (int s = 0; s < nblk; ++s) {
         // s = 0: nothing to apply yet, only block row 0; afterwards every upper tile of the rows s .. nblk - 1
         const int n = nblk - s, tiles = s == 0 ? n + ntr : n * (n + 1) / 2 + n * ntr;
-        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, info, R, n_pad, ntr, panel_last);
+        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, TIT, info, R, n_pad, ntr, panel_last);
         CP_LAUNCH_CHECK(ctx);
     }
-    k_chol_block_inverse<<<nblk, PT, size_t(PACK) * sizeof(double), ctx->stream>>>(TI, TIT);
-    CP_LAUNCH_CHECK(ctx);
     return CP_OK;
 }

@@ -93,6 +93,7 @@ struct cp_ctx {
     char *cd_box = nullptr;           // mailboxes of the multi-CU coordinate-descent team (cd_team.hip), grow-only
     size_t cd_box_bytes = 0;
     bool potrf_lds_opt_in = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
+    hipStream_t low_stream = nullptr;  // lowest-priority stream for the layer's long products (cp_wide_stream, CP_WIDE_LOWPRIO)
     bool last_cd_was_team = false;    // which kernel family the last coordinate-descent launch of THIS context ran (debug counters)
     int cd_fallbacks = 0;             // searches / fits re-run on the one-workgroup team after a hand-off time-out of the multi-CU team
     bool cd_test_fail_multi = false;  // cp_debug_cd_fail_multi: the next multi-CU launches give up at once (tests of that fallback)

@@ -48,6 +48,19 @@ extern "C" int cp_device_count(int *count) {
 #include <mutex>
 hipStream_t cp_side_stream(cp_ctx *ctx);
 hipStream_t cp_wide_stream(cp_ctx *ctx) {
+    // CP_WIDE_LOWPRIO=1: the long products of a layer (refit Gram, X^T Y: launches of 700+ workgroups that live a millisecond)
+    // go to a stream of the LOWEST priority owned by the layer's context, so that the dispatcher places the workgroups of
+    // other layers' chain kernels (normal priority) first whenever a slot frees up, instead of after every workgroup such a
+    // launch still has to place.
+    static const bool lowprio = getenv("CP_WIDE_LOWPRIO") && getenv("CP_WIDE_LOWPRIO")[0] == '1';
+    if (lowprio) {
+        if (!ctx->low_stream) {
+            int least = 0, greatest = 0;
+            hipDeviceGetStreamPriorityRange(&least, &greatest);   // numerically lower = higher priority
+            if (hipStreamCreateWithPriority(&ctx->low_stream, hipStreamNonBlocking, least) != hipSuccess) ctx->low_stream = nullptr;
+        }
+        return ctx->low_stream;
+    }
     static const int reserve = getenv("CP_WIDE_RESERVE") ? atoi(getenv("CP_WIDE_RESERVE")) : 0;
     static const bool shared = getenv("CP_GRAM_SHARED_STREAM") && getenv("CP_GRAM_SHARED_STREAM")[0] == '1';
     if (shared) return cp_side_stream(ctx);   // no CU mask: the long products of all layers simply take turns
@@ -86,6 +99,13 @@ hipStream_t cp_side_stream(cp_ctx *ctx) {
 }
 
 extern "C" int cp_ctx_create(int device, cp_ctx **out) {
+    // CP_CTX_PRIORITY (read, never written, by the library): the default HIP priority of a context's stream
+    int prio = 0;
+    if (const char *pv = getenv("CP_CTX_PRIORITY")) prio = atoi(pv);
+    return cp_ctx_create_priority(device, prio, out);
+}
+
+extern "C" int cp_ctx_create_priority(int device, int prio, cp_ctx **out) {
     if (!out) return CP_ERR_ARG;
     *out = nullptr;
     int n = 0;
@@ -106,11 +126,9 @@ extern "C" int cp_ctx_create(int device, cp_ctx **out) {
             return CP_ERR_NODEVICE;
         }
     }
-    // CP_CTX_PRIORITY (read at every creation; < 0 = higher): the HIP priority of this context's stream.  A resident layer
-    // set raises it for the layers on the job's critical path (cpmi355.shard.ResidentLayerSet), whose short dependent
-    // kernels (factorisation steps) then do not queue behind the long products of layers with slack.
-    int prio = 0;
-    if (const char *pv = getenv("CP_CTX_PRIORITY")) prio = atoi(pv);
+    // prio < 0 = higher: a resident layer set may raise it for the layers on the job's critical path
+    // (cpmi355.shard.ResidentLayerSet), whose short dependent kernels then do not queue behind the long products of layers
+    // with slack
     hipError_t se;
     if (prio != 0) {
         int least = 0, greatest = 0;
@@ -161,6 +179,7 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    if (ctx->low_stream) hipStreamDestroy(ctx->low_stream);
     delete ctx;
     return CP_OK;
 }
@@ -277,10 +296,11 @@ void cp_stage_begin(cp_ctx *ctx) {
 
 void cp_stage_mark(cp_ctx *ctx, const char *name) {
     if (!ctx->timing || ctx->n_marks >= 2 * CP_MAX_STAGES) return;
-    // mode 2: only the events that bracket the refit Gram GEMM, the factorisation chain (Cholesky steps with the forward
-    // substitution riding along) and the backward substitution (every event is a packet in the stream)
+    // mode 2: only the events that bracket the alpha search, the refit Gram GEMM, the factorisation chain (Cholesky steps
+    // with the forward substitution riding along) and the backward substitution (every event is a packet in the stream)
     if (ctx->timing_gram_only && strcmp(name, "refit_gram_begin") != 0 && strcmp(name, "refit_gram_gemm") != 0 &&
-        strcmp(name, "refit_chol_begin") != 0 && strcmp(name, "refit_cholesky") != 0 && strcmp(name, "refit_solve") != 0)
+        strcmp(name, "refit_chol_begin") != 0 && strcmp(name, "refit_cholesky") != 0 && strcmp(name, "refit_solve") != 0 &&
+        strcmp(name, "cd_search_begin") != 0 && strcmp(name, "cd_alpha_search") != 0)
         return;
     ctx->mark_names[ctx->n_marks] = name;
     hipEventRecord(ctx->ev[ctx->n_marks], ctx->stream);

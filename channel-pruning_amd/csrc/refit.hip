@@ -1289,7 +1289,12 @@ int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad, con
 // band's contribution to every remaining row as ONE chip-filling f64 MFMA GEMM with K = 512
 //   forward   R[rows below] -= U[band, below]^T Y[band]       backward   R[rows above] -= (Lt[band, above])^T W[band]
 // so the factor is read once per sweep.  The coefficient lay-out / intercept tail is the caller's (k_finalize).
-constexpr int SOLVE_OB = 4;
+// blocks per band: CP_SOLVE_OB (default 4; every band costs two launches, a wider band more serial work in its strips)
+static const int SOLVE_OB = [] {
+    const char *e = getenv("CP_SOLVE_OB");
+    const int v = e ? atoi(e) : 4;
+    return v >= 1 && v <= 64 ? v : 4;
+}();
 int solve_blocked_min_blocks() {
     static const int v = [] {
         const char *e = getenv("CP_SOLVE_BLOCKED_MIN_NBLK");

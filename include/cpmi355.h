@@ -51,6 +51,9 @@ const char *cp_strerror(int code);
 const char *cp_last_error(const cp_ctx *ctx);
 int cp_device_count(int *count);
 int cp_ctx_create(int device, cp_ctx **out);
+/* The same with an explicit HIP stream priority for the context's stream (0 = default, < 0 = higher, > 0 = lower; clamped to
+ * the device's range).  cp_ctx_create() uses the environment's CP_CTX_PRIORITY (default 0). */
+int cp_ctx_create_priority(int device, int priority, cp_ctx **out);
 int cp_ctx_destroy(cp_ctx *ctx);
 /* a context with its own workspace that runs on `of`'s stream (no stream / hardware queue of its own): the per-job
  * contexts of cp_prune_layers.  Destroy it before `of`. */

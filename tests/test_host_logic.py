@@ -552,7 +552,7 @@ def test_resident_layer_set_chunks_streams_and_latency_layers(monkeypatch):
     created, calls = [], []
 
     class FakeCtx:
-        def __init__(self, device=0, name=None):
+        def __init__(self, device=0, name=None, priority=None):
             self.name = name or "ctx%d" % len(created)
             created.append(self.name)
 
