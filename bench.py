@@ -229,39 +229,87 @@ class Env:
             self.dist.destroy_process_group()
 
 
+def git_head():
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
 def pmc_traffic(pattern, round_tag):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 counter passes (separate --pmc runs
-    of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads,
-    WRITE_SIZE as reported).  None when the profile files are absent."""
-    out = {}
+    """-> (HBM bytes per launch of the kernel whose name contains `pattern`, "<files>@<commit of the library they profiled>")
+    from the committed rocprofv3 counter passes (separate --pmc runs of `bench.py --profile-mode`; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads, WRITE_SIZE as reported).  (None, None) when absent."""
+    out, commit = {}, None
     for key, fname, scale in (("fetch", "%s_pmc_fetch_size_kb.md" % round_tag, 2.0),
                               ("write", "%s_pmc_write_size_kb.md" % round_tag, 1.0)):
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.isfile(path):
-            return None
+            return None, None
         for line in open(path):
+            if line.startswith("commit:"):
+                commit = line.split(":", 1)[1].strip()
             if pattern in line:
                 try:
                     out[key] = float(line.split("|")[3]) * 1024.0 * scale
                 except (ValueError, IndexError):
                     pass
     if len(out) != 2:
-        return None
-    return out["fetch"] + out["write"]
+        return None, None
+    return out["fetch"] + out["write"], "profiles/%s_pmc_{fetch,write}_size_kb.md@%s" % (round_tag, commit or "unknown")
 
 
-def roofline_object(g_ms, g_fl, ctx0, note, traffic):
-    if not g_ms or sum(g_ms) <= 0:
+def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job):
+    """`roofline` of the JSON line.  The kernel classes of the job's MFMA work, each timed live with HIP events on its launch
+    stream during the timed jobs (cp_enable_stage_timing mode 2): the refit Gram GEMM (one launch per layer) and the
+    factorisation chain (the Cholesky step launches of a layer, with the forward substitution riding along).  The one
+    with the larger sum over the job is THE roofline kernel; both are listed under `kernels`, next to the two
+    latency-bound chains (alpha search, backward substitution) whose sums say where the rest of the time goes."""
+    if not cls_ms["refit_gram"] or sum(cls_ms["refit_gram"]) <= 0:
         return None
-    achieved = sum(g_fl) / (sum(g_ms) * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_gemm_tn_f64 (refit Gram G = Xs^T Xs, f64 MFMA 16x16x4)",
-            "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + "
-                            "WRITE_SIZE passes committed under profiles/",
-            "avg_launch_ms": round(sum(g_ms) / len(g_ms), 4), "launches": len(g_ms),
-            "flops_per_launch": "N*p^2 (symmetric half of 2*N*p^2), p = kept*k*k",
-            "peak_measured_probe": round(ctx0.probe_mfma_f64(), 2), "note": note}
+    probe_tf, ghz, cyc = ctx0.probe_mfma_f64_clock()
+    per_job = {k: sum(v) / max(1, jobs) for k, v in cls_ms.items()}
+    gram = {"kernel": "k_gemm_tn_f64<lower, refit Gram> (G = Xs^T Xs, one launch per layer)",
+            "flops_per_launch": "N p^2 (symmetric half of 2 N p^2), p = kept k k",
+            "achieved": round(sum(g_fl) / (sum(cls_ms["refit_gram"]) * 1e-3) / 1e12, 3),
+            "avg_launch_ms": round(sum(cls_ms["refit_gram"]) / len(cls_ms["refit_gram"]), 4), "launches": len(cls_ms["refit_gram"]),
+            "sum_ms_per_job": round(per_job["refit_gram"], 3), "pmc_pattern": "k_gemm_tn_f64<1, 2,"}
+    chol = None
+    if cls_ms["cholesky_chain"] and sum(cls_ms["cholesky_chain"]) > 0:
+        chol = {"kernel": "k_chol_step (blocked Cholesky, one launch per 128-column step; per layer: p/128 launches)",
+                "flops_per_launch": "per layer: p^3 / 3 + p^2 n (the forward substitution rides in the same launches)",
+                "achieved": round(sum(chol_fl) / (sum(cls_ms["cholesky_chain"]) * 1e-3) / 1e12, 3),
+                "avg_launch_ms": round(sum(cls_ms["cholesky_chain"]) / len(cls_ms["cholesky_chain"]), 4),
+                "launches": len(cls_ms["cholesky_chain"]), "sum_ms_per_job": round(per_job["cholesky_chain"], 3),
+                "pmc_pattern": "k_chol_step", "avg_launch_note": "one bracket = all step launches of a layer"}
+    top = gram if chol is None or per_job["refit_gram"] >= per_job["cholesky_chain"] else chol
+    traffic, source = pmc_traffic(top["pmc_pattern"], round_tag) if job == "vgg16" else (None, None)
+    for k in (gram, chol):
+        if k is not None:
+            k["frac"] = round(k["achieved"] / F64_MFMA_PEAK_TFLOPS, 4)
+            k["frac_of_measured_peak"] = round(k["achieved"] / probe_tf, 4)
+    out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": top["frac"], "traffic": traffic, "traffic_source": source,
+           "traffic_note": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + WRITE_SIZE "
+                           "passes of `bench.py --profile-mode`, committed under profiles/ (taken at the commit named)",
+           "dominant_by": "sum of launch time per job among the MFMA kernels, HIP events on the launch streams during the timed jobs",
+           "avg_launch_ms": top["avg_launch_ms"], "launches": top["launches"], "flops_per_launch": top["flops_per_launch"],
+           "peak_nominal": F64_MFMA_PEAK_TFLOPS,
+           "peak_measured": round(probe_tf, 2), "frac_of_measured_peak": top["frac_of_measured_peak"],
+           "effective_ghz": round(ghz, 3), "cycles_per_mfma_measured": round(cyc, 1),
+           "peak_note": "peak = 78.6 TFLOP/s, AMD's FP64 matrix figure (64 cycles per v_mfma_f64_16x16x4_f64 and SIMD at 2.4 GHz); "
+                        "peak_measured = back-to-back MFMAs, 2 waves per SIMD x 8 accumulators, stamped with s_memtime / "
+                        "s_memrealtime in this run: the pipe issues one instruction per ~102 cycles whatever the number of "
+                        "waves, at the full clock (effective_ghz) -- no throttle (profiles/r04_mfma_clock.md)",
+           "kernels": [k for k in (gram, chol) if k is not None],
+           "latency_bound_chains_ms_per_job": {"alpha_search (one workgroup-team per layer)": round(per_job["alpha_search"], 3),
+                                               "backward_substitution (banded)": round(per_job["backward_substitution"], 3)},
+           "note": "brackets are stream time of a layer while the other layers of the job share the CUs; sums over the "
+                   "layers of a job exceed job_ms because the layers overlap"}
+    for k in out["kernels"]:
+        k.pop("pmc_pattern", None)
+    return out
 
 
 # ==================================================================================================================
@@ -356,6 +404,8 @@ def bench_job(args, env, job):
     for cx in ctxs:
         cx.enable_stage_timing(2)      # timed region: only the two events around the roofline kernel
     g_ms, g_fl, exch_ms = [], [], []
+    cls_ms = {"alpha_search": [], "refit_gram": [], "cholesky_chain": [], "backward_substitution": []}   # per launch / bracket, in the job
+    chol_fl = []
     sync_all()
     env.barrier()
     t0 = time.perf_counter()
@@ -370,6 +420,15 @@ def bench_job(args, env, job):
                     if name == "refit_gram_gemm":
                         g_ms.append(ms)
                         g_fl.append(float(pr.N) * int(pr.refit_info.p) ** 2)
+                        cls_ms["refit_gram"].append(ms)
+                    elif name == "cd_alpha_search":
+                        cls_ms["alpha_search"].append(ms)
+                    elif name == "refit_cholesky":
+                        cls_ms["cholesky_chain"].append(ms)
+                        pp = float(int(pr.refit_info.p))
+                        chol_fl.append(pp ** 3 / 3.0 + pp * pp * float(pr.n))    # + the forward substitution riding along
+                    elif name == "refit_solve":
+                        cls_ms["backward_substitution"].append(ms)
     sync_all()
     env.barrier()
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
@@ -384,6 +443,7 @@ def bench_job(args, env, job):
     # ---- outside the timed region: every layer of this rank ALONE (latency, per-stage times, roofline kernel alone) ----
     per_layer = {}
     alone_g_ms, alone_g_fl, alone_g_ex = [], [], []
+    alone_c_ms, alone_c_fl = [], []
     stage_by_c = {}
     for j, pr in ([] if args.profile_mode else probs.items()):
         spec = specs[own[j]]
@@ -407,6 +467,13 @@ def bench_job(args, env, job):
                                    "cd_kernel": ("one wave", "two waves", "team (one workgroup)", "multi-CU team")[
                                        pr.ctx.cd_kernel_form(spec["c"], CD_FLAGS)]}
         stage_by_c.setdefault("c%d_k%d_n%d" % (spec["c"], spec["k"], spec["n"]), st)
+        if "prefactor_cholesky" in st:        # latency mode: the full Gram (P = c k k columns) factored during the search
+            alone_c_ms.append(st["prefactor_cholesky"])
+            alone_c_fl.append(float(spec["c"] * kk) ** 3 / 3.0)
+        elif "refit_cholesky" in st:
+            alone_c_ms.append(st["refit_cholesky"])
+            pp_ = float(int(pr.refit_info.p))
+            alone_c_fl.append(pp_ ** 3 / 3.0 + pp_ * pp_ * spec["n"])
         if "refit_gram_gemm" in st:
             alone_g_ms.append(st["refit_gram_gemm"])
             alone_g_fl.append(float(spec["N"]) * int(pr.refit_info.p) ** 2)
@@ -473,19 +540,21 @@ def bench_job(args, env, job):
         fl = [layer_flops(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         by = [algorithmic_bytes(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
-        roof = roofline_object(g_ms, g_fl, roots[0],
-                               "launch duration over the timed region, i.e. while the other layers of the job share the "
-                               "CUs; alone = the same kernel of every layer with the chip to itself; job_mfma = the "
-                               "whole job against the same peak",
-                               pmc_traffic("k_gemm_tn_f64<1, 2,", PROFILE_TAG) if job == "vgg16" else None)
+        roof = roofline_object(cls_ms, g_fl, chol_fl, jobs, roots[0], PROFILE_TAG, job)
         if roof is not None and alone_g_ms:
             a1 = sum(alone_g_fl) / (sum(alone_g_ms) * 1e-3) / 1e12
-            roof["alone"] = {"achieved": round(a1, 3), "frac": round(a1 / F64_MFMA_PEAK_TFLOPS, 4),
-                             "avg_launch_ms": round(sum(alone_g_ms) / len(alone_g_ms), 4),
-                             "executed_tflops": round(sum(alone_g_ex) / (sum(alone_g_ms) * 1e-3) / 1e12, 3),
+            roof["alone"] = {"refit_gram": {"achieved": round(a1, 3), "frac": round(a1 / F64_MFMA_PEAK_TFLOPS, 4),
+                                            "avg_launch_ms": round(sum(alone_g_ms) / len(alone_g_ms), 4),
+                                            "executed_tflops": round(sum(alone_g_ex) / (sum(alone_g_ms) * 1e-3) / 1e12, 3)},
                              "note": "one layer at a time = latency mode: the launch computes the Gram of ALL c channels on the "
                                      "side stream during the alpha search (executed N (c k^2)^2); achieved counts only the "
                                      "algorithmic N p^2 of the kept channels"}
+            if alone_c_ms:
+                a2 = sum(alone_c_fl) / (sum(alone_c_ms) * 1e-3) / 1e12
+                roof["alone"]["cholesky_chain"] = {"achieved": round(a2, 3), "frac": round(a2 / F64_MFMA_PEAK_TFLOPS, 4),
+                                                   "avg_ms_per_layer": round(sum(alone_c_ms) / len(alone_c_ms), 4),
+                                                   "note": "p^3/3 of the matrix the layer really factored alone (single-layer calls "
+                                                           "factor the FULL Gram, P = c k k columns, during the alpha search)"}
         out = {
             "metric": JOB_TEXT[job][1],
             "value": round(layers_per_s, 3), "unit": "layers/s", "n_gpus": env.world, "steps": args.steps,
@@ -540,7 +609,7 @@ def bench_job(args, env, job):
 
 # measured ms of one layer alone by channel count (profiles/r02_*): the LPT costs of the vgg16 job
 VGG16_COST_MS = {64: 1.5, 128: 3.0, 256: 6.8, 512: 15.5}
-PROFILE_TAG = "r03"      # profiles/<tag>_pmc_{fetch,write}_size_kb.md feed roofline.traffic
+PROFILE_TAG = "r04"      # profiles/<tag>_pmc_{fetch,write}_size_kb.md feed roofline.traffic
 
 
 # ==================================================================================================================
@@ -761,9 +830,9 @@ def bench_block(args, env):
         layers_per_s = len(BLOCK_LAYERS) * world * passes / elapsed
         g_ms = [ms for w in workers for ms in w.stage_acc.get("refit_gram_gemm", [])]
         g_fl = [f for w in workers for f in w.gram_flops]
-        roof = roofline_object(g_ms, g_fl, workers[0].ctx,
-                               "launch duration over the timed region, i.e. while the other layers in flight share the CUs",
-                               pmc_traffic("k_gemm_tn_f64<1, 2,", PROFILE_TAG))
+        bcls = {"alpha_search": [ms for w in workers for ms in w.stage_acc.get("cd_alpha_search", [])], "refit_gram": g_ms,
+                "cholesky_chain": [], "backward_substitution": [ms for w in workers for ms in w.stage_acc.get("refit_solve", [])]}
+        roof = roofline_object(bcls, g_fl, [], passes, workers[0].ctx, PROFILE_TAG, "block")
         fl = [layer_flops(w.c, w.n, int(w.prob.refit_info.p)) for w in groups[0]]
         alg_l = sum(f[0] for f in fl) / len(fl)
         calls = sum(w.calls for w in workers)

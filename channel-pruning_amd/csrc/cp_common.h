@@ -92,8 +92,6 @@ struct cp_ctx {
     int itq_sweeps = 0;               // Jacobi sweeps of the last cp_itq_iterate (all alternations)
     char *cd_box = nullptr;           // mailboxes of the multi-CU coordinate-descent team (cd_team.hip), grow-only
     size_t cd_box_bytes = 0;
-    bool potrf_lds_opt_in = false;    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
-    hipStream_t low_stream = nullptr;  // lowest-priority stream for the layer's long products (cp_wide_stream, CP_WIDE_LOWPRIO)
     bool last_cd_was_team = false;    // which kernel family the last coordinate-descent launch of THIS context ran (debug counters)
     int cd_fallbacks = 0;             // searches / fits re-run on the one-workgroup team after a hand-off time-out of the multi-CU team
     bool cd_test_fail_multi = false;  // cp_debug_cd_fail_multi: the next multi-CU launches give up at once (tests of that fallback)
@@ -117,10 +115,6 @@ int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
 
 #define CP_LAUNCH_CHECK(ctx) CP_HIP(ctx, hipGetLastError())
 
-// The device's shared stream for the LONG chip-filling GEMMs (refit Gram, X^T Y: workgroups that live for a millisecond),
-// created with a CU mask that leaves CP_WIDE_RESERVE CUs (default 0 = feature off, nullptr) to everybody else: a
-// one-workgroup helper or a Cholesky diagonal block of another layer otherwise waits for such a workgroup to retire.
-hipStream_t cp_wide_stream(cp_ctx *ctx);
 hipStream_t cp_side_stream(cp_ctx *ctx);   // the device's shared stream for work that overlaps a context's own chain (never null)
 // A pending precompute that nobody will consume (error exit, an unrelated refit, new contents in its buffers): wait for the
 // side / chain stream work that still reads X / Y, then forget it.
@@ -128,26 +122,6 @@ void cp_precompute_void(cp_ctx *ctx);
 int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n,
                                 double rank_hint = 0.0);
 void cp_precompute_release(cp_ctx *ctx);
-// run `body` (launches on ctx->stream) on the wide stream instead, ordered after / before the context's own stream
-template <class F>
-static inline int cp_on_wide_stream(cp_ctx *ctx, F &&body) {
-    hipStream_t wide = cp_wide_stream(ctx);
-    if (!wide) return body();
-    if (!ctx->ev_fork) {
-        if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
-            return body();
-    }
-    hipStream_t own = ctx->stream;
-    if (hipEventRecord(ctx->ev_fork, own) != hipSuccess || hipStreamWaitEvent(wide, ctx->ev_fork, 0) != hipSuccess) return body();
-    ctx->stream = wide;
-    const int rc = body();
-    ctx->stream = own;
-    if (hipEventRecord(ctx->ev_join, wide) != hipSuccess || hipStreamWaitEvent(own, ctx->ev_join, 0) != hipSuccess)
-        return cp_set_error(ctx, CP_ERR_HIP, "wide stream join failed");
-    return rc;
-}
-
 // hipStreamSynchronize(ctx->stream), with the time spent blocked added to ctx->wait_ms
 hipError_t cp_stream_wait(cp_ctx *ctx);
 
@@ -178,21 +152,6 @@ enum { CP_GEMM_GENERIC = 0, CP_GEMM_LASSO_GRAM = 1, CP_GEMM_REFIT_GRAM = 2, CP_G
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda,
                    const double *B, int ldb, double beta, double *C, int ldc, int tri);
 size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri);
-// an operand given as a centred VIEW of the caller's array instead of a staged k-major f64 matrix:
-//   element (k, col) = (double) base[k * ld + (chan ? chan[col / kk] * kk + col % kk : col)] - mean[col],  0 outside nrows x ncols
-struct cp_gemm_src {
-    const void *base = nullptr;
-    int is_f32 = 0;
-    int64_t ld = 0;            // elements between consecutive rows of base
-    const int *chan = nullptr; // DEVICE kept-channel list (null: columns are taken as they are)
-    int kk = 1;
-    const double *mean = nullptr;  // DEVICE [ncols]
-    int ncols = 0;
-    int64_t nrows = 0;
-};
-bool cp_gemm_tn_src_supported(const cp_ctx *ctx, int M, int N, int K, int tri);   // false: stage the operand and use cp_gemm_tn_f64
-int cp_gemm_tn_f64_src(cp_ctx *ctx, int M, int N, int K, double alpha, const cp_gemm_src &A, const cp_gemm_src &B, double beta,
-                       double *C, int ldc, int tri);
 // two products of the same shape (different operands / K), one launch when neither needs split-K
 int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const double *A1, const double *B1, double *C1,
                         int K2, const double *A2, const double *B2, double *C2, int lda, int ldb, int ldc, int tri);

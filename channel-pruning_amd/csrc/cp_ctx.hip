@@ -46,45 +46,6 @@ extern "C" int cp_device_count(int *count) {
 }
 
 #include <mutex>
-hipStream_t cp_side_stream(cp_ctx *ctx);
-hipStream_t cp_wide_stream(cp_ctx *ctx) {
-    // CP_WIDE_LOWPRIO=1: the long products of a layer (refit Gram, X^T Y: launches of 700+ workgroups that live a millisecond)
-    // go to a stream of the LOWEST priority owned by the layer's context, so that the dispatcher places the workgroups of
-    // other layers' chain kernels (normal priority) first whenever a slot frees up, instead of after every workgroup such a
-    // launch still has to place.
-    static const bool lowprio = getenv("CP_WIDE_LOWPRIO") && getenv("CP_WIDE_LOWPRIO")[0] == '1';
-    if (lowprio) {
-        if (!ctx->low_stream) {
-            int least = 0, greatest = 0;
-            hipDeviceGetStreamPriorityRange(&least, &greatest);   // numerically lower = higher priority
-            if (hipStreamCreateWithPriority(&ctx->low_stream, hipStreamNonBlocking, least) != hipSuccess) ctx->low_stream = nullptr;
-        }
-        return ctx->low_stream;
-    }
-    static const int reserve = getenv("CP_WIDE_RESERVE") ? atoi(getenv("CP_WIDE_RESERVE")) : 0;
-    static const bool shared = getenv("CP_GRAM_SHARED_STREAM") && getenv("CP_GRAM_SHARED_STREAM")[0] == '1';
-    if (shared) return cp_side_stream(ctx);   // no CU mask: the long products of all layers simply take turns
-    if (reserve <= 0 || reserve >= ctx->cu_count) return nullptr;
-    static std::mutex mu;
-    static hipStream_t streams[64] = {};
-    static bool tried[64] = {};
-    if (ctx->device < 0 || ctx->device >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!tried[ctx->device]) {
-        tried[ctx->device] = true;
-        const int words = (ctx->cu_count + 31) / 32;
-        std::vector<uint32_t> mask(words, 0xffffffffu);
-        const int stride = ctx->cu_count / reserve;     // clear every stride-th CU bit: spread over the XCDs whatever the order
-        for (int i = 0; i < reserve; ++i) {
-            const int bit = i * stride + stride - 1;
-            mask[bit / 32] &= ~(1u << (bit % 32));
-        }
-        hipStream_t st = nullptr;
-        if (hipExtStreamCreateWithCUMask(&st, uint32_t(words), mask.data()) == hipSuccess) streams[ctx->device] = st;
-    }
-    return streams[ctx->device];
-}
-
 hipStream_t cp_side_stream(cp_ctx *ctx) {
     static std::mutex mu;
     static hipStream_t streams[64] = {};
@@ -179,7 +140,6 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
-    if (ctx->low_stream) hipStreamDestroy(ctx->low_stream);
     delete ctx;
     return CP_OK;
 }

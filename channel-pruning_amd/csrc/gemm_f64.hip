@@ -107,16 +107,11 @@ struct GemmSecond {
     int K;
 };
 
-// SRC: the operands are not staged k-major f64 matrices but VIEWS of the caller's arrays, centred on the fly:
-//   element (k, col) = (double) base[k * ld + (chan ? chan[col / kk] * kk + col % kk : col)] - mean[col]   (0 outside
-//   nrows x ncols), base float32 or float64 -- exactly the value the staging kernel k_gather_center_xy used to write, so
-// the product is bit-identical while the N x p float64 copy of the kept columns (and its HBM round trip) disappears.
-template <int TRI, int TAG, int WT, int NTH, bool SRC = false>
+template <int TRI, int TAG, int WT, int NTH>
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
 k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
               const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
-              double *__restrict__ P, int splits, int kchunk, int n_tiles, int tiles_n, GemmSecond second,
-              cp_gemm_src sa = cp_gemm_src{}, cp_gemm_src sb = cp_gemm_src{}) {
+              double *__restrict__ P, int splits, int kchunk, int n_tiles, int tiles_n, GemmSecond second) {
     if (blockIdx.y == 1) {
         A = second.A;
         B = second.B;
@@ -182,48 +177,13 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     // prefetched tile makes a round trip through it, with the global-load latency exposed in every k-stage)
     typedef double v2f64 __attribute__((ext_vector_type(2)));
     v2f64 ar[NPASS], br[NPASS];
-    // SRC: this thread's two columns of either operand never change over k: source offsets and means once
-    size_t aoff[2] = {0, 0}, boff[2] = {0, 0};
-    double amean[2] = {0., 0.}, bmean[2] = {0., 0.};
-    bool aval[2] = {false, false}, bval[2] = {false, false};
-    if constexpr (SRC) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int ca = m0 + lcol + e, cb = n0 + lcol + e;
-            aval[e] = ca < sa.ncols;
-            bval[e] = cb < sb.ncols;
-            if (aval[e]) {
-                aoff[e] = sa.chan ? size_t(sa.chan[ca / sa.kk]) * sa.kk + ca % sa.kk : size_t(ca);
-                amean[e] = sa.mean[ca];
-            }
-            if (bval[e]) {
-                boff[e] = sb.chan ? size_t(sb.chan[cb / sb.kk]) * sb.kk + cb % sb.kk : size_t(cb);
-                bmean[e] = sb.mean[cb];
-            }
-        }
-    }
-    auto src_elem = [](const cp_gemm_src &sx, int64_t row, size_t off, double mean, bool valid) -> double {
-        if (!valid || row >= sx.nrows) return 0.0;
-        const size_t idx = size_t(row) * sx.ld + off;
-        const double v = sx.is_f32 ? double(static_cast<const float *>(sx.base)[idx]) : static_cast<const double *>(sx.base)[idx];
-        return v - mean;
-    };
     auto load_tile = [&](int kt) {
-        if constexpr (SRC) {
+        const double *a = Ag + size_t(kt) * BK * lda;
+        const double *b = Bg + size_t(kt) * BK * ldb;
 #pragma unroll
-            for (int i = 0; i < NPASS; ++i) {
-                const int64_t row = int64_t(k0) + int64_t(kt) * BK + lrow + RPP * i;
-                ar[i] = v2f64{src_elem(sa, row, aoff[0], amean[0], aval[0]), src_elem(sa, row, aoff[1], amean[1], aval[1])};
-                br[i] = v2f64{src_elem(sb, row, boff[0], bmean[0], bval[0]), src_elem(sb, row, boff[1], bmean[1], bval[1])};
-            }
-        } else {
-            const double *a = Ag + size_t(kt) * BK * lda;
-            const double *b = Bg + size_t(kt) * BK * ldb;
-#pragma unroll
-            for (int i = 0; i < NPASS; ++i) {
-                ar[i] = *reinterpret_cast<const v2f64 *>(a + size_t(RPP * i) * lda);
-                br[i] = *reinterpret_cast<const v2f64 *>(b + size_t(RPP * i) * ldb);
-            }
+        for (int i = 0; i < NPASS; ++i) {
+            ar[i] = *reinterpret_cast<const v2f64 *>(a + size_t(RPP * i) * lda);
+            br[i] = *reinterpret_cast<const v2f64 *>(b + size_t(RPP * i) * ldb);
         }
     };
 
@@ -381,8 +341,7 @@ GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri, bool in_plac
     const int nk = K / BK;
     // Workgroups to aim for when splitting K.  Every split writes a full partial plane (PMC: the
     // refit Gram wrote ~3x its input bytes with 16 planes), so stay near one workgroup per CU.
-    static const int mult4 = getenv("CP_GEMM_SPLIT_X4") ? atoi(getenv("CP_GEMM_SPLIT_X4")) : 6;
-    const int target = ctx->cu_count * mult4 / 4;
+    const int target = ctx->cu_count * 6 / 4;
     int splits = 1;
     if (!p.small && p.n_tiles < target / 2 && nk >= 16) {
         splits = (target + p.n_tiles - 1) / p.n_tiles;
@@ -409,18 +368,7 @@ size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri) {
 }
 
 static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
-                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second,
-                       const cp_gemm_src *sa = nullptr, const cp_gemm_src *sb = nullptr);
-
-bool cp_gemm_tn_src_supported(const cp_ctx *ctx, int M, int N, int K, int tri) {
-    return !make_plan(ctx, M, N, K, tri).small && (tri == CP_TRI_NONE || tri == CP_TRI_LOWER_MIRROR);
-}
-
-// C = alpha A^T B + beta C with both operands given as centred views of the caller's arrays (see the kernel)
-int cp_gemm_tn_f64_src(cp_ctx *ctx, int M, int N, int K, double alpha, const cp_gemm_src &A, const cp_gemm_src &B, double beta,
-                       double *C, int ldc, int tri) {
-    return gemm_launch(ctx, M, N, K, alpha, nullptr, 2, nullptr, 2, beta, C, ldc, tri, nullptr, &A, &B);
-}
+                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second);
 
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
                    int ldb, double beta, double *C, int ldc, int tri) {
@@ -441,8 +389,7 @@ int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const d
 }
 
 static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
-                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second,
-                       const cp_gemm_src *sa, const cp_gemm_src *sb) {
+                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second) {
     if (M <= 0 || N <= 0) return CP_OK;
     if (M % BM || N % BN || K % BK || (lda & 1) || (ldb & 1) || (tri != CP_TRI_NONE && M != N))
         return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn: unaligned shape M=%d N=%d K=%d lda=%d ldb=%d", M, N, K, lda,
@@ -457,12 +404,11 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
         P = cp_arena_take_t<double>(ctx, size_t(p.splits) * M * N);
         if (!P) return cp_set_error(ctx, CP_ERR_NOMEM, "gemm_tn: arena exhausted (split-K partials)");
     }
-    // CP_GEMM_GRID_CAP (experiment; 0 = one workgroup per tile): at most that many workgroups per launch, the rest of
-    // the tile list walked by the resident ones
-    static const int grid_cap = getenv("CP_GEMM_GRID_CAP") ? atoi(getenv("CP_GEMM_GRID_CAP")) / 8 * 8 : 0;
-    int gx = p.n_tiles * p.splits;
-    if (grid_cap >= 8 && gx > grid_cap && !in_place) gx = grid_cap;
-    const dim3 grid(gx, second ? 2 : 1);
+    // (The kernel walks the tile list with stride gridDim.x, so a launch may carry fewer workgroups than tiles.  Capping
+    //  the grid at 64 .. 512 resident workgroups -- nothing left queued in the dispatcher behind which other streams'
+    //  kernels would wait -- was measured in round 4: vgg16 job 46.4 / 35.4 / 31.9 / 31.0 ms at 64 / 128 / 256 / 512
+    //  against 30.7 with one workgroup per tile; not used.)
+    const dim3 grid(p.n_tiles * p.splits, second ? 2 : 1);
     const GemmSecond sec = second ? *second : GemmSecond{nullptr, nullptr, nullptr, 0};
 #define CP_GEMM_LAUNCH(T, G)                                                                                  \
     do {                                                                                                      \
@@ -475,17 +421,7 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
     } while (0)
     const int tag = ctx->gemm_tag;
     ctx->gemm_tag = CP_GEMM_GENERIC;
-    if (sa && sb) {   // centred views of the caller's arrays (refit Gram / X^T Y): large-tile instantiations only
-        if (p.small || second) return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn (source views): unsupported plan");
-        if (tri == CP_TRI_LOWER_MIRROR)
-            k_gemm_tn_f64<CP_TRI_LOWER_MIRROR, CP_GEMM_REFIT_GRAM, 64, 512, true><<<grid, 512, 0, ctx->stream>>>(
-                M, N, K, alpha, nullptr, 2, nullptr, 2, beta, C, ldc, P, p.splits, p.kchunk, p.n_tiles, p.tiles_n, sec, *sa, *sb);
-        else if (tri == CP_TRI_NONE)
-            k_gemm_tn_f64<CP_TRI_NONE, CP_GEMM_REFIT_XTY, 64, 512, true><<<grid, 512, 0, ctx->stream>>>(
-                M, N, K, alpha, nullptr, 2, nullptr, 2, beta, C, ldc, P, p.splits, p.kchunk, p.n_tiles, p.tiles_n, sec, *sa, *sb);
-        else
-            return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn (source views): unsupported triangle mode");
-    } else if (tri == CP_TRI_NONE) {
+    if (tri == CP_TRI_NONE) {
         if (tag == CP_GEMM_REFIT_XTY)
             CP_GEMM_LAUNCH(CP_TRI_NONE, CP_GEMM_REFIT_XTY);
         else

@@ -9,9 +9,9 @@
 //   column means (two-stage deterministic reduction)                         HBM bound
 //   Xs = gather(X, kept channels) - xbar,  Yc = Y - ybar  (tile-padded)      HBM bound
 //   G = Xs^T Xs (p x p, f64 MFMA, symmetric half),  R = Xs^T Yc (p x n)      MFMA bound
-//   Cholesky G = U^T U, blocked by 128: diagonal block factorised + inverted in LDS by one
-//   workgroup, panel solve and trailing update are cp_gemm_tn_f64 calls      MFMA / launch bound
-//   block forward / backward substitution with the inverted diagonal blocks  MFMA / launch bound
+//   Cholesky G = U^T U, blocked by 128, one launch per step with the right-hand sides riding along
+//   (chol_step.hip: lazy trailing update, forward substitution for free)     MFMA / chain bound
+//   block backward substitution with the inverted diagonal blocks            MFMA / launch bound
 // The normal equations square the condition number, so they are only trusted while every Cholesky pivot stays
 // above PIV_TOL (1e-6) of its original diagonal (error about eps / pivot ratio <= 1e-9).  Otherwise, and when
 // N - 1 < p, the solve is redone by refit_robust() below, which is as accurate as the reference's gelsd
@@ -160,439 +160,11 @@ __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, 
     dg0[i] = d;
 }
 
-// ---- Cholesky diagonal block: U^T U = A (128 x 128), TI = U^-1, TIT = U^-T ----------------
-// One 4-wave workgroup, block resident in LDS (128 x 136 doubles).  Eight 16-column panels:
-//   (1) wave 0 factors the 16x16 diagonal sub-block (rank-1 steps, rsq + 2 Newton steps per pivot)
-//   (2) all threads solve U12 = U11^-T A12 by forward substitution, one column per thread
-//   (3) all waves apply A22 -= U12^T U12 on v_mfma_f64_16x16x4_f64, one 16x16 tile at a time
-// then the 16x16 diagonal inverses (4 lanes per column, quad reductions) and the off-diagonal
-// blocks of U^-1 by block back-substitution on MFMA (V_ij = -T_ii sum_k U_ik V_kj), block columns
-// spread over the waves.  info[0] receives 1 + global column of the first pivot
-// <= piv_tol * original diagonal (also NaN).
+// ---- factorisation: chol_step.hip -------------------------------------------------------------------
+// info of a factorisation: [0] first failed pivot + 1 (also NaN), [1 + b] diagonal block b done
+constexpr int chol_info_count(int nblk) { return 8 + 2 * nblk; }
 typedef double v4f64c __attribute__((ext_vector_type(4)));
-constexpr int PNB = 16, NPAN = NB / PNB, DLD = 136;
-constexpr int PT = 512;  // threads of the factorisation kernel (8 waves)
-// info[0] first failed pivot, info[1 + b] diagonal block b done, then one flag per tile (row-major nblk x nblk)
-constexpr int chol_info_count(int nblk) { return 8 + 2 * nblk + 4 * nblk * nblk; }  // covers both flag lay-outs below
-
-#ifndef CP_POTRF_TIMERS
-#define CP_POTRF_TIMERS 0
-#endif
-__device__ unsigned long long g_potrf_debug[8];  // phase cycle counters of the last diagonal-block kernel (timers on)
-
-__device__ __forceinline__ double read_lane_c(double v, int lane) {  // lane: compile-time constant after unrolling
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// value of lane (16 * (l / 16) + I) for every lane l: one DPP move per half instead of a
-// v_readlane round trip through an SGPR pair (half the issue slots, no SGPR -> VALU hazard)
-template <int I>
-__device__ __forceinline__ double row_bcast(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + I, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + I, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row_bcast_i(double v, int i) {  // i: constant after unrolling
-    switch (i) {
-        case 0: return row_bcast<0>(v);
-        case 1: return row_bcast<1>(v);
-        case 2: return row_bcast<2>(v);
-        case 3: return row_bcast<3>(v);
-        case 4: return row_bcast<4>(v);
-        case 5: return row_bcast<5>(v);
-        case 6: return row_bcast<6>(v);
-        case 7: return row_bcast<7>(v);
-        case 8: return row_bcast<8>(v);
-        case 9: return row_bcast<9>(v);
-        case 10: return row_bcast<10>(v);
-        case 11: return row_bcast<11>(v);
-        case 12: return row_bcast<12>(v);
-        case 13: return row_bcast<13>(v);
-        case 14: return row_bcast<14>(v);
-        default: return row_bcast<15>(v);
-    }
-}
-
-__device__ __forceinline__ double rsqrt_nr(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * fma(-0.5 * x * y, y, 1.5);
-    y = y * fma(-0.5 * x * y, y, 1.5);
-    return y;
-}
-
-// The whole factorisation in ONE launch (left-looking, one workgroup per upper 128 x 128 tile, row-major task
-// order).  Workgroup (i, j), i <= j:
-//   S = G[i,j] - sum_{b<i} U[b,i]^T U[b,j]      accumulated on MFMA as the rows b complete (tile flags), so that only
-//                                                the last k-block is left when row i - 1 finishes;
-//   i == j:  S -> LDS, the in-LDS factorisation below (U_ii, TI_i = U_ii^-1, TIT_i), diagonal flag info[1 + i];
-//   i <  j:  wait for the diagonal flag, U[i,j] = TI_i^T S (S through LDS), also stored transposed into Lt[j,i],
-//            tile flag info[1 + nblk + i nblk + j].
-// A workgroup waits only for workgroups with a smaller index of the same launch, which the dispatcher starts
-// first, so it can never be starved by its own waiters.  With many layers in flight every launch in a dependent chain
-// costs tens of microseconds of dispatch latency: the 2 launches per block step this replaces were 3 ms of a
-// 4 ms layer there.
-__device__ __forceinline__ void flag_wait(const int *flag, int *info) {
-    for (int spin = 0; spin < (1 << 26); ++spin) {
-        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-        __builtin_amdgcn_s_sleep(4);
-    }
-    atomicCAS(info, 0, 0x7fffffff);  // never observed; the caller then reports a failed factorisation instead of hanging
-}
-
-template <bool FUSED>
-__device__ __forceinline__ void potrf_body(const double *G, double *Uout, double *Lt, int ld, int blk_or_nblk,
-                                           const double *__restrict__ dg0, double piv_tol, double *TI, double *TIT,
-                                           int *info, int task) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    int blk = blk_or_nblk;
-    if constexpr (FUSED) {
-        const int nblk = blk_or_nblk;
-        blk = 0;
-        int jcol;
-        {   // task -> (blk, jcol): row blk holds nblk - blk tiles
-            int t = task;
-            while (t >= nblk - blk) {
-                t -= nblk - blk;
-                ++blk;
-            }
-            jcol = blk + t;
-        }
-        int *tile_flag = info + 1 + nblk;
-        {
-            const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
-            v4f64c acc[NB / 16];
-            {
-                const double *Gij = G + (size_t(blk) * NB + wave * 16 + fk) * ld + size_t(jcol) * NB + fi;
-    #pragma unroll
-                for (int t = 0; t < NB / 16; ++t)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][r] = Gij[size_t(4 * r) * ld + 16 * t];
-            }
-            for (int b = 0; b < blk; ++b) {
-                if (tid == 0) {
-                    flag_wait(tile_flag + b * nblk + blk, info);
-                    if (jcol != blk) flag_wait(tile_flag + b * nblk + jcol, info);
-                }
-                __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const double *Ubi = Uout + size_t(b) * NB * ld + size_t(blk) * NB + wave * 16 + fi;
-                const double *Ubj = Uout + size_t(b) * NB * ld + size_t(jcol) * NB + fi;
-    #pragma unroll 2
-                for (int q = 0; q < NB / 4; ++q) {
-                    const double av = -Ubi[size_t(4 * q + fk) * ld];
-    #pragma unroll
-                    for (int t = 0; t < NB / 16; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ubj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
-                }
-            }
-            // S -> LDS (the diagonal path factors it there; the panel path needs every row of it in every wave)
-    #pragma unroll
-            for (int t = 0; t < NB / 16; ++t)
-    #pragma unroll
-                for (int r = 0; r < 4; ++r) sm[(wave * 16 + fk + 4 * r) * DLD + 16 * t + fi] = acc[t][r];
-            if (jcol != blk) {
-                if (tid == 0) flag_wait(info + 1 + blk, info);
-                __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const int j = jcol;
-                const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
-                const double *Sb = sm + fi;
-                double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
-    #pragma unroll
-                for (int t = 0; t < NB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
-    #pragma unroll 2
-                for (int q = 0; q < NB / 4; ++q) {
-                    const double av = TIb[size_t(4 * q + fk) * NB];
-    #pragma unroll
-                    for (int t = 0; t < NB / 16; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Sb[(4 * q + fk) * DLD + 16 * t], acc[t], 0, 0, 0);
-                }
-                // U[blk, j] and its transpose Lt[j, blk] (what the backward substitution reads; no separate transpose pass)
-                double *Ltj = Lt + size_t(j) * NB * ld + size_t(blk) * NB + wave * 16;
-    #pragma unroll
-                for (int t = 0; t < NB / 16; ++t)
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
-                        Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
-                    }
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(tile_flag + blk * nblk + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-        }
-    } else {
-        if (task > 0) {
-            const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
-            int *flag = info + 1 + blk;
-            if (tid == 0) flag_wait(flag, info);  // bounded; running out is reported as a failed factorisation
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const int j = blk + task;
-            const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
-            const double *Gbj = G + size_t(blk) * NB * ld + size_t(j) * NB + fi;
-            double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
-            v4f64c acc[NB / 16];
-    #pragma unroll
-            for (int t = 0; t < NB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
-    #pragma unroll 2
-            for (int q = 0; q < NB / 4; ++q) {
-                const double av = TIb[size_t(4 * q + fk) * NB];
-    #pragma unroll
-                for (int t = 0; t < NB / 16; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Gbj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
-            }
-            // U[blk, j] and its transpose Lt[j, blk] (what the backward substitution reads; no separate transpose pass)
-            double *Ltj = Lt + size_t(j) * NB * ld + size_t(blk) * NB + wave * 16;
-    #pragma unroll
-            for (int t = 0; t < NB / 16; ++t)
-    #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
-                    Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
-                }
-            return;
-        }
-    }
-    double *A = sm;                        // NB x DLD
-    double *Tl = sm + NB * DLD;            // NPAN x 16 x 16 : inverses of the diagonal sub-blocks
-    double *dinv = Tl + NPAN * PNB * PNB;  // NB : 1 / U[i,i]
-    double *dref = dinv + NB;              // NB : original diagonal (pivot reference)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fk = lane >> 4, fi = lane & 15;
-    double *Ub = Uout + size_t(blk) * NB * ld + size_t(blk) * NB;
-    if constexpr (!FUSED) {
-        const double *Gb = G + size_t(blk) * NB * ld + size_t(blk) * NB;
-        for (int e = tid; e < NB * NB / 2; e += PT) {
-            const int r = e / (NB / 2), cc = (e % (NB / 2)) * 2;
-            *reinterpret_cast<double2 *>(&A[r * DLD + cc]) = *reinterpret_cast<const double2 *>(&Gb[size_t(r) * ld + cc]);
-        }
-    }
-    if (tid < NB) dref[tid] = dg0[blk * NB + tid];
-    __syncthreads();
-    // phase timers (tests/tools/potrf_phases.py): compiled in only with -DCP_POTRF_TIMERS=1 -- every s_memtime
-    // drains the wave's outstanding LDS / scalar traffic first
-#if CP_POTRF_TIMERS
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = __builtin_readcyclecounter();
-#define CP_PH(i) { const unsigned long long tn_ = __builtin_readcyclecounter(); tph[i] += tn_ - tlast; tlast = tn_; }
-#else
-#define CP_PH(i)
-#endif
-    CP_PH(0)
-
-    for (int p = 0; p < NPAN; ++p) {
-        const int k0 = p * PNB;
-        // (1) 16x16 diagonal sub-block on wave 0, in registers: lane j (< 16; the other lanes shadow
-        // them harmlessly) owns column j.  Per pivot: broadcast the pivot (readlane), scale row k,
-        // then for every later row i broadcast U[k,i] and apply a[i] -= U[k,i] U[k,j].
-        if (wave == 0) {
-            double a[PNB];
-#pragma unroll
-            for (int i = 0; i < PNB; ++i) a[i] = A[(k0 + i) * DLD + k0 + fi];
-            const double refv = dref[k0 + fi];
-#pragma unroll
-            for (int k = 0; k < PNB; ++k) {
-                double piv = row_bcast_i(a[k], k);
-                const double ref = row_bcast_i(refv, k);
-                if (!(piv > piv_tol * ref)) {
-                    if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
-                    piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
-                }
-                const double inv = rsqrt_nr(piv);
-                const double u = a[k] * inv;  // U[k, j] for j > k
-                a[k] = fi == k ? piv * inv : u;
-#pragma unroll
-                for (int i = k + 1; i < PNB; ++i) a[i] = fma(-row_bcast_i(u, i), u, a[i]);
-                if (lane == 0) dinv[k0 + k] = inv;
-            }
-            if (lane < PNB) {
-#pragma unroll
-                for (int i = 0; i < PNB; ++i)
-                    if (fi >= i) A[(k0 + i) * DLD + k0 + fi] = a[i];
-            }
-        }
-        __syncthreads();
-        CP_PH(1)
-        // (2) U12 = U11^-T A12: thread t owns column k0 + 16 + t
-        const int rest = NB - k0 - PNB;
-        if (tid < rest) {
-            const int col = k0 + PNB + tid;
-            double x[PNB];
-#pragma unroll
-            for (int i = 0; i < PNB; ++i) x[i] = A[(k0 + i) * DLD + col];
-#pragma unroll
-            for (int i = 0; i < PNB; ++i) {
-                double sacc = x[i];
-#pragma unroll
-                for (int k = 0; k < i; ++k) sacc = fma(-A[(k0 + k) * DLD + k0 + i], x[k], sacc);
-                x[i] = sacc * dinv[k0 + i];
-            }
-#pragma unroll
-            for (int i = 0; i < PNB; ++i) A[(k0 + i) * DLD + col] = x[i];
-        }
-        __syncthreads();
-        CP_PH(2)
-        // (3) A22 -= U12^T U12 on the upper tiles (ti <= tj) of the trailing (rest/16)^2 grid
-        const int rt = rest / PNB, ntile = rt * (rt + 1) / 2;
-        for (int e = wave; e < ntile; e += PT / 64) {
-            int a = int((sqrtf(8.f * float(e) + 1.f) - 1.f) * 0.5f);
-            while ((a + 1) * (a + 2) / 2 <= e) ++a;
-            while (a * (a + 1) / 2 > e) --a;
-            const int b = e - a * (a + 1) / 2;  // b <= a
-            const int ci = k0 + PNB + b * PNB, cj = k0 + PNB + a * PNB;  // tile rows ci.., cols cj.. (ci <= cj)
-            v4f64c acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = A[(ci + fk + 4 * r) * DLD + cj + fi];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const double av = -A[(k0 + kk * 4 + fk) * DLD + ci + fi];
-                const double bv = A[(k0 + kk * 4 + fk) * DLD + cj + fi];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) A[(ci + fk + 4 * r) * DLD + cj + fi] = acc[r];
-        }
-        __syncthreads();
-        CP_PH(3)
-    }
-
-    // T_p = U_pp^-1 (upper 16x16): task = (panel, column j), 4 lanes per task split the k-sum
-    for (int pass = 0; pass < NPAN * PNB * 4 / PT; ++pass) {
-        const int task = pass * (PT / 4) + (tid >> 2), g = tid & 3;
-        const int p = task >> 4, j = task & 15, k0 = p * PNB;
-        double *Tp = Tl + p * PNB * PNB;
-        for (int i = PNB - 1; i >= 0; --i) {
-            double sacc = 0.0;
-            for (int k = i + 1 + g; k <= j; k += 4) sacc = fma(A[(k0 + i) * DLD + k0 + k], Tp[k * PNB + j], sacc);
-            sacc += __shfl_xor(sacc, 1, 64);
-            sacc += __shfl_xor(sacc, 2, 64);
-            const double t = i <= j ? ((i == j ? 1.0 : 0.0) - sacc) * dinv[k0 + i] : 0.0;
-            if (g == 0) Tp[i * PNB + j] = t;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    CP_PH(4)
-
-    // off-diagonal blocks of V = U^-1: V_ij = -T_ii * sum_{k=i+1..j} U_ik V_kj, stored (untransposed)
-    // at block position (j, i) of A's lower part.  Block columns per wave: {7}, {6,1}, {5,2}, {4,3}.
-    for (int which = 0; which < (PT == 256 ? 2 : 1); ++which) {
-        const int jb = which == 0 ? 7 - wave : wave;  // 4 waves: {7}, {6,1}, {5,2}, {4,3}; 8 waves: one block column each
-        if (which == 1 && wave == 0) break;
-        if (jb < 1) break;
-        for (int ib = jb - 1; ib >= 0; --ib) {
-            v4f64c S = {0., 0., 0., 0.};
-            for (int kb = ib + 1; kb <= jb; ++kb) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double av = A[(ib * PNB + fi) * DLD + kb * PNB + kk * 4 + fk];  // U_ik[i][k]
-                    const double bv = kb == jb ? Tl[jb * PNB * PNB + (kk * 4 + fk) * PNB + fi]
-                                               : A[(jb * PNB + kk * 4 + fk) * DLD + kb * PNB + fi];  // V_kj[k][j]
-                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, S, 0, 0, 0);
-                }
-            }
-            v4f64c V = {0., 0., 0., 0.};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const double av = -Tl[ib * PNB * PNB + fi * PNB + kk * 4 + fk];  // -T_ii[i][k]
-                V = __builtin_amdgcn_mfma_f64_16x16x4f64(av, S[kk], V, 0, 0, 0);  // S rows 4kk.. sit in S[kk]
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) A[(jb * PNB + fk + 4 * r) * DLD + ib * PNB + fi] = V[r];
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    CP_PH(5)
-
-    double *TIb = TI + size_t(blk) * NB * NB, *TITb = TIT + size_t(blk) * NB * NB;
-    for (int e = tid; e < NB * NB; e += PT) {
-        const int r = e / NB, cc = e - r * NB;
-        const int rb = r >> 4, cb = cc >> 4, ri = r & 15, ci = cc & 15;
-        // V[r, cc] (upper): diagonal blocks in Tl, block (rb < cb) at A block position (cb, rb)
-        const double v_rc = rb < cb ? A[(cb * PNB + ri) * DLD + rb * PNB + ci]
-                                    : (rb == cb ? Tl[rb * PNB * PNB + ri * PNB + ci] : 0.0);
-        // V[cc, r] for the transposed copy
-        const double v_cr = cb < rb ? A[(rb * PNB + ci) * DLD + cb * PNB + ri]
-                                    : (rb == cb ? Tl[rb * PNB * PNB + ci * PNB + ri] : 0.0);
-        const bool up = cc > r || (cc == r);
-        const bool in_diag_lower = rb == cb && ci < ri;
-        Ub[size_t(r) * ld + cc] = (up && !in_diag_lower) ? A[r * DLD + cc] : 0.0;  // U, lower part zeroed
-        TIb[e] = v_rc;
-        TITb[e] = v_cr;
-    }
-    CP_PH(6)
-#undef CP_PH
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // TI_b is complete
-#if CP_POTRF_TIMERS
-        for (int i = 0; i < 8; ++i) g_potrf_debug[i] = tph[i];
-#endif
-    }
-}
-
-template <bool FUSED>
-__global__ void __launch_bounds__(PT) k_potrf(const double *G, double *Uout, double *Lt, int ld, int blk_or_nblk,
-                                              const double *__restrict__ dg0, double piv_tol, double *TI, double *TIT,
-                                              int *info) {
-    potrf_body<FUSED>(G, Uout, Lt, ld, blk_or_nblk, dg0, piv_tol, TI, TIT, info, int(blockIdx.x));
-}
-
-// The panel of block step `blk` as its own launch: U[blk, j] = U_bb^-T G[blk, j] (and the transposed copy into Lt) for
-// j = blk + 1 + blockIdx.x.  No LDS: with the panel inside the diagonal block's launch every panel workgroup reserved the
-// 158 KB that kernel declares and sat on a CU spinning for the diagonal block; in a busy chip each of them first had to
-// find a CU with no GEMM workgroup on it (k_potrf 173 us per launch in the vgg16 job against 59 us alone).
-__global__ void __launch_bounds__(PT) k_potrf_panel(const double *G, double *Uout, double *Lt, int ld, int blk,
-                                                    const double *__restrict__ TI) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
-    const int j = blk + 1 + blockIdx.x;
-    const double *TIb = TI + size_t(blk) * NB * NB + wave * 16 + fi;
-    const double *Gbj = G + size_t(blk) * NB * ld + size_t(j) * NB + fi;
-    double *Ubj = Uout + size_t(blk) * NB * ld + size_t(j) * NB + fi;
-    v4f64c acc[NB / 16];
-#pragma unroll
-    for (int t = 0; t < NB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
-#pragma unroll 2
-    for (int q = 0; q < NB / 4; ++q) {
-        const double av = TIb[size_t(4 * q + fk) * NB];
-#pragma unroll
-        for (int t = 0; t < NB / 16; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Gbj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
-    }
-    double *Ltj = Lt + size_t(j) * NB * ld + size_t(blk) * NB + wave * 16;
-#pragma unroll
-    for (int t = 0; t < NB / 16; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Ubj[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
-            Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
-        }
-}
-
-// several factorisations in one launch (cp_prune_layers): blockIdx.y = job, blockIdx.x = its tile task.  Workgroups
-// are dispatched x-fastest, so a job's tasks still start in task order.
-struct PotrfJob {
-    const double *G;
-    double *U, *Lt;
-    int ld, nblk;
-    const double *dg0;
-    double piv_tol;
-    double *TI, *TIT;
-    int *info;
-};
 constexpr int CP_REFIT_MAX_BATCH = 16;
-struct PotrfBatch {
-    PotrfJob j[CP_REFIT_MAX_BATCH];
-};
-__global__ void __launch_bounds__(PT) k_potrf_batch(PotrfBatch b) {
-    const PotrfJob &a = b.j[blockIdx.y];
-    if (int(blockIdx.x) >= a.nblk * (a.nblk + 1) / 2) return;
-    potrf_body<true>(a.G, a.U, a.Lt, a.ld, a.nblk, a.dg0, a.piv_tol, a.TI, a.TIT, a.info, int(blockIdx.x));
-}
 
 __global__ void __launch_bounds__(RT) k_axpy(double *__restrict__ y, const double *__restrict__ x, size_t count) {
     size_t i = blockIdx.x * size_t(RT) + threadIdx.x;
@@ -629,337 +201,6 @@ __global__ void __launch_bounds__(RT) k_finalize(const double *__restrict__ W, i
         if (b_host) b_host[j] = ymean[j] - tot;
     }
     (void)n;
-}
-
-// =============================================================================================================
-// Cholesky as ONE launch of persistent workgroups over an ordered task queue, 64 x 64 tiles.
-//
-// The serial chain of a blocked factorisation is  (last update of the diagonal tile) -> (factor + invert it)
-// -> (apply the inverse to the panel tiles)  once per block step, and each link is one CU's worth of work: with
-// 128-tiles that is 14 + 45 + 14 us per step, 2.5 ms for p = 4350 however many CUs are idle.  64-tiles cut every
-// link by 4-8x at twice the steps.  Tasks = upper tiles (i, j), i <= j, in row-major order, LEFT-looking:
-//     S = G[i,j] - sum_{b<i} U[b,i]^T U[b,j]         on MFMA, as the rows b complete (one flag per tile)
-//     i == j : S -> LDS, U_ii = chol(S), T_i = U_ii^-1 (16-column panels, DPP broadcasts, MFMA updates), flag(i)
-//              every second diagonal tile also assembles the 128-block inverse the substitution kernels use:
-//              [T_a, -T_a U_ab T_b; 0, T_b]
-//     i <  j : wait for flag(i), U[i,j] = T_i^T S (also stored transposed into Lt[j,i]), tile flag
-// A workgroup takes its next task from an atomic counter, so a task only ever waits for LOWER-numbered tasks, all of
-// which have been claimed by workgroups that are running: no workgroup waits for one that has not been dispatched,
-// whatever else occupies the chip (the hazard of the blockIdx-ordered one-launch variant above).  37 KB of LDS per
-// workgroup (the 128-tile kernel held a CU's whole LDS while it waited).
-// info: [0] first failed pivot + 1, [1] task counter, [2 + d] diagonal flags, [2 + n64 + i n64 + j] tile flags.
-constexpr int TB = 64, TLD = 72, T_NPAN = TB / PNB, PT64 = 256;
-struct Potrf64Job {
-    const double *G;
-    double *U, *Lt;
-    int ld, n64;
-    const double *dg0;
-    double piv_tol;
-    double *TI, *TIT;   // 128-block inverses (nblk x 128 x 128), as the substitution kernels expect them
-    int *info;
-};
-
-__device__ __forceinline__ bool flag_ready(const int *flag) {
-    return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-}
-
-__device__ void potrf64_task(const Potrf64Job &a, int i, int j, double *sm, int *sh_i) {
-    double *A = sm;                          // TB x TLD
-    double *Tl = sm + TB * TLD;              // T_NPAN x 16 x 16
-    double *dinv = Tl + T_NPAN * PNB * PNB;  // TB
-    double *dref = dinv + TB;                // TB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fk = lane >> 4, fi = lane & 15;
-    const int ld = a.ld, n64 = a.n64;
-    int *diag_flag = a.info + 2, *tile_flag = a.info + 2 + n64;
-#if CP_POTRF_TIMERS
-    unsigned long long t_last = __builtin_readcyclecounter();
-#define CP_T64(slot) { const unsigned long long tn_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_potrf_debug[slot], tn_ - t_last); t_last = tn_; }
-#else
-#define CP_T64(slot)
-#endif
-    // ---- S = G[i,j] - sum_b U[b,i]^T U[b,j]: wave w owns rows 16 w .. 16 w + 15 ----
-    v4f64c acc[TB / 16];
-    {
-        const double *Gij = a.G + (size_t(i) * TB + wave * 16 + fk) * ld + size_t(j) * TB + fi;
-#pragma unroll
-        for (int t = 0; t < TB / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = Gij[size_t(4 * r) * ld + 16 * t];
-    }
-    int b = 0;
-    while (b < i) {
-        if (tid == 0) {   // how many further rows are complete (at least one: wait for it)
-            int e = b;
-            while (e < i && flag_ready(tile_flag + e * n64 + i) && (j == i || flag_ready(tile_flag + e * n64 + j))) ++e;
-            if (e == b) {
-                flag_wait(tile_flag + b * n64 + i, a.info);
-                if (j != i) flag_wait(tile_flag + b * n64 + j, a.info);
-                e = b + 1;
-            }
-            *sh_i = e;
-        }
-        __syncthreads();
-        const int e = *sh_i;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        for (; b < e; ++b) {
-            const double *Ubi = a.U + size_t(b) * TB * ld + size_t(i) * TB + wave * 16 + fi;
-            const double *Ubj = a.U + size_t(b) * TB * ld + size_t(j) * TB + fi;
-#pragma unroll 4
-            for (int q = 0; q < TB / 4; ++q) {
-                const double av = -Ubi[size_t(4 * q + fk) * ld];
-#pragma unroll
-                for (int t = 0; t < TB / 16; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ubj[size_t(4 * q + fk) * ld + 16 * t], acc[t], 0, 0, 0);
-            }
-        }
-        __syncthreads();   // sh_i is rewritten next round
-    }
-#pragma unroll
-    for (int t = 0; t < TB / 16; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) A[(wave * 16 + fk + 4 * r) * TLD + 16 * t + fi] = acc[t][r];
-    const int B128 = i >> 1, half = i & 1;
-    double *TIb = a.TI + size_t(B128) * NB * NB, *TITb = a.TIT + size_t(B128) * NB * NB;
-    if (i != j) {
-        CP_T64(3)
-        // ---- panel tile: U[i,j] = T_i^T S ----
-        if (tid == 0) flag_wait(diag_flag + i, a.info);
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        CP_T64(4)
-        const double *Ti = TIb + size_t(half) * (TB * NB + TB) + wave * 16 + fi;   // T_i[k][m] at Ti[k * NB + m]
-#pragma unroll
-        for (int t = 0; t < TB / 16; ++t) acc[t] = v4f64c{0., 0., 0., 0.};
-#pragma unroll 4
-        for (int q = 0; q < TB / 4; ++q) {
-            const double av = Ti[size_t(4 * q + fk) * NB];
-#pragma unroll
-            for (int t = 0; t < TB / 16; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, A[(4 * q + fk) * TLD + 16 * t + fi], acc[t], 0, 0, 0);
-        }
-        double *Uij = a.U + size_t(i) * TB * ld + size_t(j) * TB + fi;
-        double *Ltj = a.Lt + size_t(j) * TB * ld + size_t(i) * TB + wave * 16;
-#pragma unroll
-        for (int t = 0; t < TB / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Uij[size_t(wave * 16 + fk + 4 * r) * ld + 16 * t] = acc[t][r];
-                Ltj[size_t(16 * t + fi) * ld + fk + 4 * r] = acc[t][r];
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(tile_flag + i * n64 + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        CP_T64(5)
-        if (tid == 0) atomicAdd(&g_potrf_debug[7], 1ull);
-        return;
-    }
-    CP_T64(0)
-    // ---- diagonal tile: factor in LDS ----
-    if (tid < TB) dref[tid] = a.dg0[i * TB + tid];
-    __syncthreads();
-    for (int p = 0; p < T_NPAN; ++p) {
-        const int k0 = p * PNB;
-        if (wave == 0) {   // 16 x 16 diagonal sub-block in registers: lane j (< 16) owns column j
-            double c[PNB];
-#pragma unroll
-            for (int r = 0; r < PNB; ++r) c[r] = A[(k0 + r) * TLD + k0 + fi];
-            const double refv = dref[k0 + fi];
-#pragma unroll
-            for (int k = 0; k < PNB; ++k) {
-                double piv = row_bcast_i(c[k], k);
-                const double ref = row_bcast_i(refv, k);
-                if (!(piv > a.piv_tol * ref)) {
-                    if (lane == 0) atomicCAS(a.info, 0, i * TB + k0 + k + 1);
-                    piv = ref > 0 ? ref : 1.0;   // harmless pivot; the result is discarded by the caller
-                }
-                const double inv = rsqrt_nr(piv);
-                const double u = c[k] * inv;
-                c[k] = fi == k ? piv * inv : u;
-#pragma unroll
-                for (int r = k + 1; r < PNB; ++r) c[r] = fma(-row_bcast_i(u, r), u, c[r]);
-                if (lane == 0) dinv[k0 + k] = inv;
-            }
-            if (lane < PNB) {
-#pragma unroll
-                for (int r = 0; r < PNB; ++r)
-                    if (fi >= r) A[(k0 + r) * TLD + k0 + fi] = c[r];
-            }
-        }
-        __syncthreads();
-        const int rest = TB - k0 - PNB;
-        if (tid < rest) {   // U12 = U11^-T A12, one column per thread
-            const int col = k0 + PNB + tid;
-            double x[PNB];
-#pragma unroll
-            for (int r = 0; r < PNB; ++r) x[r] = A[(k0 + r) * TLD + col];
-#pragma unroll
-            for (int r = 0; r < PNB; ++r) {
-                double sacc = x[r];
-#pragma unroll
-                for (int k = 0; k < r; ++k) sacc = fma(-A[(k0 + k) * TLD + k0 + r], x[k], sacc);
-                x[r] = sacc * dinv[k0 + r];
-            }
-#pragma unroll
-            for (int r = 0; r < PNB; ++r) A[(k0 + r) * TLD + col] = x[r];
-        }
-        __syncthreads();
-        const int rt = rest / PNB, ntile = rt * (rt + 1) / 2;   // A22 -= U12^T U12 on the upper 16-tiles
-        for (int e = wave; e < ntile; e += PT64 / 64) {
-            int aa = 0;
-            while ((aa + 1) * (aa + 2) / 2 <= e) ++aa;
-            const int bb = e - aa * (aa + 1) / 2;
-            const int ci = k0 + PNB + bb * PNB, cj = k0 + PNB + aa * PNB;
-            v4f64c u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) u[r] = A[(ci + fk + 4 * r) * TLD + cj + fi];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                u = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[(k0 + kk * 4 + fk) * TLD + ci + fi], A[(k0 + kk * 4 + fk) * TLD + cj + fi], u, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) A[(ci + fk + 4 * r) * TLD + cj + fi] = u[r];
-        }
-        __syncthreads();
-    }
-    CP_T64(1)
-    // T_p = U_pp^-1 (upper 16 x 16): task = (panel, column), 4 lanes per task split the k-sum
-    {
-        const int task = tid >> 2, g = tid & 3;
-        const int p = task >> 4, jj = task & 15, k0 = p * PNB;
-        double *Tp = Tl + p * PNB * PNB;
-        for (int r = PNB - 1; r >= 0; --r) {
-            double sacc = 0.0;
-            for (int k = r + 1 + g; k <= jj; k += 4) sacc = fma(A[(k0 + r) * TLD + k0 + k], Tp[k * PNB + jj], sacc);
-            sacc += __shfl_xor(sacc, 1, 64);
-            sacc += __shfl_xor(sacc, 2, 64);
-            const double tv = r <= jj ? ((r == jj ? 1.0 : 0.0) - sacc) * dinv[k0 + r] : 0.0;
-            if (g == 0) Tp[r * PNB + jj] = tv;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    // off-diagonal 16-blocks of V = U^-1: V_ij = -T_ii sum_{k=i+1..j} U_ik V_kj, stored at block (j, i) of A's lower part;
-    // block column jb = 3 - wave
-    {
-        const int jb = T_NPAN - 1 - wave;
-        if (jb >= 1) {
-            for (int ib = jb - 1; ib >= 0; --ib) {
-                v4f64c Sx = {0., 0., 0., 0.};
-                for (int kb = ib + 1; kb <= jb; ++kb) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const double av = A[(ib * PNB + fi) * TLD + kb * PNB + kk * 4 + fk];
-                        const double bv = kb == jb ? Tl[jb * PNB * PNB + (kk * 4 + fk) * PNB + fi]
-                                                   : A[(jb * PNB + kk * 4 + fk) * TLD + kb * PNB + fi];
-                        Sx = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Sx, 0, 0, 0);
-                    }
-                }
-                v4f64c V = {0., 0., 0., 0.};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    V = __builtin_amdgcn_mfma_f64_16x16x4f64(-Tl[ib * PNB * PNB + fi * PNB + kk * 4 + fk], Sx[kk], V, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) A[(jb * PNB + fk + 4 * r) * TLD + ib * PNB + fi] = V[r];
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    __syncthreads();
-    // write U_ii (lower part zeroed), gather V = U_ii^-1 (upper) per thread, then overwrite A with V
-    double vreg[TB * TB / PT64];
-    double *Ub = a.U + size_t(i) * TB * ld + size_t(i) * TB;
-#pragma unroll
-    for (int q = 0; q < TB * TB / PT64; ++q) {
-        const int e = q * PT64 + tid, r = e / TB, cc = e - r * TB;
-        const int rb = r >> 4, cb = cc >> 4, ri = r & 15, ci = cc & 15;
-        vreg[q] = rb < cb ? A[(cb * PNB + ri) * TLD + rb * PNB + ci] : (rb == cb ? Tl[rb * PNB * PNB + ri * PNB + ci] : 0.0);
-        Ub[size_t(r) * ld + cc] = cc >= r ? A[r * TLD + cc] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < TB * TB / PT64; ++q) {
-        const int e = q * PT64 + tid, r = e / TB, cc = e - r * TB;
-        A[r * TLD + cc] = vreg[q];
-    }
-    __syncthreads();
-    // the diagonal quadrant of the 128-block inverse and of its transpose; the empty quadrant below / left of it
-    {
-        double *TIq = TIb + size_t(half) * (TB * NB + TB), *TITq = TITb + size_t(half) * (TB * NB + TB);
-        for (int e = tid; e < TB * TB; e += PT64) {
-            const int r = e / TB, cc = e - r * TB;
-            TIq[r * NB + cc] = A[r * TLD + cc];
-            TITq[r * NB + cc] = A[cc * TLD + r];
-            if (!half) {
-                TIb[(TB + r) * NB + cc] = 0.0;    // TI  bottom-left
-                TITb[r * NB + TB + cc] = 0.0;     // TIT top-right
-            }
-        }
-    }
-    if (half) {   // off-diagonal quadrant: -T_a U_ab T_b, with T_a from the previous diagonal task, T_b = A
-        const double *Uab = a.U + size_t(i - 1) * TB * ld + size_t(i) * TB;
-        v4f64c x[TB / 16];
-#pragma unroll
-        for (int t = 0; t < TB / 16; ++t) x[t] = v4f64c{0., 0., 0., 0.};
-#pragma unroll 4
-        for (int q = 0; q < TB / 4; ++q) {   // X[m][n] = sum_k U_ab[m][k] T_b[k][n]
-            const double av = Uab[size_t(wave * 16 + fi) * ld + 4 * q + fk];
-#pragma unroll
-            for (int t = 0; t < TB / 16; ++t)
-                x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, A[(4 * q + fk) * TLD + 16 * t + fi], x[t], 0, 0, 0);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < TB / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) A[(wave * 16 + fk + 4 * r) * TLD + 16 * t + fi] = x[t][r];
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < TB / 16; ++t) x[t] = v4f64c{0., 0., 0., 0.};
-#pragma unroll 4
-        for (int q = 0; q < TB / 4; ++q) {   // TR[m][n] = -sum_k T_a[m][k] X[k][n]
-            const double av = -TIb[size_t(wave * 16 + fi) * NB + 4 * q + fk];
-#pragma unroll
-            for (int t = 0; t < TB / 16; ++t)
-                x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, A[(4 * q + fk) * TLD + 16 * t + fi], x[t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < TB / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = wave * 16 + fk + 4 * r, n = 16 * t + fi;
-                TIb[m * NB + TB + n] = x[t][r];         // TI  top-right
-                TITb[(TB + n) * NB + m] = x[t][r];      // TIT bottom-left
-            }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(diag_flag + i, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    CP_T64(2)
-    if (tid == 0) atomicAdd(&g_potrf_debug[6], 1ull);
-#undef CP_T64
-}
-
-struct Potrf64Batch {
-    Potrf64Job j[16];
-};
-__global__ void __launch_bounds__(PT64) k_potrf64(Potrf64Batch bt) {   // blockIdx.y = job; persistent over the job's task queue
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ int sh[2];
-    const Potrf64Job &a = bt.j[blockIdx.y];
-    const int n64 = a.n64, ntasks = n64 * (n64 + 1) / 2;
-    for (;;) {
-        if (threadIdx.x == 0) sh[0] = atomicAdd(a.info + 1, 1);
-        __syncthreads();
-        const int task = sh[0];
-        __syncthreads();
-        if (task >= ntasks) return;
-        int i = 0, t = task;
-        while (t >= n64 - i) {
-            t -= n64 - i;
-            ++i;
-        }
-        potrf64_task(a, i, i + t, sm, sh + 1);
-        __syncthreads();
-    }
 }
 
 // The same for large (p, n): 32 x 32 tiles through LDS so that both the reads of W (rows of n_pad) and the writes of coef
@@ -1035,111 +276,14 @@ struct Chol {
     int p, p_pad, nblk;
 };
 
-bool chol_tasks_requested() {
-    static const bool on = [] {
-        const char *e = getenv("CP_CHOL_TASKS");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
-bool chol_fused_requested() {
-    static const bool on = [] {
-        const char *e = getenv("CP_CHOL_FUSED");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
-// one launch for up to 16 factorisations (grid.y = job): persistent workgroups over each job's ordered task queue
-int chol_factor_tasks(cp_ctx *ctx, const Chol *chs, int count, double piv_tol) {
-    const size_t lds = (size_t(TB) * TLD + size_t(T_NPAN) * PNB * PNB + 2 * TB) * sizeof(double);
-    static const int cap_mult = getenv("CP_CHOL_WG_PER_CU") ? atoi(getenv("CP_CHOL_WG_PER_CU")) : 2;
-    Potrf64Batch bt;
-    memset(&bt, 0, sizeof(bt));
-    int max_tasks = 0;
-    for (int l = 0; l < count; ++l) {
-        const Chol &ch = chs[l];
-        const int n64 = ch.p_pad / TB;
-        bt.j[l] = Potrf64Job{ch.G, ch.U, ch.Lt, ch.p_pad, n64, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info};
-        max_tasks = std::max(max_tasks, n64 * (n64 + 1) / 2);
-    }
-    const int per_job = std::max(1, std::min(max_tasks, ctx->cu_count * cap_mult / count));
-    k_potrf64<<<dim3(per_job, count), PT64, lds, ctx->stream>>>(bt);
-    CP_LAUNCH_CHECK(ctx);
-    return CP_OK;
-}
-
-// G = U^T U (upper, into ch.U), TI/TIT per diagonal block, and the off-diagonal blocks of Lt = U^T.
-// fwd_R (optional, p_pad x fwd_n_pad): right-hand sides whose forward substitution U^T y = r rides in the launches of the
-// factorisation (chol_step.hip); *fwd_done tells the caller whether it did (then only the backward sweep is left).
+// G = U^T U (upper, into ch.U), TI / TIT per diagonal block, the off-diagonal blocks of Lt = U^T: one launch per
+// 128-column step (chol_step.hip).  fwd_R (optional, p_pad x fwd_n_pad): right-hand sides whose forward substitution
+// U^T y = r rides in those launches; *fwd_done tells the caller that only the backward sweep is left.
 int chol_factor(cp_ctx *ctx, Chol &ch, double piv_tol, double *fwd_R = nullptr, int fwd_n_pad = 0, bool *fwd_done = nullptr) {
-    const int ld = ch.p_pad;
-    if (fwd_done) *fwd_done = false;
-    const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
-    if (!ctx->potrf_lds_opt_in) {  // > 64 KB of dynamic LDS needs an explicit opt-in (per device; idempotent)
-        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        ctx->potrf_lds_opt_in = true;
-    }
-    // CP_CHOL_FUSED=1 selects the one-launch factorisation.  It is NOT the default: its workgroups wait for each other
-    // for up to a millisecond while holding a whole CU's LDS, and workgroups of one launch are only dispatched in order
-    // PER XCD -- with enough factorisations in flight to oversubscribe the CUs (measured: 18 streams x batches of 8)
-    // two launches can hold the slots each other's next workgroups need, and only the bounded spins get them out.
-    // The default (diagonal block + panel in one launch, trailing update as a GEMM) has no such cycle: a panel
-    // workgroup waits only for workgroup 0 of its own launch, which an XCD always dispatches before its later ones.
-    // CP_CHOL_TASKS=1: the one-launch task-queue factorisation (k_potrf64).  Correct (the whole GPU suite passes on it) and
-    // free of the dispatch-order hazard, but measured SLOWER than the two-launches-per-block-step scheme below: 1.40 vs 0.94 ms
-    // at p = 1179, 5.0 vs 4.3 ms at p = 4140 -- per 64-column step its chain is 17 us (factor) + 20 us (invert, publish) +
-    // 15-20 us (panel tile: dependent loads of T_i, scattered Lt stores, agent-scope release) against 94 us per 128 columns
-    // here (tests/tools/potrf64_phases.py).  Kept opt-in.
-    static const bool steps = !(getenv("CP_CHOL_STEPS") && getenv("CP_CHOL_STEPS")[0] == '0');
-    if (steps) {   // one launch per block step, lazy trailing update (chol_step.hip)
-        static const bool fuse_fwd = !(getenv("CP_CHOL_FUSE_FORWARD") && getenv("CP_CHOL_FUSE_FORWARD")[0] == '0');
-        const bool fwd = fuse_fwd && fwd_R && fwd_n_pad > 0 && fwd_n_pad % NB == 0;
-        if (fwd_done) *fwd_done = fwd;
-        return cp_chol_factor_steps(ctx, ch.G, ch.U, ch.Lt, ld, ch.nblk, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info,
-                                    fwd ? fwd_R : nullptr, fwd ? fwd_n_pad : 0);
-    }
-    if (chol_tasks_requested()) return chol_factor_tasks(ctx, &ch, 1, piv_tol);
-    static const bool fused = chol_fused_requested();
-    if (fused) {  // one launch, left-looking, a workgroup per tile
-        k_potrf<true><<<ch.nblk * (ch.nblk + 1) / 2, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, ch.nblk, ch.dg0, piv_tol,
-                                                                             ch.TI, ch.TIT, ch.info);
-        CP_LAUNCH_CHECK(ctx);
-        return CP_OK;
-    }
-    // CP_CHOL_PANEL_SPLIT=1: the panel as its own LDS-free launch.  Measured neutral (4.30 vs 4.29 ms alone at p = 4250, vgg16
-    // job 32.7 vs 32.8 ms), so the one-launch form stays.
-    static const bool split_panel = getenv("CP_CHOL_PANEL_SPLIT") && getenv("CP_CHOL_PANEL_SPLIT")[0] == '1';
-    // (Look-ahead -- step b's update cut into the block row the next panel needs, on this stream, and the rows below it on a
-    //  side stream behind an event, so that potrf(b + 1) overlaps them -- was built and measured in round 3: same numbers, but
-    //  two cross-stream event hand-offs per step cost more than the overlap gives: refit of a c = 512 layer alone 7.0 -> 16.1 ms,
-    //  vgg16 job 31.1 -> 32.9 ms.  Removed.)
-    for (int b = 0; b < ch.nblk; ++b) {
-        if (split_panel) {   // diagonal block (one workgroup), then its panel U12 = U11^-T G12 as a light launch of its own
-            k_potrf<false><<<1, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info);
-            CP_LAUNCH_CHECK(ctx);
-            if (ch.nblk - b - 1 > 0) {
-                k_potrf_panel<<<ch.nblk - b - 1, PT, 0, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.TI);
-                CP_LAUNCH_CHECK(ctx);
-            }
-        } else {             // diagonal block + its panel in one launch (workgroups 1.. wait for workgroup 0's flag)
-            k_potrf<false><<<ch.nblk - b, PT, lds, ctx->stream>>>(ch.G, ch.U, ch.Lt, ld, b, ch.dg0, piv_tol, ch.TI, ch.TIT,
-                                                                  ch.info);
-            CP_LAUNCH_CHECK(ctx);
-        }
-        const int rest = (ch.nblk - b - 1) * NB;
-        if (rest > 0) {
-            double *U12 = ch.U + size_t(b) * NB * ld + size_t(b + 1) * NB;
-            // G22 -= U12^T U12 (upper tiles)
-            double *G22 = ch.G + size_t(b + 1) * NB * ld + size_t(b + 1) * NB;
-            CP_TRY(cp_gemm_tn_f64(ctx, rest, rest, NB, -1.0, U12, ld, U12, ld, 1.0, G22, ld, CP_TRI_UPPER));
-        }
-    }
-    return CP_OK;
+    const bool fwd = fwd_R && fwd_n_pad > 0 && fwd_n_pad % NB == 0;
+    if (fwd_done) *fwd_done = fwd;
+    return cp_chol_factor_steps(ctx, ch.G, ch.U, ch.Lt, ch.p_pad, ch.nblk, ch.dg0, piv_tol, ch.TI, ch.TIT, ch.info,
+                                fwd ? fwd_R : nullptr, fwd ? fwd_n_pad : 0);
 }
 
 // Rm <- (U^T U)^-1 Rm (p_pad x n_pad), in place, ONE launch.  Triangular solves are independent per
@@ -1289,19 +433,8 @@ int chol_solve(cp_ctx *ctx, const Chol &ch, double *Rm, double *, int n_pad, con
 // band's contribution to every remaining row as ONE chip-filling f64 MFMA GEMM with K = 512
 //   forward   R[rows below] -= U[band, below]^T Y[band]       backward   R[rows above] -= (Lt[band, above])^T W[band]
 // so the factor is read once per sweep.  The coefficient lay-out / intercept tail is the caller's (k_finalize).
-// blocks per band: CP_SOLVE_OB (default 4; every band costs two launches, a wider band more serial work in its strips)
-static const int SOLVE_OB = [] {
-    const char *e = getenv("CP_SOLVE_OB");
-    const int v = e ? atoi(e) : 4;
-    return v >= 1 && v <= 64 ? v : 4;
-}();
-int solve_blocked_min_blocks() {
-    static const int v = [] {
-        const char *e = getenv("CP_SOLVE_BLOCKED_MIN_NBLK");
-        return e ? atoi(e) : 16;
-    }();
-    return v;
-}
+constexpr int SOLVE_OB = 4;   // blocks per band (8: measured equal in the vgg16 job, 27.8 vs 27.6 ms)
+constexpr int solve_blocked_min_blocks() { return 16; }   // banded substitution from 16 blocks (p > 1920) on
 size_t chol_solve_blocked_workspace(const cp_ctx *ctx, int p_pad, int n_pad) {
     return cp_gemm_tn_workspace(ctx, p_pad, n_pad, SOLVE_OB * NB, CP_TRI_NONE);
 }
@@ -1390,21 +523,6 @@ __global__ void __launch_bounds__(RT) k_scale_rows(double *__restrict__ M, int l
 }  // namespace
 
 extern "C" int cp_debug_itq_sweeps(cp_ctx *ctx) { return ctx ? ctx->itq_sweeps : -1; }
-
-extern "C" int cp_debug_potrf_reset(cp_ctx *ctx) {
-    if (!ctx) return CP_ERR_ARG;
-    CP_HIP(ctx, cp_stream_wait(ctx));
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    CP_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_potrf_debug), z, sizeof(z)));
-    return CP_OK;
-}
-
-extern "C" int cp_debug_potrf_cycles(cp_ctx *ctx, unsigned long long *out8) {
-    if (!ctx || !out8) return CP_ERR_ARG;
-    CP_HIP(ctx, cp_stream_wait(ctx));
-    CP_HIP(ctx, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_potrf_debug), 8 * sizeof(unsigned long long)));
-    return CP_OK;
-}
 
 namespace {
 
@@ -1699,59 +817,29 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
 
 int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
     if (!ctxs || n_ctx <= 0 || n_ctx > CP_REFIT_MAX_BATCH) return CP_ERR_ARG;
-    PotrfBatch pb;
     StripBatch sb;
-    memset(&pb, 0, sizeof(pb));
     memset(&sb, 0, sizeof(sb));
-    int nj = 0, max_tasks = 0, max_strips = 0;
+    int nj = 0, max_strips = 0;
     cp_ctx *ctx0 = nullptr;
+    bool fwd_all = true;   // every layer's forward substitution rode in its factorisation's launches
     for (int l = 0; l < n_ctx; ++l) {
         cp_ctx *c = ctxs[l];
         if (!c || !c->refit_pending) continue;
         if (!ctx0) ctx0 = c;
         const cp_refit_deferred &d = c->deferred;
-        pb.j[nj] = PotrfJob{d.G, d.U, d.Lt, d.p_pad, d.nblk, d.dg0, PIV_TOL, d.TI, d.TIT, d.info};
         const bool blocked = d.nblk >= solve_blocked_min_blocks();   // large factor: banded substitution below, not a strip job
         sb.j[nj] = StripJob{d.U, d.Lt, d.p_pad, d.TI, d.TIT, d.nblk, d.Rm, blocked ? 0 : d.n_pad,
                             StripFinal{d.p, d.n, d.xmean, d.ymean, d.W_out, d.b_out, d.W_host, d.b_host, d.info, d.info_host}};
-        max_tasks = std::max(max_tasks, d.nblk * (d.nblk + 1) / 2);
         if (!blocked) max_strips = std::max(max_strips, d.n_pad / 16);
         ++nj;
+        Chol ch{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
+        bool fwd = false;
+        CP_TRY(chol_factor(c, ch, PIV_TOL, d.Rm, d.n_pad, &fwd));
+        fwd_all = fwd_all && fwd;
     }
     if (nj == 0) return CP_OK;
     cp_ctx *ctx = ctx0;
-    bool fwd_all = true;   // every layer's forward substitution rode in its factorisation's launches
-    if (chol_fused_requested()) {  // all factorisations as one launch (see chol_factor for why this is opt-in)
-        fwd_all = false;
-        const size_t lds = (size_t(NB) * DLD + size_t(NPAN) * PNB * PNB + 2 * NB) * sizeof(double);
-        // > 64 KB of dynamic LDS needs an explicit opt-in: per device, idempotent, a few microseconds -- done on every call
-        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_potrf_batch),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        k_potrf_batch<<<dim3(max_tasks, nj), PT, lds, ctx->stream>>>(pb);
-        CP_LAUNCH_CHECK(ctx);
-    } else if (!chol_tasks_requested()) {
-        for (int l = 0; l < n_ctx; ++l) {
-            cp_ctx *c = ctxs[l];
-            if (!c || !c->refit_pending) continue;
-            const cp_refit_deferred &d = c->deferred;
-            Chol ch{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
-            bool fwd = false;
-            CP_TRY(chol_factor(c, ch, PIV_TOL, d.Rm, d.n_pad, &fwd));
-            fwd_all = fwd_all && fwd;
-        }
-    } else {   // every factorisation of the batch in ONE launch (grid.y = job)
-        fwd_all = false;
-        Chol chs[CP_REFIT_MAX_BATCH];
-        int cnt = 0;
-        for (int l = 0; l < n_ctx; ++l) {
-            cp_ctx *c = ctxs[l];
-            if (!c || !c->refit_pending) continue;
-            const cp_refit_deferred &d = c->deferred;
-            chs[cnt++] = Chol{d.G, d.U, d.Lt, d.TI, d.TIT, d.dg0, d.gmax, d.info, d.p, d.p_pad, d.nblk};
-        }
-        CP_TRY(chol_factor_tasks(ctx, chs, cnt, PIV_TOL));
-    }
-    // the substitutions of every layer of the batch: one launch (no workgroup waits for another one)
+    // the (backward) substitutions of every layer of the batch: one launch (no workgroup waits for another one)
     if (max_strips > 0) {
         if (fwd_all)
             k_solve_strips_batch<2><<<dim3(max_strips, nj), 512, 0, ctx->stream>>>(sb);
@@ -2217,8 +1305,10 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         CP_LAUNCH_CHECK(ctx);
         cp_stage_mark(ctx, "refit_means");
     }
-    // The centred rows are only materialised (k_gather_center_xy: N_pad x p_pad float64) when the rank-revealing path needs
-    // them; the normal equations read X / Y in place through centred views (cp_gemm_tn_f64_src).
+    // The centred rows of the kept channels, staged once as float64 (k_gather_center_xy: N_pad x p_pad): what both long
+    // products read.  (Letting the GEMM loader gather / convert / centre X itself -- no staging copy, 174 MB less HBM
+    // traffic per c = 512 layer, bit-identical -- was built and measured in round 3: every operand element is then
+    // converted once per tile that uses it with 4-byte loads, Gram 2.20 -> 3.77 ms; removed.)
     bool staged = false;
     auto stage_rows = [&]() -> int {
         if (staged) return CP_OK;
@@ -2232,17 +1322,6 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         staged = true;
         return CP_OK;
     };
-    // CP_REFIT_VIEWS=1: no staging copy, the GEMM loader gathers / converts / centres X itself.  Bit-identical results and
-    // 174 MB less HBM traffic per c = 512 layer, but every operand element is then gathered and converted once per tile that
-    // uses it (34x at p = 4250) with 4-byte scalar loads instead of 16-byte ones: the Gram went 2.20 -> 3.77 ms (c = 512),
-    // 0.50 -> 0.79 ms (c = 256) and the vgg16 job 34.6 -> 42.4 ms, so the 0.09 ms staging pass stays the default.
-    static const bool views_wanted = getenv("CP_REFIT_VIEWS") && getenv("CP_REFIT_VIEWS")[0] == '1';
-    const bool use_views = views_wanted && cp_gemm_tn_src_supported(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR) &&
-                           cp_gemm_tn_src_supported(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE);
-    cp_gemm_src vx, vy;
-    vx.base = X; vx.is_f32 = x_dtype == CP_F32; vx.ld = int64_t(c) * kk; vx.chan = dchan; vx.kk = kk; vx.mean = xmean;
-    vx.ncols = p; vx.nrows = N;
-    vy.base = Y; vy.is_f32 = 0; vy.ld = n; vy.chan = nullptr; vy.kk = 1; vy.mean = ymean; vy.ncols = n; vy.nrows = N;
     // Gram and right-hand side into (Gd, Rd), diagonal prepared (ridge, unit pad diagonal, dg0, gmax, info = 0)
     auto normal_equations = [&](double *Gd, double *Rd, bool mark) -> int {
         if (from_pre && mark) {   // the kept rows / columns of the precomputed full normal equations
@@ -2253,32 +1332,17 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
             CP_LAUNCH_CHECK(ctx);
             return CP_OK;
         }
-        if (!use_views || !mark) {   // the fallback paths work on the rows themselves
-            CP_TRY(stage_rows());
-            if (mark) cp_stage_mark(ctx, "refit_gather_center");
-        }
-        auto products = [&]() -> int {
-            if (mark) cp_stage_mark(ctx, "refit_gram_begin");   // opens the bracket of the roofline kernel (timing mode 2)
-            ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
-            ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
-            if (use_views && mark)
-                CP_TRY(cp_gemm_tn_f64_src(ctx, p_pad, p_pad, int(N_pad), 1.0, vx, vx, 0.0, Gd, p_pad, CP_TRI_LOWER_MIRROR));
-            else
-                CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad,
-                                      CP_TRI_LOWER_MIRROR));
-            if (mark) cp_stage_mark(ctx, "refit_gram_reduce");
-            ctx->gemm_tag = CP_GEMM_REFIT_XTY;
-            ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
-            if (use_views && mark)
-                CP_TRY(cp_gemm_tn_f64_src(ctx, p_pad, n_pad, int(N_pad), 1.0, vx, vy, 0.0, Rd, n_pad, CP_TRI_NONE));
-            else
-                CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
-            if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
-            return CP_OK;
-        };
-        // the two long products of a big layer go to the device's shared CU-masked stream (when enabled)
-        if (nblk >= 8) CP_TRY(cp_on_wide_stream(ctx, products));
-        else CP_TRY(products());
+        CP_TRY(stage_rows());
+        if (mark) cp_stage_mark(ctx, "refit_gather_center");
+        if (mark) cp_stage_mark(ctx, "refit_gram_begin");   // opens the bracket of the refit Gram GEMM (timing mode 2)
+        ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
+        ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
+        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad, CP_TRI_LOWER_MIRROR));
+        if (mark) cp_stage_mark(ctx, "refit_gram_reduce");
+        ctx->gemm_tag = CP_GEMM_REFIT_XTY;
+        ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
+        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
+        if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
         k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;
@@ -2602,7 +1666,7 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
     // alternation are left: B^T = UU^T P1 and RU = G T.
     bool warm = false;
     int total_sweeps = 0;
-    static const double itq_tol = getenv("CP_ITQ_TOL") ? atof(getenv("CP_ITQ_TOL")) : 0.0;   // 0: the standard rounding-level tolerance (1e-12 / 1e-10 measured no faster)
+    const double itq_tol = 0.0;   // the standard rounding-level tolerance of the Jacobi sweeps (1e-12 / 1e-10 measured no faster)
     for (int st = 0; st < n_stage; ++st)
         for (int it = 0; it < iters[st]; ++it) {
             CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, UU, np_, P1, np_, 0.0, BT, np_, CP_TRI_NONE));      // B^T
