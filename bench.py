@@ -500,7 +500,7 @@ def bench_job(args, env, job):
             for j in sorted(probs):
                 spec = specs[own[j]]
                 X, W2, Y = host_data[spec["layer_id"]]
-                pr = LayerProblem(ctx0, X.astype(x_dtype, copy=False), W2, Y, flags=CD_FLAGS)
+                pr = LayerProblem(ctx0, X.astype(x_dtype, copy=False), W2, Y, flags=CD_FLAGS, defer_upload=True)   # as dictionary() does
                 h2d += pr.h2d_bytes
                 prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
                 pr.free()
@@ -510,8 +510,8 @@ def bench_job(args, env, job):
         t_seq, h2d = sequential_pass(np.float32)   # steady state
         pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "first_pass_ms": round(first * 1e3, 2),
                 "h2d_bytes": int(h2d), "layers_per_s_with_h2d": round(len(specs) / t_seq, 2),
-                "note": "every layer uploaded from pageable host memory (hipMemcpy) and pruned, one after another on one "
-                        "stream: what the drop-in dictionary() does per call; never part of `value`.  first_pass_ms: the "
+                "note": "every layer pruned from pageable host arrays, one after another: what the drop-in dictionary() does per "
+                        "call (cp_prune_layer_h2d: the sampled rows first, X and Y streamed in behind the alpha search); never part of `value`.  first_pass_ms: the "
                         "context's workspaces still growing from layer to layer.  X as float32 (the bytes the reference's "
                         "float64 arrays hold: Caffe blobs); x_float64 = the same pass with X uploaded as the float64 array "
                         "the reference hands to dictionary() (2x the bytes, the astype() excluded)"}

@@ -107,6 +107,9 @@ SIGNATURES = {
     "cp_prune_layer": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int,
                                 _c_dbl, _c_dbl, _c_dbl, _c_dbl, _vp, _c_int, _c_int, _c_dbl, _c_int, _c_dbl,
                                 _vp, _vp, _vp, ctypes.POINTER(PruneResult)]),
+    "cp_prune_layer_h2d": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp, _c_int,
+                                    _c_dbl, _c_dbl, _c_dbl, _c_dbl, _vp, _c_int, _c_int, _c_dbl, _c_int, _c_dbl,
+                                    _vp, _vp, _vp, ctypes.POINTER(PruneResult)]),
     "cp_prune_layers": (_c_int, [_c_int, ctypes.POINTER(_vp), _vp, _vp]),
     "cp_result_host": (_c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_c_int),
                                 ctypes.POINTER(_c_int)]),
@@ -459,14 +462,32 @@ class Context:
         return W.reshape(n.value, p.value), b
 
     def prune_layer(self, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, alpha_right0, rank, lbound, rbound,
-                    seeds, ridge, flags=0, max_iter=1000, tol=1e-4, borrow=False):
+                    seeds, ridge, flags=0, max_iter=1000, tol=1e-4, borrow=False, X_host=None, Y_host=None):
         """One dictionary() worth of device work in a single foreign call (cp_prune_layer).
         -> (PruneResult, mask bool[c], W f64[n, p], b f64[n]); res.fits_used == -1: search did not settle.
-        borrow: W, b are result_host() views instead of fresh arrays."""
+        borrow: W, b are result_host() views instead of fresh arrays.
+        X_host / Y_host (C-contiguous host arrays): X / Y are device buffers the call fills from them, the upload running
+        behind the alpha search (cp_prune_layer_h2d)."""
         samples = np.ascontiguousarray(samples, dtype=np.int64)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
         mask = np.zeros(int(c), dtype=np.uint8)
         res = PruneResult()
+        if X_host is not None:
+            W = None if borrow else np.empty(int(n) * int(c) * int(kk), dtype=np.float64)
+            b = None if borrow else np.empty(int(n), dtype=np.float64)
+            self._check(self.lib.cp_prune_layer_h2d(self.h, _ptr(X), X_host.ctypes.data, x_dtype, int(N), int(c), int(kk),
+                                                    _ptr(W2), w_dtype, int(n), _ptr(Y), Y_host.ctypes.data,
+                                                    samples.ctypes.data, int(samples.shape[0]), float(alpha_right0),
+                                                    float(rank), float(lbound), float(rbound), seeds.ctypes.data,
+                                                    int(seeds.shape[0]), int(max_iter), float(tol), int(flags), float(ridge),
+                                                    mask.ctypes.data, None if borrow else W.ctypes.data,
+                                                    None if borrow else b.ctypes.data, ctypes.byref(res)), "cp_prune_layer_h2d")
+            if res.fits_used < 0:
+                return res, None, None, None
+            if borrow:
+                W, b = self.result_host()
+                return res, mask.astype(bool), W, b
+            return res, mask.astype(bool), W[:int(n) * int(res.p)].reshape(int(n), int(res.p)), b
         if borrow:
             self._check(self.lib.cp_prune_layer(self.h, _ptr(X), x_dtype, int(N), int(c), int(kk), _ptr(W2), w_dtype,
                                                 int(n), _ptr(Y), samples.ctypes.data, int(samples.shape[0]),

@@ -110,6 +110,7 @@ class LayerProblem:
         self.h2d_bytes = W2.nbytes
         self.Xd, self.Yd = Xd, Yd
         self._borrowed = ("Xd", "Yd")
+        self._pending = None
         self.W2d = ctx.to_device(W2)
         self._alloc_outputs(flags)
         return self
@@ -128,9 +129,12 @@ class LayerProblem:
         self.margins = []       # [(edge_margin, gap_margin)] per fit: cp_cd_result's tie sentinels (-1 = not tracked)
         self.refit_info = None
 
-    def __init__(self, ctx, X, W2, Y, flags=0):
+    def __init__(self, ctx, X, W2, Y, flags=0, defer_upload=False):
+        """defer_upload: X and Y get their device buffers but stay on the host until the first prune_fused(), which streams
+        them in behind the alpha search (cp_prune_layer_h2d); any other use uploads them first (ensure_resident)."""
         self.ctx = ctx
         self._borrowed = ()
+        self._pending = None
         X = np.ascontiguousarray(X)
         W2 = np.ascontiguousarray(W2)
         if X.dtype not in (np.float32, np.float64):
@@ -146,13 +150,27 @@ class LayerProblem:
             raise ValueError("inconsistent shapes X%s W2%s Y%s" % (X.shape, W2.shape, Y.shape))
         self.x_dtype, self.w_dtype = _np_dtype_code(X), _np_dtype_code(W2)
         self.h2d_bytes = X.nbytes + W2.nbytes + Y.nbytes
-        self.Xd = ctx.to_device(X)
+        if defer_upload:
+            self.Xd = ctx.empty(X.nbytes)
+            self.Yd = ctx.empty(Y.nbytes)
+            self._pending = (X, Y)          # keeps the host arrays alive until they are on the device
+        else:
+            self.Xd = ctx.to_device(X)
+            self.Yd = ctx.to_device(Y)
         self.W2d = ctx.to_device(W2)
-        self.Yd = ctx.to_device(Y)
         self._alloc_outputs(flags)
+
+    def ensure_resident(self):
+        """X and Y on the device (a no-op unless the upload was deferred and nothing has streamed them in yet)"""
+        if self._pending is not None:
+            X, Y = self._pending
+            self._pending = None
+            self.ctx._check(self.ctx.lib.cp_memcpy_h2d(self.ctx.h, self.Xd.ptr, X.ctypes.data, X.nbytes), "cp_memcpy_h2d")
+            self.ctx._check(self.ctx.lib.cp_memcpy_h2d(self.ctx.h, self.Yd.ptr, Y.ctypes.data, Y.nbytes), "cp_memcpy_h2d")
 
     # -- decompose.py:425-437 + Lasso.fit preprocessing ------------------------------
     def lasso_gram(self, samples):
+        self.ensure_resident()
         self.S = int(len(samples))
         self.ctx.lasso_gram(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype, self.n,
                             self.Yd, samples, self.Qd, self.qd, self.statsd)
@@ -197,10 +215,12 @@ class LayerProblem:
         self.S = int(len(samples))
         mark = rng_mark(rng)
         seeds = draw_seeds(rng, MAX_FITS)
+        pending, self._pending = self._pending, None     # the call leaves X and Y resident whatever its outcome
         res, idxs, W, b = self.ctx.prune_layer(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype,
                                                self.n, self.Yd, samples, alpha_right0, rank, lbound, rbound, seeds,
                                                ridge, flags=self.flags | precompute_flag(latency_mode, rank, self.c),
-                                               borrow=getattr(self, "borrow_results", False))
+                                               borrow=getattr(self, "borrow_results", False),
+                                               X_host=pending[0] if pending else None, Y_host=pending[1] if pending else None)
         rng_rewind(rng, mark)
         if res.fits_used < 0:
             return None
@@ -256,6 +276,7 @@ class LayerProblem:
 
     # -- decompose.py:622-623 -> fc_kernel ------------------------------------------------
     def refit(self, idxs, ridge=0.0):
+        self.ensure_resident()
         idxs = np.asarray(idxs, dtype=bool)
         info = self.ctx.lstsq_refit(self.Xd, self.x_dtype, self.N, self.c, self.kk, idxs.astype(np.uint8), self.Yd,
                                     self.n, ridge, self.Wout, self.bout)
@@ -267,6 +288,7 @@ class LayerProblem:
 
     # -- decompose.py:615-617 -> nonlinear_fc ------------------------------------------------
     def refit_nonlinear(self, idxs, iters=(30, 20), lambdas=(0.1, 1.0)):
+        self.ensure_resident()
         idxs = np.asarray(idxs, dtype=bool)
         info = self.ctx.nonlinear_fc(self.Xd, self.x_dtype, self.N, self.c, self.kk, idxs.astype(np.uint8), self.Yd,
                                      self.n, self.Wout, self.bout, iters=iters, lambdas=lambdas)

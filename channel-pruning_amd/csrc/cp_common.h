@@ -92,6 +92,9 @@ struct cp_ctx {
     int itq_sweeps = 0;               // Jacobi sweeps of the last cp_itq_iterate (all alternations)
     char *cd_box = nullptr;           // mailboxes of the multi-CU coordinate-descent team (cd_team.hip), grow-only
     size_t cd_box_bytes = 0;
+    char *stage = nullptr;             // page-locked staging of the sampled rows (cp_prune_layer_h2d), grow-only
+    size_t stage_bytes = 0;
+    hipEvent_t ev_upload = nullptr;    // the side-stream uploads of cp_prune_layer_h2d have landed
     bool last_cd_was_team = false;    // which kernel family the last coordinate-descent launch of THIS context ran (debug counters)
     int cd_fallbacks = 0;             // searches / fits re-run on the one-workgroup team after a hand-off time-out of the multi-CU team
     bool cd_test_fail_multi = false;  // cp_debug_cd_fail_multi: the next multi-CU launches give up at once (tests of that fallback)
@@ -120,7 +123,7 @@ hipStream_t cp_side_stream(cp_ctx *ctx);   // the device's shared stream for wor
 // side / chain stream work that still reads X / Y, then forget it.
 void cp_precompute_void(cp_ctx *ctx);
 int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n,
-                                double rank_hint = 0.0);
+                                double rank_hint = 0.0, bool fork_recorded = false);
 void cp_precompute_release(cp_ctx *ctx);
 // hipStreamSynchronize(ctx->stream), with the time spent blocked added to ctx->wait_ms
 hipError_t cp_stream_wait(cp_ctx *ctx);

@@ -135,6 +135,8 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     if (ctx->layer_ws) hipFree(ctx->layer_ws);
     if (ctx->cd_box) hipFree(ctx->cd_box);
     if (ctx->pinned) hipHostFree(ctx->pinned);
+    if (ctx->stage) hipHostFree(ctx->stage);
+    if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
     for (int i = 0; i < 2 * CP_MAX_STAGES; ++i)
         if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);

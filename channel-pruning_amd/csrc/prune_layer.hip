@@ -4,6 +4,7 @@
 // held) per layer.  Composition of the public entry points; no arithmetic of its own.
 #include "cp_common.h"
 
+#include <algorithm>
 #include <chrono>
 #include <memory>
 #include <vector>
@@ -69,17 +70,61 @@ extern "C" int cp_result_host(cp_ctx *ctx, const double **b, const double **W, i
     return CP_OK;
 }
 
-extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const void *W2,
-                              int w_dtype, int n, const double *Y, const int64_t *samples, int S,
-                              double alpha_right0, double rank, double lbound, double rbound,
-                              const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
-                              double ridge, uint8_t *mask_out, double *W_out, double *b_out,
-                              cp_prune_result *res) {
+namespace {
+
+// Operands of a dictionary() call that still sit in the caller's (pageable) host arrays: cp_prune_layer_h2d.
+struct HostOperands {
+    const void *X = nullptr;      // [N, c, kk], x_dtype
+    const double *Y = nullptr;    // [N, n]
+};
+
+size_t elt_size(int dtype) { return dtype == CP_F32 ? 4 : 8; }
+
+// The sampled rows of X and Y, gathered on the host into page-locked memory, go to the device first (a few MB): the LASSO
+// operands and the alpha search -- milliseconds of one workgroup -- need nothing else.  -> compact device copies.
+int stage_sampled_rows(cp_ctx *ctx, const HostOperands &h, int x_dtype, int c, int kk, int n, const int64_t *samples, int S,
+                       void *Xs_dev, double *Ys_dev) {
+    const size_t xrow = size_t(c) * kk * elt_size(x_dtype), yrow = size_t(n) * 8;
+    const size_t need = size_t(S) * (xrow + yrow);
+    if (need > ctx->stage_bytes) {
+        if (ctx->stage) {
+            CP_HIP(ctx, cp_stream_wait(ctx));
+            CP_HIP(ctx, hipHostFree(ctx->stage));
+            ctx->stage = nullptr;
+            ctx->stage_bytes = 0;
+        }
+        CP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), cp_align_up(need, 1 << 16), hipHostMallocDefault));
+        ctx->stage_bytes = cp_align_up(need, 1 << 16);
+    }
+    char *xs = ctx->stage, *ys = ctx->stage + size_t(S) * xrow;
+    const char *X = static_cast<const char *>(h.X);
+    const char *Y = reinterpret_cast<const char *>(h.Y);
+    for (int s = 0; s < S; ++s) {
+        memcpy(xs + size_t(s) * xrow, X + size_t(samples[s]) * xrow, xrow);
+        memcpy(ys + size_t(s) * yrow, Y + size_t(samples[s]) * yrow, yrow);
+    }
+    CP_HIP(ctx, hipMemcpyAsync(Xs_dev, xs, size_t(S) * xrow, hipMemcpyHostToDevice, ctx->stream));
+    CP_HIP(ctx, hipMemcpyAsync(Ys_dev, ys, size_t(S) * yrow, hipMemcpyHostToDevice, ctx->stream));
+    return CP_OK;
+}
+
+// One dictionary() call.  host.X / host.Y null: X and Y are resident (cp_prune_layer).  Otherwise X / Y are the device
+// buffers the call FILLS from the host arrays, behind the alpha search:
+//     own stream    sampled rows (page-locked, a few MB) -> LASSO operands -> alpha search (async)
+//     side stream   X, Y from the caller's pageable arrays (the host thread stages them while the search runs), then the
+//                   overlapped normal equations of the refit (cp_refit_precompute_enqueue) when the flags ask for them
+//     own stream    wait for the search, mask, refit (ordered after the uploads)
+int prune_layer_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const void *W2, int w_dtype, int n,
+                     const double *Y, const HostOperands &host, const int64_t *samples, int S, double alpha_right0, double rank,
+                     double lbound, double rbound, const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
+                     double ridge, uint8_t *mask_out, double *W_out, double *b_out, cp_prune_result *res) {
     if (!ctx || !X || !W2 || !Y || !mask_out || !res || (W_out == nullptr) != (b_out == nullptr))
         return ctx ? cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer: null argument") : CP_ERR_ARG;
     if (c <= 0 || n <= 0 || kk <= 0 || N <= 0 || max_fits < 0 || max_fits > CP_MAX_FITS)
         return cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer: bad size (c=%d n=%d kk=%d N=%lld max_fits=%d)", c, n, kk,
                             (long long)N, max_fits);
+    const bool streamed = host.X != nullptr;
+    if (streamed && !host.Y) return cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer_h2d: Y_host missing");
     CP_HIP(ctx, hipSetDevice(ctx->device));
     PrecomputeScope pre_scope(ctx);
     memset(res, 0, sizeof(*res));
@@ -87,30 +132,86 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     const size_t cc = size_t(c);
     const size_t n_q = cp_align_up(cc * cc, 32), n_v = cp_align_up(cc, 32), n_w = cp_align_up(size_t(n) * cc * kk, 32),
                  n_b = cp_align_up(size_t(n), 32);
-    CP_TRY(layer_ws_reserve(ctx, (n_q + 3 * n_v + n_w + n_b) * sizeof(double)));
+    const size_t n_xs = streamed ? cp_align_up(size_t(std::max(S, 1)) * cc * kk, 32) : 0,
+                 n_ys = streamed ? cp_align_up(size_t(std::max(S, 1)) * n, 32) : 0;
+    CP_TRY(layer_ws_reserve(ctx, (n_q + 3 * n_v + n_w + n_b + n_xs + n_ys) * sizeof(double)));
     double *Q = reinterpret_cast<double *>(ctx->layer_ws);
     double *q = Q + n_q, *stats = q + n_v, *w = stats + n_v, *Wd = w + n_v, *bd = Wd + n_w;
+    double *Xs_dev = bd + n_b, *Ys_dev = Xs_dev + n_xs;
+    const size_t x_bytes = size_t(N) * cc * kk * elt_size(x_dtype), y_bytes = size_t(N) * n * 8;
+    hipStream_t side = streamed ? cp_side_stream(ctx) : nullptr;
+    auto upload_rest = [&]() -> int {   // X, Y on the side stream; the host thread stages the pageable arrays meanwhile
+        if (ctx->pre.ready && (X == ctx->pre.X || Y == ctx->pre.Y)) cp_precompute_void(ctx);   // new contents
+        CP_HIP(ctx, hipMemcpyAsync(const_cast<void *>(X), host.X, x_bytes, hipMemcpyHostToDevice, side));
+        CP_HIP(ctx, hipMemcpyAsync(const_cast<double *>(Y), host.Y, y_bytes, hipMemcpyHostToDevice, side));
+        if (!ctx->ev_upload) CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
+        CP_HIP(ctx, hipEventRecord(ctx->ev_upload, side));
+        return CP_OK;
+    };
 
     std::vector<double> w_host(cc);
     if (rank >= double(c)) {  // decompose.py:487-488: nothing to select
         for (size_t i = 0; i < cc; ++i) mask_out[i] = 1;
         res->fits_used = 0;
         res->alpha = 0.0;
+        if (streamed) {
+            CP_TRY(upload_rest());
+            CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
+        }
     } else {
         if (!samples || S <= 0 || !seeds || max_fits == 0)
             return cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer: samples / seeds missing");
         const double t0 = now_ms(), w0 = ctx->wait_ms;
-        CP_TRY(cp_lasso_gram(ctx, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, S, Q, q, stats));
-        if ((flags & CP_REFIT_PRECOMPUTE) && ridge == 0.0) CP_TRY(cp_refit_precompute_enqueue(ctx, X, x_dtype, N, c, kk, Y, n, (flags & CP_REFIT_PREFACTOR) ? rank : 0.0));
-        const double t1 = now_ms();
-        ctx->host_ms[0] = t1 - t0;
+        const bool precompute = (flags & CP_REFIT_PRECOMPUTE) && ridge == 0.0;
         int fits_used = 0;
         double alpha = 0.0;
-        const int rc = cp_lasso_alpha_search(ctx, Q, c, q, stats, c, double(S) * double(n), alpha_right0, rank, lbound,
-                                             rbound, seeds, max_fits, max_iter, tol, flags, w, &fits_used, &alpha,
-                                             res->fit_log, res->fit_alpha);
+        int rc;
+        if (!streamed) {
+            CP_TRY(cp_lasso_gram(ctx, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, S, Q, q, stats));
+            if (precompute) CP_TRY(cp_refit_precompute_enqueue(ctx, X, x_dtype, N, c, kk, Y, n, (flags & CP_REFIT_PREFACTOR) ? rank : 0.0));
+            ctx->host_ms[0] = now_ms() - t0;
+            rc = cp_lasso_alpha_search(ctx, Q, c, q, stats, c, double(S) * double(n), alpha_right0, rank, lbound, rbound, seeds,
+                                       max_fits, max_iter, tol, flags, w, &fits_used, &alpha, res->fit_log, res->fit_alpha);
+        } else {
+            for (int s = 0; s < S; ++s)
+                if (samples[s] < 0 || samples[s] >= N) return cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer_h2d: sample out of range");
+            CP_TRY(stage_sampled_rows(ctx, host, x_dtype, c, kk, n, samples, S, Xs_dev, Ys_dev));
+            std::vector<int64_t> iota(static_cast<size_t>(S), 0);
+            for (int s = 0; s < S; ++s) iota[size_t(s)] = s;
+            // the same rows in the same order as cp_lasso_gram(X, samples) reads them: identical Q, q, stats
+            CP_TRY(cp_lasso_gram(ctx, Xs_dev, x_dtype, S, c, kk, W2, w_dtype, n, Ys_dev, iota.data(), S, Q, q, stats));
+            cp_search_job sj;
+            sj.Q = Q; sj.ldq = c; sj.q = q; sj.stats = stats; sj.c = c; sj.M = double(S) * double(n);
+            sj.alpha_right0 = alpha_right0; sj.rank = rank; sj.lbound = lbound; sj.rbound = rbound; sj.seeds = seeds;
+            sj.max_fits = max_fits; sj.max_iter = max_iter; sj.tol = tol; sj.flags = flags; sj.w = w;
+            cp_ctx *one[1] = {ctx};
+            if (precompute) {   // what the side stream's work has to wait for on this stream ends here, BEFORE the search
+                if (!ctx->ev_fork) {
+                    CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                    CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+                }
+                CP_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            }
+            CP_TRY(cp_alpha_search_enqueue_batch(one, 1, &sj));   // asynchronous: the uploads below run under it
+            CP_TRY(upload_rest());
+            if (precompute)   // on the side stream, i.e. behind the uploads
+                CP_TRY(cp_refit_precompute_enqueue(ctx, X, x_dtype, N, c, kk, Y, n, (flags & CP_REFIT_PREFACTOR) ? rank : 0.0, true));
+            ctx->host_ms[0] = now_ms() - t0;
+            bool timed_out = false;
+            CP_HIP(ctx, cp_stream_wait(ctx));
+            rc = cp_alpha_search_collect(ctx, c, max_fits, &fits_used, &alpha, res->fit_log, res->fit_alpha, &timed_out);
+            if (timed_out && cp_cd_kernel_form(c, flags) == CP_CD_FORM_MULTI) {   // the one-workgroup team, bit-identical
+                ++ctx->cd_fallbacks;
+                CP_TRY(cp_alpha_search_enqueue_batch(one, 1, &sj, false));
+                CP_HIP(ctx, cp_stream_wait(ctx));
+                rc = cp_alpha_search_collect(ctx, c, max_fits, &fits_used, &alpha, res->fit_log, res->fit_alpha, &timed_out);
+            }
+            CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));   // whatever follows on this stream reads X, Y
+        }
+        const double t1 = t0 + ctx->host_ms[0];
         if (rc == CP_ERR_NUMERIC) {  // did not settle within max_fits: the caller replays fit by fit
             res->fits_used = -1;
+            if (streamed) CP_HIP(ctx, cp_stream_wait(ctx));   // X, Y complete before the caller touches them
             return CP_OK;
         }
         CP_TRY(rc);
@@ -141,6 +242,31 @@ extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N
     }
     ctx->host_ms[3] = now_ms() - t3;  // copies back + last wait
     return CP_OK;
+}
+
+}  // namespace
+
+extern "C" int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const void *W2,
+                              int w_dtype, int n, const double *Y, const int64_t *samples, int S,
+                              double alpha_right0, double rank, double lbound, double rbound,
+                              const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
+                              double ridge, uint8_t *mask_out, double *W_out, double *b_out,
+                              cp_prune_result *res) {
+    return prune_layer_impl(ctx, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, HostOperands{}, samples, S, alpha_right0, rank, lbound,
+                            rbound, seeds, max_fits, max_iter, tol, flags, ridge, mask_out, W_out, b_out, res);
+}
+
+extern "C" int cp_prune_layer_h2d(cp_ctx *ctx, void *X_dev, const void *X_host, int x_dtype, int64_t N, int c, int kk,
+                                  const void *W2, int w_dtype, int n, double *Y_dev, const double *Y_host,
+                                  const int64_t *samples, int S, double alpha_right0, double rank, double lbound,
+                                  double rbound, const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
+                                  double ridge, uint8_t *mask_out, double *W_out, double *b_out, cp_prune_result *res) {
+    if (!X_host || !Y_host) return ctx ? cp_set_error(ctx, CP_ERR_ARG, "cp_prune_layer_h2d: host operands missing") : CP_ERR_ARG;
+    HostOperands h;
+    h.X = X_host;
+    h.Y = Y_host;
+    return prune_layer_impl(ctx, X_dev, x_dtype, N, c, kk, W2, w_dtype, n, Y_dev, h, samples, S, alpha_right0, rank, lbound, rbound,
+                            seeds, max_fits, max_iter, tol, flags, ridge, mask_out, W_out, b_out, res);
 }
 
 

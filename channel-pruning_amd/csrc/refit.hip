@@ -937,7 +937,7 @@ bool prefactor_wanted() {
 // milliseconds, the rest of the chip is idle meanwhile.  Ordered after everything already on ctx->stream; the refit
 // (cp_lstsq_refit_impl) waits for it and gathers.  Skipped (returns CP_OK, pre.ready = false) when N - 1 < P.
 int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n,
-                                double rank_hint) {
+                                double rank_hint, bool fork_recorded) {
     cp_precompute &pc = ctx->pre;
     pc.ready = false;
     pc.factored = false;
@@ -1017,7 +1017,9 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
             CP_HIP(ctx, hipEventCreateWithFlags(&pc.gram_done, hipEventDisableTiming));
         }
     }
-    CP_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // after whatever still reads the previous precompute
+    // after whatever still reads the previous precompute; fork_recorded: the caller recorded ev_fork at the point of its own
+    // stream the worker has to wait for (cp_prune_layer_h2d: before the alpha search it has already enqueued)
+    if (!fork_recorded) CP_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     CP_HIP(ctx, hipStreamWaitEvent(w->stream, ctx->ev_fork, 0));
     if (cp_arena_reserve(w, (size_t(N_pad) * (P_pad + n_pad) + size_t(RB) * (P_pad + n_pad)) * 8 + size_t(c) * 4 + ws + (1 << 16)) != CP_OK)
         return cp_set_error(ctx, CP_ERR_NOMEM, "refit precompute: arena");
@@ -1076,9 +1078,10 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
             }
             k_diag_prepare<<<1, 1024, 0, w->stream>>>(pc.Gw, P_pad, P, P_pad, 0.0, pc.dg0, pc.gmax, pc.finfo, chol_info_count(nblkF));
             Chol chF{pc.Gw, pc.U, pc.Lt, pc.TI, pc.TIT, pc.dg0, pc.gmax, pc.finfo, P, P_pad, nblkF};
-            if ((rc = chol_factor(w, chF, PIV_TOL)) != CP_OK) break;
+            bool fwd = false;   // F = L^-1 R rides in the launches of the factorisation
+            if ((rc = chol_factor(w, chF, PIV_TOL, pc.F, n_pad, &fwd)) != CP_OK) break;
             cp_stage_mark(w, "prefactor_cholesky");
-            if ((rc = chol_solve_any(w, chF, pc.F, n_pad, 1)) != CP_OK) break;
+            if (!fwd && (rc = chol_solve_any(w, chF, pc.F, n_pad, 1)) != CP_OK) break;
             cp_stage_mark(w, "prefactor_forward");
         } while (false);
         if (rc == CP_OK && hipEventRecord(pc.done, w->stream) != hipSuccess) rc = CP_ERR_HIP;

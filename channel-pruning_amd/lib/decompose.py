@@ -89,7 +89,9 @@ def dictionary(X, W2, Y, alpha=1e-4, rank=None, DEBUG=0, B2=None, rank_tol=.1, v
     W2 = np.asarray(W2)
     if X.shape[2] != X.shape[-1]:
         raise ValueError("square kernels only (the reference assumes w = h, decompose.py:401-402)")
-    prob = LayerProblem(default_context(), X, W2, Y, flags=_flags())
+    # the operands are the caller's host arrays: only the sampled rows go to the device before the alpha search starts, X and
+    # Y stream in behind it (cp_prune_layer_h2d); the other cd modes upload them first
+    prob = LayerProblem(default_context(), X, W2, Y, flags=_flags(), defer_upload=True)
     try:
         idxs, newW2, newB2 = prune_resident(prob, rank, W2, alpha=alpha)
     finally:

@@ -276,6 +276,16 @@ int cp_prune_layer(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, in
                    const uint32_t *seeds, int max_fits, int max_iter, double tol, int flags,
                    double ridge, uint8_t *mask_out, double *W_out, double *b_out,
                    cp_prune_result *res);
+/* The same call for operands that still sit in the caller's host arrays -- what the reference's dictionary(X, W2, Y, ...)
+ * (lib/decompose.py:386) is handed: X_dev / Y_dev are device buffers of the right size that the call FILLS from X_host
+ * [N, c, kk] (x_dtype) / Y_host [N, n] (float64).  Only the S sampled rows are uploaded before the LASSO operands and the
+ * alpha search start; the rest streams in on a second stream while the search runs, and the refit is ordered after it.
+ * Results are bit-identical to cp_prune_layer on resident operands.  W2: device, as in cp_prune_layer. */
+int cp_prune_layer_h2d(cp_ctx *ctx, void *X_dev, const void *X_host, int x_dtype, int64_t N, int c, int kk, const void *W2,
+                       int w_dtype, int n, double *Y_dev, const double *Y_host, const int64_t *samples, int S,
+                       double alpha_right0, double rank, double lbound, double rbound, const uint32_t *seeds, int max_fits,
+                       int max_iter, double tol, int flags, double ridge, uint8_t *mask_out, double *W_out, double *b_out,
+                       cp_prune_result *res);
 
 /* HOST pointers to the b [n] and W [n, p] of the last cp_prune_layer (or cp_prune_layers job) on this context, in
  * the context's page-locked result block, where the last refit kernel wrote them: no copy, DMA-able, valid until the

@@ -1,5 +1,8 @@
-"""Per-call cost of the drop-in flow for one layer: upload (LayerProblem), prune_layer, free -- what dictionary() does.
-python tools/dropin_latency.py [c ...]"""
+"""Per-call cost of the drop-in flow for one layer, from HOST arrays as dictionary() receives them:
+  resident : LayerProblem(X, W2, Y) uploaded first, then prune_layer          (upload / prune / free)
+  streamed : LayerProblem(..., defer_upload=True) + prune_layer               (what lib.decompose.dictionary() does: only
+             the sampled rows go up before the alpha search, X and Y stream in behind it -- cp_prune_layer_h2d)
+for X as float32 and as the float64 array the reference hands over.  python tools/dropin_latency.py [c ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
@@ -9,26 +12,30 @@ from cpmi355 import capi, LayerProblem, prune_layer
 
 ctx = capi.Context(0)
 widths = [int(a) for a in sys.argv[1:]] or [512, 256]
+specs = bench.cpjobs.JOBS["vgg16"]()
 for c in widths:
-    spec = [s for s in bench.vgg16_specs() if s["c"] == c][0]
-    X, W2, Y = bench.synth(spec["layer_id"], spec["c"], spec["n"])[:3]
-    rows = []
-    ctx.enable_stage_timing(1)
-    for rep in range(int(os.environ.get("REPS", "8"))):
-        t0 = time.perf_counter()
-        pr = LayerProblem(ctx, X, W2, Y)
-        ctx.sync()
-        t1 = time.perf_counter()
-        prune_layer(pr, spec["rank"], 1e-3, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
-        t2 = time.perf_counter()
-        import ctypes
-        h4 = (ctypes.c_double * 4)()
-        ctx.lib.cp_debug_host_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
-        ctx.lib.cp_debug_host_times(ctx.h, h4)
-        if (t2 - t1) > 0.03:
-            print("   slow call: host ms (operands, search, refit, copies+wait) =", [round(v, 2) for v in h4],
-                  "device stages:", {k: round(v, 2) for k, v in ctx.last_stage_times() if v > 0.5})
-        pr.free()
-        t3 = time.perf_counter()
-        rows.append(tuple(round((b - a) * 1e3, 2) for a, b in ((t0, t1), (t1, t2), (t2, t3))))
-    print("c=%d upload / prune / free ms:" % c, rows)
+    spec = [s for s in specs if s["c"] == c][-1]
+    X32, W2, Y = bench.cpjobs.synth(spec)[:3]
+    for xname, X in (("float32", X32), ("float64", X32.astype(np.float64))):
+        ref = None
+        for mode in ("resident", "streamed"):
+            rows = []
+            for rep in range(int(os.environ.get("REPS", "6"))):
+                t0 = time.perf_counter()
+                pr = LayerProblem(ctx, X, W2, Y, defer_upload=(mode == "streamed"))
+                ctx.sync()
+                t1 = time.perf_counter()
+                out = prune_layer(pr, spec["rank"], 1e-3, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
+                t2 = time.perf_counter()
+                pr.free()
+                t3 = time.perf_counter()
+                rows.append((t1 - t0, t2 - t1, t3 - t2, t3 - t0))
+                if ref is None:
+                    ref = out
+                else:
+                    assert np.array_equal(ref[0], out[0]) and np.array_equal(ref[1], out[1]) and np.array_equal(ref[2], out[2]), \
+                        "streamed upload changed the result"
+            best = min(rows, key=lambda r: r[3])
+            med = sorted(r[3] for r in rows)[len(rows) // 2]
+            print("c=%d X %s %-8s: setup+upload %.2f  prune %.2f  free %.2f  total %.2f ms (median total %.2f)" % (
+                c, xname, mode, best[0] * 1e3, best[1] * 1e3, best[2] * 1e3, best[3] * 1e3, med * 1e3))
