@@ -345,9 +345,9 @@ def bench_job(args, env, job):
     for s in specs:       # measured single-layer latencies (ms, profiles/r02_*) as LPT costs; model when absent
         s["cost"] = (VGG16_COST_MS.get(s["c"], None) if job == "vgg16" else None) or \
             shard.layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"])
-    # --scaling weak (default): every rank prunes its OWN instance of the whole job (per-GPU work fixed; the only
-    # collective is the uint8 all_gather of the channel masks); strong: the layers of ONE instance are sharded over the ranks
-    # (LPT) and every rank ends with every layer's (mask, W, b) (one mask all_gather + one all_gather of the packed results)
+    # --scaling strong (default): the layers of ONE job instance are sharded over the ranks (LPT) and every rank ends with
+    # every layer's (mask, W, b) (one mask all_gather + one all_gather of the packed results); weak: every rank prunes its OWN
+    # instance of the whole job (per-GPU work fixed; the only collective is the uint8 all_gather of the channel masks)
     weak = args.scaling == "weak"
     owner = [env.rank] * len(specs) if weak else shard.plan_owners(specs, env.world)
     own = [i for i in range(len(specs)) if owner[i] == env.rank]
@@ -494,22 +494,26 @@ def bench_job(args, env, job):
         from cpmi355.pruner import LayerProblem
         ctx0 = roots[0]
 
+        seq_layer_ms = {}
+
         def sequential_pass(x_dtype):
             t1 = time.perf_counter()
             h2d = 0
             for j in sorted(probs):
                 spec = specs[own[j]]
                 X, W2, Y = host_data[spec["layer_id"]]
+                t_l = time.perf_counter()
                 pr = LayerProblem(ctx0, X.astype(x_dtype, copy=False), W2, Y, flags=CD_FLAGS, defer_upload=True)   # as dictionary() does
                 h2d += pr.h2d_bytes
                 prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
                 pr.free()
+                seq_layer_ms[spec["name"]] = round((time.perf_counter() - t_l) * 1e3, 2)
             return time.perf_counter() - t1, h2d
 
         first, _ = sequential_pass(np.float32)     # first pass: workspaces of the context grow layer by layer (cold)
         t_seq, h2d = sequential_pass(np.float32)   # steady state
         pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "first_pass_ms": round(first * 1e3, 2),
-                "h2d_bytes": int(h2d), "layers_per_s_with_h2d": round(len(specs) / t_seq, 2),
+                "h2d_bytes": int(h2d), "layers_per_s_with_h2d": round(len(specs) / t_seq, 2), "per_layer_ms": dict(seq_layer_ms),
                 "note": "every layer pruned from pageable host arrays, one after another: what the drop-in dictionary() does per "
                         "call (cp_prune_layer_h2d: the sampled rows first, X and Y streamed in behind the alpha search); never part of `value`.  first_pass_ms: the "
                         "context's workspaces still growing from layer to layer.  X as float32 (the bytes the reference's "
@@ -525,6 +529,53 @@ def bench_job(args, env, job):
             del x64
             pcie["x_float64"] = {"job_ms_sequential_with_h2d": round(t64 * 1e3, 2), "h2d_bytes": int(h64),
                                  "layers_per_s_with_h2d": round(len(specs) / t64, 2)}
+
+    # ---- N > 1, strong scaling: the bound of this mode and, in the same run, the replica throughput of the N GPUs ----
+    strong_bound, replica = None, None
+    if not weak:
+        alone = {k_: v_["ms_alone"] for k_, v_ in per_layer.items()}
+        if env.dist is not None:
+            every = [None] * env.world
+            env.dist.all_gather_object(every, alone)
+            alone = {k_: v_ for d_ in every for k_, v_ in d_.items()}
+        if alone:
+            longest = max(alone, key=lambda k_: alone[k_])
+            exch = float(np.mean(exch_ms)) if exch_ms else 0.0
+            strong_bound = {"longest_layer_alone": longest, "longest_layer_alone_ms": round(alone[longest], 3),
+                            "sum_of_layers_alone_ms": round(sum(alone.values()), 3),
+                            "job_ms_lower_bound_any_gpu_count": round(alone[longest] + exch, 3),
+                            "note": "one GPU already overlaps the layers of a job (job_ms at N = 1 against sum_of_layers_alone_ms); "
+                                    "more GPUs cannot push ONE job below its longest layer alone + the exchange.  The >= 6x of "
+                                    "north_star at 8 GPUs exists only as throughput over independent jobs: replica_throughput",
+                            "row_sharding": "cpmi355.shard.prune_layer_rows (rows of one layer over several ranks: two all-reduces, "
+                                            "Gram p^2 doubles) divides a layer's Gram, not its search; it pays when N p^2 / 49 TFLOP/s "
+                                            "exceeds 2 x 8 p^2 B / link bandwidth, i.e. N > ~5000 rows per rank at 150 GB/s: not at "
+                                            "the 5000-sample jobs, marginal at vgg16_5x (N = 20000); tools/rowshard_bench.py"}
+        if env.world > 1 and not args.profile_mode:
+            # every rank prunes its OWN instance of the whole job (weak scaling, what --scaling weak times as `value`)
+            rset.close()
+            host_data.clear()
+            rset = shard.ResidentLayerSet(env.local_rank, specs, lambda sp: cpjobs.synth(sp)[:3], per_stream=per_stream,
+                                          flags=CD_FLAGS, borrow_results=True)
+            rroots = [ch["ctxs"][0] for ch in rset.chunks]
+            for _ in range(2):
+                rset()
+            for cx in rroots:
+                cx.sync()
+            env.barrier()
+            t_r = time.perf_counter()
+            rjobs = max(3, int(np.ceil(1.0 / max(job_ms * 1e-3 * min(env.world, 3), 1e-3))))
+            for _ in range(rjobs):
+                res_r = rset()
+                shard.gather_masks(specs, res_r, env.dist)
+            for cx in rroots:
+                cx.sync()
+            env.barrier()
+            el_r = env.max_over_ranks(time.perf_counter() - t_r)
+            replica = {"value": round(len(specs) * env.world * rjobs / el_r, 3), "unit": "layers/s", "job_instances": env.world,
+                       "jobs_timed_per_rank": rjobs, "job_ms_per_instance": round(el_r / rjobs * 1e3, 3),
+                       "note": "every GPU prunes its own instance of the whole job; the only collective is ONE uint8 all_gather of "
+                               "the channel masks per job"}
 
     # ---- verification on rank 0 (outside the timed region) ----
     out = None
@@ -605,6 +656,12 @@ def bench_job(args, env, job):
             "pcie_inclusive": pcie,
             "upload_and_setup_s": round(t0 - t_up0, 2),
         }
+        if replica is not None:
+            out["replica_throughput"] = replica
+        if not weak:
+            # what sharding ONE job's layers can give: a job cannot be shorter than its longest layer alone (every layer's alpha
+            # search is one serial chain, cd_team.hip), whatever the number of GPUs
+            out["strong_scaling_bound"] = strong_bound
         if env.world == 1 and not args.no_cpu_baseline and not args.profile_mode:
             # bounded sample (about 20 s of CPU work): the cheapest layers of the job by the cost model
             order = sorted(specs, key=lambda s: shard.layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"]))
@@ -1004,8 +1061,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=("vgg16", "resnet50", "vgg16_5x", "block"),
                     default=os.environ.get("CP_BENCH_WORKLOAD", "vgg16"))
-    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("CP_BENCH_SCALING", "weak"),
-                    help="N > 1: weak = one instance of the job per GPU (default); strong = ONE instance, layers sharded over the GPUs")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("CP_BENCH_SCALING", "strong"),
+                    help="N > 1: strong (default) = ONE job instance, its layers sharded over the GPUs (BASELINE configs[2]); the line "
+                         "also carries replica_throughput (one instance per GPU) and strong_scaling_bound; weak = replicas as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU port on every layer of the job (the default for vgg16: ~45 s)")
     ap.add_argument("--cpu-sample", action="store_true", help="vgg16: CPU port on the five cheapest layers only (~5 s)")

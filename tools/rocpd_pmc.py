@@ -18,6 +18,8 @@ def main():
     q = ("select s.%s, count(*), avg(e.value), min(e.value), max(e.value) from %s e "
          "join %s p on e.pmc_id = p.id join %s d on e.event_id = d.event_id join %s s on d.kernel_id = s.id "
          "where p.name = ? group by s.%s order by 3 desc" % (name_col, pe, ip, kd, ks, name_col))
+    import os
+    print("commit: %s" % os.environ.get("CP_COMMIT", "unknown"))       # the library the pass profiled (bench.py: traffic_source)
     print("| kernel | dispatches | avg %s | min | max |" % counter)
     print("|---|---|---|---|---|")
     for name, n, avg, mn, mx in db.execute(q, (counter,)):
