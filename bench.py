@@ -557,7 +557,7 @@ def bench_job(args, env, job):
             host_data.clear()
             rset = shard.ResidentLayerSet(env.local_rank, specs, lambda sp: cpjobs.synth(sp)[:3], per_stream=per_stream,
                                           flags=CD_FLAGS, borrow_results=True)
-            rroots = [ch["ctxs"][0] for ch in rset.chunks]
+            rroots = roots = [ch["ctxs"][0] for ch in rset.chunks]     # the contexts of the sharded set are closed
             for _ in range(2):
                 rset()
             for cx in rroots:
