@@ -492,7 +492,7 @@ def bench_job(args, env, job):
     pcie = None
     if env.world == 1 and not args.profile_mode:
         from cpmi355.pruner import LayerProblem
-        ctx0 = roots[0]
+        ctx0 = cpmi355.Context(env.local_rank)     # a context of its own, as a caller of dictionary() has (default_context)
 
         seq_layer_ms = {}
 
@@ -529,6 +529,8 @@ def bench_job(args, env, job):
             del x64
             pcie["x_float64"] = {"job_ms_sequential_with_h2d": round(t64 * 1e3, 2), "h2d_bytes": int(h64),
                                  "layers_per_s_with_h2d": round(len(specs) / t64, 2)}
+
+        ctx0.close()
 
     # ---- N > 1, strong scaling: the bound of this mode and, in the same run, the replica throughput of the N GPUs ----
     strong_bound, replica = None, None
@@ -1037,6 +1039,144 @@ def bench_sequential_alpha(args, env):
     return out
 
 
+# ==================================================================================================================
+# workload: r3 -- the three steps Net.R3 runs per conv of VGG-16
+# ==================================================================================================================
+VGG16_CONVS = [("conv1_1", 3, 64), ("conv1_2", 64, 64), ("conv2_1", 64, 128), ("conv2_2", 128, 128), ("conv3_1", 128, 256),
+               ("conv3_2", 256, 256), ("conv3_3", 256, 256), ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3", 512, 512),
+               ("conv5_1", 512, 512), ("conv5_2", 512, 512), ("conv5_3", 512, 512)]
+# /root/reference/lib/net.py:1309-1327: the 3C-4x ranks (conv5_x as listed, the others x 4 / dic.keep with dic.keep = 3)
+R3_RANK = {"conv1_2": 17, "conv2_1": 37, "conv2_2": 47, "conv3_1": 83, "conv3_2": 89, "conv3_3": 106, "conv4_1": 175,
+           "conv4_2": 192, "conv4_3": 227, "conv5_1": 398, "conv5_2": 390, "conv5_3": 379}
+R3_PRUNED = ("conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv4_1", "conv4_2")   # alldic + pooldic (net.py:1307-1308)
+
+
+def r3_plan():
+    """Per conv of the reference's R3 loop (net.py:1339-1459, conv1_2 .. conv5_3): the shapes VH_decompose, ITQ_decompose and
+    dictionary_kernel see -- input channels already reduced when the conv was the consumer of an earlier pruning."""
+    plan, kept_in = [], {}
+    for i, (name, c, n) in enumerate(VGG16_CONVS[1:], start=1):
+        rank = R3_RANK[name] if name.startswith("conv5") else int(R3_RANK[name] * 4.0 / 3.0)
+        d_c = max(int(n / 1.15), rank)
+        step = dict(name=name, c=kept_in.get(name, c), n=n, rank=rank, d_c=d_c, prune=None)
+        if name in R3_PRUNED and i + 1 < len(VGG16_CONVS):
+            nxt, _, n_next = VGG16_CONVS[i + 1]
+            step["prune"] = dict(consumer=nxt, n_next=n_next)
+            kept_in[nxt] = d_c
+        plan.append(step)
+    return plan
+
+
+def r3_operands(step, seed, N=N_SAMPLES):
+    rs = np.random.RandomState(seed)
+    c, n = step["c"], step["n"]
+    X = np.maximum(rs.randn(N, c, 3, 3), 0).astype(np.float32)
+    W = (rs.randn(n, c, 3, 3) * 0.05).astype(np.float32)
+    Y = X.reshape(N, -1).astype(np.float64) @ W.reshape(n, -1).T.astype(np.float64) + 0.01 * rs.randn(N, n)
+    feat = Y + 0.02 * rs.randn(N, n)          # the response of the spatially decomposed conv at the same points
+    out = dict(X=X, W=W, Y=Y, feat=feat)
+    if step["prune"]:
+        n2 = step["prune"]["n_next"]
+        Xo = np.maximum(rs.randn(N, n, 3, 3), 0).astype(np.float32)
+        W2 = (rs.randn(n2, n, 3, 3) * 0.05).astype(np.float32)
+        out.update(Xo=Xo, W2=W2, Y2=Xo.reshape(N, -1).astype(np.float64) @ W2.reshape(n2, -1).T.astype(np.float64) + 0.01 * rs.randn(N, n2))
+    return out
+
+
+def bench_r3(args, env):
+    """`--workload r3`: what Net.R3 (/root/reference/lib/net.py:1292-1471) runs per conv of VGG-16 -- spatial decomposition
+    (VH_decompose with the ReLU-aware refit of H: 50 alternations), channel decomposition (ITQ_decompose: 50 alternations, each
+    a rank-truncated SVD) and, for the 7 convs of alldic / pooldic, channel pruning against the next conv (dictionary) -- at
+    the reference's 3C-4x ranks, N = 5000 sampled points per conv, through the drop-in functions of lib/decompose.py from
+    host arrays.  Synthetic per-conv operands; the forward passes that re-extract features between the steps (Caffe in the
+    reference, a torch provider in lib/provider.py) are not part of the timed work."""
+    import cpmi355
+    import lib.cfgs as cfgs
+    import lib.decompose as D
+    ctx = cpmi355.default_context(env.local_rank)
+    plan = r3_plan()
+    data = [r3_operands(st, 4000 + i) for i, st in enumerate(plan)]
+
+    def one_pass(record=None):
+        cfgs.alpha = 1e-3
+        for i, (st, d) in enumerate(zip(plan, data)):
+            np.random.seed(2000 + i)
+            t0 = time.perf_counter()
+            V, H, VHr, b = D.VH_decompose(d["W"], rank=st["rank"], DEBUG=True, X=d["X"], Y=d["Y"])
+            ctx.sync()
+            t1 = time.perf_counter()
+            D.ITQ_decompose(d["feat"], d["Y"], H, st["rank"], bias=b, DEBUG=0, Wr=VHr)
+            ctx.sync()
+            t2 = time.perf_counter()
+            if st["prune"]:
+                D.dictionary(d["Xo"].astype(np.float64, copy=False), d["W2"], d["Y2"], rank=st["d_c"])
+                ctx.sync()
+            t3 = time.perf_counter()
+            if record is not None:
+                r = record.setdefault(st["name"], dict(vh=[], itq=[], prune=[]))
+                r["vh"].append((t1 - t0) * 1e3)
+                r["itq"].append((t2 - t1) * 1e3)
+                r["prune"].append((t3 - t2) * 1e3)
+
+    for _ in range(max(1, min(args.warmup, 2))):
+        one_pass()
+    rec = {}
+    steps = max(1, min(args.steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass(rec)
+    elapsed = time.perf_counter() - t0
+    job_ms = elapsed / steps * 1e3
+    per = {k: {"c": st["c"], "n": st["n"], "rank": st["rank"], "d_c": st["d_c"] if st["prune"] else None,
+               "vh_ms": round(min(rec[k]["vh"]), 2), "itq_ms": round(min(rec[k]["itq"]), 2),
+               "prune_ms": round(min(rec[k]["prune"]), 2) if st["prune"] else None}
+           for k, st in ((st["name"], st) for st in plan)}
+    out = {"metric": "conv layers decomposed + pruned/sec (VGG-16 3C 4x steps of Net.R3, 5k samples)",
+           "value": round(len(plan) * steps / elapsed, 3), "unit": "layers/s", "n_gpus": 1, "steps": steps,
+           "warmup": max(1, min(args.warmup, 2)), "ms_per_step": round(job_ms, 2), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "r3: the 12 convs conv1_2 .. conv5_3 of VGG-16, per conv VH_decompose (rank-truncated SVD + 50 ReLU-aware "
+                                  "refits) -> ITQ_decompose (50 alternations) -> dictionary() for the 7 convs the reference prunes (alldic + "
+                                  "pooldic), 3C-4x ranks of /root/reference/lib/net.py:1309-1327, N = 5000; one after another as R3 does; "
+                                  "1 step = 1 pass over the 12 convs",
+                      "layers_per_job": len(plan)},
+           "job_ms": round(job_ms, 2),
+           "stage_ms_per_job": {"spatial_decomposition (VH)": round(sum(v["vh_ms"] for v in per.values()), 2),
+                                "channel_decomposition (ITQ)": round(sum(v["itq_ms"] for v in per.values()), 2),
+                                "channel_pruning (dictionary)": round(sum(v["prune_ms"] or 0.0 for v in per.values()), 2)},
+           "per_conv": per, "roofline": None,
+           "note": "host-inclusive: every call starts from NumPy arrays, as Net.R3 hands them over; latency-bound by the Jacobi "
+                   "sweeps of the SVDs (svd_jacobi.hip) -- no roofline kernel is named for this workload"}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import cp_oracle
+        from threadpoolctl import threadpool_limits
+        sample = [0, 1]                               # conv1_2, conv2_1: about 20-40 s of CPU work at 8 BLAS threads
+        secs = {}
+        with threadpool_limits(limits=8):
+            for i in sample:
+                st, d = plan[i], data[i]
+                np.random.seed(2000 + i)
+                t0 = time.perf_counter()
+                V, H, VHr, b = cp_oracle.vh_decompose_oracle(d["W"].astype(np.float64), rank=st["rank"], X=d["X"].astype(np.float64), Y=d["Y"])
+                t1 = time.perf_counter()
+                cp_oracle.itq_decompose_oracle(d["feat"], d["Y"], H, st["rank"], bias=b, Wr=VHr)
+                t2 = time.perf_counter()
+                if st["prune"]:
+                    cp_oracle.dictionary_oracle(d["Xo"].astype(np.float64), d["W2"], d["Y2"], st["d_c"], alpha_in=1e-3,
+                                                lasso="sklearn", ls="sklearn")
+                t3 = time.perf_counter()
+                secs[st["name"]] = dict(vh_s=round(t1 - t0, 2), itq_s=round(t2 - t1, 2), prune_s=round(t3 - t2, 2))
+        cpu_s = sum(sum(v.values()) for v in secs.values())
+        gpu_ms = sum(per[plan[i]["name"]]["vh_ms"] + per[plan[i]["name"]]["itq_ms"] + (per[plan[i]["name"]]["prune_ms"] or 0.0) for i in sample)
+        out["cpu_baseline"] = {"value": round(len(sample) / cpu_s, 4), "unit": "layers/s", "cores": 8, "kind": "port",
+                               "sample": "the first %d convs (%s): scipy gesvd / sklearn restatement of the three steps (oracle/cp_oracle.py), "
+                                         "8 BLAS threads: %.1f s" % (len(sample), ", ".join(plan[i]["name"] for i in sample), cpu_s),
+                               "per_conv_s": secs, "gpu_ms_same_convs": round(gpu_ms, 2),
+                               "speedup_same_convs": round(cpu_s * 1e3 / gpu_ms, 1), "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
+    return out
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -1059,7 +1199,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("vgg16", "resnet50", "vgg16_5x", "block"),
+    ap.add_argument("--workload", choices=("vgg16", "resnet50", "vgg16_5x", "block", "r3"),
                     default=os.environ.get("CP_BENCH_WORKLOAD", "vgg16"))
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("CP_BENCH_SCALING", "strong"),
                     help="N > 1: strong (default) = ONE job instance, its layers sharded over the GPUs (BASELINE configs[2]); the line "
@@ -1092,6 +1232,10 @@ def main():
         if env.world != 1:
             raise SystemExit("bench.py: --sequential-alpha is a one-GPU mode (every layer needs the previous layer's alpha)")
         out = bench_sequential_alpha(args, env)
+    elif args.workload == "r3":
+        if env.world != 1:
+            raise SystemExit("bench.py: --workload r3 is a one-GPU workload (R3 is a sequential loop over the convs)")
+        out = bench_r3(args, env)
     elif args.workload != "block":
         out = bench_job(args, env, args.workload)
         if out is not None and not args.profile_mode and env.world == 1 and not args.sequential_alpha:
