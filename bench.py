@@ -354,9 +354,57 @@ def bench_job(args, env, job):
     host_data = {}
 
     def operands(spec):
-        X, W2, Y, _ = cpjobs.synth(spec)
-        host_data[spec["layer_id"]] = (X, W2, Y)
-        return X, W2, Y
+        if spec["layer_id"] not in host_data:
+            X, W2, Y, _ = cpjobs.synth(spec)
+            host_data[spec["layer_id"]] = (X, W2, Y)
+        return host_data[spec["layer_id"]]
+
+    if env.world == 1 and not args.profile_mode:
+        for sp_ in specs:
+            operands(sp_)
+    # ---- PCIe-inclusive, BEFORE the resident set exists (the state of a process that just calls dictionary()): every layer
+    # ---- pruned from its pageable host arrays, one after another ----
+    pcie = None
+    if env.world == 1 and not args.profile_mode:
+        from cpmi355.pruner import LayerProblem
+        ctx0 = cpmi355.Context(env.local_rank)     # a context of its own, as a caller of dictionary() has (default_context)
+
+        seq_layer_ms = {}
+
+        def sequential_pass(x_dtype):
+            t1 = time.perf_counter()
+            h2d = 0
+            for spec in specs:
+                X, W2, Y = host_data[spec["layer_id"]]
+                t_l = time.perf_counter()
+                pr = LayerProblem(ctx0, X.astype(x_dtype, copy=False), W2, Y, flags=CD_FLAGS, defer_upload=True)   # as dictionary() does
+                h2d += pr.h2d_bytes
+                prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
+                pr.free()
+                seq_layer_ms[spec["name"]] = round((time.perf_counter() - t_l) * 1e3, 2)
+            return time.perf_counter() - t1, h2d
+
+        first, _ = sequential_pass(np.float32)     # first pass: workspaces of the context grow layer by layer (cold)
+        t_seq, h2d = sequential_pass(np.float32)   # steady state
+        pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "first_pass_ms": round(first * 1e3, 2),
+                "h2d_bytes": int(h2d), "layers_per_s_with_h2d": round(len(specs) / t_seq, 2), "per_layer_ms": dict(seq_layer_ms),
+                "note": "every layer pruned from pageable host arrays, one after another: what the drop-in dictionary() does per "
+                        "call (cp_prune_layer_h2d: the sampled rows first, X and Y streamed in behind the alpha search); never part of `value`.  first_pass_ms: the "
+                        "context's workspaces still growing from layer to layer.  X as float32 (the bytes the reference's "
+                        "float64 arrays hold: Caffe blobs); x_float64 = the same pass with X uploaded as the float64 array "
+                        "the reference hands to dictionary() (2x the bytes, the astype() excluded)"}
+        if not args.no_pcie_f64:
+            x64 = {lid: v[0].astype(np.float64) for lid, v in host_data.items()}
+            saved = dict(host_data)
+            for lid in x64:
+                host_data[lid] = (x64[lid],) + saved[lid][1:]
+            t64, h64 = sequential_pass(np.float64)
+            host_data.update(saved)
+            del x64
+            pcie["x_float64"] = {"job_ms_sequential_with_h2d": round(t64 * 1e3, 2), "h2d_bytes": int(h64),
+                                 "layers_per_s_with_h2d": round(len(specs) / t64, 2)}
+
+        ctx0.close()
 
     t_up0 = time.perf_counter()
     per_stream = args.per_stream or (1 if job != "resnet50" else 2)
@@ -487,50 +535,6 @@ def bench_job(args, env, job):
             # latency mode: the launch computed the Gram of ALL c channels during the alpha search (CP_REFIT_PRECOMPUTE)
             alone_g_ex.append(float(spec["N"]) * (spec["c"] * kk) ** 2 if ("refit_gather_normal_eq" in st or "refit_backward" in st)
                               else float(spec["N"]) * int(pr.refit_info.p) ** 2)
-
-    # ---- PCIe-inclusive: upload of a layer's operands from pageable host memory + its pruning, layer after layer ----
-    pcie = None
-    if env.world == 1 and not args.profile_mode:
-        from cpmi355.pruner import LayerProblem
-        ctx0 = cpmi355.Context(env.local_rank)     # a context of its own, as a caller of dictionary() has (default_context)
-
-        seq_layer_ms = {}
-
-        def sequential_pass(x_dtype):
-            t1 = time.perf_counter()
-            h2d = 0
-            for j in sorted(probs):
-                spec = specs[own[j]]
-                X, W2, Y = host_data[spec["layer_id"]]
-                t_l = time.perf_counter()
-                pr = LayerProblem(ctx0, X.astype(x_dtype, copy=False), W2, Y, flags=CD_FLAGS, defer_upload=True)   # as dictionary() does
-                h2d += pr.h2d_bytes
-                prune_layer(pr, spec["rank"], 1e-3, rank_tol=.1, rng=np.random.RandomState(1234 + spec["layer_id"]), mode="device")
-                pr.free()
-                seq_layer_ms[spec["name"]] = round((time.perf_counter() - t_l) * 1e3, 2)
-            return time.perf_counter() - t1, h2d
-
-        first, _ = sequential_pass(np.float32)     # first pass: workspaces of the context grow layer by layer (cold)
-        t_seq, h2d = sequential_pass(np.float32)   # steady state
-        pcie = {"job_ms_sequential_with_h2d": round(t_seq * 1e3, 2), "first_pass_ms": round(first * 1e3, 2),
-                "h2d_bytes": int(h2d), "layers_per_s_with_h2d": round(len(specs) / t_seq, 2), "per_layer_ms": dict(seq_layer_ms),
-                "note": "every layer pruned from pageable host arrays, one after another: what the drop-in dictionary() does per "
-                        "call (cp_prune_layer_h2d: the sampled rows first, X and Y streamed in behind the alpha search); never part of `value`.  first_pass_ms: the "
-                        "context's workspaces still growing from layer to layer.  X as float32 (the bytes the reference's "
-                        "float64 arrays hold: Caffe blobs); x_float64 = the same pass with X uploaded as the float64 array "
-                        "the reference hands to dictionary() (2x the bytes, the astype() excluded)"}
-        if not args.no_pcie_f64:
-            x64 = {lid: v[0].astype(np.float64) for lid, v in host_data.items()}
-            saved = dict(host_data)
-            for lid in x64:
-                host_data[lid] = (x64[lid],) + saved[lid][1:]
-            t64, h64 = sequential_pass(np.float64)
-            host_data.update(saved)
-            del x64
-            pcie["x_float64"] = {"job_ms_sequential_with_h2d": round(t64 * 1e3, 2), "h2d_bytes": int(h64),
-                                 "layers_per_s_with_h2d": round(len(specs) / t64, 2)}
-
-        ctx0.close()
 
     # ---- N > 1, strong scaling: the bound of this mode and, in the same run, the replica throughput of the N GPUs ----
     strong_bound, replica = None, None

@@ -305,24 +305,30 @@ class LayerProblem:
 
 GLOBAL_RNG = np.random  # module-level legacy RandomState: randint / get_state / set_state
 
-TIE_ULPS = 64.0          # a decision within this many float64 ulp of its threshold is reported (tie_report)
+# A decision whose relative margin is below this is reported (tie_report).  A HEURISTIC, not a bound: the device solves the
+# Gram-form recurrence, the reference scikit-learn's DATA form; the two differ by about eps (|q_i| + |H_i|) times the
+# accumulation growth over the S n sampled rows, which is not relative to alpha -- where q_i and H_i cancel (|q_i|, |H_i| >>
+# alpha) the reference can flip a decision at a margin far above a few ulp of alpha.  2^20 eps = 2.3e-10 of alpha leaves room
+# for |q_i| + |H_i| up to ~1e4 alpha at 64 ulp of accumulated error; no reference golden comes that close (asserted by
+# tests/test_gpu_parity.py::_check_against_golden).
+# Only the dead-zone edge and the duality-gap stop are watched; the d_w_max / w_max < tol early-exit test is not.
+TIE_MARGIN = 2.0 ** 20 * float(np.finfo(np.float64).eps)
 
 
 def tie_report(prob):
     """The tie sentinels of the last search on `prob` (cp_cd_result.edge_margin / gap_margin per fit) -> dict
         edge_margin   smallest relative distance of a coefficient, at its last update of a fit, from the edge of its dead zone
         gap_margin    smallest relative distance of a duality gap from its stopping threshold
-        suspect       True when either is within TIE_ULPS ulp: the reference (scikit-learn's DATA form of the recurrence,
-                      lib/decompose.py:449, 456) may have decided that coefficient / that stop the other way, so the mask
-                      is not pinned by rounding-level agreement alone
+        suspect       True when either is below TIE_MARGIN (a heuristic, see there): the reference (scikit-learn's DATA form
+                      of the recurrence, lib/decompose.py:449, 456) may have decided that coefficient / that stop the other
+                      way, so the mask is not pinned by rounding-level agreement alone
         tracked       False when the kernel form does not report the sentinels (-1)."""
-    eps = np.finfo(np.float64).eps
     edges = [m[0] for m in prob.margins if m[0] >= 0]
     gaps = [m[1] for m in prob.margins if m[1] >= 0]
     edge = min(edges) if edges else None
     gap = min(gaps) if gaps else None
     return dict(edge_margin=edge, gap_margin=gap, tracked=bool(edges or gaps),
-                suspect=bool((edge is not None and edge <= TIE_ULPS * eps) or (gap is not None and gap <= TIE_ULPS * eps)))
+                suspect=bool((edge is not None and edge <= TIE_MARGIN) or (gap is not None and gap <= TIE_MARGIN)))
 
 
 def prune_layer(prob, rank, alpha_in, rank_tol=.1, rng=None, ridge=0.0, mode="device", alpha_arg=1e-4,

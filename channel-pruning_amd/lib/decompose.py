@@ -20,7 +20,7 @@ import warnings
 
 from cpmi355 import LayerProblem, default_context, prune_layer
 from cpmi355 import capi as _capi
-from cpmi355.pruner import tie_report
+from cpmi355.pruner import TIE_MARGIN, tie_report
 
 from . import cfgs
 from .cfgs import c as dcfgs
@@ -73,9 +73,9 @@ def prune_resident(prob, rank, W2_host, alpha=1e-4):
         # the device solves the LASSO on Z^T Z, the reference on Z itself (Lasso.fit(Z, reY), decompose.py:449, 456): the two
         # agree to rounding, so a coefficient this close to the edge of its dead zone (or a stop this close to its
         # threshold) may have gone the other way there -- the mask is then not guaranteed identical
-        warnings.warn("dictionary(): a LASSO decision was taken within %g ulp of its threshold (edge margin %s, duality-gap "
-                      "margin %s): the selected channels may differ from the CPU reference's at this tie"
-                      % (64, ties["edge_margin"], ties["gap_margin"]), RuntimeWarning, stacklevel=2)
+        warnings.warn("dictionary(): a LASSO decision was taken within a relative margin of %.1e of its threshold (edge margin "
+                      "%s, duality-gap margin %s): the selected channels may differ from the CPU reference's at this tie"
+                      % (TIE_MARGIN, ties["edge_margin"], ties["gap_margin"]), RuntimeWarning, stacklevel=2)
     if not dcfgs.autodet:
         cfgs.alpha = alpha_out                           # decompose.py:626-627 (`if not norank`)
     return idxs, newW2, newB2

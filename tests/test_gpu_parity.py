@@ -168,8 +168,9 @@ def test_tie_sentinels_fire_at_constructed_ties_and_only_there(ctx):
     default variant fires (a coefficient's last update within 64 ulp of the edge of its dead zone).  On a generic problem
     and on every dictionary() golden (checked in _check_against_golden) the margins stay orders of magnitude away."""
     import cp_oracle
-    from cpmi355.pruner import TIE_ULPS
     eps = np.finfo(np.float64).eps
+    from cpmi355.pruner import TIE_MARGIN
+    assert TIE_MARGIN >= 64 * eps
     g = np.load(os.path.join(GOLDEN_DIR, "t01_ties.npz"))
     seed = int(g["seed"])
     fired = 0
@@ -191,7 +192,7 @@ def test_tie_sentinels_fire_at_constructed_ties_and_only_there(ctx):
         assert np.array_equal(ctx.to_host(wd, (c,), np.float64), w0)
         assert r.edge_margin >= 0.0 and r.gap_margin >= 0.0
         if len(set(sups)) > 1:
-            assert r.edge_margin <= TIE_ULPS * eps, (t, r.edge_margin, sups)
+            assert r.edge_margin <= 64 * eps, (t, r.edge_margin, sups)     # a constructed tie sits within rounding of the edge
             fired += 1
     assert fired >= 1
     Q, q, yty, M = _cd_problem(64)
