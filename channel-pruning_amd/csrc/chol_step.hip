@@ -8,8 +8,10 @@
 // block + panel, then the trailing update as a GEMM) become one, and that launch overlaps the one serial piece of a step
 // (the 128 x 128 factorisation in one workgroup) with the chip-filling part of the previous step:
 //
-//   launch s, one workgroup per upper tile (i, j), s <= i <= j < nblk, row s first:
-//     every tile   S = G[i,j] - U[s-1,i]^T U[s-1,j]         the update of step s - 1, applied only now (K = 128, MFMA)
+//   launch s, one workgroup per upper tile (i, j), s <= i <= j < nblk, row s first (the rows below it only at even s):
+//     every tile   S = G[i,j] - sum_r U[r,i]^T U[r,j]        the updates not applied yet: r = s - 1, or s - 2 and s - 1 --
+//                                                           the tiles below block row s are touched at every SECOND launch
+//                                                           with K = 256 (MFMA)
 //     (s, s)       S = U_ss^T U_ss in LDS, T_q = (16 x 16 diagonal blocks)^-1, flag, U_ss^-1  -> U[s,s], operator, TI_s, TIT_s
 //     (s, j > s)   wait for the flag, U[s,j] = U_ss^-T S by block forward substitution          -> U[s,j], Lt[j,s]
 //     (i > s, j)   G[i,j] = S
@@ -100,13 +102,13 @@ __device__ __forceinline__ void flag_wait(const int *flag, int *info) {
     atomicCAS(info, 0, 0x7fffffff);  // never observed; the caller then reports a failed factorisation instead of hanging
 }
 
-// acc[t] (wave w: rows 16 t + fk + 4 r, column 16 w + fi of the tile) -= A^T B over K = 128, A = U[s-1, i-block], B = U[s-1, j-block]
-// or, for a right-hand-side tile, Y[s-1, j-block] (k-major 128 x 128 blocks, leading dimensions ld / ldb).  Both operands go through LDS in chunks of KCH k-rows (wide coalesced
+// acc[t] (wave w: rows 16 t + fk + 4 r, column 16 w + fi of the tile) -= A^T B over K = 128 kcnt, A = U[r0 .., i-block], B = U[r0 .., j-block]
+// or, for a right-hand-side tile, Y[r0 .., j-block] (k-major blocks of kcnt consecutive block rows, leading dimensions ld / ldb).  Both operands go through LDS in chunks of KCH k-rows (wide coalesced
 // loads, the next chunk in flight while the current one is multiplied); SAME: A and B are the same block (diagonal tile),
 // and only the upper blocks t <= w are wanted.
 template <bool SAME>
 __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *__restrict__ Ab, int ld,
-                                            const double *__restrict__ Bb, int ldb, double *sm) {
+                                            const double *__restrict__ Bb, int ldb, int kcnt, double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     double *As = sm, *Bs = SAME ? sm : sm + KCH * SLD;
     constexpr int PER = KCH * NB / 2 / PT;   // double2 loads per thread, operand and chunk (= 2)
@@ -122,8 +124,10 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *_
             if constexpr (!SAME) br[i] = *reinterpret_cast<const v2f64s *>(bb + goffb);
         }
     };
+    // kcnt (1 or 2) consecutive block rows of the operands: K = 128 kcnt, the rows of a block row are contiguous in k
+    const int nch = kcnt * (NB / KCH);
     gload(0);
-    for (int ch = 0; ch < NB / KCH; ++ch) {
+    for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int e = tid + PT * i, r = e >> 6, c = (e & 63) * 2;
@@ -131,7 +135,7 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *_
             if constexpr (!SAME) *reinterpret_cast<v2f64s *>(&Bs[r * SLD + c]) = br[i];
         }
         __syncthreads();
-        if (ch + 1 < NB / KCH) gload(ch + 1);
+        if (ch + 1 < nch) gload(ch + 1);
 #pragma unroll
         for (int kk = 0; kk < KCH / 4; ++kk) {
             const double b = Bs[(kk * 4 + fk) * SLD + 16 * wave + fi];
@@ -381,13 +385,14 @@ __device__ __noinline__ void diag_inverse(const double *sm, double *__restrict__
 struct Tile {
     double *T;          // the 128 x 128 tile (G[i,j] or R[i,jr])
     int ldt;
-    const double *B;    // U[s-1, j-block] or Y[s-1, jr-block]
+    const double *B;    // U[r0, j-block] or Y[r0, jr-block]: the first of the kcnt block rows to apply
     int ldb;
+    int kcnt;           // block rows to apply: 0 (nothing yet), 1 or 2
 };
 
-// acc <- the tile, then the update of step s - 1 (see the head of the file)
+// acc <- the tile, then the pending updates (see the head of the file)
 template <bool DIAG>
-__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *__restrict__ Ai, int ld, int s,
+__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *__restrict__ Ai, int ld,
                                                  double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     const int toff = fk * t_.ldt + 16 * wave + fi;   // lane's offset inside a (16 t + 4 r)-row band of the tile: scalar base + 32-bit offset
@@ -400,7 +405,7 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = (t_.T + size_t(16 * t + 4 * r) * t_.ldt)[toff];
     }
-    if (s > 0) tile_update<DIAG>(acc, Ai, ld, t_.B, t_.ldb, sm);
+    if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, t_.B, t_.ldb, t_.kcnt, sm);
 }
 
 // the three roles of a workgroup of launch s; each is a function of its own (not inlined) so that the register allocation of
@@ -409,7 +414,7 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile
 __device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const double *__restrict__ Ai, int ld, int s, double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     v4f64s acc[NPAN];
-    tile_load_update<false>(acc, t_, Ai, ld, s, sm);
+    tile_load_update<false>(acc, t_, Ai, ld, sm);
     const int toff = fk * t_.ldt + 16 * wave + fi;
 #pragma unroll
     for (int t = 0; t < NPAN; ++t)
@@ -424,7 +429,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const 
                                                                  double *sm) {
     {
         v4f64s acc[NPAN];
-        tile_load_update<true>(acc, t_, Ai, ld, s, sm);
+        tile_load_update<true>(acc, t_, Ai, ld, sm);
         diag_to_lds(acc, sm, dg0 + size_t(s) * NB);
     }
     diag_factor_lds(sm, piv_tol, info, s);
@@ -439,7 +444,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
                                                                   const double *__restrict__ Gss, int *info, double *sm) {
     const int tid = threadIdx.x;
     v4f64s acc[NPAN];
-    tile_load_update<false>(acc, t_, Ai, ld, s, sm);
+    tile_load_update<false>(acc, t_, Ai, ld, sm);
     if (tid == 0) flag_wait(info + 1 + s, info);  // bounded; running out is reported as a failed factorisation
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -473,13 +478,18 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
     }
     const bool rhs = jt >= nblk - i;
     const int j = rhs ? jt - (nblk - i) : i + jt;     // right-hand-side tile column, or block column of the factor
-    const double *Urow = U + size_t(s > 0 ? s - 1 : 0) * NB * ld;   // block row s - 1 of U (unused at s = 0)
+    // Block rows still to apply to this tile.  The tiles below block row s are only touched at EVEN s >= 2, with the two block
+    // rows s - 2 and s - 1 at once (K = 256: half the read-modify-write passes over G, 10.7 instead of 8 flop per byte); the
+    // tiles of block row s have therefore seen every row below s - 2 (s even) or s - 1 (s odd) and apply the rest themselves.
+    const int kcnt = s == 0 ? 0 : ((s & 1) ? 1 : 2), r0 = s - kcnt;
+    const double *Urow = U + size_t(r0) * NB * ld;
     const double *Ai = Urow + size_t(i) * NB;
     Tile t_;
+    t_.kcnt = kcnt;
     if (rhs) {
         t_.T = R + size_t(i) * NB * ldr + size_t(j) * NB;
         t_.ldt = ldr;
-        t_.B = R + size_t(s > 0 ? s - 1 : 0) * NB * ldr + size_t(j) * NB;
+        t_.B = R + size_t(r0) * NB * ldr + size_t(j) * NB;
         t_.ldb = ldr;
     } else {
         t_.T = G + size_t(i) * NB * ld + size_t(j) * NB;
@@ -524,8 +534,8 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
     const int ntr = R ? n_pad / NB : 0;
     for (int s = 0; s < nblk; ++s) {
-        // s = 0: nothing to apply yet, only block row 0; afterwards every upper tile of the rows s .. nblk - 1
-        const int n = nblk - s, tiles = s == 0 ? n + ntr : n * (n + 1) / 2 + n * ntr;
+        // block row s always; the tiles below it only at even s >= 2 (they take two block rows of updates at once)
+        const int n = nblk - s, tiles = (s >= 2 && !(s & 1)) ? n * (n + 1) / 2 + n * ntr : n + ntr;
         k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, TIT, info, R, n_pad, ntr);
         CP_LAUNCH_CHECK(ctx);
     }
