@@ -8,10 +8,12 @@
 // block + panel, then the trailing update as a GEMM) become one, and that launch overlaps the one serial piece of a step
 // (the 128 x 128 factorisation in one workgroup) with the chip-filling part of the previous step:
 //
-//   launch s, one workgroup per upper tile (i, j), s <= i <= j < nblk, row s first (the rows below it only at even s):
-//     every tile   S = G[i,j] - sum_r U[r,i]^T U[r,j]        the updates not applied yet: r = s - 1, or s - 2 and s - 1 --
-//                                                           the tiles below block row s are touched at every SECOND launch
-//                                                           with K = 256 (MFMA)
+//   launch s, one workgroup per upper tile (i, j), s <= i <= j < nblk, row s first:
+//     every tile   S = G[i,j] - sum_r U[r,i]^T U[r,j]        the updates not applied yet (MFMA).  Block row s: r = s - 1.  The
+//                                                           tiles below it are touched at every SECOND launch (even s) with
+//                                                           r = s - 2 and s - 1 (K = 256); at odd s only block row s + 1
+//                                                           rides along and takes r = s - 1 early, so that the serial piece
+//                                                           of every step stays at K = 128
 //     (s, s)       S = U_ss^T U_ss in LDS, T_q = (16 x 16 diagonal blocks)^-1, flag, U_ss^-1  -> U[s,s], operator, TI_s, TIT_s
 //     (s, j > s)   wait for the flag, U[s,j] = U_ss^-T S by block forward substitution          -> U[s,j], Lt[j,s]
 //     (i > s, j)   G[i,j] = S
@@ -478,10 +480,12 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
     }
     const bool rhs = jt >= nblk - i;
     const int j = rhs ? jt - (nblk - i) : i + jt;     // right-hand-side tile column, or block column of the factor
-    // Block rows still to apply to this tile.  The tiles below block row s are only touched at EVEN s >= 2, with the two block
-    // rows s - 2 and s - 1 at once (K = 256: half the read-modify-write passes over G, 10.7 instead of 8 flop per byte); the
-    // tiles of block row s have therefore seen every row below s - 2 (s even) or s - 1 (s odd) and apply the rest themselves.
-    const int kcnt = s == 0 ? 0 : ((s & 1) ? 1 : 2), r0 = s - kcnt;
+    // Block rows still to apply to this tile.  The tiles below block row s + 1 are only touched at EVEN s >= 2, with the two
+    // block rows s - 2 and s - 1 at once (K = 256: half the read-modify-write passes over G, 10.7 instead of 8 flop per byte).
+    // The serial piece of a step stays at K = 128 all the same: at odd s the tiles of block row s + 1 ride along and take
+    // block row s - 1 early, so the tiles of block row s -- the ones that are factored / substituted in this launch -- always
+    // find exactly one block row, s - 1, left to apply.
+    const int kcnt = s == 0 ? 0 : ((i > s && !(s & 1)) ? 2 : 1), r0 = s == 0 ? 0 : ((i > s && !(s & 1)) ? s - 2 : s - 1);
     const double *Urow = U + size_t(r0) * NB * ld;
     const double *Ai = Urow + size_t(i) * NB;
     Tile t_;
@@ -534,8 +538,11 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
     const int ntr = R ? n_pad / NB : 0;
     for (int s = 0; s < nblk; ++s) {
-        // block row s always; the tiles below it only at even s >= 2 (they take two block rows of updates at once)
-        const int n = nblk - s, tiles = (s >= 2 && !(s & 1)) ? n * (n + 1) / 2 + n * ntr : n + ntr;
+        // block row s always; at even s >= 2 every tile below it (two block rows of updates at once), at odd s block row s + 1
+        const int n = nblk - s;
+        int tiles = n + ntr;
+        if (s >= 2 && !(s & 1)) tiles = n * (n + 1) / 2 + n * ntr;
+        else if ((s & 1) && n > 1) tiles += (n - 1) + ntr;
         k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, TIT, info, R, n_pad, ntr);
         CP_LAUNCH_CHECK(ctx);
     }

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r04_call12
+OUT=$R/gpurun_out/r04_call13
 mkdir -p $OUT
 cd $R
 timeout -k 5 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "refit or fc_kernel or full_size or batch or resident or prefactored or multi_cu" < /dev/null > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
@@ -21,10 +21,10 @@ except Exception as e:
     print(sys.argv[2], "unreadable", e)
 PY
 }
-job k256 CP_NOP=1
+job pre CP_NOP=1
+job k256chain CP_LIB_PATH=$R/build_variants/k256chain/libcpmi355.so
+job pre_b CP_NOP=1
 job k128 CP_LIB_PATH=$R/build_variants/k128/libcpmi355.so
-job k256_b CP_NOP=1
-job k128_b CP_LIB_PATH=$R/build_variants/k128/libcpmi355.so
 job resnet_k256 CP_BENCH_WORKLOAD=resnet50
 job v5x_k256 CP_BENCH_WORKLOAD=vgg16_5x
 timeout -k 5 300 python $R/bench.py $Q --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
