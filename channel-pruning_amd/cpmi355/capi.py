@@ -101,6 +101,7 @@ SIGNATURES = {
     "cp_nonlinear_fc": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp, _vp,
                                  ctypes.POINTER(RefitInfo)]),
     "cp_svd_rows": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_c_int)]),
+    "cp_svd_rows_lowrank": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, ctypes.POINTER(_c_int)]),
     "cp_vh_project": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "cp_matmul_tn": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "cp_itq_iterate": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _c_int, _c_dbl, _vp, _vp, _vp]),
@@ -401,17 +402,18 @@ class Context:
         return info
 
     # -- VH_decompose pieces -------------------------------------------------------------
-    def svd_rows(self, M, r):
+    def svd_rows(self, M, r, lowrank=False):
         """Leading r singular triplets of the host matrix M[m, n] (m <= n) -> (sigma[r], Vt[r, m], SH[r, n])
-        with SH = diag(sigma) H; computed on the device (cp_svd_rows)."""
+        with SH = diag(sigma) H; computed on the device (cp_svd_rows; lowrank: M has rank <= r, cp_svd_rows_lowrank)."""
         M = np.ascontiguousarray(M, dtype=np.float64)
         m, n = M.shape
         Md = self.to_device(M)
         sd, Vd, Hd = self.empty(r * 8), self.empty(r * m * 8), self.empty(r * n * 8)
         sweeps = _c_int()
         try:
-            self._check(self.lib.cp_svd_rows(self.h, Md.ptr, m, n, int(r), sd.ptr, Vd.ptr, Hd.ptr, ctypes.byref(sweeps)),
-                        "cp_svd_rows")
+            fn = self.lib.cp_svd_rows_lowrank if lowrank else self.lib.cp_svd_rows
+            self._check(fn(self.h, Md.ptr, m, n, int(r), sd.ptr, Vd.ptr, Hd.ptr, ctypes.byref(sweeps)), "cp_svd_rows")
+            self.last_svd_sweeps = sweeps.value
             return (self.to_host(sd, (r,), np.float64), self.to_host(Vd, (r, m), np.float64),
                     self.to_host(Hd, (r, n), np.float64))
         finally:

@@ -90,6 +90,7 @@ struct cp_ctx {
     cp_precompute pre;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // hand-offs to / from the shared CU-masked stream of the long GEMMs
     int itq_sweeps = 0;               // Jacobi sweeps of the last cp_itq_iterate (all alternations)
+    int itq_ns_steps = 0, itq_sign_alternations = 0;   // Newton-Schulz steps / alternations that took the sign-function route
     char *cd_box = nullptr;           // mailboxes of the multi-CU coordinate-descent team (cd_team.hip), grow-only
     size_t cd_box_bytes = 0;
     char *stage = nullptr;             // page-locked staging of the sampled rows (cp_prune_layer_h2d), grow-only
@@ -194,6 +195,8 @@ static inline int cp_svd_me(int m) { return (m + 15) / 16 * 16; }   // rows the 
 struct SvdScratch {
     double *Wk, *R, *sig;
     int *rotated, *order;
+    // host copies left by cp_svd_rows_core: the r-th and (r + 1)-th singular value (0 if there is none) and the sum of all
+    double sigma_r = 0, sigma_next = 0, sigma_sum = 0;
     static size_t bytes(int m, int n) {
         const size_t me = size_t(cp_svd_me(m));
         return (me * n + me * me + me) * 8 + 512 + me * 4 + 1024;
@@ -208,6 +211,17 @@ struct SvdScratch {
         return Wk && R && sig && rotated && order;
     }
 };
+
+// sign_ns.hip: projector onto the r leading eigenvectors by the Newton-Schulz sign iteration; the threshold is carried from
+// call to call as a fraction of the trace
+struct SignTracker {
+    double sigma_rel = 0;   // threshold / trace(A) of the last call that found one (seeded by the caller)
+    int steps_plan = 18;    // steps to run before the first look at the residuals
+    long steps = 0;         // totals: Newton-Schulz steps, thresholds tried
+    int trials = 0;
+};
+size_t cp_sign_workspace_doubles(int np_);
+int cp_sign_projector(cp_ctx *ctx, const double *A, int np_, int r, SignTracker &tk, double *work, double *P, bool *found);
 
 int cp_svd_rows_impl(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r, double *sigma, double *Vt, int ldv,
                      double *SH, int ldsh, SvdScratch &sc, int *sweeps_out);

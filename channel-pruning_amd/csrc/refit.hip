@@ -523,6 +523,10 @@ __global__ void __launch_bounds__(RT) k_scale_rows(double *__restrict__ M, int l
 }  // namespace
 
 extern "C" int cp_debug_itq_sweeps(cp_ctx *ctx) { return ctx ? ctx->itq_sweeps : -1; }
+// what: 0 = Newton-Schulz steps, 1 = alternations that took the sign-function route (of the last cp_itq_iterate)
+extern "C" int cp_debug_itq_sign(cp_ctx *ctx, int what) {
+    return !ctx ? -1 : (what == 0 ? ctx->itq_ns_steps : ctx->itq_sign_alternations);
+}
 
 namespace {
 
@@ -1614,8 +1618,8 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, np_, int(Nr), np_, CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, np_, np_, np_, CP_TRI_NONE));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, np_, np_, rp, CP_TRI_NONE));
-    const size_t need = (7 * big + 16 * sq + size_t(rp) * np_ + size_t(RB) * np_ + 4 * size_t(np_) + 2 * size_t(n) * n) * 8 +
-                        SvdScratch::bytes(n, np_) + ws + (1 << 18);
+    const size_t need = (7 * big + 16 * sq + size_t(rp) * np_ + size_t(RB) * np_ + 4 * size_t(np_) + 2 * size_t(n) * n +
+                         cp_sign_workspace_doubles(np_)) * 8 + SvdScratch::bytes(n, np_) + ws + (1 << 18);
     CP_TRY(cp_arena_reserve(ctx, need));
     double *G = cp_arena_take_t<double>(ctx, big), *GT = cp_arena_take_t<double>(ctx, big);
     double *P1 = cp_arena_take_t<double>(ctx, big), *UU = cp_arena_take_t<double>(ctx, big);
@@ -1633,8 +1637,9 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
     double *ymean = cp_arena_take_t<double>(ctx, np_), *umean = cp_arena_take_t<double>(ctx, np_);
     double *sigma = cp_arena_take_t<double>(ctx, np_), *Vt = cp_arena_take_t<double>(ctx, size_t(n) * n);
     double *SHsq = cp_arena_take_t<double>(ctx, size_t(n) * np_);
+    double *sign_work = cp_arena_take_t<double>(ctx, cp_sign_workspace_doubles(np_));
     SvdScratch sc;
-    if (!G || !GT || !P1 || !UU || !Ub || !Zb || !Tn || !GtG || !PGi || !PiT || !T2 || !FA || !FB || !BT || !Bm || !C1 || !Mx ||
+    if (!sign_work || !G || !GT || !P1 || !UU || !Ub || !Zb || !Tn || !GtG || !PGi || !PiT || !T2 || !FA || !FB || !BT || !Bm || !C1 || !Mx ||
         !Pr || !BP || !Rp || !RpT || !Wp || !Vtp || !part || !ymean || !umean || !sigma || !Vt || !SHsq || !sc.take(ctx, n, np_))
         return cp_set_error(ctx, CP_ERR_NOMEM, "itq: arena");
     cp_stage_begin(ctx);
@@ -1667,31 +1672,52 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
     // Jacobi SVD per alternation (2.5 s per conv3 layer) becomes an n x n symmetric eigenproblem, warm-started from the
     // previous alternation's rotation (the iterate moves little: 2-3 sweeps instead of 8-10).  Two N-sized products per
     // alternation are left: B^T = UU^T P1 and RU = G T.
-    bool warm = false;
-    int total_sweeps = 0;
+    // From the third alternation on the projector V_r V_r^T comes from the matrix sign function instead (sign_ns.hip): the
+    // threshold between lambda_r and lambda_{r+1} is carried along as a fraction of the trace, seeded by the eigenvalues of
+    // the second alternation's Jacobi run, and every use is verified (trace of the projector = rank); an alternation whose
+    // threshold cannot be found goes through the Jacobi sweeps and re-seeds it.  CP_ITQ_SIGN=0: Jacobi throughout.
+    // (the first alternation starts from the rotation that diagonalised G^T G for the pseudo-inverse above: UU = G makes
+    //  B = pinv(G^T G) G^T G a projector onto eigenvectors of G^T G, so Mx has the same eigenvectors -- 2 sweeps, not 15)
+    bool warm = getenv("CP_ITQ_COLD") == nullptr;
+    int total_sweeps = 0, alt = 0, sign_alts = 0;
     const double itq_tol = 0.0;   // the standard rounding-level tolerance of the Jacobi sweeps (1e-12 / 1e-10 measured no faster)
+    const char *sign_env = getenv("CP_ITQ_SIGN");
+    const bool sign_route = !(sign_env && sign_env[0] == '0') && rank < n;
+    SignTracker tk;
     for (int st = 0; st < n_stage; ++st)
-        for (int it = 0; it < iters[st]; ++it) {
+        for (int it = 0; it < iters[st]; ++it, ++alt) {
             CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, int(Nr), 1.0, UU, np_, P1, np_, 0.0, BT, np_, CP_TRI_NONE));      // B^T
             k_transpose_2d<<<dim3(np_ / 32, np_ / 32), RT, 0, ctx->stream>>>(BT, np_, Bm, np_);                      // B
             CP_LAUNCH_CHECK(ctx);
             CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, GtG, np_, Bm, np_, 0.0, C1, np_, CP_TRI_NONE));          // GtG B
             CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, Bm, np_, C1, np_, 0.0, Mx, np_, CP_TRI_NONE));           // B^T GtG B
-            if (warm) {   // Wk = R_prev Mx, R = R_prev
-                k_pad_rows<<<np_, RT, 0, ctx->stream>>>(sc.R, me, me, me, Rp, np_);
-                CP_LAUNCH_CHECK(ctx);
-                k_transpose_2d<<<dim3(np_ / 32, np_ / 32), RT, 0, ctx->stream>>>(Rp, np_, RpT, np_);
-                CP_LAUNCH_CHECK(ctx);
-                CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, RpT, np_, Mx, np_, 0.0, Wp, np_, CP_TRI_NONE));
-                CP_HIP(ctx, hipMemcpy2DAsync(sc.Wk, size_t(np_) * 8, Wp, size_t(np_) * 8, size_t(np_) * 8, size_t(me),
-                                             hipMemcpyDeviceToDevice, ctx->stream));
+            bool have_projector = false;
+            if (sign_route && alt >= 2 && tk.sigma_rel > 0.0) {
+                CP_TRY(cp_sign_projector(ctx, Mx, np_, rank, tk, sign_work, Pr, &have_projector));
+                if (have_projector) ++sign_alts;
+                else warm = false;            // the Jacobi state is from an older alternation: start it from the matrix itself
             }
-            CP_TRY(cp_svd_rows_core(ctx, Mx, np_, n, np_, rank, sigma, Vt, n, SHsq, np_, sc, &sweeps, warm, 1e-13, itq_tol));
-            warm = getenv("CP_ITQ_COLD") == nullptr;
-            total_sweeps += sweeps;
-            k_pad_rows<<<rp, RT, 0, ctx->stream>>>(Vt, rank, n, n, Vtp, np_);
-            CP_LAUNCH_CHECK(ctx);
-            CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, rp, 1.0, Vtp, np_, Vtp, np_, 0.0, Pr, np_, CP_TRI_NONE));           // V_r V_r^T
+            if (!have_projector) {
+                if (warm) {   // Wk = R_prev Mx, R = R_prev
+                    k_pad_rows<<<np_, RT, 0, ctx->stream>>>(sc.R, me, me, me, Rp, np_);
+                    CP_LAUNCH_CHECK(ctx);
+                    k_transpose_2d<<<dim3(np_ / 32, np_ / 32), RT, 0, ctx->stream>>>(Rp, np_, RpT, np_);
+                    CP_LAUNCH_CHECK(ctx);
+                    CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, RpT, np_, Mx, np_, 0.0, Wp, np_, CP_TRI_NONE));
+                    CP_HIP(ctx, hipMemcpy2DAsync(sc.Wk, size_t(np_) * 8, Wp, size_t(np_) * 8, size_t(np_) * 8, size_t(me),
+                                                 hipMemcpyDeviceToDevice, ctx->stream));
+                }
+                CP_TRY(cp_svd_rows_core(ctx, Mx, np_, n, np_, rank, sigma, Vt, n, SHsq, np_, sc, &sweeps, warm, 1e-13, itq_tol));
+                warm = getenv("CP_ITQ_COLD") == nullptr;
+                total_sweeps += sweeps;
+                // threshold for the sign route: the geometric middle of the gap behind lambda_r, as a fraction of the trace
+                // (Mx is positive semi-definite: its singular values are its eigenvalues)
+                tk.sigma_rel = sc.sigma_sum > 0.0 && sc.sigma_r > 0.0
+                                   ? std::sqrt(sc.sigma_r * std::max(sc.sigma_next, 1e-6 * sc.sigma_r)) / sc.sigma_sum : 0.0;
+                k_pad_rows<<<rp, RT, 0, ctx->stream>>>(Vt, rank, n, n, Vtp, np_);
+                CP_LAUNCH_CHECK(ctx);
+                CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, rp, 1.0, Vtp, np_, Vtp, np_, 0.0, Pr, np_, CP_TRI_NONE));       // V_r V_r^T
+            }
             CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, BT, np_, Pr, np_, 0.0, BP, np_, CP_TRI_NONE));            // B P_r
             CP_TRY(cp_gemm_tn_f64(ctx, np_, np_, np_, 1.0, PiT, np_, BP, np_, 0.0, T2, np_, CP_TRI_NONE));           // T
             // RU = G T + U_mean; U = solve_relu(RU, Z, lambda); U_mean = mean(U); UU = U - U_mean
@@ -1704,6 +1730,8 @@ extern "C" int cp_itq_iterate(cp_ctx *ctx, const double *feature, const double *
             CP_LAUNCH_CHECK(ctx);
         }
     ctx->itq_sweeps = total_sweeps;
+    ctx->itq_ns_steps = int(tk.steps);
+    ctx->itq_sign_alternations = sign_alts;
     cp_stage_mark(ctx, "itq_iterations");
     CP_HIP(ctx, hipMemcpy2DAsync(T_out, size_t(n) * 8, T2, size_t(np_) * 8, size_t(n) * 8, size_t(n), hipMemcpyDeviceToDevice,
                                  ctx->stream));

@@ -436,6 +436,9 @@ int cp_svd_rows_core(cp_ctx *ctx, const double *M, int ldm, int m, int n, int r,
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hs[x] > hs[y]; });
     std::vector<double> hsorted(r);
     for (int k = 0; k < r; ++k) hsorted[k] = hs[order[k]];
+    sc.sigma_r = hsorted[r - 1];
+    sc.sigma_next = r < me ? hs[order[r]] : 0.0;
+    sc.sigma_sum = std::accumulate(hs.begin(), hs.end(), 0.0);
     CP_HIP(ctx, hipMemcpyAsync(sc.order, order.data(), size_t(r) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     k_take_rows<<<r, JT, 0, ctx->stream>>>(R, me, sc.order, m, Vt, ldv);
     CP_LAUNCH_CHECK(ctx);
@@ -458,6 +461,17 @@ extern "C" int cp_svd_rows(cp_ctx *ctx, const double *M, int m, int n, int r, do
     SvdScratch sc;
     if (!sc.take(ctx, m, n)) return cp_set_error(ctx, CP_ERR_NOMEM, "svd_rows: arena");
     return cp_svd_rows_impl(ctx, M, n, m, n, r, sigma, Vt, m, SH, n, sc, sweeps_out);
+}
+
+extern "C" int cp_svd_rows_lowrank(cp_ctx *ctx, const double *M, int m, int n, int r, double *sigma, double *Vt, double *SH,
+                                   int *sweeps_out) {
+    if (!ctx || !M || !sigma || !Vt || !SH || m <= 0 || n < m || r <= 0 || r > m)
+        return ctx ? cp_set_error(ctx, CP_ERR_ARG, "svd_rows: bad arguments (needs 0 < r <= m <= n)") : CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    CP_TRY(cp_arena_reserve(ctx, SvdScratch::bytes(m, n) + (1 << 16)));
+    SvdScratch sc;
+    if (!sc.take(ctx, m, n)) return cp_set_error(ctx, CP_ERR_NOMEM, "svd_rows: arena");
+    return cp_svd_rows_core(ctx, M, n, m, n, r, sigma, Vt, m, SH, n, sc, sweeps_out, false, 1e-13, 0.0);
 }
 
 // ---- VH_decompose helpers (lib/decompose.py:85-146) ------------------------------------------------------

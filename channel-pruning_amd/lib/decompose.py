@@ -198,7 +198,7 @@ def ITQ_decompose(feature, gt_feature, weight, rank, bias=None, DEBUG=False, Wr=
     assert gt_feature.shape[1] == n_filter_channels
     ctx = default_context()
     T, Y_mean, U_mean = ctx.itq_iterate(feature, gt_feature, rank)        # decompose.py:170-246
-    _, Lt, R = ctx.svd_rows(T, rank)                                      # decompose.py:249-252: L = Lt.T, R = diag(s) R
+    _, Lt, R = ctx.svd_rows(T, rank, lowrank=True)                        # decompose.py:249-252: L = Lt.T, R = diag(s) R
     L = np.ascontiguousarray(Lt.T)
     weight = np.asarray(weight)
     dim = weight.shape

@@ -229,6 +229,11 @@ int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, i
  * k-th left singular vector; sign arbitrary as with LAPACK), SH [r, n] = diag(sigma) H[:r].  *sweeps HOST. */
 int cp_svd_rows(cp_ctx *ctx, const double *M, int m, int n, int r, double *sigma, double *Vt, double *SH,
                 int *sweeps);
+/* The same for a matrix whose numerical rank is at most r -- svd(T) at the end of ITQ_decompose (decompose.py:249-252: T is
+ * the rank-`rank` map of the last alternation): rows that fall below 1e-13 of the largest row norm while the sweeps run
+ * are left alone instead of being rotated against each other (they carry rounding noise only; half the sweeps). */
+int cp_svd_rows_lowrank(cp_ctx *ctx, const double *M, int m, int n, int r, double *sigma, double *Vt, double *SH,
+                        int *sweeps);
 /* Xv[s, r*w + wi] = sum_{ci,hi} X[s,ci,hi,wi] V[(ci,hi), r]: np.tensordot(X, V, [[1,2],[1,2]]) + the transpose and
  * reshape of decompose.py:131-136.  X DEVICE [N,c,h,w] (x_dtype), Vt DEVICE [rank, c*h], Xv DEVICE [N, rank*w]. */
 int cp_vh_project(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int h, int w, const double *Vt,

@@ -877,6 +877,70 @@ def test_vh_and_itq_decompose_match_reference_goldens_at_conv3_size(ctx):
     assert relfro(Wo2 * sgn[None, :, None, None], g["W2"]) <= REL_W
 
 
+def _sign_projector(ctx, A, r, sigma_rel):
+    import ctypes
+    lib = ctx.lib
+    lib.cp_debug_sign_projector.restype = ctypes.c_int
+    lib.cp_debug_sign_projector.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                            ctypes.c_void_p, ctypes.c_void_p]
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    P = np.zeros_like(A)
+    out = np.zeros(3, dtype=np.int32)
+    rc = lib.cp_debug_sign_projector(ctx.h, A.ctypes.data, A.shape[0], r, sigma_rel, P.ctypes.data, out.ctypes.data)
+    ctx._check(rc, "cp_debug_sign_projector")
+    return P, bool(out[0]), int(out[1]), int(out[2])
+
+
+@pytest.mark.parametrize("n,r", [(40, 20), (256, 110), (300, 7), (512, 170)])
+def test_sign_function_projector_is_the_leading_eigenprojector(ctx, n, r):
+    """sign_ns.hip: (I + sign(A - sigma I)) / 2 by Newton-Schulz against numpy's eigh -- with the threshold in the gap, and
+    three times too high / too low (the trace of the projector gives the count away and the threshold is bracketed)."""
+    rs = np.random.RandomState(n + r)
+    Q, _ = np.linalg.qr(rs.randn(n, n))
+    lam = np.concatenate([np.linspace(3.0, 1.0, r), np.linspace(0.45, 1e-6, n - r)])     # gap ratio 0.45 behind lambda_r
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    w, V = np.linalg.eigh(A)
+    Vr = V[:, np.argsort(-w)[:r]]
+    P_ref = Vr @ Vr.T
+    mid = np.sqrt(1.0 * 0.45) / np.trace(A)
+    for factor, max_trials in ((1.0, 1), (3.0, 8), (1 / 3.0, 8)):
+        P, found, steps, trials = _sign_projector(ctx, A, r, mid * factor)
+        assert found and trials <= max_trials, (factor, found, steps, trials)
+        assert np.linalg.norm(P - P_ref) <= 1e-11 * np.sqrt(r), (factor, np.linalg.norm(P - P_ref))
+        assert abs(np.trace(P) - r) < 1e-9 and np.array_equal(P, P.T)
+
+
+def test_sign_function_projector_gives_up_without_a_gap(ctx):
+    """lambda_r = lambda_{r+1}: no threshold has exactly r eigenvalues above it -- reported as not found (the caller then
+    decomposes the matrix itself), never a wrong projector."""
+    n, r = 64, 10
+    rs = np.random.RandomState(5)
+    Q, _ = np.linalg.qr(rs.randn(n, n))
+    lam = np.concatenate([np.linspace(3.0, 1.0, r - 1), [0.5, 0.5], np.linspace(0.2, 0.01, n - r - 1)])
+    A = (Q * lam) @ Q.T
+    P, found, steps, trials = _sign_projector(ctx, 0.5 * (A + A.T), r, 0.5 / np.trace(A))
+    assert not found
+
+
+def test_itq_sign_route_agrees_with_the_jacobi_route(ctx, monkeypatch):
+    """cp_itq_iterate takes the rank-r projector of alternations 3..50 from the matrix sign function (sign_ns.hip);
+    CP_ITQ_SIGN=0 keeps the Jacobi eigen-decomposition throughout.  Same T, and the sign route really ran."""
+    import cp_oracle
+    X, W2, Y, B2 = cp_oracle.synth_layer(18, 1500, 24, 40, 3)
+    feature = Y + 0.05 * np.random.RandomState(18).randn(*Y.shape)
+    import ctypes
+    lib = ctx.lib
+    lib.cp_debug_itq_sign.restype = ctypes.c_int
+    lib.cp_debug_itq_sign.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    T1, ym1, um1 = ctx.itq_iterate(feature, Y, 20)
+    assert lib.cp_debug_itq_sign(ctx.h, 1) >= 44, lib.cp_debug_itq_sign(ctx.h, 1)     # 48 of the 50 alternations at best
+    monkeypatch.setenv("CP_ITQ_SIGN", "0")
+    T0, ym0, um0 = ctx.itq_iterate(feature, Y, 20)
+    assert lib.cp_debug_itq_sign(ctx.h, 1) == 0
+    assert relfro(T1, T0) <= 1e-9 and relfro(um1, um0) <= 1e-9 and np.array_equal(ym1, ym0)
+
+
 # ---------------------------------------------------------------------------------------------
 # cp_prune_layers: several layers of one width on ONE stream, their alpha searches in one launch
 # ---------------------------------------------------------------------------------------------

@@ -14,5 +14,6 @@ for rep in range(2):
     t0 = time.perf_counter(); T, ym, um = ctx.itq_iterate(feature, Y, 128); dt = time.perf_counter() - t0
     print("cp_itq_iterate %.1f ms" % (dt * 1e3), dict(ctx.last_stage_times()), "jacobi sweeps over the 50 alternations:",
           ctx.lib.cp_debug_itq_sweeps(ctypes.c_void_p(ctx.h)))
-t0 = time.perf_counter(); s, Lt, R = ctx.svd_rows(T, 128); print("final svd_rows(T) %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+for lr in (False, True):
+    t0 = time.perf_counter(); s, Lt, R = ctx.svd_rows(T, 128, lowrank=lr); print("final svd_rows(T, lowrank=%s) %.1f ms, %d sweeps" % (lr, (time.perf_counter() - t0) * 1e3, ctx.last_svd_sweeps))
 t0 = time.perf_counter(); D.ITQ_decompose(feature, Y, W2.astype(np.float64), 128, bias=B2.astype(np.float64)); print("ITQ_decompose total %.1f ms" % ((time.perf_counter() - t0) * 1e3))
