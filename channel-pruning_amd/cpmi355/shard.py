@@ -132,10 +132,9 @@ class ResidentLayerSet:
             per = max(1, min(int(per), capi_max_jobs()))
             for g0 in range(0, len(members), per):
                 group = members[g0:g0 + per]
-                # critical-path-first: the streams of the widest layers get the higher HIP priority (CP_JOB_PRIORITY=1);
-                # passed explicitly -- the environment is the caller's
-                critical = os.environ.get("CP_JOB_PRIORITY", "0") == "1" and c == max(by_width)
-                root = capi.Context(device, priority=-1 if critical else None)
+                # (the widest layers' streams at the higher HIP priority -- capi.Context(device, priority=-1) -- was
+                #  measured: vgg16 job 29.5 against 28.0 ms; not used)
+                root = capi.Context(device)
                 ctxs = [root] + [root.sibling() for _ in group[1:]]
                 probs, rngs = [], []
                 for cx, i in zip(ctxs, group):
@@ -150,15 +149,13 @@ class ResidentLayerSet:
         # of them get their full normal equations computed on the side stream meanwhile (pruner.precompute_flag); more
         # than the idle head can absorb only adds flops to a chip that is busy afterwards.
         if precompute_heaviest is None:
-            precompute_heaviest = int(os.environ.get("CP_JOB_PRECOMPUTE", "2"))
+            precompute_heaviest = 2      # vgg16 job: 29.7 / 28.0 / 27.9 / 28.0 / 28.9 / 30.0 ms with 0 .. 5
         single = [ch for ch in self.chunks if len(ch["members"]) == 1]
         single.sort(key=lambda ch: -layer_cost(*[self.specs[ch["members"][0]][k] for k in ("N", "c", "n", "k", "rank")]))
         self._latency_chunks = set(id(ch) for ch in single[:max(0, precompute_heaviest)]) if len(self.chunks) > 2 else \
             set(id(ch) for ch in single)
         # a set of one or two layers has the chip to itself: the full treatment (pruner.precompute_flag)
         self._latency_kind = "gram" if len(self.chunks) > 2 else True
-        if os.environ.get("CP_JOB_LATENCY_KIND") == "full":       # experiment: prefactored full Gram inside a job too
-            self._latency_kind = True
         self._stop = False
         self._threads = []
         for ch in self.chunks:
