@@ -84,6 +84,8 @@ struct cp_ctx {
     const char *gemm_mark = nullptr;  // if set, cp_gemm_tn_f64 marks this stage right after its main kernel
     int gemm_tag = 0;                 // selects a distinctly named instantiation of the GEMM kernel
     int cu_count = 256;
+    int *gemm_cnt = nullptr;          // arrival counters of the split tiles of cp_gemm_tn_f64 (a ring of regions, zero between launches)
+    int gemm_cnt_next = 0;
     bool defer_refit_wait = false;    // cp_prune_layers: enqueue the refit, the caller waits once for the whole batch
     bool refit_pending = false;       // set by a deferred refit: factor + solve still to be launched by the batch
     cp_refit_deferred deferred = {};

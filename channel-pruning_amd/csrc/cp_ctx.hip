@@ -134,6 +134,7 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->layer_ws) hipFree(ctx->layer_ws);
     if (ctx->cd_box) hipFree(ctx->cd_box);
+    if (ctx->gemm_cnt) hipFree(ctx->gemm_cnt);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->stage) hipHostFree(ctx->stage);
     if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
@@ -322,7 +323,12 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // 8 independent accumulators per wave, 4 waves per SIMD: measures the sustained issue
 // rate of v_mfma_f64_16x16x4_f64 (2*16*16*4 = 2048 FLOP per wave-instruction).
-__global__ void __launch_bounds__(256) k_probe_mfma_f64(double *out, int iters) {
+// The register budget is cut for >= 2 waves per SIMD ON PURPOSE: with a whole SIMD's register file to itself the compiler
+// keeps the accumulators in AccVGPRs, and the AccVGPR form of this instruction issues once per ~107 cycles and SIMD
+// (46.7 TFLOP/s) where the VGPR form -- what every kernel of the library uses -- issues once per 64-65 (77 TFLOP/s, the
+// nominal figure): tools/ubench/gemm_probe.hip part (0), profiles/r04_gemm_probe.md.  Rounds 1-4 quoted the AccVGPR
+// number as "what the matrix pipe delivers".
+__global__ void __launch_bounds__(256, 2) k_probe_mfma_f64(double *out, int iters) {
     v4f64 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = v4f64{0., 0., 0., 0.};
@@ -360,7 +366,7 @@ extern "C" int cp_probe_mfma_f64(cp_ctx *ctx, double *tflops) {
 }
 
 // the same loop with clock stamps: st[wave] = {shader cycles (s_memtime), 100 MHz ticks (s_memrealtime)} around the loop
-__global__ void __launch_bounds__(256) k_probe_mfma_f64_clock(double *out, unsigned long long *st, int iters) {
+__global__ void __launch_bounds__(256, 2) k_probe_mfma_f64_clock(double *out, unsigned long long *st, int iters) {
     v4f64 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = v4f64{0., 0., 0., 0.};
@@ -386,8 +392,8 @@ __global__ void __launch_bounds__(256) k_probe_mfma_f64_clock(double *out, unsig
 
 extern "C" int cp_probe_mfma_f64_clock(cp_ctx *ctx, double *tflops, double *ghz, double *cycles_per_mfma) {
     if (!ctx || !tflops || !ghz || !cycles_per_mfma) return CP_ERR_ARG;
-    // 2 workgroups of 4 waves per CU = 2 waves per SIMD, 8 independent accumulators each: the configuration at which the
-    // pipe saturates (tools/ubench/mfma_clock.hip: 48-49 TFLOP/s at 2, 4 and 8 waves per SIMD)
+    // 2 workgroups of 4 waves per CU = 2 waves per SIMD, 8 independent accumulators each, accumulators in VGPRs (see
+    // k_probe_mfma_f64): 72-77 TFLOP/s at 2 / 4 waves per SIMD, 64-69 cycles per instruction and SIMD (profiles/r04_gemm_probe.md)
     const int iters = 20000, blocks = ctx->cu_count * 2, waves = blocks * 4;
     CP_TRY(cp_arena_reserve(ctx, 4096 + size_t(waves) * 16));
     double *out = cp_arena_take_t<double>(ctx, 8);

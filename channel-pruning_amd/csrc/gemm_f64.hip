@@ -11,8 +11,20 @@
 // registers while the current one is multiplied.  LDS rows are padded by 16 doubles so the
 // two k-rows a 32-lane half reads land on disjoint bank halves (ds_read_b64, 64 banks).
 // Small outputs are split along K (multiples of 8 splits; split z of every tile is placed
-// on XCD z % 8 so the tiles that share a k-chunk share an L2) and reduced by a second
-// kernel in a fixed order -> bitwise run-to-run reproducible, no atomics.
+// on XCD z % 8 so the tiles that share a k-chunk share an L2); the partial sums are added in
+// a fixed order -> bitwise run-to-run reproducible, no floating-point atomics.
+//
+// Tile counts and the chip (round 4, tools/ubench/gemm_probe.hip, profiles/r04_gemm_probe.md).  The main loop runs
+// at 68-70 TFLOP/s (0.88-0.9 of the 77 the VGPR form of the instruction issues) when the tile count is a multiple of the
+// 512 workgroup slots of the chip (2 per CU), and at 52 when it is 595 -- the refit Gram of a 472-channel layer: the 83
+// tiles of the second round run alone on 83 CUs.  So the tiles beyond the last full round are split along K into
+// s chunks of their own ("tail split": s = 2 .. 8, chosen so that the chunks fill one more round as evenly as possible),
+// and the workgroup that finishes a tile's LAST chunk adds the s partial blocks in chunk order (arrival counter;
+// agent-scope release / acquire around it) -- no second launch.  The same in-kernel reduction serves the uniform
+// split when it has at most 8 chunks, and the lower-triangle products write the mirrored tile from the epilogue: the
+// separate reduce and mirror launches of rounds 1-3 (each a dispatch a busy chip makes the chain wait for) are gone
+// from every product with <= 8 chunks.
+#include <algorithm>
 #include <cstdlib>
 
 #include "cp_common.h"
@@ -107,11 +119,24 @@ struct GemmSecond {
     int K;
 };
 
+// How the workgroups of a launch divide the tiles (the tile list is ordered as decode_tile / decode_tile_blocked say):
+//   units [0, n_full)                      tile `unit` computed whole, written straight to C
+//   units [n_full, n_full + n_split * s)   tile n_full + t, k-chunk z: partial block -> Pb[t * s + z]; the last arrival
+//                                          at cnt[t] adds the s blocks in chunk order and writes C
+//   planes (legacy, > 8 chunks): every unit writes plane z of P (M x N each), k_gemm_reduce adds them
+struct GemmSched {
+    int n_full, n_split, s, kchunk;   // kchunk: k-rows per chunk of a split tile (a multiple of BK)
+    double *Pb;                       // [n_split * s] blocks of TM x TM doubles
+    int *cnt;                         // [n_split] arrival counters, zero before and after the launch
+    int planes;                       // != 0: legacy plane mode with this many uniform splits
+};
+
 template <int TRI, int TAG, int WT, int NTH>
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
 k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
               const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
-              double *__restrict__ P, int splits, int kchunk, int n_tiles, int tiles_n, GemmSecond second) {
+              double *__restrict__ P, int n_tiles, int tiles_n, GemmSched sch, GemmSecond second) {
+    int kchunk = sch.kchunk;
     if (blockIdx.y == 1) {
         A = second.A;
         B = second.B;
@@ -120,8 +145,8 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         kchunk = second.K;
     }
     // NTH = 256: 2 x 2 waves of WT x WT each; NTH = 512: 4 x 2 waves of (WT/2) x WT each (same
-    // workgroup tile, half the accumulators per wave -> 4 waves per SIMD, which is what it takes to
-    // keep the f64 MFMA pipe busy: one wave alone issues one v_mfma_f64_16x16x4 per ~140 cycles)
+    // workgroup tile, half the accumulators per wave -> 4 waves per SIMD and two workgroups per CU: while one waits at its
+    // stage barrier the other one keeps the matrix pipe busy)
     constexpr int TM = 2 * WT;              // workgroup tile edge
     constexpr int TLD = TM + LPAD;          // padded LDS row
     constexpr int TPR = TM / 2;             // threads per tile row (one double2 each)
@@ -133,39 +158,51 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     // two LDS stages: stage kt+1 is written while stage kt is being read, one barrier per k-stage
     __shared__ __attribute__((aligned(16))) double As2[2][BK * TLD];
     __shared__ __attribute__((aligned(16))) double Bs2[2][BK * TLD];
+    __shared__ int s_last;
 
     const int tid = threadIdx.x;
-    // Persistent form: a launch may carry fewer workgroups than tiles (gridDim.x a multiple of 8, so that a workgroup's
-    // virtual ids L keep its XCD); every workgroup then walks the tile list with stride gridDim.x.  A launch whose
-    // workgroups are all resident leaves nothing queued in the dispatcher behind which other streams' kernels would wait.
-    const int total_blocks = n_tiles * splits;
-    for (int L = blockIdx.x; L < total_blocks; L += gridDim.x) {
-    int tile, z;
-    if (splits > 1) {  // XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs
+    const int L = blockIdx.x;
+    // ---- unit -> (tile, chunk z of nz) ----
+    int tile, z = 0, nz = 1, t_split = -1;
+    const bool blocked = !sch.planes && n_tiles >= 64;   // many tiles: the super-tile ordered list, an XCD per contiguous range
+    if (sch.planes) {   // XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs
         const int xcd = L & 7, slot = L >> 3;
         z = xcd + 8 * (slot / n_tiles);
         tile = slot % n_tiles;
-    } else if (n_tiles >= 64) {
-        // XCD-aware: workgroup L runs on XCD L % 8 (each XCD has its own L2).  Give every XCD a CONTIGUOUS range of the
-        // super-tile ordered list (decode_tile_blocked): the workgroups resident on an XCD at any time then cover about one
-        // 8 x 8 block of tiles and share its 16 operand panels in that L2 (PMC: the p = 4250 refit Gram fetched 2.8 GB for
-        // 0.31 GB of operands with the plain order, 2.4 GB with bands of tile rows per XCD).
-        const int xcd = L & 7, slot = L >> 3;
-        const int base = n_tiles >> 3, rem = n_tiles & 7;
-        tile = xcd * base + (xcd < rem ? xcd : rem) + slot;
-        z = 0;
+        nz = sch.planes;
+    } else if (L < sch.n_full) {
+        if (blocked) {
+            // workgroup L runs on XCD L % 8 (each XCD has its own L2).  Give every XCD a CONTIGUOUS range of the
+            // super-tile ordered list (decode_tile_blocked): the workgroups resident on an XCD at any time then cover about one
+            // 8 x 8 block of tiles and share its 16 operand panels in that L2 (PMC: the p = 4250 refit Gram fetched 2.8 GB for
+            // 0.31 GB of operands with the plain order, 2.4 GB with bands of tile rows per XCD).
+            const int xcd = L & 7, slot = L >> 3;
+            const int base = sch.n_full >> 3, rem = sch.n_full & 7;
+            tile = xcd * base + (xcd < rem ? xcd : rem) + slot;
+        } else {
+            tile = L;
+        }
     } else {
-        tile = L;
-        z = 0;
+        const int u = L - sch.n_full;
+        nz = sch.s;
+        if (sch.n_full == 0 && (sch.s & 7) == 0) {   // uniform split: chunk z of every tile on XCD z % 8
+            const int xcd = L & 7, slot = L >> 3;
+            z = xcd + 8 * (slot / sch.n_split);
+            t_split = slot % sch.n_split;
+        } else {                                     // tail split: the chunks of a tile next to each other
+            t_split = u / sch.s;
+            z = u - t_split * sch.s;
+        }
+        tile = sch.n_full + t_split;
     }
     int ti, tj;
-    if (splits == 1 && n_tiles >= 64)
+    if (blocked)
         decode_tile_blocked(TRI, tile, M / TM, tiles_n, ti, tj);
     else
         decode_tile(TRI, tile, tiles_n, ti, tj);
     const int m0 = ti * TM, n0 = tj * TM;
-    const int k0 = z * kchunk;
-    int k1 = k0 + kchunk;
+    const int k0 = nz > 1 ? z * kchunk : 0;
+    int k1 = nz > 1 ? k0 + kchunk : K;
     if (k1 > K) k1 = K;
     const int nk = k1 > k0 ? (k1 - k0) / BK : 0;
 
@@ -230,7 +267,7 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     }
 
     // epilogue.  D layout of v_mfma_f64_16x16x4_f64: lane l, reg r -> row (l>>4) + 4r, col l&15.
-    if (splits > 1) {
+    if (sch.planes) {
         double *dst = P + size_t(z) * M * N;
 #pragma unroll
         for (int i = 0; i < FRM; ++i)
@@ -241,21 +278,56 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
                     const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
                     dst[size_t(row) * N + col] = acc[i][j][r];
                 }
-    } else {
+        return;
+    }
+    if (nz > 1) {
+        // partial block of chunk z, then the arrival counter of the tile: whoever arrives last adds the nz blocks in chunk
+        // order (its own included: the sum does not depend on who that is) and goes on to the epilogue
+        double *blk = sch.Pb + (size_t(t_split) * nz + z) * (TM * TM);
+#pragma unroll
+        for (int i = 0; i < FRM; ++i)
+#pragma unroll
+            for (int j = 0; j < FRN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    blk[(wm + i * 16 + fk + 4 * r) * TM + wn + j * 16 + fi] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) {
+            const int prev = __hip_atomic_fetch_add(sch.cnt + t_split, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = prev == nz - 1;
+            if (prev == nz - 1) __hip_atomic_store(sch.cnt + t_split, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const double *b0 = sch.Pb + size_t(t_split) * nz * (TM * TM);
 #pragma unroll
         for (int i = 0; i < FRM; ++i)
 #pragma unroll
             for (int j = 0; j < FRN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
-                    double v = alpha * acc[i][j][r];
-                    double *c = C + size_t(row) * ldc + col;
-                    if (beta != 0.0) v += beta * *c;
-                    *c = v;
+                    const int off = (wm + i * 16 + fk + 4 * r) * TM + wn + j * 16 + fi;
+                    double sum = b0[off];
+                    for (int zz = 1; zz < nz; ++zz) sum += b0[size_t(zz) * (TM * TM) + off];
+                    acc[i][j][r] = sum;
                 }
     }
-    }   // persistent tile loop
+#pragma unroll
+    for (int i = 0; i < FRM; ++i)
+#pragma unroll
+        for (int j = 0; j < FRN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
+                double v = alpha * acc[i][j][r];
+                double *c = C + size_t(row) * ldc + col;
+                if (beta != 0.0) v += beta * *c;
+                *c = v;
+                // lower-triangle product: the mirrored tile from the same registers (4 consecutive doubles per lane group)
+                if (TRI == CP_TRI_LOWER_MIRROR && ti != tj) C[size_t(col) * ldc + row] = v;
+            }
 }
 
 // Fixed-order reduction of the split-K partials: C = alpha * sum_z P[z] + beta * C.  One
@@ -303,28 +375,25 @@ k_gemm_reduce(int M, int N, double alpha, const double *__restrict__ P, int spli
     }
 }
 
-// splits == 1 lower-triangle product: copy tile (ti,tj), tj < ti, to (tj,ti) transposed.
-__global__ void __launch_bounds__(NTHREADS) k_mirror_lower(double *__restrict__ C, int ldc, int tiles_n) {
-    __shared__ double t[32][33];
-    int ti, tj;
-    decode_tile(CP_TRI_LOWER_MIRROR, blockIdx.x, tiles_n, ti, tj);
-    if (ti == tj) return;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (int br = 0; br < BM; br += 32)
-        for (int bc = 0; bc < BN; bc += 32) {
-            for (int y = ty; y < 32; y += 8) t[y][tx] = C[size_t(ti * BM + br + y) * ldc + tj * BN + bc + tx];
-            __syncthreads();
-            for (int y = ty; y < 32; y += 8) C[size_t(tj * BN + bc + y) * ldc + ti * BM + br + tx] = t[tx][y];
-            __syncthreads();
-        }
-}
-
 struct GemmPlan {
-    int n_tiles, tiles_n, splits, kchunk;
-    bool small;  // 64x64 tiles
+    int n_tiles, tiles_n;
+    bool small;      // 64x64 tiles
+    int planes;      // legacy plane mode: uniform splits (> 8), reduced by k_gemm_reduce; 0 otherwise
+    int n_full, n_split, s, kchunk;   // see GemmSched
 };
 
-GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri, bool in_place = false) {
+// chunks per tile for the r tiles left over after the full rounds of `slots` workgroups: the smallest s whose chunk rounds
+// ceil(r s / slots) / s come within 10 % of the best of s = 1 .. smax; 1: leave the tiles whole
+int tail_chunks(int r, int slots, int smax) {
+    double best = 1.0;
+    for (int s = 2; s <= smax; ++s) best = std::min(best, double((r * s + slots - 1) / slots) / s);
+    if (best > 0.8) return 1;
+    for (int s = 2; s <= smax; ++s)
+        if (double((r * s + slots - 1) / slots) / s <= 1.1 * best) return s;
+    return 1;
+}
+
+GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri, bool in_place = false, bool paired = false) {
     GemmPlan p;
     int tm = M / BM, tn = N / BN;
     const int big_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
@@ -338,33 +407,53 @@ GemmPlan make_plan(const cp_ctx *ctx, int M, int N, int K, int tri, bool in_plac
     }
     p.tiles_n = tn;
     p.n_tiles = tri == CP_TRI_NONE ? tm * tn : tm * (tm + 1) / 2;
+    p.planes = 0;
+    p.n_full = p.n_tiles;
+    p.n_split = 0;
+    p.s = 1;
+    p.kchunk = K;
     const int nk = K / BK;
     // Workgroups to aim for when splitting K.  Every split writes a full partial plane (PMC: the
     // refit Gram wrote ~3x its input bytes with 16 planes), so stay near one workgroup per CU.
     const int target = ctx->cu_count * 6 / 4;
-    int splits = 1;
-    if (!p.small && p.n_tiles < target / 2 && nk >= 16) {
-        splits = (target + p.n_tiles - 1) / p.n_tiles;
+    const int slots = 2 * ctx->cu_count;   // resident 512-thread workgroups (72 KB of LDS, <= 128 VGPRs each)
+    if (p.small || in_place || paired) return p;
+    if (p.n_tiles < target / 2 && nk >= 16) {
+        int splits = (target + p.n_tiles - 1) / p.n_tiles;
         splits = (splits + 7) / 8 * 8;
         const int max_splits = (nk / 4) / 8 * 8;  // keep >= 4 k-stages per split
         if (splits > max_splits) splits = max_splits;
-        if (splits < 8) splits = 1;
+        if (splits >= 8) {
+            p.kchunk = (nk + splits - 1) / splits * BK;
+            if (splits == 8) {   // the last arrival of a tile adds its eight blocks itself
+                p.n_full = 0;
+                p.n_split = p.n_tiles;
+                p.s = 8;
+            } else {
+                p.planes = splits;
+            }
+        }
+    } else if (p.n_tiles > slots && nk >= 32) {
+        const int r = p.n_tiles % slots;
+        const int s = r ? tail_chunks(r, slots, std::min(8, nk / 16)) : 1;   // >= 16 k-stages per chunk
+        if (s > 1) {
+            p.n_split = r;
+            p.n_full = p.n_tiles - r;
+            p.s = s;
+            p.kchunk = (nk + s - 1) / s * BK;
+        }
     }
-    if (splits > 1) {
-        const int per = (nk + splits - 1) / splits;
-        p.kchunk = per * BK;
-    } else {
-        p.kchunk = K;
-    }
-    p.splits = splits;
     return p;
 }
+
+constexpr int CNT_RING = 16, CNT_PER_LAUNCH = 1024;   // arrival counters: a ring of regions, one per launch
 
 }  // namespace
 
 size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri) {
     GemmPlan p = make_plan(ctx, M, N, K, tri);
-    return p.splits > 1 ? size_t(p.splits) * M * N * sizeof(double) + 256 : 0;
+    if (p.planes) return size_t(p.planes) * M * N * sizeof(double) + 256;
+    return p.n_split ? size_t(p.n_split) * p.s * BM * BN * sizeof(double) + 256 : 0;
 }
 
 static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
@@ -380,7 +469,8 @@ int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double 
 int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const double *A1, const double *B1, double *C1,
                         int K2, const double *A2, const double *B2, double *C2, int lda, int ldb, int ldc, int tri) {
     const GemmPlan p1 = make_plan(ctx, M, N, K1, tri), p2 = make_plan(ctx, M, N, K2, tri);
-    if (p1.splits == 1 && p2.splits == 1 && p1.small == p2.small && K2 % BK == 0 && C1 != A1 && C1 != B1) {
+    if (!p1.planes && !p1.n_split && !p2.planes && !p2.n_split && p1.small == p2.small && K2 % BK == 0 && C1 != A1 &&
+        C1 != B1) {
         const GemmSecond sec{A2, B2, C2, K2};
         return gemm_launch(ctx, M, N, K1, alpha, A1, lda, B1, ldb, 0.0, C1, ldc, tri, &sec);
     }
@@ -397,27 +487,36 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
     const bool in_place = (C == A || C == B);
     if (in_place && (M > BM || tri != CP_TRI_NONE))
         return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn: in-place product needs a single row tile (M <= %d)", BM);
-    GemmPlan p = make_plan(ctx, M, N, K, tri, in_place);
+    GemmPlan p = make_plan(ctx, M, N, K, tri, in_place, second != nullptr);
     double *P = nullptr;
     const size_t arena_mark = ctx->arena_used;  // P is transient: stream order makes reuse safe
-    if (p.splits > 1) {
-        P = cp_arena_take_t<double>(ctx, size_t(p.splits) * M * N);
+    GemmSched sch{p.n_full, p.n_split, p.s, p.kchunk, nullptr, nullptr, p.planes};
+    if (p.planes) {
+        P = cp_arena_take_t<double>(ctx, size_t(p.planes) * M * N);
         if (!P) return cp_set_error(ctx, CP_ERR_NOMEM, "gemm_tn: arena exhausted (split-K partials)");
+    } else if (p.n_split) {
+        if (p.n_split > CNT_PER_LAUNCH) return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn: %d split tiles", p.n_split);
+        sch.Pb = cp_arena_take_t<double>(ctx, size_t(p.n_split) * p.s * BM * BN);
+        if (!sch.Pb) return cp_set_error(ctx, CP_ERR_NOMEM, "gemm_tn: arena exhausted (split-K partial blocks)");
+        if (!ctx->gemm_cnt) {   // zeroed once: every launch leaves its counters at zero again
+            CP_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->gemm_cnt), size_t(CNT_RING) * CNT_PER_LAUNCH * sizeof(int)));
+            CP_HIP(ctx, hipMemsetAsync(ctx->gemm_cnt, 0, size_t(CNT_RING) * CNT_PER_LAUNCH * sizeof(int), ctx->stream));
+            CP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // once per context; whatever stream it is bound to later
+        }
+        sch.cnt = ctx->gemm_cnt + size_t(ctx->gemm_cnt_next) * CNT_PER_LAUNCH;
+        ctx->gemm_cnt_next = (ctx->gemm_cnt_next + 1) % CNT_RING;
     }
-    // (The kernel walks the tile list with stride gridDim.x, so a launch may carry fewer workgroups than tiles.  Capping
-    //  the grid at 64 .. 512 resident workgroups -- nothing left queued in the dispatcher behind which other streams'
-    //  kernels would wait -- was measured in round 4: vgg16 job 46.4 / 35.4 / 31.9 / 31.0 ms at 64 / 128 / 256 / 512
-    //  against 30.7 with one workgroup per tile; not used.)
-    const dim3 grid(p.n_tiles * p.splits, second ? 2 : 1);
+    const int units = p.planes ? p.n_tiles * p.planes : p.n_full + p.n_split * p.s;
+    const dim3 grid(units, second ? 2 : 1);
     const GemmSecond sec = second ? *second : GemmSecond{nullptr, nullptr, nullptr, 0};
 #define CP_GEMM_LAUNCH(T, G)                                                                                  \
     do {                                                                                                      \
         if (p.small)                                                                                          \
             k_gemm_tn_f64<T, G, 32, 256><<<grid, 256, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
-                                                                          P, p.splits, p.kchunk, p.n_tiles, p.tiles_n, sec); \
+                                                                          P, p.n_tiles, p.tiles_n, sch, sec);   \
         else                                                                                                  \
             k_gemm_tn_f64<T, G, 64, 512><<<grid, 512, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
-                                                                          P, p.splits, p.kchunk, p.n_tiles, p.tiles_n, sec); \
+                                                                          P, p.n_tiles, p.tiles_n, sch, sec);   \
     } while (0)
     const int tag = ctx->gemm_tag;
     ctx->gemm_tag = CP_GEMM_GENERIC;
@@ -442,19 +541,16 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
         cp_stage_mark(ctx, ctx->gemm_mark);
         ctx->gemm_mark = nullptr;
     }
-    if (p.splits > 1) {
+    if (p.planes) {
         if (tri == CP_TRI_NONE)
-            k_gemm_reduce<CP_TRI_NONE><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,
+            k_gemm_reduce<CP_TRI_NONE><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.planes, beta, C,
                                                                                   ldc, p.tiles_n);
         else if (tri == CP_TRI_LOWER_MIRROR)
-            k_gemm_reduce<CP_TRI_LOWER_MIRROR><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits,
+            k_gemm_reduce<CP_TRI_LOWER_MIRROR><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.planes,
                                                                                           beta, C, ldc, p.tiles_n);
         else
-            k_gemm_reduce<CP_TRI_UPPER><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.splits, beta, C,
+            k_gemm_reduce<CP_TRI_UPPER><<<p.n_tiles * RSTRIPS, NTHREADS, 0, ctx->stream>>>(M, N, alpha, P, p.planes, beta, C,
                                                                                    ldc, p.tiles_n);
-        CP_LAUNCH_CHECK(ctx);
-    } else if (tri == CP_TRI_LOWER_MIRROR && p.n_tiles > 1) {
-        k_mirror_lower<<<p.n_tiles, NTHREADS, 0, ctx->stream>>>(C, ldc, p.tiles_n);
         CP_LAUNCH_CHECK(ctx);
     }
     ctx->arena_used = arena_mark;

@@ -85,8 +85,10 @@ __global__ void __launch_bounds__(NT) k_ns_start(const double *__restrict__ A, i
 
 // C = alpha A^T B + beta D (D may be null with beta = 0); RES: also part[workgroup] = sum over the tile of
 // (delta_ij - A^T B)^2 -- the squared Frobenius distance of X^2 from the identity, summed on the host in workgroup order.
+// (register budget of two waves per SIMD: the compiler then keeps the accumulator in VGPRs -- the AccVGPR form of
+//  v_mfma_f64_16x16x4_f64 it picks for a one-wave-per-SIMD kernel issues 1.65 x slower, profiles/r04_gemm_probe.md)
 template <bool RES>
-__global__ void __launch_bounds__(NT) k_ns_gemm(const double *__restrict__ A, const double *__restrict__ B, int np_,
+__global__ void __launch_bounds__(NT, 2) k_ns_gemm(const double *__restrict__ A, const double *__restrict__ B, int np_,
                                                 double alpha, double beta, const double *__restrict__ D,
                                                 double *__restrict__ C, double *__restrict__ part) {
     const int tiles = np_ / 32, tm = blockIdx.x / tiles, tn = blockIdx.x % tiles;

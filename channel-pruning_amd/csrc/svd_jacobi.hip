@@ -268,7 +268,9 @@ __device__ __forceinline__ void jacobi_block_pair(double *__restrict__ Wk, int n
     }
 }
 
-__global__ void __launch_bounds__(JT) k_jacobi_block_round(double *__restrict__ Wk, int n, double *__restrict__ R, int me,
+// (JT, 2): a register budget of two waves per SIMD keeps the MFMA accumulators in VGPRs (the AccVGPR form of the f64 MFMA
+// issues 1.65 x slower: profiles/r04_gemm_probe.md)
+__global__ void __launch_bounds__(JT, 2) k_jacobi_block_round(double *__restrict__ Wk, int n, double *__restrict__ R, int me,
                                                            int round, double tol, int *__restrict__ rotated,
                                                            const double *__restrict__ floor2, int inner_sweeps) {
     jacobi_block_pair(Wk, n, R, me, round, blockIdx.x, tol, rotated, floor2, inner_sweeps);
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(JT) k_jacobi_block_round(double *__restrict__ 
 // ctl (ints, zeroed by the host): [0] barrier arrivals (monotone), [1] sweeps run before the first one without a rotation
 // (max_sweeps: none), [2] != 0: a barrier timed out (never observed; the host then reports an error instead of hanging),
 // [16 + s] rotations in sweep s.
-__global__ void __launch_bounds__(JT) k_jacobi_block_sweeps(double *__restrict__ Wk, int n, double *__restrict__ R, int me,
+__global__ void __launch_bounds__(JT, 2) k_jacobi_block_sweeps(double *__restrict__ Wk, int n, double *__restrict__ R, int me,
                                                             double tol, int *__restrict__ ctl,
                                                             const double *__restrict__ floor2, int inner_sweeps,
                                                             int max_sweeps) {

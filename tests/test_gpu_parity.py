@@ -313,6 +313,29 @@ def test_refit_ridge(ctx):
     assert relfro(ctx.to_host(bd, (n,), np.float64), b_ref) <= 1e-10
 
 
+@pytest.mark.parametrize("m,n,k,what", [
+    (17 * 128, 35 * 128, 1024, "595 tiles: 83 tail tiles split in 4 chunks, last arrival adds them"),
+    (36 * 128, 18 * 128 + 40, 768, "684 tiles, ragged n: 172 tail tiles split in 2 chunks"),
+    (1024, 1000, 2048, "64 tiles: uniform split in 8 chunks, in-kernel reduction"),
+    (500, 512, 4096, "16 tiles: more than 8 chunks, plane partials + reduce kernel"),
+    (8 * 128, 32 * 128, 512, "256 tiles: whole tiles only"),
+])
+def test_gemm_tn_tail_split_and_in_kernel_reduction(ctx, m, n, k, what):
+    """The f64 GEMM of the Gram builds (csrc/gemm_f64.hip) through cp_matmul_tn: every way a launch divides its tiles
+    gives A^T B to rounding level, and the same bits on every run whatever the arrival order of the chunks was
+    (the partial blocks are added in chunk order)."""
+    rng = np.random.RandomState(m + n + k)
+    A = rng.standard_normal((k, m))
+    B = rng.standard_normal((k, n))
+    ref = A.T @ B
+    first = ctx.matmul_tn(A, B)
+    scale = np.sqrt(k)
+    assert np.max(np.abs(first - ref)) < 1e-12 * scale * 8, what
+    for _ in range(6):
+        again = ctx.matmul_tn(A, B)
+        assert np.array_equal(first, again), what
+
+
 def test_patch_gather_and_assemble_y(ctx):
     """a1/a2 kernels are bit-exact copies: compare with the C restatement of net.py:629-657,1707."""
     import cp_oracle
