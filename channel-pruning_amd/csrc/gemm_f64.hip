@@ -282,39 +282,48 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     }
     if (nz > 1) {
         // partial block of chunk z, then the arrival counter of the tile: whoever arrives last adds the nz blocks in chunk
-        // order (its own included: the sum does not depend on who that is) and goes on to the epilogue
-        double *blk = sch.Pb + (size_t(t_split) * nz + z) * (TM * TM);
+        // order (its own included: the sum does not depend on who that is) and goes on to the epilogue.
+        // The blocks cross XCDs, i.e. L2s.  They are written and read with agent-scope relaxed atomics -- sc1 stores that
+        // write through the L2, sc1 loads that do not hit it -- instead of plain accesses between an agent-scope release
+        // and acquire: those fences are a write-back (per releasing wave) and an invalidation (per acquiring wave) of the
+        // WHOLE L2 of the XCD, which cost this kernel 0.2-0.4 ms per launch and slowed every kernel running next to it
+        // (vgg16 job 26.5 -> 30.5 ms, gpurun_out/r04_call23).  The workgroup barrier waits for the stores (vmcnt) before
+        // thread 0 counts the workgroup in.
+        unsigned long long *blk = reinterpret_cast<unsigned long long *>(sch.Pb) + (size_t(t_split) * nz + z) * (TM * TM);
 #pragma unroll
         for (int i = 0; i < FRM; ++i)
 #pragma unroll
             for (int j = 0; j < FRN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    blk[(wm + i * 16 + fk + 4 * r) * TM + wn + j * 16 + fi] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_store(blk + (wm + i * 16 + fk + 4 * r) * TM + wn + j * 16 + fi,
+                                       (unsigned long long)__double_as_longlong(acc[i][j][r]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (tid == 0) {
-            const int prev = __hip_atomic_fetch_add(sch.cnt + t_split, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const int prev = __hip_atomic_fetch_add(sch.cnt + t_split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = prev == nz - 1;
             if (prev == nz - 1) __hip_atomic_store(sch.cnt + t_split, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (!s_last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // chunk by chunk, eight loads (two MFMA tiles) in flight together (element by element the nz blocks would be
         // nz dependent memory latencies per element: measured 0.4 ms for eight blocks)
-        const double *b0 = sch.Pb + size_t(t_split) * nz * (TM * TM);
+        const unsigned long long *b0 = reinterpret_cast<const unsigned long long *>(sch.Pb) + size_t(t_split) * nz * (TM * TM);
 #pragma unroll
         for (int i = 0; i < FRM; ++i)
 #pragma unroll
             for (int jh = 0; jh < FRN; jh += 2) {
                 for (int zz = 0; zz < nz; ++zz) {
-                    const double *bz = b0 + size_t(zz) * (TM * TM);
+                    const unsigned long long *bz = b0 + size_t(zz) * (TM * TM);
                     double v[2][4];
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[j][r] = bz[(wm + i * 16 + fk + 4 * r) * TM + wn + (jh + j) * 16 + fi];
+                        for (int r = 0; r < 4; ++r)
+                            v[j][r] = __longlong_as_double((long long)__hip_atomic_load(
+                                bz + (wm + i * 16 + fk + 4 * r) * TM + wn + (jh + j) * 16 + fi, __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll

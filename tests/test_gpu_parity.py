@@ -327,11 +327,15 @@ def test_gemm_tn_tail_split_and_in_kernel_reduction(ctx, m, n, k, what):
     rng = np.random.RandomState(m + n + k)
     A = rng.standard_normal((k, m))
     B = rng.standard_normal((k, n))
-    ref = A.T @ B
+    A2 = rng.standard_normal((k, m))       # a second product in between: the partial blocks of a call reuse the addresses of
+    B2 = rng.standard_normal((k, n))       # the previous one, so a stale cached block would show
+    ref, ref2 = A.T @ B, A2.T @ B2
     first = ctx.matmul_tn(A, B)
-    scale = np.sqrt(k)
-    assert np.max(np.abs(first - ref)) < 1e-12 * scale * 8, what
-    for _ in range(6):
+    bound = 1e-13 * k
+    assert np.max(np.abs(first - ref)) < bound, what
+    for _ in range(4):
+        other = ctx.matmul_tn(A2, B2)
+        assert np.max(np.abs(other - ref2)) < bound, what
         again = ctx.matmul_tn(A, B)
         assert np.array_equal(first, again), what
 
