@@ -189,9 +189,17 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
             const int xcd = L & 7, slot = L >> 3;
             z = xcd + 8 * (slot / sch.n_split);
             t_split = slot % sch.n_split;
-        } else {                                     // tail split: the chunks of a tile next to each other
-            t_split = u / sch.s;
-            z = u - t_split * sch.s;
+        } else {
+            // tail split: an XCD takes a contiguous range of the tail tiles (neighbours in the super-tile order) and runs
+            // them chunk by chunk, so that the workgroups resident on it at any time share operand panels AND their k-range
+            // in its L2 as the whole tiles did.  (Chunks of a tile next to each other in the grid -- each XCD a mix of tiles
+            // and k-ranges -- made the tail round HBM-bound: the 666-tile Gram 2.39 ms against 2.17 without a tail split.)
+            const int xcd = u & 7, slot = u >> 3;   // n_full is a multiple of the slot count: u & 7 is the XCD of the workgroup
+            const int base = sch.n_split >> 3, rem = sch.n_split & 7;
+            const int cnt = base + (xcd < rem ? 1 : 0);
+            if (slot >= cnt * sch.s) return;        // the grid is padded to the XCD with the most tiles
+            z = slot / cnt;
+            t_split = xcd * base + (xcd < rem ? xcd : rem) + (slot - z * cnt);
         }
         tile = sch.n_full + t_split;
     }
@@ -307,29 +315,26 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         }
         __syncthreads();
         if (!s_last) return;
-        // chunk by chunk, eight loads (two MFMA tiles) in flight together (element by element the nz blocks would be
+        // chunk by chunk, the 16 loads of a row of MFMA tiles in flight together (element by element the nz blocks would be
         // nz dependent memory latencies per element: measured 0.4 ms for eight blocks)
         const unsigned long long *b0 = reinterpret_cast<const unsigned long long *>(sch.Pb) + size_t(t_split) * nz * (TM * TM);
 #pragma unroll
-        for (int i = 0; i < FRM; ++i)
+        for (int i = 0; i < FRM; ++i) {
+            for (int zz = 0; zz < nz; ++zz) {
+                const unsigned long long *bz = b0 + size_t(zz) * (TM * TM) + (wm + i * 16 + fk) * TM + wn + fi;
+                double v[FRN][4];
 #pragma unroll
-            for (int jh = 0; jh < FRN; jh += 2) {
-                for (int zz = 0; zz < nz; ++zz) {
-                    const unsigned long long *bz = b0 + size_t(zz) * (TM * TM);
-                    double v[2][4];
+                for (int j = 0; j < FRN; ++j)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int r = 0; r < 4; ++r)
+                        v[j][r] = __longlong_as_double((long long)__hip_atomic_load(bz + 4 * r * TM + j * 16, __ATOMIC_RELAXED,
+                                                                                     __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            v[j][r] = __longlong_as_double((long long)__hip_atomic_load(
-                                bz + (wm + i * 16 + fk + 4 * r) * TM + wn + (jh + j) * 16 + fi, __ATOMIC_RELAXED,
-                                __HIP_MEMORY_SCOPE_AGENT));
+                for (int j = 0; j < FRN; ++j)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][jh + j][r] = zz ? acc[i][jh + j][r] + v[j][r] : v[j][r];
-                }
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = zz ? acc[i][j][r] + v[j][r] : v[j][r];
             }
+        }
     }
 #pragma unroll
     for (int i = 0; i < FRM; ++i)
@@ -523,7 +528,8 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
         sch.cnt = ctx->gemm_cnt + size_t(ctx->gemm_cnt_next) * CNT_PER_LAUNCH;
         ctx->gemm_cnt_next = (ctx->gemm_cnt_next + 1) % CNT_RING;
     }
-    const int units = p.planes ? p.n_tiles * p.planes : p.n_full + p.n_split * p.s;
+    int units = p.planes ? p.n_tiles * p.planes : p.n_full + p.n_split * p.s;
+    if (!p.planes && p.n_full > 0 && p.n_split > 0) units = p.n_full + 8 * ((p.n_split + 7) / 8) * p.s;   // tail: per-XCD ranges, padded
     const dim3 grid(units, second ? 2 : 1);
     const GemmSecond sec = second ? *second : GemmSecond{nullptr, nullptr, nullptr, 0};
 #define CP_GEMM_LAUNCH(T, G)                                                                                  \
