@@ -583,6 +583,46 @@ def bench_job(args, env, job):
                        "note": "every GPU prunes its own instance of the whole job; the only collective is ONE uint8 all_gather of "
                                "the channel masks per job"}
 
+    # ---- N = 1: TWO instances of the job in flight (outside the timed region; `value` stays one job at a time).  A job alone
+    # ---- leaves the chip idle under its widest layers' alpha searches (8 ms of one workgroup each) and is bound by the matrix
+    # ---- pipe afterwards; a second, independent instance (another network, or another checkpoint of this one) fills the head
+    pipelined = None
+    if env.world == 1 and not args.profile_mode and not args.no_pipelined:
+        import threading
+        rset2 = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in own], operands, per_stream=per_stream,
+                                       flags=CD_FLAGS, borrow_results=True)
+        roots2 = [ch["ctxs"][0] for ch in rset2.chunks]
+        for cx in ctxs:
+            cx.enable_stage_timing(0)
+        rset2()
+        rset()
+        pj = max(4, int(np.ceil(0.6 / max(job_ms * 1e-3, 1e-3))))
+        outs = [None, None]
+
+        def loop(slot, rs):
+            for _ in range(pj):
+                outs[slot] = rs()
+
+        for cx in roots + roots2:
+            cx.sync()
+        th = [threading.Thread(target=loop, args=(0, rset)), threading.Thread(target=loop, args=(1, rset2))]
+        t_p = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for cx in roots + roots2:
+            cx.sync()
+        el_p = time.perf_counter() - t_p
+        same_masks = all(np.array_equal(a[0], b[0]) and np.array_equal(a[0], r[0])
+                         for a, b, r in zip(outs[0], outs[1], results))
+        pipelined = {"jobs_in_flight": 2, "jobs_timed": 2 * pj, "value": round(len(specs) * 2 * pj / el_p, 3), "unit": "layers/s",
+                     "ms_per_job": round(el_p / (2 * pj) * 1e3, 3), "masks_identical_to_the_timed_jobs": bool(same_masks),
+                     "note": "two independent instances of the whole job (own streams, contexts and host threads, operands of "
+                             "their own in HBM), each running its jobs back to back; every job does all of its work.  Not `value`: "
+                             "that stays ONE job at a time (job_ms = its latency)"}
+        rset2.close()
+
     # ---- verification on rank 0 (outside the timed region) ----
     out = None
     if env.rank == 0:
@@ -664,6 +704,8 @@ def bench_job(args, env, job):
         }
         if replica is not None:
             out["replica_throughput"] = replica
+        if pipelined is not None:
+            out["two_jobs_in_flight"] = pipelined
         if not weak:
             # what sharding ONE job's layers can give: a job cannot be shorter than its longest layer alone (every layer's alpha
             # search is one serial chain, cd_team.hip), whatever the number of GPUs
@@ -1215,6 +1257,7 @@ def main():
                     help="vgg16 on one GPU, the reference's own order: layer after layer, every search starting from the alpha "
                          "the previous layer ended with (cfgs.alpha carry, /root/reference/lib/decompose.py:491, 626-627)")
     ap.add_argument("--no-block", action="store_true", help="vgg16: skip the conv3_x single-instance figures")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-jobs-in-flight leg (N = 1)")
     ap.add_argument("--no-gather", action="store_true", help="skip the sampled-point im2col (extract_XY) measurement")
     ap.add_argument("--no-pcie-f64", action="store_true", help="skip the float64-X variant of the PCIe-inclusive pass")
     ap.add_argument("--profile-mode", action="store_true",
