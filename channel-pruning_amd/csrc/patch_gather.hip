@@ -43,6 +43,62 @@ __global__ void __launch_bounds__(256) k_patch_gather(const float *__restrict__ 
     }
 }
 
+// k = 3 (every 3 x 3 consumer of the VGG / ResNet jobs): a thread moves whole k-wide RUNS -- one 12-byte load and one
+// 12-byte store per (channel, patch row) -- instead of single elements.  The gather is bound by fabric requests in flight
+// (every run costs a 64-byte request whatever it delivers): with one element per lane three lanes share a request and a wave
+// instruction carries 21 of them; with one run per lane it carries 64, and a thread keeps U runs in flight.  Runs that touch
+// the zero padding take the element-wise path (columns outside [0, W)) or are all zero (rows outside [0, H)).
+struct __attribute__((packed, aligned(4))) Run3 {
+    float v[3];
+};
+__global__ void __launch_bounds__(256) k_patch_gather_runs3(const float *__restrict__ fmap, int B, int C, int H, int W,
+                                                            const int *__restrict__ xs, const int *__restrict__ ys, int P,
+                                                            int pad, int stride, int relu, float *__restrict__ out) {
+    const int row = blockIdx.x;  // = (batch * P + p) * B + b
+    const int bp = row / B, b = row - bp * B;
+    const int batch = bp / P;
+    const int h0 = xs[bp] * stride - pad, w0 = ys[bp] * stride - pad;
+    const int runs = C * 3;
+    const float *src = fmap + (size_t(batch) * B + b) * C * H * W;
+    float *dst = out + size_t(row) * runs * 3;
+    const bool cols_inside = w0 >= 0 && w0 + 2 < W;
+    constexpr int U = 4;
+    for (int r0 = threadIdx.x; r0 < runs; r0 += 256 * U) {
+        Run3 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 256 * u;
+            const int ch = r / 3, dh = r - ch * 3, hh = h0 + dh;
+            v[u].v[0] = v[u].v[1] = v[u].v[2] = 0.f;
+            if (r < runs && hh >= 0 && hh < H) {
+                const float *p = src + (size_t(ch) * H + hh) * W + w0;
+                if (cols_inside) {
+                    typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+                    const f3u t = *reinterpret_cast<const f3u *>(p);   // dword-aligned 12-byte load
+                    v[u].v[0] = t.x;
+                    v[u].v[1] = t.y;
+                    v[u].v[2] = t.z;
+                } else {
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw)
+                        if (w0 + dw >= 0 && w0 + dw < W) v[u].v[dw] = p[dw];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 256 * u;
+            if (r < runs) {
+                if (relu) {
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) v[u].v[dw] = v[u].v[dw] < 0.f ? 0.f : v[u].v[dw];
+                }
+                __builtin_memcpy(dst + size_t(r) * 3, &v[u], sizeof(Run3));
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_assemble_y(const float *__restrict__ feats, const float *__restrict__ bias,
                                                     const double *__restrict__ resY, int64_t total, int n,
                                                     double *__restrict__ Y) {
@@ -66,7 +122,7 @@ static int patch_gather_launch(cp_ctx *ctx, const float *fmap, int nb, int B, in
     CP_HIP(ctx, hipMemcpyAsync(dy, ys, np * 4, hipMemcpyHostToDevice, ctx->stream));
     const unsigned grid = unsigned(np * B);
     if (k == 3)
-        k_patch_gather<3><<<grid, 256, 0, ctx->stream>>>(fmap, B, C, H, W, dx, dy, P, k, pad, stride, relu, dst);
+        k_patch_gather_runs3<<<grid, 256, 0, ctx->stream>>>(fmap, B, C, H, W, dx, dy, P, pad, stride, relu, dst);
     else if (k == 1)
         k_patch_gather<1><<<grid, 256, 0, ctx->stream>>>(fmap, B, C, H, W, dx, dy, P, k, pad, stride, relu, dst);
     else
