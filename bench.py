@@ -1026,6 +1026,18 @@ def bench_patch_gather(device, C=256, H=56, W=56, B=10, P=10, nb=50, k=3, pad=1,
             ms = (time.perf_counter() - t0) / reps * 1e3
             res[name] = {"ms": round(ms, 4), "GBps_algorithmic": round(alg / ms / 1e6, 1),
                          "frac_of_hbm_peak": round(alg / (ms * 1e-3) / 8.0e12, 4)}
+            if name == "one_launch":     # the kernel alone, HIP events on the launch stream (the call also uploads the points)
+                ctx.enable_stage_timing(1)
+                kms = []
+                for _ in range(5):
+                    run()
+                    ctx.sync()
+                    kms.append(dict(ctx.last_stage_times()).get("gather_kernel", 0.0))
+                ctx.enable_stage_timing(0)
+                kms = float(np.median(kms))
+                if kms > 0:
+                    res[name].update(kernel_ms=round(kms, 4), kernel_GBps_algorithmic=round(alg / kms / 1e6, 1),
+                                     kernel_frac_of_hbm_peak=round(alg / (kms * 1e-3) / 8.0e12, 4))
         res["workload"] = "B=%d C=%d %dx%d k=%d pad=%d, %d points x %d batches: N=%d rows, %.1f MB written" % (
             B, C, H, W, k, pad, P, nb, N, alg / 2e6)
         res["note"] = ("HBM-bound gather: every sampled k-wide run of a channel row costs a whole 64-byte fabric request "
