@@ -84,11 +84,6 @@ struct cp_ctx {
     const char *gemm_mark = nullptr;  // if set, cp_gemm_tn_f64 marks this stage right after its main kernel
     int gemm_tag = 0;                 // selects a distinctly named instantiation of the GEMM kernel
     int cu_count = 256;
-    // sampled points of cp_patch_gather(_batches): a ring of page-locked slots, one packed (xs | ys) copy per call
-    char *pt_ring = nullptr;
-    size_t pt_slot_bytes = 0;
-    int pt_next = 0;
-    hipEvent_t pt_ev[8] = {};
     int *gemm_cnt = nullptr;          // arrival counters of the split tiles of cp_gemm_tn_f64 (a ring of regions, zero between launches)
     int gemm_cnt_next = 0;
     bool defer_refit_wait = false;    // cp_prune_layers: enqueue the refit, the caller waits once for the whole batch

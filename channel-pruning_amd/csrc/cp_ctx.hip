@@ -135,9 +135,6 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     if (ctx->layer_ws) hipFree(ctx->layer_ws);
     if (ctx->cd_box) hipFree(ctx->cd_box);
     if (ctx->gemm_cnt) hipFree(ctx->gemm_cnt);
-    if (ctx->pt_ring) hipHostFree(ctx->pt_ring);
-    for (hipEvent_t e : ctx->pt_ev)
-        if (e) hipEventDestroy(e);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->stage) hipHostFree(ctx->stage);
     if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
