@@ -48,9 +48,24 @@ constexpr int PACK = 36 * PNB * PNB;         // packed upper triangle of a 128 x
 constexpr int LDS_DOUBLES = PACK + 2 * NB;   // + dinv[128] + dref[128]
 static_assert(2 * KCH * SLD <= PACK, "the operand chunks and the packed tile share the same LDS");
 
-// (bi, bj) of packed slot 0 .. 35
-__device__ const unsigned char PK_BI[36] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
-__device__ const unsigned char PK_BJ[36] = {0, 1, 2, 3, 4, 5, 6, 7, 1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
+// (bi, bj) of packed slot 0 .. 35 (row-major upper triangle of the 8 x 8 block grid), three bits each, packed in two 64-bit
+// constants per table: a few scalar / vector ALU operations instead of a dependent table load from memory on the chain
+__host__ __device__ constexpr unsigned long long pk_pack(bool want_j, int first, int last) {
+    unsigned long long v = 0;
+    int slot = 0;
+    for (int bi = 0; bi < 8; ++bi)
+        for (int bj = bi; bj < 8; ++bj, ++slot)
+            if (slot >= first && slot < last) v |= (unsigned long long)(want_j ? bj : bi) << (3 * (slot - first));
+    return v;
+}
+__device__ __forceinline__ int pk_bi(int b) {
+    constexpr unsigned long long lo = pk_pack(false, 0, 21), hi = pk_pack(false, 21, 36);
+    return int(((b < 21 ? lo >> (3 * b) : hi >> (3 * (b - 21)))) & 7);
+}
+__device__ __forceinline__ int pk_bj(int b) {
+    constexpr unsigned long long lo = pk_pack(true, 0, 21), hi = pk_pack(true, 21, 36);
+    return int(((b < 21 ? lo >> (3 * b) : hi >> (3 * (b - 21)))) & 7);
+}
 // slot of block (bi, bj), bi <= bj, in the packed upper triangle (row-major)
 __device__ __forceinline__ constexpr int pk(int bi, int bj) { return bi * NPAN - bi * (bi - 1) / 2 + (bj - bi); }
 // element (r, c) of the tile, block row <= block column
@@ -83,6 +98,18 @@ __device__ __forceinline__ double row_bcast_i(double v, int i) {  // i: constant
     }
 }
 
+// The roles below are functions of their own (not inlined), so their pointer parameters arrive as GENERIC pointers and every
+// access through them would be a flat_ instruction.  A flat access counts on lgkmcnt as well as vmcnt: the s_waitcnt
+// lgkmcnt(0) in front of the first LDS read of a chunk then also waits for the global loads of the NEXT chunk that were
+// just issued -- the prefetch is gone and every chunk pays a full memory latency (745 flat_ against 4 global_ instructions in
+// this file before; a 256-deep tile update ran 95 us alone on its CU for 28 us of matrix work).  Every global operand is
+// therefore cast to the global address space at the head of its role.
+#define CP_GLOBAL __attribute__((address_space(1)))
+typedef CP_GLOBAL double *gdp;
+typedef const CP_GLOBAL double *gcdp;
+typedef CP_GLOBAL v2f64s *gv2p;
+typedef const CP_GLOBAL v2f64s *gcv2p;
+
 __device__ __forceinline__ double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
     y = y * fma(-0.5 * x * y, y, 1.5);
@@ -109,8 +136,7 @@ __device__ __forceinline__ void flag_wait(const int *flag, int *info) {
 // loads, the next chunk in flight while the current one is multiplied); SAME: A and B are the same block (diagonal tile),
 // and only the upper blocks t <= w are wanted.
 template <bool SAME>
-__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *__restrict__ Ab, int ld,
-                                            const double *__restrict__ Bb, int ldb, int kcnt, double *sm) {
+__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld, gcdp Bb, int ldb, int kcnt, double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     double *As = sm, *Bs = SAME ? sm : sm + KCH * SLD;
     constexpr int PER = KCH * NB / 2 / PT;   // double2 loads per thread, operand and chunk (= 2)
@@ -121,9 +147,9 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *_
     auto gload = [&](int ch) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const double *ab = Ab + size_t(ch * KCH + (PT >> 6) * i) * ld, *bb = Bb + size_t(ch * KCH + (PT >> 6) * i) * ldb;
-            ar[i] = *reinterpret_cast<const v2f64s *>(ab + goff);
-            if constexpr (!SAME) br[i] = *reinterpret_cast<const v2f64s *>(bb + goffb);
+            gcdp ab = Ab + size_t(ch * KCH + (PT >> 6) * i) * ld, bb = Bb + size_t(ch * KCH + (PT >> 6) * i) * ldb;
+            ar[i] = *(gcv2p)(ab + goff);
+            if constexpr (!SAME) br[i] = *(gcv2p)(bb + goffb);
         }
     };
     // kcnt (1 or 2) consecutive block rows of the operands: K = 128 kcnt, the rows of a block row are contiguous in k
@@ -158,7 +184,7 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], const double *_
 //   diag_factor_lds  U_ss^T U_ss = S in LDS.  The 16-column panel loop is the one of rounds 1-3 (wave 0 factors the 16 x 16
 //                    diagonal block in registers, one thread per column solves U12, all waves apply the rank-16 update on MFMA)
 //   diag_output      U[s,s] (upper, zeros below), T_p = U_pp^-1 into the diagonal slots, the operator P[s], the flag
-__device__ __forceinline__ void diag_to_lds(v4f64s (&acc)[NPAN], double *sm, const double *__restrict__ dg0_blk) {
+__device__ __forceinline__ void diag_to_lds(v4f64s (&acc)[NPAN], double *sm, gcdp dg0_blk) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     double *dref = sm + PACK + NB;
 #pragma unroll
@@ -257,7 +283,8 @@ __device__ __noinline__ void diag_factor_lds(double *sm, double piv_tol, int *in
 
 }
 
-__device__ __noinline__ void diag_output(double *sm, double *__restrict__ Ub, int ld, double *__restrict__ Gss, int *info, int blk) {
+__device__ __noinline__ void diag_output(double *sm, double *Ub_, int ld, double *Gss_, int *info, int blk) {
+    const gdp Ub = (gdp)Ub_, Gss = (gdp)Gss_;
     const int tid = threadIdx.x;
     const double *dinv = sm + PACK;
     // U[s,s] -> global (upper; the lower part zeroed)
@@ -290,7 +317,7 @@ __device__ __noinline__ void diag_output(double *sm, double *__restrict__ Ub, in
     // the operator goes where the tile came from: block (bi, bj) of G[s,s] (dead from here on) -- 16 lanes per 128-byte row
     for (int e = tid; e < PACK; e += PT) {
         const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        Gss[size_t(16 * PK_BI[b] + r) * ld + 16 * PK_BJ[b] + c] = sm[e];
+        Gss[size_t(16 * pk_bi(b) + r) * ld + 16 * pk_bj(b) + c] = sm[e];
     }
     __syncthreads();
     if (tid == 0) __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -299,8 +326,7 @@ __device__ __noinline__ void diag_output(double *sm, double *__restrict__ Ub, in
 // U[s,j] = U_ss^-T S for the tile in `acc`: block forward substitution over the eight 16-row blocks with the operator in
 // LDS; a wave owns 16 columns of the tile, so the eight steps are register-to-register (the D lay-out of one MFMA is the B
 // operand of the next).  Also writes the transposed tile Lt[j,s] (what the backward substitution reads).
-__device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *sm, double *__restrict__ Usj, int ldu,
-                                            double *__restrict__ Ltjs, int ld) {
+__device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *sm, gdp Usj, int ldu, gdp Ltjs, int ld) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fk = lane >> 4, fi = lane & 15;
 #pragma unroll
     for (int q = 0; q < NPAN; ++q) {
@@ -333,7 +359,7 @@ __device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *s
 // workgroups substitute.  V = U^-1 by block back-substitution, V_ij = -T_i sum_{k=i+1..j} U_ik V_kj: wave jb owns block
 // column jb and keeps its V blocks in registers (the D lay-out of a block is the B operand of the next product).
 template <int JB>
-__device__ __forceinline__ void inverse_column(const double *sm, double *__restrict__ TIb, double *__restrict__ TITb) {
+__device__ __forceinline__ void inverse_column(const double *sm, gdp TIb, gdp TITb) {
     const int lane = threadIdx.x & 63, fk = lane >> 4, fi = lane & 15;
     v4f64s V[JB + 1];
     {
@@ -370,7 +396,8 @@ __device__ __forceinline__ void inverse_column(const double *sm, double *__restr
         }
 }
 
-__device__ __noinline__ void diag_inverse(const double *sm, double *__restrict__ TIb, double *__restrict__ TITb) {
+__device__ __noinline__ void diag_inverse(const double *sm, double *TIb_, double *TITb_) {
+    const gdp TIb = (gdp)TIb_, TITb = (gdp)TITb_;
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
         case 0: inverse_column<0>(sm, TIb, TITb); break;
         case 1: inverse_column<1>(sm, TIb, TITb); break;
@@ -394,8 +421,8 @@ struct Tile {
 
 // acc <- the tile, then the pending updates (see the head of the file)
 template <bool DIAG>
-__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *__restrict__ Ai, int ld,
-                                                 double *sm) {
+__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *Ai_, int ld, double *sm) {
+    const gcdp T = (gcdp)t_.T, Bop = (gcdp)t_.B, Ai = (gcdp)Ai_;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     const int toff = fk * t_.ldt + 16 * wave + fi;   // lane's offset inside a (16 t + 4 r)-row band of the tile: scalar base + 32-bit offset
 #pragma unroll
@@ -405,9 +432,9 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile
             continue;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = (t_.T + size_t(16 * t + 4 * r) * t_.ldt)[toff];
+        for (int r = 0; r < 4; ++r) acc[t][r] = (T + size_t(16 * t + 4 * r) * t_.ldt)[toff];
     }
-    if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, t_.B, t_.ldb, t_.kcnt, sm);
+    if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm);
 }
 
 // the three roles of a workgroup of launch s; each is a function of its own (not inlined) so that the register allocation of
@@ -418,10 +445,11 @@ __device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const 
     v4f64s acc[NPAN];
     tile_load_update<false>(acc, t_, Ai, ld, sm);
     const int toff = fk * t_.ldt + 16 * wave + fi;
+    const gdp T = (gdp)t_.T;
 #pragma unroll
     for (int t = 0; t < NPAN; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) (t_.T + size_t(16 * t + 4 * r) * t_.ldt)[toff] = acc[t][r];
+        for (int r = 0; r < 4; ++r) (T + size_t(16 * t + 4 * r) * t_.ldt)[toff] = acc[t][r];
     __builtin_amdgcn_endpgm();
 }
 
@@ -432,7 +460,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const 
     {
         v4f64s acc[NPAN];
         tile_load_update<true>(acc, t_, Ai, ld, sm);
-        diag_to_lds(acc, sm, dg0 + size_t(s) * NB);
+        diag_to_lds(acc, sm, (gcdp)dg0 + size_t(s) * NB);
     }
     diag_factor_lds(sm, piv_tol, info, s);
     diag_output(sm, Uss, ld, t_.T, info, s);     // ... and the flag: the panel workgroups go on from here
@@ -452,10 +480,10 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int e = tid; e < PACK / 2; e += PT) {   // the operator of block s, left in G[s,s] by the diagonal role
         const int b = e >> 7, r = (e >> 3) & 15, c = (e & 7) * 2;
-        reinterpret_cast<v2f64s *>(sm)[e] = *reinterpret_cast<const v2f64s *>(Gss + size_t(16 * PK_BI[b] + r) * ld + 16 * PK_BJ[b] + c);
+        reinterpret_cast<v2f64s *>(sm)[e] = *(gcv2p)((gcdp)Gss + size_t(16 * pk_bi(b) + r) * ld + 16 * pk_bj(b) + c);
     }
     __syncthreads();
-    panel_solve(acc, sm, out, ldo, Ltjs, ld);
+    panel_solve(acc, sm, (gdp)out, ldo, (gdp)Ltjs, ld);
     __builtin_amdgcn_endpgm();
 }
 
