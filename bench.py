@@ -418,7 +418,7 @@ def bench_job(args, env, job):
             k_, v_ = item.split(":")
             per_stream[int(k_)] = int(v_)
     rset = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in own], operands, per_stream=per_stream,
-                                  flags=CD_FLAGS, borrow_results=True)
+                                  flags=CD_FLAGS, borrow_results=True, precompute_heaviest=args.precompute_heaviest)
     probs = rset.problems()           # index in `own` order -> LayerProblem
     ctxs = [cx for ch in rset.chunks for cx in ch["ctxs"]]
     roots = [ch["ctxs"][0] for ch in rset.chunks]
@@ -1269,6 +1269,8 @@ def main():
                     help="vgg16 on one GPU, the reference's own order: layer after layer, every search starting from the alpha "
                          "the previous layer ended with (cfgs.alpha carry, /root/reference/lib/decompose.py:491, 626-627)")
     ap.add_argument("--no-block", action="store_true", help="vgg16: skip the conv3_x single-instance figures")
+    ap.add_argument("--precompute-heaviest", type=int, default=None,
+                    help="layers whose full normal equations are computed under their alpha search (default: the library's 2)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-jobs-in-flight leg (N = 1)")
     ap.add_argument("--no-gather", action="store_true", help="skip the sampled-point im2col (extract_XY) measurement")
     ap.add_argument("--no-pcie-f64", action="store_true", help="skip the float64-X variant of the PCIe-inclusive pass")
