@@ -410,6 +410,17 @@ __device__ __noinline__ void diag_inverse(const double *sm, double *TIb_, double
     }
 }
 
+#ifdef CP_CHOL_STAMPS   // diagnostic build (tools/ubench/chol_bulk.hip): shader-clock stamps of the phases of a bulk workgroup
+__device__ unsigned long long cp_chol_stamps[4096 * 4];
+#define CP_STAMP(slot)                                                                                       \
+    do {                                                                                                     \
+        __builtin_amdgcn_s_waitcnt(0);                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) cp_chol_stamps[blockIdx.x * 4 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define CP_STAMP(slot) do { } while (0)
+#endif
+
 // A tile of launch s: where it lives, and the B operand of its update (block row s - 1 of U, or of Y for a right-hand side)
 struct Tile {
     double *T;          // the 128 x 128 tile (G[i,j] or R[i,jr])
@@ -434,7 +445,9 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = (T + size_t(16 * t + 4 * r) * t_.ldt)[toff];
     }
+    CP_STAMP(1);
     if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm);
+    CP_STAMP(2);
 }
 
 // the three roles of a workgroup of launch s; each is a function of its own (not inlined) so that the register allocation of
@@ -443,6 +456,7 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile
 __device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const double *__restrict__ Ai, int ld, int s, double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     v4f64s acc[NPAN];
+    CP_STAMP(0);
     tile_load_update<false>(acc, t_, Ai, ld, sm);
     const int toff = fk * t_.ldt + 16 * wave + fi;
     const gdp T = (gdp)t_.T;
@@ -450,6 +464,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const 
     for (int t = 0; t < NPAN; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) (T + size_t(16 * t + 4 * r) * t_.ldt)[toff] = acc[t][r];
+    CP_STAMP(3);
     __builtin_amdgcn_endpgm();
 }
 

@@ -1,0 +1,94 @@
+// The factorisation launches of csrc/chol_step.hip ALONE on a 4608 x 4608 matrix: per launch the time and the workgroup
+// count, and for the workgroups of one bulk launch (every tile below the block row: 256-deep updates) the shader-clock
+// stamps of their phases -- tile load | update loop | store.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../channel-pruning_amd/csrc chol_bulk.hip -o chol_bulk
+#define CP_CHOL_STAMPS
+#include "../../channel-pruning_amd/csrc/chol_step.hip"
+
+#include <algorithm>
+#include <cmath>
+
+int cp_set_error(cp_ctx *, int code, const char *fmt, ...) {
+    fprintf(stderr, "cp_set_error %d: %s\n", code, fmt);
+    return code;
+}
+
+__global__ void k_fill(double *G, int p) {
+    const size_t n = size_t(p) * p;
+    for (size_t e = blockIdx.x * size_t(blockDim.x) + threadIdx.x; e < n; e += size_t(gridDim.x) * blockDim.x) {
+        const int i = int(e / p), j = int(e % p);
+        G[e] = i == j ? 2.0 * p : sin(1e-3 * double(i + 1) * double(j + 1));
+    }
+}
+__global__ void k_diag(const double *G, int p, double *dg0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p) dg0[i] = G[size_t(i) * p + i];
+}
+
+int main() {
+    const int nblk = 36, p = nblk * NB;
+    double *G, *U, *Lt, *TI, *TIT, *dg0;
+    int *info;
+    hipMalloc(&G, size_t(p) * p * 8);
+    hipMalloc(&U, size_t(p) * p * 8);
+    hipMalloc(&Lt, size_t(p) * p * 8);
+    hipMalloc(&TI, size_t(nblk) * NB * NB * 8);
+    hipMalloc(&TIT, size_t(nblk) * NB * NB * 8);
+    hipMalloc(&dg0, size_t(p) * 8);
+    hipMalloc(&info, 4096);
+    hipMemset(U, 0, size_t(p) * p * 8);
+    hipMemset(Lt, 0, size_t(p) * p * 8);
+    if (lds_opt_in(0) != hipSuccess) return 1;
+    const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    std::vector<unsigned long long> st(4096 * 4);
+    for (int pass = 0; pass < 2; ++pass) {
+        k_fill<<<2048, 256>>>(G, p);
+        k_diag<<<(p + 255) / 256, 256>>>(G, p, dg0);
+        hipMemset(info, 0, 4096);
+        hipDeviceSynchronize();
+        float total = 0;
+        if (pass) printf("| step | workgroups | us |\n|---|---|---|\n");
+        for (int s = 0; s < nblk; ++s) {
+            const int n = nblk - s;
+            int tiles = n;
+            if (s >= 2 && !(s & 1)) tiles = n * (n + 1) / 2;
+            else if ((s & 1) && n > 1) tiles += n - 1;
+            hipEventRecord(e0);
+            k_chol_step<<<tiles, PT, lds>>>(G, U, Lt, p, nblk, s, dg0, 1e-12, TI, TIT, info, nullptr, 0, 0);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            total += ms;
+            if (pass && (s < 12 || s % 4 == 0)) printf("| %d | %d | %.1f |\n", s, tiles, ms * 1e3);
+            if (pass && s == 4) hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(cp_chol_stamps), st.size() * 8);
+        }
+        int h[4];
+        hipMemcpy(h, info, 16, hipMemcpyDeviceToHost);
+        if (pass) printf("\nall %d steps: %.3f ms (info[0] = %d)\n", nblk, total, h[0]);
+    }
+    // step 4: workgroups [0, 32) are block row 4 (diagonal + panels), the rest bulk tiles with K = 256
+    const int n4 = nblk - 4, tiles4 = n4 * (n4 + 1) / 2;
+    std::vector<double> load, upd, store, all;
+    unsigned long long first = ~0ull, last = 0;
+    for (int w = n4; w < tiles4; ++w) {
+        const unsigned long long *q = &st[size_t(w) * 4];
+        if (!q[0] || !q[3]) continue;
+        load.push_back(double(q[1] - q[0]));
+        upd.push_back(double(q[2] - q[1]));
+        store.push_back(double(q[3] - q[2]));
+        all.push_back(double(q[3] - q[0]));
+        first = std::min(first, q[0]);
+        last = std::max(last, q[3]);
+    }
+    auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+    auto mx = [](std::vector<double> v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
+    printf("\nstep 4, %zu bulk workgroups (256-deep update of a 128 x 128 tile), shader cycles (100 MHz s_memtime? no: readcyclecounter): median / max\n", all.size());
+    printf("| tile load | update loop (16 chunks) | store | whole | first entry .. last exit |\n|---|---|---|---|---|\n");
+    printf("| %.0f / %.0f | %.0f / %.0f | %.0f / %.0f | %.0f / %.0f | %.0f |\n", med(load), mx(load), med(upd), mx(upd), med(store),
+           mx(store), med(all), mx(all), double(last - first));
+    return 0;
+}
