@@ -306,9 +306,11 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job):
            "peak_measured": round(probe_tf, 2), "frac_of_measured_peak": top["frac_of_measured_peak"],
            "effective_ghz": round(ghz, 3), "cycles_per_mfma_measured": round(cyc, 1),
            "peak_note": "peak = 78.6 TFLOP/s, AMD's FP64 matrix figure (64 cycles per v_mfma_f64_16x16x4_f64 and SIMD at 2.4 GHz); "
-                        "peak_measured = back-to-back MFMAs, 2 waves per SIMD x 8 accumulators, stamped with s_memtime / "
-                        "s_memrealtime in this run: the pipe issues one instruction per ~102 cycles whatever the number of "
-                        "waves, at the full clock (effective_ghz) -- no throttle (profiles/r04_mfma_clock.md)",
+                        "peak_measured = back-to-back MFMAs with VGPR accumulators (the form every kernel of the library "
+                        "uses), 2 waves per SIMD x 8 accumulators, stamped with s_memtime / s_memrealtime in this run: one "
+                        "instruction per 64-69 cycles at the full clock (effective_ghz).  With AccVGPR accumulators the same "
+                        "instruction issues once per ~107 cycles (46.7 TFLOP/s): the figure quoted as the ceiling until the "
+                        "middle of round 4 (profiles/r04_gemm_probe.md, r04_mfma_clock.md)",
            "kernels": [k for k in (gram, chol) if k is not None],
            "latency_bound_chains_ms_per_job": {"alpha_search (one workgroup-team per layer)": round(per_job["alpha_search"], 3),
                                                "backward_substitution (banded)": round(per_job["backward_substitution"], 3)},
@@ -554,7 +556,7 @@ def bench_job(args, env, job):
                                     "more GPUs cannot push ONE job below its longest layer alone + the exchange.  The >= 6x of "
                                     "north_star at 8 GPUs exists only as throughput over independent jobs: replica_throughput",
                             "row_sharding": "cpmi355.shard.prune_layer_rows (rows of one layer over several ranks: two all-reduces, "
-                                            "Gram p^2 doubles) divides a layer's Gram, not its search; it pays when N p^2 / 49 TFLOP/s "
+                                            "Gram p^2 doubles) divides a layer's Gram, not its search; it pays when N p^2 / 68 TFLOP/s "
                                             "exceeds 2 x 8 p^2 B / link bandwidth, i.e. N > ~5000 rows per rank at 150 GB/s: not at "
                                             "the 5000-sample jobs, marginal at vgg16_5x (N = 20000); tools/rowshard_bench.py"}
         if env.world > 1 and not args.profile_mode:

@@ -16,8 +16,10 @@ struct Stamp {
     unsigned long long cyc, real;
 };
 
-template <int NACC>
-__global__ void __launch_bounds__(256) k_mfma(double *out, Stamp *st, int iters, double a0) {
+// MINW = 1: a whole SIMD's register file for one wave -- the compiler then keeps the accumulators in AccVGPRs; MINW = 2: a
+// budget of 256 registers -- VGPR accumulators, the form the kernels of the library use.  Same instruction, other issue rate.
+template <int NACC, int MINW>
+__global__ void __launch_bounds__(256, MINW) k_mfma(double *out, Stamp *st, int iters, double a0) {
     v4 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = v4{0., 0., 0., 0.};
@@ -98,6 +100,7 @@ int main() {
         printf("| %s | %d | %d | %.3f | %.2f | %.3f | %.3f..%.3f | %.1f |\n", name, wps, used_cus, ms, tf, ghz[waves / 2], ghz[0],
                ghz[waves - 1], cpi);
     };
+    for (int form = 0; form < 2; ++form)
     for (int lng = 0; lng < 2; ++lng) {
         for (int wps : {1, 2, 4, 8}) {
             for (int used : {1, cus}) {
@@ -106,14 +109,18 @@ int main() {
                 const int blocks = used * wps;
                 const int waves = blocks * 4;
                 const int iters = (lng ? 400000 : 1000) / wps;
-                k_mfma<8><<<blocks, 256>>>(out, st, 50, 0.5);
+                if (form == 0 && wps > 2) continue;   // the AccVGPR build holds 2 waves per SIMD at most
+                auto kern = form ? k_mfma<8, 2> : k_mfma<8, 1>;
+                kern<<<blocks, 256>>>(out, st, 50, 0.5);
                 hipEventRecord(e0);
-                k_mfma<8><<<blocks, 256>>>(out, st, iters, 0.5);
+                kern<<<blocks, 256>>>(out, st, iters, 0.5);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
                 hipEventElapsedTime(&ms, e0, e1);
-                report(lng ? "mfma_f64 long" : "mfma_f64 short", wps, used, waves, double(iters) * 8.0, ms, true);
+                report(form ? (lng ? "mfma_f64 VGPR acc, long" : "mfma_f64 VGPR acc, short")
+                            : (lng ? "mfma_f64 AccVGPR acc, long" : "mfma_f64 AccVGPR acc, short"),
+                       wps, used, waves, double(iters) * 8.0, ms, true);
             }
         }
     }
@@ -130,15 +137,15 @@ int main() {
     }
     // one wave alone, dependent chain of MFMAs on ONE accumulator: the latency of the instruction
     {
-        k_mfma<1><<<1, 64>>>(out, st, 50, 0.5);
+        k_mfma<1, 2><<<1, 64>>>(out, st, 50, 0.5);
         hipEventRecord(e0);
-        k_mfma<1><<<1, 64>>>(out, st, 20000, 0.5);
+        k_mfma<1, 2><<<1, 64>>>(out, st, 20000, 0.5);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(h.data(), st, sizeof(Stamp), hipMemcpyDeviceToHost);
-        printf("one wave, one accumulator (dependent chain): %.1f cycles per MFMA at %.3f GHz\n", double(h[0].cyc) / 20000.0,
+        printf("one wave, one VGPR accumulator (dependent chain): %.1f cycles per MFMA at %.3f GHz\n", double(h[0].cyc) / 20000.0,
                double(h[0].cyc) / double(h[0].real) * 0.1);
     }
     return 0;
