@@ -117,6 +117,7 @@ SIGNATURES = {
     "cp_probe_mfma_f64": (_c_int, [_vp, ctypes.POINTER(_c_dbl)]),
     "cp_probe_mfma_f64_clock": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_dbl)]),
     "cp_probe_hbm_copy": (_c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_c_dbl)]),
+    "cp_debug_gemm_units": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int]),
     "cp_last_stage_times": (_c_int, [_vp, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_float)]),
     "cp_stage_name": (ctypes.c_char_p, [_vp, _c_int]),
     "cp_enable_stage_timing": (_c_int, [_vp, _c_int]),

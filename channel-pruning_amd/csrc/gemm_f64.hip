@@ -36,7 +36,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 16, LPAD = 16, LLD = BM + LPAD;  // LLD = 144
 constexpr int NTHREADS = 256;
 
-__device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int &ti, int &tj) {
+__host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+__host__ __device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int &ti, int &tj) {
     if (tri == CP_TRI_NONE) {
         ti = tile / tiles_n;
         tj = tile - ti * tiles_n;
@@ -62,17 +64,17 @@ __device__ __forceinline__ void decode_tile(int tri, int tile, int tiles_n, int 
 // 8 x 8 super-block: its tiles share 8 + 8 operand panels in the XCD's L2 instead of the 2-3 + tiles_n panels of a band of
 // tile rows.  tiles_m = tile rows (TRI_NONE), tiles_n = tile columns (= tiles per side for the triangles).
 constexpr int SB = 8;
-__device__ __forceinline__ void decode_tile_blocked(int tri, int idx, int tiles_m, int tiles_n, int &ti, int &tj) {
+__host__ __device__ __forceinline__ void decode_tile_blocked(int tri, int idx, int tiles_m, int tiles_n, int &ti, int &tj) {
     if (tri == CP_TRI_NONE) {
         const int per_row = SB * tiles_n;                      // tiles of a full block row
         int I = idx / per_row;
         const int nbr = (tiles_m + SB - 1) / SB;
         if (I > nbr - 1) I = nbr - 1;
         const int rem = idx - I * per_row;
-        const int h = min(SB, tiles_m - I * SB);
+        const int h = imin(SB, tiles_m - I * SB);
         const int J = rem / (h * SB);
         const int r2 = rem - J * h * SB;
-        const int w = min(SB, tiles_n - J * SB);
+        const int w = imin(SB, tiles_n - J * SB);
         ti = I * SB + r2 / w;
         tj = J * SB + r2 % w;
         return;
@@ -80,12 +82,12 @@ __device__ __forceinline__ void decode_tile_blocked(int tri, int idx, int tiles_
     const int T = tiles_n;
     int I = 0, before = 0;                                     // block row I holds h S I + h (h + 1) / 2 tiles
     for (;; ++I) {
-        const int h = min(SB, T - I * SB);
+        const int h = imin(SB, T - I * SB);
         const int cnt = h * SB * I + h * (h + 1) / 2;
         if (idx < before + cnt) break;
         before += cnt;
     }
-    const int h = min(SB, T - I * SB);
+    const int h = imin(SB, T - I * SB);
     const int rem = idx - before;
     int a, b;
     if (rem < h * SB * I) {                                    // a full block left of the diagonal
@@ -131,6 +133,64 @@ struct GemmSched {
     int planes;                       // != 0: legacy plane mode with this many uniform splits
 };
 
+// unit (= workgroup id) of a launch -> its tile and k-chunk.  Host and device: cp_debug_gemm_units replays the kernel's own
+// mapping for the CPU test that every tile / chunk of every shape is covered exactly once (tests/test_host_logic.py).
+struct GemmUnit {
+    int ti, tj, z, nz, t_split;
+    bool idle;
+};
+__host__ __device__ __forceinline__ GemmUnit gemm_unit(int tri, int L, int n_tiles, int tiles_m, int tiles_n, const GemmSched &sch) {
+    GemmUnit u{0, 0, 0, 1, -1, false};
+    int tile;
+    const bool blocked = !sch.planes && n_tiles >= 64;   // many tiles: the super-tile ordered list, an XCD per contiguous range
+    if (sch.planes) {   // XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs
+        const int xcd = L & 7, slot = L >> 3;
+        u.z = xcd + 8 * (slot / n_tiles);
+        tile = slot % n_tiles;
+        u.nz = sch.planes;
+    } else if (L < sch.n_full) {
+        if (blocked) {
+            // workgroup L runs on XCD L % 8 (each XCD has its own L2).  Give every XCD a CONTIGUOUS range of the
+            // super-tile ordered list (decode_tile_blocked): the workgroups resident on an XCD at any time then cover about one
+            // 8 x 8 block of tiles and share its 16 operand panels in that L2 (PMC: the p = 4250 refit Gram fetched 2.8 GB for
+            // 0.31 GB of operands with the plain order, 2.4 GB with bands of tile rows per XCD).
+            const int xcd = L & 7, slot = L >> 3;
+            const int base = sch.n_full >> 3, rem = sch.n_full & 7;
+            tile = xcd * base + (xcd < rem ? xcd : rem) + slot;
+        } else {
+            tile = L;
+        }
+    } else {
+        const int v = L - sch.n_full;
+        u.nz = sch.s;
+        if (sch.n_full == 0 && (sch.s & 7) == 0) {   // uniform split: chunk z of every tile on XCD z % 8
+            const int xcd = L & 7, slot = L >> 3;
+            u.z = xcd + 8 * (slot / sch.n_split);
+            u.t_split = slot % sch.n_split;
+        } else {
+            // tail split: an XCD takes a contiguous range of the tail tiles (neighbours in the super-tile order) and runs
+            // them chunk by chunk, so that the workgroups resident on it at any time share operand panels AND their k-range
+            // in its L2 as the whole tiles did.  (Chunks of a tile next to each other in the grid -- each XCD a mix of tiles
+            // and k-ranges -- made the tail round HBM-bound: the 666-tile Gram 2.39 ms against 2.17 without a tail split.)
+            const int xcd = v & 7, slot = v >> 3;   // n_full is a multiple of the slot count: v & 7 is the XCD of the workgroup
+            const int base = sch.n_split >> 3, rem = sch.n_split & 7;
+            const int cnt = base + (xcd < rem ? 1 : 0);
+            if (slot >= cnt * sch.s) {
+                u.idle = true;
+                return u;
+            }
+            u.z = slot / cnt;
+            u.t_split = xcd * base + (xcd < rem ? xcd : rem) + (slot - u.z * cnt);
+        }
+        tile = sch.n_full + u.t_split;
+    }
+    if (blocked)
+        decode_tile_blocked(tri, tile, tiles_m, tiles_n, u.ti, u.tj);
+    else
+        decode_tile(tri, tile, tiles_n, u.ti, u.tj);
+    return u;
+}
+
 template <int TRI, int TAG, int WT, int NTH>
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
 k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
@@ -163,51 +223,9 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     const int tid = threadIdx.x;
     const int L = blockIdx.x;
     // ---- unit -> (tile, chunk z of nz) ----
-    int tile, z = 0, nz = 1, t_split = -1;
-    const bool blocked = !sch.planes && n_tiles >= 64;   // many tiles: the super-tile ordered list, an XCD per contiguous range
-    if (sch.planes) {   // XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs
-        const int xcd = L & 7, slot = L >> 3;
-        z = xcd + 8 * (slot / n_tiles);
-        tile = slot % n_tiles;
-        nz = sch.planes;
-    } else if (L < sch.n_full) {
-        if (blocked) {
-            // workgroup L runs on XCD L % 8 (each XCD has its own L2).  Give every XCD a CONTIGUOUS range of the
-            // super-tile ordered list (decode_tile_blocked): the workgroups resident on an XCD at any time then cover about one
-            // 8 x 8 block of tiles and share its 16 operand panels in that L2 (PMC: the p = 4250 refit Gram fetched 2.8 GB for
-            // 0.31 GB of operands with the plain order, 2.4 GB with bands of tile rows per XCD).
-            const int xcd = L & 7, slot = L >> 3;
-            const int base = sch.n_full >> 3, rem = sch.n_full & 7;
-            tile = xcd * base + (xcd < rem ? xcd : rem) + slot;
-        } else {
-            tile = L;
-        }
-    } else {
-        const int u = L - sch.n_full;
-        nz = sch.s;
-        if (sch.n_full == 0 && (sch.s & 7) == 0) {   // uniform split: chunk z of every tile on XCD z % 8
-            const int xcd = L & 7, slot = L >> 3;
-            z = xcd + 8 * (slot / sch.n_split);
-            t_split = slot % sch.n_split;
-        } else {
-            // tail split: an XCD takes a contiguous range of the tail tiles (neighbours in the super-tile order) and runs
-            // them chunk by chunk, so that the workgroups resident on it at any time share operand panels AND their k-range
-            // in its L2 as the whole tiles did.  (Chunks of a tile next to each other in the grid -- each XCD a mix of tiles
-            // and k-ranges -- made the tail round HBM-bound: the 666-tile Gram 2.39 ms against 2.17 without a tail split.)
-            const int xcd = u & 7, slot = u >> 3;   // n_full is a multiple of the slot count: u & 7 is the XCD of the workgroup
-            const int base = sch.n_split >> 3, rem = sch.n_split & 7;
-            const int cnt = base + (xcd < rem ? 1 : 0);
-            if (slot >= cnt * sch.s) return;        // the grid is padded to the XCD with the most tiles
-            z = slot / cnt;
-            t_split = xcd * base + (xcd < rem ? xcd : rem) + (slot - z * cnt);
-        }
-        tile = sch.n_full + t_split;
-    }
-    int ti, tj;
-    if (blocked)
-        decode_tile_blocked(TRI, tile, M / TM, tiles_n, ti, tj);
-    else
-        decode_tile(TRI, tile, tiles_n, ti, tj);
+    const GemmUnit un = gemm_unit(TRI, L, n_tiles, M / TM, tiles_n, sch);
+    if (un.idle) return;                             // the grid of a tail split is padded to the XCD with the most tiles
+    const int ti = un.ti, tj = un.tj, z = un.z, nz = un.nz, t_split = un.t_split;
     const int m0 = ti * TM, n0 = tj * TM;
     const int k0 = nz > 1 ? z * kchunk : 0;
     int k1 = nz > 1 ? k0 + kchunk : K;
@@ -578,4 +596,35 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
     }
     ctx->arena_used = arena_mark;
     return CP_OK;
+}
+
+// The plan of a launch and (units != null) the tile / chunk of every workgroup of it, computed on the HOST by the functions the
+// kernel runs (make_plan, gemm_unit): lets a CPU test sweep every shape for "each tile exactly once, each split tile by
+// exactly s chunks".  plan[9]: n_tiles, tiles_n, small, planes, n_full, n_split, s, kchunk, units.
+// units[5 * u]: ti, tj, z, nz, idle.  Returns the number of units, or a negative error code.
+extern "C" int cp_debug_gemm_units(int cu_count, int M, int N, int K, int tri, int32_t *plan, int32_t *units, int max_units) {
+    if (cu_count <= 0 || M <= 0 || N <= 0 || K <= 0 || !plan) return -CP_ERR_ARG;
+    if (M % BM || N % BN || K % BK || (tri != CP_TRI_NONE && M != N)) return -CP_ERR_ARG;
+    cp_ctx tmp;
+    tmp.cu_count = cu_count;
+    const GemmPlan p = make_plan(&tmp, M, N, K, tri);
+    int n_units = p.planes ? p.n_tiles * p.planes : p.n_full + p.n_split * p.s;
+    if (!p.planes && p.n_full > 0 && p.n_split > 0) n_units = p.n_full + 8 * ((p.n_split + 7) / 8) * p.s;
+    const int32_t pl[9] = {p.n_tiles, p.tiles_n, p.small ? 1 : 0, p.planes, p.n_full, p.n_split, p.s, p.kchunk, n_units};
+    memcpy(plan, pl, sizeof(pl));
+    if (units) {
+        if (max_units < n_units) return -CP_ERR_ARG;
+        const GemmSched sch{p.n_full, p.n_split, p.s, p.kchunk, nullptr, nullptr, p.planes};
+        const int tm_edge = p.small ? 64 : 128;
+        for (int L = 0; L < n_units; ++L) {
+            const GemmUnit u = gemm_unit(tri, L, p.n_tiles, M / tm_edge, p.tiles_n, sch);
+            int32_t *o = units + 5 * size_t(L);
+            o[0] = u.ti;
+            o[1] = u.tj;
+            o[2] = u.z;
+            o[3] = u.nz;
+            o[4] = u.idle ? 1 : 0;
+        }
+    }
+    return n_units;
 }

@@ -340,6 +340,14 @@ int cp_probe_mfma_f64(cp_ctx *ctx, double *tflops);
 int cp_probe_mfma_f64_clock(cp_ctx *ctx, double *tflops, double *ghz, double *cycles_per_mfma);
 int cp_probe_hbm_copy(cp_ctx *ctx, size_t bytes, double *gbps);
 
+/* Test hook (host only, no GPU needed): how a launch of the f64 "TN" GEMM behind the Gram builds (C[M,N] = A^T B, tri as in
+ * the library: 0 general, 1 lower tiles + mirror, 2 upper tiles) divides its 128 x 128 tiles over its workgroups on a chip of
+ * cu_count CUs -- whole tiles, the tail tiles split along K (added by the last arrival), uniform split-K.  Computed by the same
+ * functions the launch and the kernel use.  plan[9] = {n_tiles, tiles_n, small, planes, n_full, n_split, s, kchunk, units};
+ * units (or NULL): 5 int32 per workgroup = {tile row, tile column, chunk, chunks of the tile, idle}.  Returns the number of
+ * workgroups, or -CP_ERR_ARG. */
+int cp_debug_gemm_units(int cu_count, int M, int N, int K, int tri, int32_t *plan, int32_t *units, int max_units);
+
 /* Per-stage device timings (ms, HIP events on the ctx stream) of the most recent
  * cp_lasso_gram / cp_lstsq_refit call; names in cp_stage_name().  Used by bench.py. */
 #define CP_MAX_STAGES 32

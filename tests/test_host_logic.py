@@ -734,3 +734,59 @@ def test_gather_masks_world_size_2_gloo():
     for r in range(2):
         for i, c in enumerate((16, 5, 9)):
             assert got[0][1][r][i] == (np.random.RandomState(10 * r + i).rand(c) < 0.5).tolist()
+
+
+def test_gemm_launch_covers_every_tile_and_chunk_exactly_once():
+    """The f64 GEMM behind the Gram builds divides its 128 x 128 tiles over the workgroups of a launch in three ways (whole
+    tiles in an XCD-contiguous super-tile order, the tail tiles split along K, uniform split-K).  cp_debug_gemm_units replays
+    the plan and the kernel's own workgroup -> (tile, chunk) mapping on the host: for every shape up to 40 x 40 tiles, every
+    triangle mode and several K, each tile of the product is produced exactly once -- by one whole-tile workgroup, or by the
+    chunks 0 .. s-1 of a split -- and the chunks cover K."""
+    import ctypes
+    from cpmi355 import capi
+    lib = capi.load()
+    plan = (ctypes.c_int32 * 9)()
+    seen_modes = set()
+    for tri in (0, 1, 2):
+        for K in (128, 400, 768, 5008, 20000):
+            for tm in list(range(1, 41)):
+                for tn in ([tm] if tri else sorted({1, 2, 4, 7, tm, 35, 40})):
+                    M, N = tm * 128, tn * 128
+                    n = lib.cp_debug_gemm_units(256, M, N, K, tri, plan, None, 0)
+                    assert n > 0
+                    n_tiles, tiles_n, small, planes, n_full, n_split, s, kchunk, units_n = list(plan)
+                    assert units_n == n
+                    units = (ctypes.c_int32 * (5 * n))()
+                    assert lib.cp_debug_gemm_units(256, M, N, K, tri, plan, units, n) == n
+                    u = np.frombuffer(units, dtype=np.int32).reshape(n, 5)
+                    live = u[u[:, 4] == 0]
+                    edge = 64 if small else 128
+                    rows, cols = M // edge, N // edge
+                    want = {(i, j) for i in range(rows) for j in range(cols)
+                            if tri == 0 or (tri == 1 and j <= i) or (tri == 2 and i <= j)}
+                    assert len(want) == n_tiles
+                    got = {}
+                    for ti, tj, z, nz, _ in live:
+                        got.setdefault((int(ti), int(tj)), []).append((int(z), int(nz)))
+                    assert set(got) == want, (tri, K, tm, tn)
+                    for t, zs in got.items():
+                        nz = zs[0][1]
+                        assert sorted(z for z, _ in zs) == list(range(nz)) and all(k == nz for _, k in zs), (tri, K, tm, tn, t)
+                        if nz > 1:                       # the chunks cover the k range
+                            assert kchunk % 16 == 0 and kchunk * nz >= K
+                    split_tiles = sum(1 for zs in got.values() if zs[0][1] > 1)
+                    if planes:
+                        assert split_tiles == n_tiles and n == n_tiles * planes and planes > 8
+                        seen_modes.add("planes")
+                    elif n_split:
+                        assert split_tiles == n_split and 2 <= s <= 8 and n_full + n_split == n_tiles
+                        if n_full:                       # tail split: whole rounds of the chip's 512 slots first
+                            assert n_full % 512 == 0 and n_split < 512
+                            seen_modes.add("tail")
+                        else:
+                            assert s == 8
+                            seen_modes.add("uniform8")
+                    else:
+                        assert split_tiles == 0 and n == n_tiles
+                        seen_modes.add("whole")
+    assert seen_modes == {"planes", "tail", "uniform8", "whole"}
