@@ -52,21 +52,6 @@ struct cp_precompute {
     hipEvent_t gram_done = nullptr;
 };
 
-// The column means of ALL c k^2 columns of a layer and of Y, computed on the device's means stream WHILE the layer's alpha
-// search runs (cp_refit_means_enqueue, refit.hip): the refit then only picks the kept columns' means instead of reading X
-// once more at the head of its chain.  One shot, like cp_precompute: consumed by the refit cp_prune_layer issues next.
-struct cp_means_ahead {
-    bool ready = false;
-    const void *X = nullptr;
-    const double *Y = nullptr;
-    int64_t N = 0;
-    int c = 0, kk = 0, n = 0, x_dtype = 0, P_pad = 0, n_pad = 0;
-    char *buf = nullptr;           // xmean [P_pad] | ymean [n_pad] | part_x [64 P_pad] | part_y [64 n_pad] | identity channels [c]
-    size_t buf_bytes = 0;
-    double *xmean = nullptr, *ymean = nullptr;
-    hipEvent_t fork = nullptr, done = nullptr;
-};
-
 struct cp_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -105,7 +90,6 @@ struct cp_ctx {
     bool refit_pending = false;       // set by a deferred refit: factor + solve still to be launched by the batch
     cp_refit_deferred deferred = {};
     cp_precompute pre;
-    cp_means_ahead means;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // hand-offs to / from the shared CU-masked stream of the long GEMMs
     int itq_sweeps = 0;               // Jacobi sweeps of the last cp_itq_iterate (all alternations)
     int itq_ns_steps = 0, itq_sign_alternations = 0;   // Newton-Schulz steps / alternations that took the sign-function route
@@ -138,9 +122,6 @@ int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
 #define CP_LAUNCH_CHECK(ctx) CP_HIP(ctx, hipGetLastError())
 
 hipStream_t cp_side_stream(cp_ctx *ctx);   // the device's shared stream for work that overlaps a context's own chain (never null)
-hipStream_t cp_means_stream(cp_ctx *ctx);  // a second shared stream: the short column-mean passes do not queue behind the side stream's long products
-int cp_refit_means_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n);
-void cp_means_release(cp_ctx *ctx);
 // A pending precompute that nobody will consume (error exit, an unrelated refit, new contents in its buffers): wait for the
 // side / chain stream work that still reads X / Y, then forget it.
 void cp_precompute_void(cp_ctx *ctx);

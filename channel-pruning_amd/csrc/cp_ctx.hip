@@ -59,19 +59,6 @@ hipStream_t cp_side_stream(cp_ctx *ctx) {
     return streams[ctx->device];
 }
 
-hipStream_t cp_means_stream(cp_ctx *ctx) {
-    static std::mutex mu;
-    static hipStream_t streams[64] = {};
-    if (ctx->device < 0 || ctx->device >= 64) return ctx->stream;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!streams[ctx->device]) {
-        hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return ctx->stream;
-        streams[ctx->device] = st;
-    }
-    return streams[ctx->device];
-}
-
 extern "C" int cp_ctx_create(int device, cp_ctx **out) {
     // CP_CTX_PRIORITY (read, never written, by the library): the default HIP priority of a context's stream
     int prio = 0;
@@ -144,7 +131,6 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     cp_precompute_release(ctx);
-    cp_means_release(ctx);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->layer_ws) hipFree(ctx->layer_ws);
     if (ctx->cd_box) hipFree(ctx->cd_box);

@@ -35,19 +35,10 @@ struct PrecomputeScope {
     explicit PrecomputeScope(cp_ctx *c) : ctx(c) {
         cp_precompute_void(ctx);      // left over from a call that failed midway
         ctx->pre.armed = true;
-        drop_means();
     }
     ~PrecomputeScope() {
         ctx->pre.armed = false;
         cp_precompute_void(ctx);      // no-op after a refit that consumed it
-        drop_means();
-    }
-    // column means computed ahead (cp_refit_means_enqueue) that no refit picked up: their pass still reads X / Y
-    void drop_means() {
-        if (ctx->means.ready) {
-            (void)hipEventSynchronize(ctx->means.done);
-            ctx->means.ready = false;
-        }
     }
 };
 
@@ -178,7 +169,6 @@ int prune_layer_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, 
         if (!streamed) {
             CP_TRY(cp_lasso_gram(ctx, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, S, Q, q, stats));
             if (precompute) CP_TRY(cp_refit_precompute_enqueue(ctx, X, x_dtype, N, c, kk, Y, n, (flags & CP_REFIT_PREFACTOR) ? rank : 0.0));
-            else CP_TRY(cp_refit_means_enqueue(ctx, X, x_dtype, N, c, kk, Y, n));   // the refit's column means, under the search
             ctx->host_ms[0] = now_ms() - t0;
             rc = cp_lasso_alpha_search(ctx, Q, c, q, stats, c, double(S) * double(n), alpha_right0, rank, lbound, rbound, seeds,
                                        max_fits, max_iter, tol, flags, w, &fits_used, &alpha, res->fit_log, res->fit_alpha);

@@ -940,84 +940,6 @@ bool prefactor_wanted() {
 // flops of the masked Gram, but off the critical path: the alpha search that decides the mask is one workgroup busy for
 // milliseconds, the rest of the chip is idle meanwhile.  Ordered after everything already on ctx->stream; the refit
 // (cp_lstsq_refit_impl) waits for it and gathers.  Skipped (returns CP_OK, pre.ready = false) when N - 1 < P.
-// xmean[i] = xf[col(i)] for i < p (col(i) = chan[i / kk] kk + i % kk), zero in the padding; ymean copied
-__global__ void __launch_bounds__(RT) k_pick_means(const double *__restrict__ xf, const double *__restrict__ yf,
-                                                   const int *__restrict__ chan, int kk, int p, int p_pad, int n_pad,
-                                                   double *__restrict__ xmean, double *__restrict__ ymean) {
-    const int i = blockIdx.x * RT + threadIdx.x;
-    if (i < p_pad) xmean[i] = i < p ? xf[size_t(chan[i / kk]) * kk + i % kk] : 0.0;
-    if (i < n_pad) ymean[i] = yf[i];
-}
-
-void cp_means_release(cp_ctx *ctx) {
-    cp_means_ahead &m = ctx->means;
-    if (m.buf) {
-        hipStreamSynchronize(cp_means_stream(ctx));
-        hipFree(m.buf);
-    }
-    if (m.fork) hipEventDestroy(m.fork);
-    if (m.done) hipEventDestroy(m.done);
-    m = cp_means_ahead{};
-}
-
-// Column sums of ALL columns of X and of Y -> means, on the means stream, behind whatever the context's stream has queued so
-// far.  Same row blocks, same order of additions per column as the refit's own pass over the kept columns: the refit picks
-// bit-identical means (k_pick_means) instead of reading X again at the head of its chain (in the vgg16 job that pass takes
-// 1.1 ms per c = 512 layer next to the other layers' products, 29 us alone).
-int cp_refit_means_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n) {
-    cp_means_ahead &m = ctx->means;
-    m.ready = false;
-    const int P = c * kk;
-    const int P_pad = int(cp_align_up(size_t(P), NB)), n_pad = int(cp_align_up(size_t(n), 128));
-    const int RB = 64, rows_per_block = int((N + RB - 1) / RB);
-    hipStream_t ms = cp_means_stream(ctx);
-    const size_t bytes = (size_t(P_pad) + n_pad + size_t(RB) * (P_pad + n_pad)) * 8 + cp_align_up(size_t(c) * 4, 256) + 256;
-    if (bytes > m.buf_bytes) {
-        CP_HIP(ctx, hipStreamSynchronize(ms));
-        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (m.buf) CP_HIP(ctx, hipFree(m.buf));
-        m.buf = nullptr;
-        m.buf_bytes = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&m.buf), bytes) != hipSuccess)
-            return cp_set_error(ctx, CP_ERR_NOMEM, "refit means: hipMalloc(%zu)", bytes);
-        m.buf_bytes = bytes;
-    }
-    if (!m.fork) {
-        CP_HIP(ctx, hipEventCreateWithFlags(&m.fork, hipEventDisableTiming));
-        CP_HIP(ctx, hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
-    }
-    m.xmean = reinterpret_cast<double *>(m.buf);
-    m.ymean = m.xmean + P_pad;
-    double *part_x = m.ymean + n_pad, *part_y = part_x + size_t(RB) * P_pad;
-    int *chan = reinterpret_cast<int *>(part_y + size_t(RB) * n_pad);
-    CP_HIP(ctx, hipEventRecord(m.fork, ctx->stream));
-    CP_HIP(ctx, hipStreamWaitEvent(ms, m.fork, 0));
-    k_iota<<<(c + RT - 1) / RT, RT, 0, ms>>>(chan, c);
-    CP_LAUNCH_CHECK(ctx);
-    const int gx = (P + RT - 1) / RT, gy = (n + RT - 1) / RT;
-    if (x_dtype == CP_F32)
-        k_colsum_xy<float><<<dim3(gx + gy, RB), RT, 0, ms>>>(static_cast<const float *>(X), Y, N, c, kk, n, chan, P, gx,
-                                                            rows_per_block, part_x, P_pad, part_y, n_pad);
-    else
-        k_colsum_xy<double><<<dim3(gx + gy, RB), RT, 0, ms>>>(static_cast<const double *>(X), Y, N, c, kk, n, chan, P, gx,
-                                                             rows_per_block, part_x, P_pad, part_y, n_pad);
-    CP_LAUNCH_CHECK(ctx);
-    k_mean_finish_xy<<<gx + gy, RT, 0, ms>>>(part_x, P_pad, P, part_y, n_pad, n, gx, RB, 1.0 / double(N), m.xmean, m.ymean);
-    CP_LAUNCH_CHECK(ctx);
-    CP_HIP(ctx, hipEventRecord(m.done, ms));
-    m.X = X;
-    m.Y = Y;
-    m.N = N;
-    m.c = c;
-    m.kk = kk;
-    m.n = n;
-    m.x_dtype = x_dtype;
-    m.P_pad = P_pad;
-    m.n_pad = n_pad;
-    m.ready = true;
-    return CP_OK;
-}
-
 int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n,
                                 double rank_hint, bool fork_recorded) {
     cp_precompute &pc = ctx->pre;
@@ -1375,15 +1297,6 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     if (from_pre) {
         CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, pc.done, 0));
         CP_HIP(ctx, hipMemcpyAsync(ymean, pc.ymean, size_t(n_pad) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    } else if (cp_means_ahead &ma = ctx->means; ma.ready && ma.X == X && ma.Y == Y && ma.N == N && ma.c == c && ma.kk == kk &&
-               ma.n == n && ma.x_dtype == x_dtype && ma.n_pad == n_pad) {
-        // the means of all columns were computed while the alpha search ran (cp_refit_means_enqueue): pick the kept ones
-        ma.ready = false;
-        CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ma.done, 0));
-        k_pick_means<<<(std::max(p_pad, n_pad) + RT - 1) / RT, RT, 0, ctx->stream>>>(ma.xmean, ma.ymean, dchan, kk, p, p_pad, n_pad,
-                                                                                   xmean, ymean);
-        CP_LAUNCH_CHECK(ctx);
-        cp_stage_mark(ctx, "refit_means");
     } else {   // column means, then gather + centre (three launches)
         const int gx = (p + RT - 1) / RT, gy = (n + RT - 1) / RT;
         dim3 gs(gx + gy, RB);
