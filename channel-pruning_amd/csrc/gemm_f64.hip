@@ -6,9 +6,9 @@
 //   refit Gram   G = Xc^T Xc, R = Xc^T Yc  (K = N samples)            lib/decompose.py:622 -> LinearRegression
 //   Cholesky trailing updates / block solves (K = 128).
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves, 64x64 per wave = 4x4 MFMA
-// tiles, 128 accumulator VGPRs), BK = 16 per LDS stage, next stage prefetched into
-// registers while the current one is multiplied.  LDS rows are padded by 16 doubles so the
+// Tiling: 128x128 output tile per 512-thread workgroup (8 waves as 4 x 2, 32x64 per wave = 2x4 MFMA
+// tiles, 64 accumulator VGPRs: two workgroups per CU), BK = 16 per LDS stage, next stage prefetched into
+// registers while the current one is multiplied; 64x64 tiles of 256 threads for the skinny K <= 512 products.  LDS rows are padded by 16 doubles so the
 // two k-rows a 32-lane half reads land on disjoint bank halves (ds_read_b64, 64 banks).
 // Small outputs are split along K (multiples of 8 splits; split z of every tile is placed
 // on XCD z % 8 so the tiles that share a k-chunk share an L2); the partial sums are added in
@@ -19,8 +19,8 @@
 // 512 workgroup slots of the chip (2 per CU), and at 52 when it is 595 -- the refit Gram of a 472-channel layer: the 83
 // tiles of the second round run alone on 83 CUs.  So the tiles beyond the last full round are split along K into
 // s chunks of their own ("tail split": s = 2 .. 8, chosen so that the chunks fill one more round as evenly as possible),
-// and the workgroup that finishes a tile's LAST chunk adds the s partial blocks in chunk order (arrival counter;
-// agent-scope release / acquire around it) -- no second launch.  The same in-kernel reduction serves the uniform
+// and the workgroup that finishes a tile's LAST chunk adds the s partial blocks in chunk order (arrival counter; the
+// blocks cross the XCDs as sc1 stores / loads, no whole-L2 fences: see the epilogue) -- no second launch.  The same in-kernel reduction serves the uniform
 // split when it has at most 8 chunks, and the lower-triangle products write the mirrored tile from the epilogue: the
 // separate reduce and mirror launches of rounds 1-3 (each a dispatch a busy chip makes the chain wait for) are gone
 // from every product with <= 8 chunks.
