@@ -71,33 +71,6 @@ __device__ __forceinline__ constexpr int pk(int bi, int bj) { return bi * NPAN -
 // element (r, c) of the tile, block row <= block column
 #define CP_PK(r, c) sm[pk((r) >> 4, (c) >> 4) * 256 + ((r) & 15) * 16 + ((c) & 15)]
 
-template <int I>
-__device__ __forceinline__ double row_bcast(double v) {   // value of lane 16 (l / 16) + I for every lane l (DPP row broadcast)
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + I, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + I, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row_bcast_i(double v, int i) {  // i: constant after unrolling
-    switch (i) {
-        case 0: return row_bcast<0>(v);
-        case 1: return row_bcast<1>(v);
-        case 2: return row_bcast<2>(v);
-        case 3: return row_bcast<3>(v);
-        case 4: return row_bcast<4>(v);
-        case 5: return row_bcast<5>(v);
-        case 6: return row_bcast<6>(v);
-        case 7: return row_bcast<7>(v);
-        case 8: return row_bcast<8>(v);
-        case 9: return row_bcast<9>(v);
-        case 10: return row_bcast<10>(v);
-        case 11: return row_bcast<11>(v);
-        case 12: return row_bcast<12>(v);
-        case 13: return row_bcast<13>(v);
-        case 14: return row_bcast<14>(v);
-        default: return row_bcast<15>(v);
-    }
-}
-
 // The roles below are functions of their own (not inlined), so their pointer parameters arrive as GENERIC pointers and every
 // access through them would be a flat_ instruction.  A flat access counts on lgkmcnt as well as vmcnt: the s_waitcnt
 // lgkmcnt(0) in front of the first LDS read of a chunk then also waits for the global loads of the NEXT chunk that were

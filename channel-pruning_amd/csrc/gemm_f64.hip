@@ -33,7 +33,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LPAD = 16, LLD = BM + LPAD;  // LLD = 144
+constexpr int BM = 128, BN = 128, BK = 16, LPAD = 16;   // LDS rows of BM + LPAD = 144 doubles
 constexpr int NTHREADS = 256;
 
 __host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
