@@ -1056,7 +1056,8 @@ def bench_sequential_alpha(args, env):
     """`--sequential-alpha`: the 12 layers of the vgg16 job one after another on ONE GPU with the reference's alpha carry --
     what Net.R3's loop does (/root/reference/lib/net.py:1407-1457 calls dictionary() layer by layer and cfgs.alpha, written
     at decompose.py:626-627, is the next call's right bracket, :491).  Nothing overlaps: layer l + 1 needs layer l's alpha.
-    No reference goldens exist for the carried alphas, so the masks are checked against the CPU port run the same way."""
+    Checked against the UNMODIFIED reference run the same way (tests/golden/C01_vgg16_alpha_chain.npz, oracle/gen_golden.py
+    --chain): masks and the chain of carried alphas identical; the CPU port run the same way is the cpu_baseline of the line."""
     import cpmi355
     from cpmi355.pruner import LayerProblem, prune_layer
     specs = cpjobs.JOBS["vgg16"]()
@@ -1090,6 +1091,12 @@ def bench_sequential_alpha(args, env):
                                   "the previous layer's final alpha (the reference's cfgs.alpha carry); 1 step = 1 pass over the 12 layers",
                       "layers_per_job": len(specs)},
            "job_ms": round(job_ms, 3), "alpha_chain": [float(a) for _, a in res]}
+    chain_path = os.path.join(ROOT, "tests", "golden", "C01_vgg16_alpha_chain.npz")
+    if os.path.exists(chain_path):
+        g = np.load(chain_path)
+        out["masks_and_alpha_chain_identical_to_the_reference_chain"] = bool(
+            all(np.array_equal(res[i][0], g["idxs_%02d" % i]) and res[i][1] == float(g["alpha_out"][i]) for i in range(len(specs))))
+        out["reference_chain_seconds"] = round(float(np.sum(g["ref_seconds"])), 1)
     if not args.no_cpu_baseline:
         cpu_masks = []
         out["cpu_baseline"] = cpu_baseline_object(specs, specs, {}, job_ms, True, carry_alpha=True, masks_out=cpu_masks)

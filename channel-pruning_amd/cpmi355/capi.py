@@ -39,7 +39,7 @@ CP_MAX_FITS = 64
 
 class PruneResult(ctypes.Structure):
     _fields_ = [("fits_used", ctypes.c_int32), ("nnz", ctypes.c_int32), ("p", ctypes.c_int32),
-                ("refit_rank", ctypes.c_int32), ("fallback", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("refit_rank", ctypes.c_int32), ("fallback", ctypes.c_int32), ("uploaded", ctypes.c_int32),
                 ("alpha", ctypes.c_double), ("fit_log", CdResult * CP_MAX_FITS),
                 ("fit_alpha", ctypes.c_double * CP_MAX_FITS)]
 
@@ -478,13 +478,18 @@ class Context:
         if X_host is not None:
             W = None if borrow else np.empty(int(n) * int(c) * int(kk), dtype=np.float64)
             b = None if borrow else np.empty(int(n), dtype=np.float64)
-            self._check(self.lib.cp_prune_layer_h2d(self.h, _ptr(X), X_host.ctypes.data, x_dtype, int(N), int(c), int(kk),
-                                                    _ptr(W2), w_dtype, int(n), _ptr(Y), Y_host.ctypes.data,
-                                                    samples.ctypes.data, int(samples.shape[0]), float(alpha_right0),
-                                                    float(rank), float(lbound), float(rbound), seeds.ctypes.data,
-                                                    int(seeds.shape[0]), int(max_iter), float(tol), int(flags), float(ridge),
-                                                    mask.ctypes.data, None if borrow else W.ctypes.data,
-                                                    None if borrow else b.ctypes.data, ctypes.byref(res)), "cp_prune_layer_h2d")
+            try:
+                self._check(self.lib.cp_prune_layer_h2d(self.h, _ptr(X), X_host.ctypes.data, x_dtype, int(N), int(c), int(kk),
+                                                        _ptr(W2), w_dtype, int(n), _ptr(Y), Y_host.ctypes.data,
+                                                        samples.ctypes.data, int(samples.shape[0]), float(alpha_right0),
+                                                        float(rank), float(lbound), float(rbound), seeds.ctypes.data,
+                                                        int(seeds.shape[0]), int(max_iter), float(tol), int(flags),
+                                                        float(ridge), mask.ctypes.data, None if borrow else W.ctypes.data,
+                                                        None if borrow else b.ctypes.data, ctypes.byref(res)),
+                            "cp_prune_layer_h2d")
+            except CpError as e:
+                e.uploaded = bool(res.uploaded)     # did X_dev / Y_dev receive the host arrays before the error?
+                raise
             if res.fits_used < 0:
                 return res, None, None, None
             if borrow:

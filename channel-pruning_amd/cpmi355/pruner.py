@@ -215,12 +215,22 @@ class LayerProblem:
         self.S = int(len(samples))
         mark = rng_mark(rng)
         seeds = draw_seeds(rng, MAX_FITS)
-        pending, self._pending = self._pending, None     # the call leaves X and Y resident whatever its outcome
-        res, idxs, W, b = self.ctx.prune_layer(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype,
-                                               self.n, self.Yd, samples, alpha_right0, rank, lbound, rbound, seeds,
-                                               ridge, flags=self.flags | precompute_flag(latency_mode, rank, self.c),
-                                               borrow=getattr(self, "borrow_results", False),
-                                               X_host=pending[0] if pending else None, Y_host=pending[1] if pending else None)
+        pending, self._pending = self._pending, None
+        try:
+            res, idxs, W, b = self.ctx.prune_layer(self.Xd, self.x_dtype, self.N, self.c, self.kk, self.W2d, self.w_dtype,
+                                                   self.n, self.Yd, samples, alpha_right0, rank, lbound, rbound, seeds,
+                                                   ridge, flags=self.flags | precompute_flag(latency_mode, rank, self.c),
+                                                   borrow=getattr(self, "borrow_results", False),
+                                                   X_host=pending[0] if pending else None,
+                                                   Y_host=pending[1] if pending else None)
+        except capi.CpError as e:
+            # an error return that came before the streamed upload was enqueued (bad argument, allocation failure ...)
+            # leaves Xd / Yd empty: the host arrays stay pending, so a later refit() / lasso_gram() uploads them instead
+            # of reading uninitialised device memory (cp_prune_result.uploaded)
+            if pending is not None and not getattr(e, "uploaded", False):
+                self._pending = pending
+            rng_rewind(rng, mark)
+            raise
         rng_rewind(rng, mark)
         if res.fits_used < 0:
             return None

@@ -359,12 +359,14 @@ def exchange_results(specs, owner, mine, dist, device=None, staging=None):
     return results
 
 
-def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None, owner=None, staging=None):
+def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None, owner=None, staging=None,
+                  force_exchange=False):
     """specs: list of dicts with at least N, c, n, k, rank; compute_fn(spec) -> (idxs, W, b), or
     compute_many(list of this rank's specs) -> list of (idxs, W, b) (a GpuLayerBatches or a ResidentLayerSet).
     Every rank returns the full list of results in layer order.  `dist` is an initialised
     torch.distributed module (None = single process); owner[i] (default: LPT over layer_cost) says which rank
-    prunes layer i."""
+    prunes layer i.  force_exchange: run the two collectives even in a process group of ONE rank (the RCCL path on a
+    one-GPU box: all_gather_into_tensor on device tensors, the page-locked return buffer)."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     if owner is None:
@@ -377,7 +379,7 @@ def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=N
         got = [compute_fn(specs[i]) for i in own]
     for i, (idxs, W, b) in zip(own, got):
         mine[i] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
-    if dist is None or world == 1:
+    if dist is None or (world == 1 and not force_exchange):
         return [mine[i] for i in range(len(specs))]
     return exchange_results(specs, owner, mine, dist, device, staging)
 

@@ -313,7 +313,7 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         // write through the L2, sc1 loads that do not hit it -- instead of plain accesses between an agent-scope release
         // and acquire: those fences are a write-back (per releasing wave) and an invalidation (per acquiring wave) of the
         // WHOLE L2 of the XCD, which cost this kernel 0.2-0.4 ms per launch and slowed every kernel running next to it
-        // (vgg16 job 26.5 -> 30.5 ms, gpurun_out/r04_call23).  The workgroup barrier waits for the stores (vmcnt) before
+        // (vgg16 job 26.5 -> 30.5 ms, gpurun_out/r04_call23).  Each wave waits for its stores (explicit vmcnt(0), below) before the barrier, then
         // thread 0 counts the workgroup in.
         unsigned long long *blk = reinterpret_cast<unsigned long long *>(sch.Pb) + (size_t(t_split) * nz + z) * (TM * TM);
 #pragma unroll
@@ -325,6 +325,11 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
                     __hip_atomic_store(blk + (wm + i * 16 + fk + 4 * r) * TM + wn + j * 16 + fi,
                                        (unsigned long long)__double_as_longlong(acc[i][j][r]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
+        // every wave waits for ITS OWN write-through stores to be acknowledged before the barrier: the compiler puts no
+        // s_waitcnt vmcnt(0) between relaxed stores and s_barrier (checked in the gfx950 ISA: `llvm-objdump -d` of this
+        // kernel shows `s_waitcnt vmcnt(0)` directly before the `s_barrier` below only with this statement), and without it
+        // another wave's block could still be in flight when thread 0 counts the workgroup in.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             const int prev = __hip_atomic_fetch_add(sch.cnt + t_split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -140,12 +140,26 @@ int prune_layer_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, 
     double *Xs_dev = bd + n_b, *Ys_dev = Xs_dev + n_xs;
     const size_t x_bytes = size_t(N) * cc * kk * elt_size(x_dtype), y_bytes = size_t(N) * n * 8;
     hipStream_t side = streamed ? cp_side_stream(ctx) : nullptr;
+    // The copies out of the caller's pageable arrays must not outlive the call: the Python side drops its references to
+    // those arrays when the call raises.  Whatever way the function returns after upload_rest(), the side stream's copies
+    // are complete (a successful return has waited on ctx->stream, which is ordered behind ev_upload; an error return
+    // synchronises with the event here).
+    struct UploadJoin {
+        cp_ctx *ctx;
+        bool enqueued = false;
+        ~UploadJoin() {
+            if (enqueued && ctx->ev_upload) (void)hipEventSynchronize(ctx->ev_upload);
+        }
+    } upload_join{ctx};
+    res->uploaded = 0;
     auto upload_rest = [&]() -> int {   // X, Y on the side stream; the host thread stages the pageable arrays meanwhile
         if (ctx->pre.ready && (X == ctx->pre.X || Y == ctx->pre.Y)) cp_precompute_void(ctx);   // new contents
         CP_HIP(ctx, hipMemcpyAsync(const_cast<void *>(X), host.X, x_bytes, hipMemcpyHostToDevice, side));
         CP_HIP(ctx, hipMemcpyAsync(const_cast<double *>(Y), host.Y, y_bytes, hipMemcpyHostToDevice, side));
         if (!ctx->ev_upload) CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
         CP_HIP(ctx, hipEventRecord(ctx->ev_upload, side));
+        upload_join.enqueued = true;
+        res->uploaded = 1;            // from here on X_dev / Y_dev hold (or are about to hold) the caller's arrays
         return CP_OK;
     };
 

@@ -867,6 +867,44 @@ int cp_refit_batch_factor_solve(cp_ctx *const *ctxs, int n_ctx) {
 // ---- full normal equations during the alpha search ------------------------------------------------------------
 namespace {
 
+// The kept-channel list from the mask, handed over as a KERNEL ARGUMENT (a bit per channel, c <= 2048 -> 256 B of kernarg):
+// chan[j] = index of the j-th kept channel.  Replaces a hipMemcpyAsync out of pageable host memory at the one point of a
+// layer where everything waits for the host -- between the end of the alpha search and the first launch of the refit: the
+// runtime stages such a copy through its own page-locked buffer and a copy kernel (rocprof timeline of the vgg16 job:
+// 0.4-1.3 ms between the end of the search kernel and that copy kernel, the copy kernel itself 120-550 us on the busy chip).
+constexpr int CHAN_BITS_MAX = 2048;
+struct ChanBits {
+    unsigned long long w[CHAN_BITS_MAX / 64];
+};
+__global__ void __launch_bounds__(256) k_chan_from_bits(ChanBits bits, int c, int *__restrict__ chan) {
+    const int t = threadIdx.x, c0 = t * 8;          // 8 channels per thread, inside one 64-bit word
+    if (c0 >= c) return;
+    const int wi = c0 >> 6, sh = c0 & 63;
+    int pos = 0;
+    for (int i = 0; i < wi; ++i) pos += __popcll(bits.w[i]);
+    pos += __popcll(bits.w[wi] & ((1ull << sh) - 1ull));
+    unsigned m = unsigned(bits.w[wi] >> sh) & 0xffu;
+    for (int b = 0; b < 8 && c0 + b < c; ++b)
+        if (m & (1u << b)) chan[pos++] = c0 + b;
+}
+bool chan_kernarg_wanted() {
+    static const bool on = !(getenv("CP_REFIT_CHAN_KERNARG") && getenv("CP_REFIT_CHAN_KERNARG")[0] == '0');
+    return on;
+}
+// the kept-channel list on the device, ordered on ctx->stream
+int upload_chan(cp_ctx *ctx, const std::vector<int> &chan, int c, int *dchan) {
+    if (c <= CHAN_BITS_MAX && chan_kernarg_wanted()) {
+        ChanBits bits;
+        memset(&bits, 0, sizeof(bits));
+        for (int ch : chan) bits.w[ch >> 6] |= 1ull << (ch & 63);
+        k_chan_from_bits<<<1, 256, 0, ctx->stream>>>(bits, c, dchan);
+        CP_LAUNCH_CHECK(ctx);
+        return CP_OK;
+    }
+    CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), chan.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    return CP_OK;
+}
+
 __global__ void __launch_bounds__(RT) k_iota(int *__restrict__ v, int count) {
     const int i = blockIdx.x * RT + threadIdx.x;
     if (i < count) v[i] = i;
@@ -907,6 +945,14 @@ void cp_precompute_release(cp_ctx *ctx) {
         hipStreamSynchronize(pc.worker->stream);
         if (pc.worker->arena) hipFree(pc.worker->arena);
         if (pc.worker->pinned) hipHostFree(pc.worker->pinned);
+        // everything else a worker context can have acquired lazily (the split GEMM's arrival counters, ...)
+        if (pc.worker->gemm_cnt) hipFree(pc.worker->gemm_cnt);
+        if (pc.worker->layer_ws) hipFree(pc.worker->layer_ws);
+        if (pc.worker->cd_box) hipFree(pc.worker->cd_box);
+        if (pc.worker->stage) hipHostFree(pc.worker->stage);
+        if (pc.worker->ev_upload) hipEventDestroy(pc.worker->ev_upload);
+        if (pc.worker->ev_fork) hipEventDestroy(pc.worker->ev_fork);
+        if (pc.worker->ev_join) hipEventDestroy(pc.worker->ev_join);
         for (int i = 0; i < 2 * CP_MAX_STAGES; ++i)
             if (pc.worker->ev[i]) hipEventDestroy(pc.worker->ev[i]);
         delete pc.worker;
@@ -916,6 +962,7 @@ void cp_precompute_release(cp_ctx *ctx) {
         hipStreamSynchronize(pc.chain_stream);
         hipStreamDestroy(pc.chain_stream);
     }
+    if (pc.own_side) hipStreamDestroy(pc.own_side);
     if (pc.buf) hipFree(pc.buf);
     if (pc.fbuf) hipFree(pc.fbuf);
     if (pc.done) hipEventDestroy(pc.done);
@@ -955,6 +1002,10 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
         w->cu_count = ctx->cu_count;
         w->own_stream = nullptr;
         w->stream = cp_side_stream(ctx);
+        // CP_SIDE_STREAM_PER_CTX=1: a side stream per context, so that several layers' normal equations run side by side
+        // under their searches instead of taking turns on the device's one shared stream
+        static const bool per_ctx = getenv("CP_SIDE_STREAM_PER_CTX") && getenv("CP_SIDE_STREAM_PER_CTX")[0] == '1';
+        if (per_ctx && hipStreamCreateWithFlags(&pc.own_side, hipStreamNonBlocking) == hipSuccess) w->stream = pc.own_side;
         for (int i = 0; i < 2 * CP_MAX_STAGES; ++i) hipEventCreate(&w->ev[i]);
         w->timing = ctx->timing;
         w->timing_gram_only = ctx->timing_gram_only;
@@ -1170,8 +1221,8 @@ int refit_from_full_factor(cp_ctx *ctx, cp_precompute &pc, const std::vector<int
     cp_stage_begin(ctx);
     CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, pc.done, 0));
     CP_HIP(ctx, hipMemcpyAsync(flag_host, pc.finfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (!drop.empty()) CP_HIP(ctx, hipMemcpyAsync(ddrop, drop.data(), drop.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CP_TRY(upload_chan(ctx, chan, c, dchan));
+    if (!drop.empty()) CP_TRY(upload_chan(ctx, drop, c, ddrop));
     CP_HIP(ctx, cp_stream_wait(ctx));
     cp_stage_mark(ctx, "refit_wait_prefactor");
     if (*flag_host != 0) return CP_OK;          // the full Gram is not safely positive definite
@@ -1287,7 +1338,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     double *b_host = host_out ? reinterpret_cast<double *>(ctx->pinned + 64) : nullptr;
     double *W_host = host_out ? b_host + n : nullptr;
     cp_stage_begin(ctx);
-    CP_HIP(ctx, hipMemcpyAsync(dchan, chan.data(), size_t(kept) * 4, hipMemcpyHostToDevice, ctx->stream));
+    CP_TRY(upload_chan(ctx, chan, c, dchan));
     // full normal equations already under way on the side stream (cp_refit_precompute_enqueue): one shot
     cp_precompute &pc = ctx->pre;
     const bool from_pre = pc.armed && pc.ready && pc.X == X && pc.Y == Y && pc.N == N && pc.c == c && pc.kk == kk && pc.n == n &&

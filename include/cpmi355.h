@@ -261,7 +261,9 @@ typedef struct cp_prune_result {
     int32_t p;          /* nnz * kk: columns of W_out */
     int32_t refit_rank; /* cp_refit_info.rank */
     int32_t fallback;   /* cp_refit_info.fallback */
-    int32_t reserved;
+    int32_t uploaded;   /* cp_prune_layer_h2d: 1 once the copies of X_host / Y_host into X_dev / Y_dev were enqueued
+                           (they are complete when the call returns, whatever it returns); 0: an error return came
+                           before that and X_dev / Y_dev hold nothing */
     double alpha;       /* alpha of the accepted fit (decompose.py:525) */
     cp_cd_result fit_log[CP_MAX_FITS];
     double fit_alpha[CP_MAX_FITS];

@@ -12,7 +12,7 @@ Per case the file holds: params (json), samples, the per-fit log
 ``cfgs.alpha`` after the call, and the next draw of numpy's global RNG after the call
 (pins the RNG-stream consumption: 1 + #fits draws, SURVEY.md section 8b "Ownership").
 
-Usage:  python oracle/gen_golden.py [--only NAME ...] [--skip-large]
+Usage:  python oracle/gen_golden.py [--only NAME ...] [--skip-large] | --chain
 """
 import argparse
 import json
@@ -182,12 +182,52 @@ def run_reference(p):
                 alpha_out=alpha_out, rng_next=rng_next, seconds=dt)
 
 
+def run_chain():
+    """--chain: the UNMODIFIED reference over the 12 layers of the vgg16 job (cpmi355/jobs.py::vgg16_4x, the operands of the
+    goldens V01..V12) ONE AFTER ANOTHER with `cfgs.alpha` CARRIED from layer to layer, as Net.R3's loop does
+    (/root/reference/lib/net.py:1407-1457 calls dictionary() per conv; decompose.py:626-627 writes cfgs.alpha, :491 reads it as
+    the next call's right bracket).  Per layer: np.random.seed(1234 + layer_id) as in every other golden; the first layer
+    starts from cfgs.alpha = 1e-3.  -> tests/golden/C01_vgg16_alpha_chain.npz: per layer the mask, the per-fit log, alpha_in /
+    alpha_out, the RNG draw after the call, a sketch of the weights and the bias."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "channel-pruning_amd"))
+    from cpmi355 import jobs
+    specs = jobs.vgg16_4x()
+    alpha = 1e-3
+    out = dict(names=json.dumps([s["name"] for s in specs]), versions=json.dumps(versions()))
+    chain_in, chain_out, rng_next, secs = [], [], [], []
+    for i, spec in enumerate(specs):
+        p = dict(layer_id=spec["layer_id"], N=spec["N"], c=spec["c"], n=spec["n"], k=spec["k"], rank=spec["rank"],
+                 residual=spec["residual"], alpha_in=alpha)
+        r = run_reference(p)
+        wm = r["newW2"].reshape(r["newW2"].shape[0], -1)
+        out["idxs_%02d" % i] = r["idxs"]
+        out["fits_%02d" % i] = r["fits"]
+        out["samples_%02d" % i] = r["samples"]
+        out["newB2_%02d" % i] = r["newB2"]
+        out["newW2_sketch_%02d" % i] = wm @ cp_oracle.sketch_matrix(wm.shape[1])
+        out["newW2_rownorm_%02d" % i] = np.linalg.norm(wm, axis=1)
+        chain_in.append(alpha)
+        alpha = r["alpha_out"]
+        chain_out.append(alpha)
+        rng_next.append(r["rng_next"])
+        secs.append(r["seconds"])
+        print("%-24s alpha_in %.6g -> alpha_out %.6g  kept %4d/%4d  fits %2d  %.2fs" % (
+            spec["name"], chain_in[-1], alpha, int(r["idxs"].sum()), spec["c"], len(r["fits"]), r["seconds"]), flush=True)
+    out.update(alpha_in=np.array(chain_in), alpha_out=np.array(chain_out), rng_next=np.array(rng_next, dtype=np.int64),
+               ref_seconds=np.array(secs))
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "C01_vgg16_alpha_chain.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
     ap.add_argument("--skip-large", action="store_true")
+    ap.add_argument("--chain", action="store_true", help="only the cfgs.alpha chain over the 12 layers of the vgg16 job")
     args = ap.parse_args()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if args.chain:
+        run_chain()
+        return
     for name, p in CASES.items():
         if args.only and name not in args.only:
             continue

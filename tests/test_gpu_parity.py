@@ -1093,7 +1093,7 @@ def test_resident_layer_set_vgg16_job_matches_reference_goldens(flags):
         rset.close()
 
 
-def _nccl_worker(rank, world, port, q, backend="nccl"):
+def _nccl_worker(rank, world, port, q, backend="nccl", force_exchange=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
@@ -1119,11 +1119,19 @@ def _nccl_worker(rank, world, port, q, backend="nccl"):
     rset = shard.ResidentLayerSet(gpu, own, lambda s: data[s["layer_id"]], per_stream=2, flags=3, borrow_results=True)
     ok = True
     for _ in range(2):                                # twice: the lent result blocks and the staging buffers are reused
-        res = shard.prune_sharded(specs, compute_many=rset, dist=dist, owner=owner, staging="device")
+        res = shard.prune_sharded(specs, compute_many=rset, dist=dist, owner=owner, staging="device",
+                                  force_exchange=force_exchange)
         for s, (idxs, W, b) in zip(specs, res):
             g = np.load(os.path.join(GOLDEN_DIR, s["name"] + ".npz"))
             ok = ok and np.array_equal(idxs, g["idxs"]) and W.shape == g["newW2"].shape
             ok = ok and relfro(W, g["newW2"]) <= REL_W and relfro(b, g["newB2"]) <= REL_W
+    if force_exchange:       # the other two collectives of the package through the same backend
+        every = shard.gather_masks(specs, res, dist)
+        ok = ok and len(every) == world and all(np.array_equal(every[0][i], res[i][0]) for i in range(len(specs)))
+        t = torch.arange(1000, dtype=torch.float64, device=torch.device("cuda", gpu))
+        shard.allreduce_sum(dist, t)
+        ok = ok and bool(torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64) * world))
+        ok = ok and dist.get_backend() == backend and shard.LAST_EXCHANGE_MS.get("bytes_sent", 0) > 0
     rset.close()
     q.put((rank, bool(ok), len(own)))
     dist.barrier()
@@ -1148,6 +1156,24 @@ def test_prune_sharded_device_staging_two_ranks_one_gpu():
     assert all(ok for _, ok, _ in got) and all(cnt > 0 for _, _, cnt in got)
 
 
+def test_prune_sharded_exchange_through_rccl_in_a_process_group_of_one():
+    """The RCCL branch of the exchange on the hardware there is: a process group of ONE rank with backend "nccl" (= RCCL) on
+    this GPU runs exactly what every rank of an 8-GPU job runs -- results lent from the page-locked result blocks, packed
+    into an HBM segment, all_gather_into_tensor on DEVICE tensors (masks, then the packed float64 segment), the segments
+    back through a page-locked buffer -- plus gather_masks and the all-reduce of the row-sharded path; results = the
+    reference goldens."""
+    import multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 29400 + (os.getpid() % 200)
+    pr = mpc.Process(target=_nccl_worker, args=(0, 1, port, q, "nccl", True))
+    pr.start()
+    got = q.get(timeout=600)
+    pr.join(timeout=120)
+    assert pr.exitcode == 0
+    assert got[1] and got[2] == 6
+
+
 def test_prune_sharded_two_gpus_rccl():
     """world size 2 on two MI355X over RCCL ("nccl"): LPT split, masks all_gather, all_gather of the packed (W, b); both ranks end
     with every layer's reference-golden result.  Skipped on a one-GPU box (the gloo twin runs in tests/test_host_logic.py)."""
@@ -1169,3 +1195,36 @@ def test_prune_sharded_two_gpus_rccl():
         pr.join(timeout=120)
         assert pr.exitcode == 0
     assert all(ok for _, ok, _ in got) and all(cnt > 0 for _, _, cnt in got)
+
+
+def test_alpha_carry_over_the_vgg16_job_matches_the_reference_chain(ctx):
+    """The 12 layers of the vgg16 job one after another with `cfgs.alpha` carried from call to call, as Net.R3's loop runs
+    them (/root/reference/lib/net.py:1407-1457; decompose.py:491 reads the carried alpha as the right bracket, :626-627 writes
+    it): against the UNMODIFIED reference run the same way (oracle/gen_golden.py --chain -> C01_vgg16_alpha_chain.npz).
+    Every layer: mask, per-fit (alpha, nnz, n_iter), carried alpha and RNG stream identical; weights <= 1e-5 (sketch)."""
+    import cp_oracle
+    import lib.cfgs as cfgs
+    import lib.decompose as D
+    from cpmi355 import jobs
+    g = np.load(os.path.join(GOLDEN_DIR, "C01_vgg16_alpha_chain.npz"))
+    specs = jobs.vgg16_4x()
+    assert json.loads(str(g["names"])) == [s["name"] for s in specs]
+    cfgs.alpha = 1e-3
+    for i, spec in enumerate(specs):
+        X, W2, Y, B2 = jobs.synth(spec)
+        assert cfgs.alpha == float(g["alpha_in"][i])
+        np.random.seed(1234 + spec["layer_id"])
+        idxs, newW2, newB2 = D.dictionary(X.astype(np.float64), W2, Y, rank=spec["rank"], B2=B2)
+        rng_next = int(np.random.randint(0, 2147483647))
+        info = D.last_call_info
+        assert np.array_equal(idxs, g["idxs_%02d" % i]), "layer %s: mask differs from the reference chain" % spec["name"]
+        fits = np.array(info["fits"], dtype=np.float64).reshape(-1, 3)
+        assert np.array_equal(fits, g["fits_%02d" % i])
+        assert np.array_equal(info["samples"], g["samples_%02d" % i])
+        assert cfgs.alpha == float(g["alpha_out"][i])
+        assert rng_next == int(g["rng_next"][i])
+        wm = np.asarray(newW2, dtype=np.float64).reshape(newW2.shape[0], -1)
+        assert np.allclose(np.linalg.norm(wm, axis=1), g["newW2_rownorm_%02d" % i], rtol=1e-4)
+        assert relfro(wm @ cp_oracle.sketch_matrix(wm.shape[1]), g["newW2_sketch_%02d" % i]) <= REL_W
+        assert relfro(newB2, g["newB2_%02d" % i]) <= REL_W
+    cfgs.alpha = 1e-3

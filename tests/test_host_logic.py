@@ -173,6 +173,81 @@ def test_exchange_results_three_ranks_one_of_them_empty():
     assert seg[1] == 0 and offs[0] == 0 and offs[2] == int(np.prod(shapes[0])) + 3 and seg[0] == int(np.prod(shapes[1])) + 4
 
 
+def _vgg16_world8_specs():
+    """the vgg16 job's layer table with the costs bench.py plans with, channel counts scaled down 8x (the exchange logic sees
+    the real owner table and segment structure; the payload stays small)"""
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import jobs
+    cost = {64: 1.5, 128: 3.0, 256: 6.8, 512: 15.5}      # bench.py::VGG16_COST_MS
+    return [dict(layer_id=s["layer_id"], name=s["name"], N=40, c=s["c"] // 8, n=s["n"] // 8, k=s["k"], rank=s["rank"] // 8,
+                 cost=cost[s["c"]]) for s in jobs.vgg16_4x()]
+
+
+def _exchange8_worker(rank, world, port, q, case):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import hashlib
+
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = _vgg16_world8_specs()
+    if case == "five_layers":
+        specs = specs[7:]                 # the five widest layers alone: three of the eight ranks own nothing
+    owner = shard.plan_owners(specs, world)
+    mine = {}
+    for i, s in enumerate(specs):
+        if owner[i] == rank:
+            rs = np.random.RandomState(70 + i)
+            idxs = rs.rand(s["c"]) < 0.87
+            idxs[0] = True
+            mine[i] = (idxs, rs.randn(s["n"], int(idxs.sum()), s["k"], s["k"]), rs.randn(s["n"]))
+    res = shard.exchange_results(specs, owner, mine, dist)
+    q.put((rank, owner, [(r[0].tolist(), tuple(r[1].shape), hashlib.sha1(np.ascontiguousarray(r[1]).tobytes()).hexdigest(),
+                          hashlib.sha1(np.ascontiguousarray(r[2]).tobytes()).hexdigest()) for r in res],
+           dict(shard.LAST_EXCHANGE_MS)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["vgg16_job", "five_layers"])
+def test_exchange_results_world_size_8_with_the_vgg16_owner_table(case):
+    """A dry run of the 8-GPU exchange on CPU (gloo, eight processes): the vgg16 job's owner table as bench.py plans it (LPT
+    over the measured costs: uneven segments, ranks with two or three layers), and the five widest layers alone (three ranks
+    own nothing: empty segments).  Every rank ends with every layer's bytes exactly as its owner produced them."""
+    import hashlib
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + (7 if case == "five_layers" else 0)
+    procs = [ctx.Process(target=_exchange8_worker, args=(r, 8, port, q, case)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    owner = got[0][1]
+    assert all(g[1] == owner for g in got) and all(g[2] == got[0][2] for g in got)
+    specs = _vgg16_world8_specs()
+    specs = specs[7:] if case == "five_layers" else specs
+    loads = [sum(1 for o in owner if o == r) for r in range(8)]
+    if case == "vgg16_job":
+        assert min(loads) >= 1 and max(loads) >= 2 and sorted(owner[7:]) == sorted(set(owner[7:]))   # a GPU per 512-channel layer
+    else:
+        assert loads.count(0) == 3 and max(loads) == 1
+    for i, (m, shape, hw, hb) in enumerate(got[0][2]):
+        s = specs[i]
+        rs = np.random.RandomState(70 + i)
+        idxs = rs.rand(s["c"]) < 0.87
+        idxs[0] = True
+        W, b = rs.randn(s["n"], int(idxs.sum()), s["k"], s["k"]), rs.randn(s["n"])
+        assert m == idxs.tolist() and shape == W.shape
+        assert hw == hashlib.sha1(W.tobytes()).hexdigest() and hb == hashlib.sha1(b.tobytes()).hexdigest()
+    sent = [g[3]["bytes_sent"] for g in got]
+    assert sum(sent) == sum(g[3]["bytes_received"] for g in got) // 7
+    assert all((sent[r] == 0) == (loads[r] == 0) for r in range(8))
+
+
 def test_sharded_pruning_world_size_2_gloo():
     """Two ranks split four layers, then every rank holds every layer's (mask, W, b); the union of
     the work is exactly one call per layer and the results equal a single-process run."""

@@ -290,3 +290,31 @@ def test_three_operation_division_is_correctly_rounded():
     out = subprocess.run([exe, "20000000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "random: 0 mismatches" in out.stdout and "adversarial: 0 mismatches" in out.stdout \
         and "structured: 0 mismatches" in out.stdout, out.stdout
+
+
+def test_oracle_follows_the_reference_alpha_chain_on_the_first_layers_of_the_vgg16_job():
+    """C01_vgg16_alpha_chain.npz = the unmodified reference over V01..V12 with cfgs.alpha carried (oracle/gen_golden.py
+    --chain).  The port (C Gram-form CD + numpy lstsq) run the same way reproduces the chain on its first four layers
+    (c = 64, 64, 128, 128: seconds on CPU; the whole chain is the GPU test's): masks, per-fit logs, carried alphas, RNG."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import jobs
+    g = np.load(os.path.join(GOLDEN_DIR, "C01_vgg16_alpha_chain.npz"))
+    specs = jobs.vgg16_4x()
+    assert json.loads(str(g["names"])) == [s["name"] for s in specs]
+    assert float(g["alpha_in"][0]) == 1e-3 and np.array_equal(g["alpha_in"][1:], g["alpha_out"][:-1])
+    assert len(set(g["alpha_out"].tolist())) >= 4         # the carry is live: the layers do end at different alphas
+    alpha = 1e-3
+    for i, spec in enumerate(specs[:4]):
+        X, W2, Y, B2 = jobs.synth(spec)
+        np.random.seed(1234 + spec["layer_id"])
+        log = []
+        idxs, newW2, newB2, alpha = cp_oracle.dictionary_oracle(X.astype(np.float64), W2, Y, spec["rank"], B2, alpha_in=alpha,
+                                                                lasso="c_gram", ls="numpy", log=log)
+        rng_next = int(np.random.randint(0, 2147483647))
+        fits = np.array([(f[1], f[2], f[3]) for f in log if f[0] == "fit"], dtype=np.float64).reshape(-1, 3)
+        assert np.array_equal(idxs, g["idxs_%02d" % i])
+        assert np.array_equal(fits, g["fits_%02d" % i])
+        assert alpha == float(g["alpha_out"][i]) and rng_next == int(g["rng_next"][i])
+        wm = newW2.reshape(newW2.shape[0], -1)
+        assert relfro(wm @ cp_oracle.sketch_matrix(wm.shape[1]), g["newW2_sketch_%02d" % i]) <= 1e-8
