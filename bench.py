@@ -267,7 +267,7 @@ def pmc_traffic(pattern, round_tag):
     return out["fetch"] + out["write"], "profiles/%s_pmc_{fetch,write}_size_kb.md@%s" % (round_tag, commit or "unknown")
 
 
-def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job):
+def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=None, cd_steps_ns=None):
     """`roofline` of the JSON line.  The kernel classes of the job's MFMA work, each timed live with HIP events on its launch
     stream during the timed jobs (cp_enable_stage_timing mode 2): the refit Gram GEMM (one launch per layer) and the
     factorisation chain (the Cholesky step launches of a layer, with the forward substitution riding along).  The one
@@ -294,10 +294,42 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job):
                 "pmc_pattern": "k_chol_step", "avg_launch_note": "one bracket = all step launches of a layer"}
     top = gram if chol is None or per_job["refit_gram"] >= per_job["cholesky_chain"] else chol
     traffic, source = pmc_traffic(top["pmc_pattern"], round_tag) if job == "vgg16" else (None, None)
-    for k in (gram, chol):
-        if k is not None:
-            k["frac"] = round(k["achieved"] / F64_MFMA_PEAK_TFLOPS, 4)
-            k["frac_of_measured_peak"] = round(k["achieved"] / probe_tf, 4)
+    # algorithmic HBM bytes per launch, averaged over the job's launches: Gram 8 N p + 8 p^2 (the staged rows read once, the
+    # Gram written once); factorisation step: G and R read once, U and Y written once, spread over the layer's p / 128 launches
+    n_gram = max(1, len(g_fl))
+    gram["traffic_algorithmic"] = None
+    for k, flops, cls in ((gram, g_fl, "refit_gram"), (chol, chol_fl, "cholesky_chain")):
+        if k is None:
+            continue
+        k["frac"] = round(k["achieved"] / F64_MFMA_PEAK_TFLOPS, 4)
+        k["frac_of_measured_peak"] = round(k["achieved"] / probe_tf, 4)
+        # what the chip does, not what one stream sees: the flops of all the concurrent brackets of this class in a job
+        # divided by the wall window they span (cp_last_stage_spans: one clock for all the layers' streams)
+        w = (windows or {}).get(cls) or []
+        if w and sum(w) > 0:
+            tf = sum(flops) / (sum(w) * 1e-3) / 1e12
+            k["chip_level"] = {"achieved": round(tf, 3), "frac": round(tf / F64_MFMA_PEAK_TFLOPS, 4),
+                               "window_ms_per_job": round(sum(w) / len(w), 3),
+                               "note": "flops of all the layers' brackets of this class in a job / the wall window from the first "
+                                       "begin to the last end (the brackets of different layers overlap)"}
+        t_k, src_k = pmc_traffic(k["pmc_pattern"], round_tag) if job == "vgg16" else (None, None)
+        if t_k is not None:
+            k["traffic"] = t_k
+            k["traffic_source"] = src_k
+    if job == "vgg16" and g_fl:
+        # p from N p^2; 8 N p + 8 p^2 per Gram launch
+        ps = [np.sqrt(f / N_SAMPLES) for f in g_fl]
+        gram["traffic_algorithmic"] = round(float(np.mean([8.0 * N_SAMPLES * p_ + 8.0 * p_ * p_ for p_ in ps])), 1)
+        if gram.get("traffic"):
+            gram["traffic_ratio"] = round(gram["traffic"] / gram["traffic_algorithmic"], 2)
+        if chol is not None and chol_fl:
+            # per layer: G (upper half, 4 p^2 B) + R (8 p n) read, U (4 p^2) + Y (8 p n) written; per launch: / (p / 128)
+            per_launch = [(8.0 * p_ * p_ + 16.0 * p_ * 512.0) / max(1.0, np.ceil(p_ / 128.0)) for p_ in ps]
+            chol["traffic_algorithmic"] = round(float(np.sum([(8.0 * p_ * p_ + 16.0 * p_ * 512.0) for p_ in ps]) /
+                                                      max(1.0, np.sum([np.ceil(p_ / 128.0) for p_ in ps]))), 1)
+            if chol.get("traffic"):
+                chol["traffic_ratio"] = round(chol["traffic"] / chol["traffic_algorithmic"], 2)
+            del per_launch
     out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": top["frac"], "traffic": traffic, "traffic_source": source,
            "traffic_note": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + WRITE_SIZE "
@@ -316,6 +348,12 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job):
            "kernels": [k for k in (gram, chol) if k is not None],
            "latency_bound_chains_ms_per_job": {"alpha_search (one workgroup-team per layer)": round(per_job["alpha_search"], 3),
                                                "backward_substitution (banded)": round(per_job["backward_substitution"], 3)},
+           "alpha_search": {"ns_per_step_in_the_job_by_channels": {str(c_): round(float(np.mean(v_)), 1)
+                                                                   for c_, v_ in sorted((cd_steps_ns or {}).items())},
+                            "cycles_per_step_in_the_job_by_channels": {str(c_): round(float(np.mean(v_)) * ghz, 1)
+                                                                       for c_, v_ in sorted((cd_steps_ns or {}).items())},
+                            "note": "bracket of the whole search of a layer / (sum of n_iter over its fits x channels): one "
+                                    "coordinate step of scikit-learn's Gram-form recurrence; cycles at effective_ghz"},
            "note": "brackets are stream time of a layer while the other layers of the job share the CUs; sums over the "
                    "layers of a job exceed job_ms because the layers overlap"}
     for k in out["kernels"]:
@@ -469,25 +507,38 @@ def bench_job(args, env, job):
     env.barrier()
     t0 = time.perf_counter()
     epoch0 = time.time()
+    windows = {"refit_gram": [], "cholesky_chain": []}     # per job: wall window the concurrent brackets of a class span (ms)
+    cd_steps_ns = {}                                        # channel count -> [ns per coordinate step, in the job]
     for _ in range(args.steps):
         for _ in range(reps):
+            if roots:
+                roots[0].stage_epoch()       # one clock for the brackets of all the layers' streams (cp_last_stage_spans)
             results = one_job()
             if env.dist is not None:
                 exch_ms.append(shard.LAST_EXCHANGE_MS.get("total", 0.0))
+            span = {"refit_gram": [], "cholesky_chain": []}
             for j, pr in probs.items():
-                for name, ms in pr.ctx.last_stage_times():
+                for name, ms, begin in pr.ctx.last_stage_spans(roots[0]):
                     if name == "refit_gram_gemm":
                         g_ms.append(ms)
                         g_fl.append(float(pr.N) * int(pr.refit_info.p) ** 2)
                         cls_ms["refit_gram"].append(ms)
+                        span["refit_gram"].append((begin, begin + ms))
                     elif name == "cd_alpha_search":
                         cls_ms["alpha_search"].append(ms)
+                        steps_ = sum(f[2] for f in pr.fits) * pr.c
+                        if steps_ > 0:
+                            cd_steps_ns.setdefault(pr.c, []).append(ms * 1e6 / steps_)
                     elif name == "refit_cholesky":
                         cls_ms["cholesky_chain"].append(ms)
                         pp = float(int(pr.refit_info.p))
                         chol_fl.append(pp ** 3 / 3.0 + pp * pp * float(pr.n))    # + the forward substitution riding along
+                        span["cholesky_chain"].append((begin, begin + ms))
                     elif name == "refit_solve":
                         cls_ms["backward_substitution"].append(ms)
+            for k_, v_ in span.items():
+                if v_ and min(b for b, _ in v_) >= 0:
+                    windows[k_].append(max(e for _, e in v_) - min(b for b, _ in v_))
     sync_all()
     env.barrier()
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
@@ -648,7 +699,7 @@ def bench_job(args, env, job):
         fl = [layer_flops(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         by = [algorithmic_bytes(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
-        roof = roofline_object(cls_ms, g_fl, chol_fl, jobs, roots[0], PROFILE_TAG, job)
+        roof = roofline_object(cls_ms, g_fl, chol_fl, jobs, roots[0], PROFILE_TAG, job, windows=windows, cd_steps_ns=cd_steps_ns)
         if roof is not None and alone_g_ms:
             a1 = sum(alone_g_fl) / (sum(alone_g_ms) * 1e-3) / 1e12
             roof["alone"] = {"refit_gram": {"achieved": round(a1, 3), "frac": round(a1 / F64_MFMA_PEAK_TFLOPS, 4),
@@ -1315,6 +1366,13 @@ def main():
                 single, group = block_single_instance(env.local_rank)
                 close_workers(group)
                 out["conv3_block_single_instance"] = single
+                # north_star's headline shape (BASELINE.json configs[1]: the conv3_x block, rank = c / 2, 5000 samples, one
+                # MI355X) as a first-class number next to `value` (configs[2] on one GPU): layers/s of ONE instance of the
+                # block, its three layers side by side, masks checked against the reference goldens L01..L03
+                out["value_conv3_block"] = {"value": single["layers_per_s"], "unit": "layers/s", "ms_per_pass": single["ms_per_pass"],
+                                            "mask_parity_vs_reference_golden": single["mask_parity_vs_reference_golden"],
+                                            "workload": "conv3_x block (conv2_2->conv3_1 c=128, conv3_1->conv3_2 and "
+                                                        "conv3_2->conv3_3 c=256; n=256, k=3, rank=c/2), N=5000, one instance"}
             if not args.no_gather:
                 out["patch_gather"] = bench_patch_gather(env.local_rank)
     else:

@@ -121,6 +121,9 @@ SIGNATURES = {
     "cp_last_stage_times": (_c_int, [_vp, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_float)]),
     "cp_stage_name": (ctypes.c_char_p, [_vp, _c_int]),
     "cp_enable_stage_timing": (_c_int, [_vp, _c_int]),
+    "cp_stage_epoch": (_c_int, [_vp]),
+    "cp_last_stage_spans": (_c_int, [_vp, _vp, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_float),
+                                     ctypes.POINTER(ctypes.c_float)]),
 }
 
 _lib = None
@@ -589,6 +592,18 @@ class Context:
         ms = (ctypes.c_float * CP_MAX_STAGES)()
         self._check(self.lib.cp_last_stage_times(self.h, ctypes.byref(cnt), ms), "cp_last_stage_times")
         return [(self.lib.cp_stage_name(self.h, i).decode(), float(ms[i])) for i in range(cnt.value)]
+
+    def stage_epoch(self):
+        """the reference event of last_stage_spans(epoch_of=self): recorded on this context's stream now"""
+        self._check(self.lib.cp_stage_epoch(self.h), "cp_stage_epoch")
+
+    def last_stage_spans(self, epoch_of):
+        """-> [(stage name, ms, begin in ms after epoch_of.stage_epoch())]: the brackets of several contexts on one clock"""
+        cnt = _c_int()
+        ms = (ctypes.c_float * CP_MAX_STAGES)()
+        begin = (ctypes.c_float * CP_MAX_STAGES)()
+        self._check(self.lib.cp_last_stage_spans(self.h, epoch_of.h, ctypes.byref(cnt), ms, begin), "cp_last_stage_spans")
+        return [(self.lib.cp_stage_name(self.h, i).decode(), float(ms[i]), float(begin[i])) for i in range(cnt.value)]
 
 
 def device_count():

@@ -34,6 +34,7 @@
 // (rocprof timeline of the job: the first steps of a factorisation took 1.1-1.4 ms next to other layers' Gram GEMMs).
 #include "cp_common.h"
 
+#include <cstdlib>
 #include <mutex>
 
 typedef double v4f64s __attribute__((ext_vector_type(4)));
@@ -96,21 +97,37 @@ __device__ __forceinline__ double read_lane(double v, int lane) {   // lane: wav
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void flag_wait(const int *flag, int *info) {
-    for (int spin = 0; spin < (1 << 26); ++spin) {
-        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+// spin_limit: 1 << 26 polls of ~100 ns (seconds); 0 in the test of the time-out path (cp_debug_chol_fail_flag_wait)
+__device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_limit) {
+    // RELAXED agent-scope load (global_load ... sc1: never served from this XCD's non-coherent L2 lines).  An ACQUIRE here is a
+    // `buffer_inv sc1` after EVERY poll -- an invalidation of the whole L2 of the XCD, issued by ~35 panel workgroups for
+    // ~45 us per step, on top of the one all their waves issued after the wait: during a job's factorisation phase every
+    // XCD lost its L2 contents every microsecond or two, for every kernel running next to this one.  The operator the flag
+    // announces is read with sc1 loads as well (role_panel), so no fence is needed at all.
+    for (int spin = 0; spin < spin_limit; ++spin) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         __builtin_amdgcn_s_sleep(2);
     }
-    atomicCAS(info, 0, 0x7fffffff);  // never observed; the caller then reports a failed factorisation instead of hanging
+    // Not observed outside the test: the host reads info[0] != 0 as "this factorisation is not to be trusted" and the refit
+    // goes on to its rank-revealing path (refit.hip: refit_solve_tail -> refit_robust), which factors again -- a slower
+    // route to the same result, never a failed layer and never a hang.
+    atomicCAS(info, 0, 0x7fffffff);
 }
 
 // acc[t] (wave w: rows 16 t + fk + 4 r, column 16 w + fi of the tile) -= A^T B over K = 128 kcnt, A = U[r0 .., i-block], B = U[r0 .., j-block]
 // or, for a right-hand-side tile, Y[r0 .., j-block] (k-major blocks of kcnt consecutive block rows, leading dimensions ld / ldb).  Both operands go through LDS in chunks of KCH k-rows (wide coalesced
 // loads, the next chunk in flight while the current one is multiplied); SAME: A and B are the same block (diagonal tile),
 // and only the upper blocks t <= w are wanted.
+// Block column of the DIAGONAL tile a wave owns.  Column w has w + 1 upper blocks, and waves w and w + 4 share a SIMD: with
+// column = wave the four SIMDs carry 6 / 8 / 10 / 12 blocks of the K = 128 update (the serial piece of a step waits for the
+// last); with the columns handed out as 7, 6, 5, 4 | 0, 1, 2, 3 every SIMD carries 9.
+__device__ __forceinline__ int diag_col(int wave, int balanced) { return balanced ? (wave < 4 ? 7 - wave : wave - 4) : wave; }
+
 template <bool SAME>
-__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld, gcdp Bb, int ldb, int kcnt, double *sm) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld, gcdp Bb, int ldb, int kcnt, double *sm,
+                                            int balanced = 0) {
+    const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
+    const int wave = SAME ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6), balanced) : __builtin_amdgcn_readfirstlane(tid >> 6);
     double *As = sm, *Bs = SAME ? sm : sm + KCH * SLD;
     constexpr int PER = KCH * NB / 2 / PT;   // double2 loads per thread, operand and chunk (= 2)
     v2f64s ar[PER], br[PER];
@@ -157,8 +174,9 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld
 //   diag_factor_lds  U_ss^T U_ss = S in LDS.  The 16-column panel loop is the one of rounds 1-3 (wave 0 factors the 16 x 16
 //                    diagonal block in registers, one thread per column solves U12, all waves apply the rank-16 update on MFMA)
 //   diag_output      U[s,s] (upper, zeros below), T_p = U_pp^-1 into the diagonal slots, the operator P[s], the flag
-__device__ __forceinline__ void diag_to_lds(v4f64s (&acc)[NPAN], double *sm, gcdp dg0_blk) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+__device__ __forceinline__ void diag_to_lds(v4f64s (&acc)[NPAN], double *sm, gcdp dg0_blk, int balanced) {
+    const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
+    const int wave = diag_col(__builtin_amdgcn_readfirstlane(tid >> 6), balanced);
     double *dref = sm + PACK + NB;
 #pragma unroll
     for (int t = 0; t < NPAN; ++t) {
@@ -256,6 +274,157 @@ __device__ __noinline__ void diag_factor_lds(double *sm, double piv_tol, int *in
 
 }
 
+// ---- the diagonal role, second form (round 5): look-ahead over the 16-column panels ---------------------------------------
+// What the first form leaves on the chain per panel: the 16 x 16 factorisation by ONE wave while seven wait at a barrier, the
+// U12 substitution as one thread per column (16 dependent steps of LDS broadcasts), the trailing update, three barriers; then,
+// after the last panel, the inversion of the eight diagonal blocks, U[s,s] and the operator to global memory, the flag.
+// Here:
+//   * the in-register factorisation of a diagonal block carries the identity along (the same row operations): it ends with
+//     U_pp AND U_pp^-T = T_p^T in registers, so T_p goes straight to its slot of the operator and no inversion pass is left;
+//   * U_pj = T_p^T A_pj is four MFMAs per 16 x 16 block (wave per block column) instead of a thread per column;
+//   * wave 0 applies panel p to block (p + 1, p + 1) FIRST and factors it while waves 1 .. 7 apply panel p to the other 27
+//     (... 0) blocks: the factorisation of the next diagonal block hides the trailing update (or the other way round);
+//   * U[s,s] and the operator leave for global memory block by block as they become final (fire-and-forget stores issued by
+//     the wave that holds the block in registers); after the last panel only the flag is left.
+// Two barriers per panel.  LDS as before: the packed upper triangle; the diagonal slots end up holding T_p.
+__device__ __forceinline__ void store_block_global(gdp Ub, CP_GLOBAL unsigned long long *Go, int ld, int bi, int bj, const v4f64s &y,
+                                                   int fk, int fi, bool upper_only) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * bi + fk + 4 * r, col = 16 * bj + fi;
+        const double v = (upper_only && fi < fk + 4 * r) ? 0.0 : y[r];
+        Ub[row * ld + col] = v;                                            // U[s,s]
+        if (Go) __hip_atomic_store(Go + row * ld + col, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);              // operator: strictly upper blocks of U_ss
+    }
+}
+
+// wave 0: v = the (fully updated) diagonal block p in the D lay-out -> U_pp (global U[s,s]), T_p (LDS slot + operator)
+__device__ __forceinline__ void factor_block_inreg(v4f64s v, double *sm, int p, double piv_tol, int *info, int blk, gdp Ub,
+                                                   CP_GLOBAL unsigned long long *Go, int ld, int lane, int fk, int fi) {
+    const double *dref = sm + PACK + NB;
+    const int k0 = p * PNB;
+    v4f64s w;                                   // the identity carried along: ends as U_pp^-T (lower triangular)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = (fk + 4 * r == fi) ? 1.0 : 0.0;
+    const double refv = dref[k0 + fi];
+#pragma unroll
+    for (int k = 0; k < PNB; ++k) {
+        const int kr = k >> 2, kq = k & 3, src = kq * 16 + k;
+        double piv = read_lane(v[kr], src);
+        const double ref = read_lane(refv, k);
+        if (!(piv > piv_tol * ref)) {   // wave-uniform
+            if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
+            piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
+        }
+        const double inv = rsqrt_nr(piv);
+        if (fk == kq) {
+            v[kr] = fi == k ? piv * inv : v[kr] * inv;      // row k of U (columns >= k meaningful)
+            w[kr] = w[kr] * inv;                            // row k of U^-T
+        }
+        const double urow = __shfl(v[kr], kq * 16 + fi, 64);           // U[k, fi]
+        const double xrow = __shfl(w[kr], kq * 16 + fi, 64);           // U^-T[k, fi]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double ucol = __shfl(v[kr], kq * 16 + fk + 4 * r, 64);   // U[k, fk + 4 r]
+            if (fk + 4 * r > k) {
+                v[r] = fma(-ucol, urow, v[r]);
+                w[r] = fma(-ucol, xrow, w[r]);
+            }
+        }
+    }
+    double *Dp = sm + pk(p, p) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = fk + 4 * r;
+        Dp[fi * 16 + row] = w[r];                                           // T_p[fi][row] = U^-T[row][fi]
+        Ub[(k0 + row) * ld + k0 + fi] = fi >= row ? v[r] : 0.0;             // U_pp, zeros below the diagonal
+        __hip_atomic_store(Go + (k0 + fi) * ld + k0 + row, (unsigned long long)__double_as_longlong(w[r]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);                       // operator, diagonal slot: T_p
+    }
+}
+
+__device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, int *info, int blk, double *Ub_, double *Gss_, int ld) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+    const gdp Ub = (gdp)Ub_;
+    CP_GLOBAL unsigned long long *const Go = (CP_GLOBAL unsigned long long *)Gss_;
+    // the blocks below the diagonal of U[s,s] are zero
+    for (int e = tid; e < 28 * 256; e += PT) {
+        const int r = (e >> 4) & 15, c = e & 15;
+        int a = 0, q = e >> 8;                  // the q-th of the 28 strictly upper block pairs (a, a + 1 + q') ...
+        while (q >= 7 - a) {
+            q -= 7 - a;
+            ++a;
+        }
+        Ub[(16 * (a + 1 + q) + r) * ld + 16 * a + c] = 0.0;   // ... mirrored: block row a + 1 + q, block column a
+    }
+    if (wave == 0) {
+        v4f64s v;
+        const double *D0 = sm + pk(0, 0) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = D0[(fk + 4 * r) * 16 + fi];
+        factor_block_inreg(v, sm, 0, piv_tol, info, blk, Ub, Go, ld, lane, fk, fi);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < NPAN; ++p) {
+        // phase A: U_pj = T_p^T A_pj, wave w -> block column p + 1 + w
+        const int j = p + 1 + wave;
+        if (j < NPAN) {
+            const double *Tp = sm + pk(p, p) * 256;
+            double *Cp = sm + pk(p, j) * 256;
+            v4f64s y = {0., 0., 0., 0.};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tp[(4 * r + fk) * 16 + fi], Cp[(4 * r + fk) * 16 + fi], y, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cp[(fk + 4 * r) * 16 + fi] = y[r];
+            store_block_global(Ub, Go, ld, p, j, y, fk, fi, false);
+        }
+        __syncthreads();
+        if (p + 1 >= NPAN) break;
+        // phase B: wave 0 takes block (p + 1, p + 1) -- update, then factor -- the others the rest of the trailing blocks
+        const int rt = NPAN - p - 1;                     // trailing grid: rt x rt blocks, upper triangle
+        if (wave == 0) {
+            const double *Rq = sm + pk(p, p + 1) * 256;
+            const double *Cq = sm + pk(p + 1, p + 1) * 256;
+            v4f64s c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = Cq[(fk + 4 * r) * 16 + fi];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double rv = Rq[(kk * 4 + fk) * 16 + fi];
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(-rv, rv, c, 0, 0, 0);
+            }
+            factor_block_inreg(c, sm, p + 1, piv_tol, info, blk, Ub, Go, ld, lane, fk, fi);
+        } else {
+            const int ntile = rt * (rt + 1) / 2;
+            for (int e = wave; e < ntile; e += PT / 64 - 1) {        // e = 0 is wave 0's block
+                int a = int((sqrtf(8.f * float(e) + 1.f) - 1.f) * 0.5f);
+                while ((a + 1) * (a + 2) / 2 <= e) ++a;
+                while (a * (a + 1) / 2 > e) --a;
+                const int b = e - a * (a + 1) / 2;  // b <= a
+                const int bi = p + 1 + b, bj = p + 1 + a;
+                double *Cij = sm + pk(bi, bj) * 256;
+                const double *Ri = sm + pk(p, bi) * 256, *Rj = sm + pk(p, bj) * 256;
+                v4f64s c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[r] = Cij[(fk + 4 * r) * 16 + fi];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ri[(kk * 4 + fk) * 16 + fi], Rj[(kk * 4 + fk) * 16 + fi], c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cij[(fk + 4 * r) * 16 + fi] = c[r];
+            }
+        }
+        __syncthreads();
+    }
+    // every wave's stores of the operator have to be out before the flag goes up (see diag_output)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __noinline__ void diag_output(double *sm, double *Ub_, int ld, double *Gss_, int *info, int blk) {
     const gdp Ub = (gdp)Ub_, Gss = (gdp)Gss_;
     const int tid = threadIdx.x;
@@ -287,13 +456,24 @@ __device__ __noinline__ void diag_output(double *sm, double *Ub_, int ld, double
         for (int i = 0; i < PNB; ++i) Dp[i * 16 + j] = tcol[i];
     }
     __syncthreads();
-    // the operator goes where the tile came from: block (bi, bj) of G[s,s] (dead from here on) -- 16 lanes per 128-byte row
-    for (int e = tid; e < PACK; e += PT) {
-        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        Gss[size_t(16 * pk_bi(b) + r) * ld + 16 * pk_bj(b) + c] = sm[e];
+    // the operator goes where the tile came from: block (bi, bj) of G[s,s] (dead from here on) -- 16 lanes per 128-byte row.
+    // Hand-off to the panel workgroups (other CUs, other XCDs = other L2s) without fences: the operator is written with
+    // relaxed agent-scope atomics (global_store ... sc1: write-through) and read with sc1 loads (role_panel); every wave
+    // waits for ITS stores (vmcnt) before the barrier, then thread 0 raises the flag the same way.  An agent-scope release /
+    // acquire pair would be a write-back / invalidation of the whole L2 of the XCD (gemm_f64.hip tells what that costs).
+    {
+        typedef CP_GLOBAL unsigned long long *gup;
+        const gup Go = (gup)Gss_;
+#pragma unroll
+        for (int i = 0; i < PACK / PT; ++i) {
+            const int e = tid + PT * i, b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            __hip_atomic_store(Go + (16 * pk_bi(b) + r) * ld + 16 * pk_bj(b) + c, (unsigned long long)__double_as_longlong(sm[e]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // U[s,j] = U_ss^-T S for the tile in `acc`: block forward substitution over the eight 16-row blocks with the operator in
@@ -384,11 +564,11 @@ __device__ __noinline__ void diag_inverse(const double *sm, double *TIb_, double
 }
 
 #ifdef CP_CHOL_STAMPS   // diagnostic build (tools/ubench/chol_bulk.hip): shader-clock stamps of the phases of a bulk workgroup
-__device__ unsigned long long cp_chol_stamps[4096 * 4];
+__device__ unsigned long long cp_chol_stamps[4096 * 8];
 #define CP_STAMP(slot)                                                                                       \
     do {                                                                                                     \
         __builtin_amdgcn_s_waitcnt(0);                                                                       \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) cp_chol_stamps[blockIdx.x * 4 + (slot)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) cp_chol_stamps[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define CP_STAMP(slot) do { } while (0)
@@ -405,9 +585,11 @@ struct Tile {
 
 // acc <- the tile, then the pending updates (see the head of the file)
 template <bool DIAG>
-__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *Ai_, int ld, double *sm) {
+__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *Ai_, int ld, double *sm,
+                                                 int balanced = 0) {
     const gcdp T = (gcdp)t_.T, Bop = (gcdp)t_.B, Ai = (gcdp)Ai_;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
+    const int wave = DIAG ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6), balanced) : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int toff = fk * t_.ldt + 16 * wave + fi;   // lane's offset inside a (16 t + 4 r)-row band of the tile: scalar base + 32-bit offset
 #pragma unroll
     for (int t = 0; t < NPAN; ++t) {
@@ -419,7 +601,7 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile
         for (int r = 0; r < 4; ++r) acc[t][r] = (T + size_t(16 * t + 4 * r) * t_.ldt)[toff];
     }
     CP_STAMP(1);
-    if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm);
+    if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm, balanced);
     CP_STAMP(2);
 }
 
@@ -444,34 +626,58 @@ __device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const 
 __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const double *__restrict__ Ai, double *__restrict__ Uss,
                                                                  int ld, int s, const double *__restrict__ dg0, double piv_tol,
                                                                  double *__restrict__ TIb, double *__restrict__ TITb, int *info,
-                                                                 double *sm) {
+                                                                 int form, double *sm) {
+    CP_STAMP(0);
     {
         v4f64s acc[NPAN];
-        tile_load_update<true>(acc, t_, Ai, ld, sm);
-        diag_to_lds(acc, sm, (gcdp)dg0 + size_t(s) * NB);
+        tile_load_update<true>(acc, t_, Ai, ld, sm, form & 2);
+        diag_to_lds(acc, sm, (gcdp)dg0 + size_t(s) * NB, form & 2);
     }
-    diag_factor_lds(sm, piv_tol, info, s);
-    diag_output(sm, Uss, ld, t_.T, info, s);     // ... and the flag: the panel workgroups go on from here
+    CP_STAMP(3);
+    if (form & 1) {     // look-ahead form: U[s,s], the operator and the flag leave from inside
+        diag_factor_lookahead(sm, piv_tol, info, s, Uss, t_.T, ld);
+        CP_STAMP(4);
+    } else {
+        diag_factor_lds(sm, piv_tol, info, s);
+        CP_STAMP(4);
+        diag_output(sm, Uss, ld, t_.T, info, s);     // ... and the flag: the panel workgroups go on from here
+    }
+    CP_STAMP(5);
     diag_inverse(sm, TIb, TITb);
+    CP_STAMP(6);
     __builtin_amdgcn_endpgm();
 }
 
 // out / ldo: where U[s,j] (or Y[s,jr]) goes; Ltjs: the transposed copy of a factor tile, null for a right-hand side
 __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const double *__restrict__ Ai, int ld, int s,
                                                                   double *__restrict__ out, int ldo, double *__restrict__ Ltjs,
-                                                                  const double *__restrict__ Gss, int *info, double *sm) {
+                                                                  const double *__restrict__ Gss, int *info, int spin_limit,
+                                                                  double *sm) {
     const int tid = threadIdx.x;
     v4f64s acc[NPAN];
+    CP_STAMP(0);
     tile_load_update<false>(acc, t_, Ai, ld, sm);
-    if (tid == 0) flag_wait(info + 1 + s, info);  // bounded; running out is reported as a failed factorisation
+    if (tid == 0) flag_wait(info + 1 + s, info, spin_limit);  // bounded; running out is reported as a failed factorisation
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int e = tid; e < PACK / 2; e += PT) {   // the operator of block s, left in G[s,s] by the diagonal role
-        const int b = e >> 7, r = (e >> 3) & 15, c = (e & 7) * 2;
-        reinterpret_cast<v2f64s *>(sm)[e] = *(gcv2p)((gcdp)Gss + size_t(16 * pk_bi(b) + r) * ld + 16 * pk_bj(b) + c);
+    CP_STAMP(3);
+    // the operator of block s, left in G[s,s] by the diagonal role of this launch: sc1 loads (see flag_wait), 18 per thread
+    {
+        static_assert(PACK % PT == 0, "operator words per thread");
+        typedef const CP_GLOBAL unsigned long long *gcup;
+        const gcup Go = (gcup)Gss;
+        unsigned long long w[PACK / PT];
+#pragma unroll
+        for (int i = 0; i < PACK / PT; ++i) {      // all the loads in flight together
+            const int e = tid + PT * i, b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            w[i] = __hip_atomic_load(Go + (16 * pk_bi(b) + r) * ld + 16 * pk_bj(b) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < PACK / PT; ++i) sm[tid + PT * i] = __longlong_as_double((long long)w[i]);
     }
     __syncthreads();
+    CP_STAMP(4);
     panel_solve(acc, sm, (gdp)out, ldo, (gdp)Ltjs, ld);
+    CP_STAMP(5);
     __builtin_amdgcn_endpgm();
 }
 
@@ -481,7 +687,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
 __global__ void __launch_bounds__(PT, 4)
 k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int s,
             const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, double *__restrict__ TIT, int *info,
-            double *__restrict__ R, int ldr, int ntr) {
+            double *__restrict__ R, int ldr, int ntr, int prio, int spin_limit, int diag_form) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     int i = s, jt;
     {   // tile -> (i, jt): block row i holds nblk - i factor tiles, then ntr right-hand-side tiles; row s first.
@@ -518,15 +724,19 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
         t_.ldb = ld;
     }
     const double *Gss = G + size_t(s) * NB * ld + size_t(s) * NB;   // where the diagonal role leaves the operator of block s
+    // The workgroups of block row s are the serial piece of the step: their waves get the higher issue priority over the
+    // bulk workgroups (of this or any other layer's launch) that share their SIMDs (CP_CHOL_PRIO, default on).
+    if (prio && i == s) __builtin_amdgcn_s_setprio(3);
     if (i > s)            // below the block row of this step: the updated tile goes back
         role_bulk(t_, Ai, ld, s, sm);
     else if (!rhs && j == s)
         role_diag(t_, Ai, U + size_t(s) * NB * ld + size_t(s) * NB, ld, s, dg0, piv_tol, TI + size_t(s) * NB * NB,
-                  TIT + size_t(s) * NB * NB, info, sm);
+                  TIT + size_t(s) * NB * NB, info, diag_form, sm);
     else if (!rhs)
-        role_panel(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB, Gss, info, sm);
+        role_panel(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB, Gss, info,
+                   spin_limit, sm);
     else
-        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, sm);
+        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, spin_limit, sm);
 }
 
 hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explicit opt-in, once per device
@@ -553,14 +763,59 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     CP_HIP(ctx, lds_opt_in(ctx->device));
     const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
     const int ntr = R ? n_pad / NB : 0;
+    static const int prio = !(getenv("CP_CHOL_PRIO") && getenv("CP_CHOL_PRIO")[0] == '0');
+    // CP_CHOL_DIAG: bit 0 = look-ahead form of the 128 x 128 factorisation, bit 1 = balanced K = 128 update of the diagonal tile
+    static const int diag_form = getenv("CP_CHOL_DIAG") ? atoi(getenv("CP_CHOL_DIAG")) : 3;
+    int spin_limit = 1 << 26;
+    if (ctx->chol_test_fail_flag_waits > 0) {   // test hook: the panel workgroups of THIS factorisation give up at once
+        --ctx->chol_test_fail_flag_waits;
+        spin_limit = 0;
+    }
     for (int s = 0; s < nblk; ++s) {
         // block row s always; at even s >= 2 every tile below it (two block rows of updates at once), at odd s block row s + 1
         const int n = nblk - s;
         int tiles = n + ntr;
         if (s >= 2 && !(s & 1)) tiles = n * (n + 1) / 2 + n * ntr;
         else if ((s & 1) && n > 1) tiles += (n - 1) + ntr;
-        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, TIT, info, R, n_pad, ntr);
+        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, TIT, info, R, n_pad, ntr, prio, spin_limit, diag_form);
         CP_LAUNCH_CHECK(ctx);
     }
+    return CP_OK;
+}
+
+// Test hooks (not part of the public ABI).  cp_debug_chol_fail_flag_wait: the next `count` factorisations on this context run
+// with a spin limit of 0 -- their panel workgroups do not wait for the diagonal workgroup's flag, report the time-out in
+// info[0] and go on with whatever they find: the real time-out path of flag_wait.
+extern "C" int cp_debug_chol_fail_flag_wait(cp_ctx *ctx, int count) {
+    if (!ctx) return CP_ERR_ARG;
+    ctx->chol_test_fail_flag_waits = count;
+    return CP_OK;
+}
+
+namespace {
+__global__ void __launch_bounds__(256) k_lds_hog(unsigned long long ticks_100mhz, int *sink) {
+    extern __shared__ __attribute__((aligned(16))) double hog_sm[];
+    hog_sm[threadIdx.x] = double(threadIdx.x);     // the allocation is what matters: nothing else fits on the CU meanwhile
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(32);
+    if (hog_sm[(threadIdx.x + 1) & 255] < 0.0) sink[0] = 1;
+}
+}  // namespace
+
+// cp_debug_lds_hog: n_wg workgroups that each hold lds_bytes of LDS (up to 160 KB: a whole CU) for `usec` microseconds on
+// the context's stream -- a filler that keeps LDS-hungry workgroups of other launches (k_chol_step: 75 KB) off the CUs.
+extern "C" int cp_debug_lds_hog(cp_ctx *ctx, int lds_bytes, int usec, int n_wg) {
+    if (!ctx || lds_bytes < 2048 || lds_bytes > 160 * 1024 || usec < 0 || n_wg <= 0) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        CP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds_hog), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (cp_arena_reserve(ctx, 4096) != CP_OK) return CP_ERR_NOMEM;
+    k_lds_hog<<<n_wg, 256, size_t(lds_bytes), ctx->stream>>>(static_cast<unsigned long long>(usec) * 100ull,
+                                                              reinterpret_cast<int *>(ctx->arena));
+    CP_LAUNCH_CHECK(ctx);
     return CP_OK;
 }

@@ -78,6 +78,7 @@ struct cp_ctx {
     bool timing_gram_only = false;  // cp_enable_stage_timing(ctx, 2)
     int n_marks = 0;
     hipEvent_t ev[2 * CP_MAX_STAGES] = {};
+    hipEvent_t ev_epoch = nullptr;    // cp_stage_epoch: the common clock of several contexts' stage brackets
     const char *mark_names[2 * CP_MAX_STAGES] = {};
     int n_stages = 0;
     const char *stage_names[CP_MAX_STAGES] = {};
@@ -101,6 +102,7 @@ struct cp_ctx {
     hipEvent_t ev_upload = nullptr;    // the side-stream uploads of cp_prune_layer_h2d have landed
     bool last_cd_was_team = false;    // which kernel family the last coordinate-descent launch of THIS context ran (debug counters)
     int cd_fallbacks = 0;             // searches / fits re-run on the one-workgroup team after a hand-off time-out of the multi-CU team
+    int chol_test_fail_flag_waits = 0;   // cp_debug_chol_fail_flag_wait: that many factorisations run with a spin limit of 0 (tests)
     bool cd_test_fail_multi = false;  // cp_debug_cd_fail_multi: the next multi-CU launches give up at once (tests of that fallback)
 };
 

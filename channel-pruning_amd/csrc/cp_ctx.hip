@@ -138,6 +138,7 @@ extern "C" int cp_ctx_destroy(cp_ctx *ctx) {
     if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->stage) hipHostFree(ctx->stage);
     if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
+    if (ctx->ev_epoch) hipEventDestroy(ctx->ev_epoch);
     for (int i = 0; i < 2 * CP_MAX_STAGES; ++i)
         if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -282,35 +283,47 @@ extern "C" int cp_enable_stage_timing(cp_ctx *ctx, int on) {
     return CP_OK;
 }
 
-// Resolves and clears the marks recorded since the previous call (synchronises the stream).
-extern "C" int cp_last_stage_times(cp_ctx *ctx, int *count, float *ms) {
-    if (!ctx || !count || !ms) return CP_ERR_ARG;
+extern "C" int cp_stage_epoch(cp_ctx *ctx) {
+    if (!ctx) return CP_ERR_ARG;
+    CP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->ev_epoch) CP_HIP(ctx, hipEventCreate(&ctx->ev_epoch));
+    CP_HIP(ctx, hipEventRecord(ctx->ev_epoch, ctx->stream));
+    return CP_OK;
+}
+
+// Resolves and clears the marks recorded since the previous call (synchronises the stream).  epoch_of / begin_ms (both or
+// neither): when each bracket began, in ms after epoch_of's cp_stage_epoch (-1 where that cannot be told).
+extern "C" int cp_last_stage_spans(cp_ctx *ctx, cp_ctx *epoch_of, int *count, float *ms, float *begin_ms) {
+    if (!ctx || !count || !ms || (begin_ms != nullptr) != (epoch_of != nullptr)) return CP_ERR_ARG;
     CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipEvent_t epoch = epoch_of ? epoch_of->ev_epoch : nullptr;
+    if (epoch && hipEventSynchronize(epoch) != hipSuccess) epoch = nullptr;
     ctx->n_stages = 0;
-    for (int i = 1; i < ctx->n_marks && ctx->n_stages < CP_MAX_STAGES; ++i) {
-        if (!ctx->mark_names[i]) continue;
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, ctx->ev[i - 1], ctx->ev[i]) != hipSuccess) t = -1.f;
-        ctx->stage_names[ctx->n_stages] = ctx->mark_names[i];
-        ctx->stage_ms[ctx->n_stages] = t;
-        ++ctx->n_stages;
-    }
-    ctx->n_marks = 0;
-    if (cp_ctx *w = ctx->pre.worker) {   // the stages of the overlapped precompute (side stream) belong to this call too
-        hipStreamSynchronize(w->stream);
-        for (int i = 1; i < w->n_marks && ctx->n_stages < CP_MAX_STAGES; ++i) {
-            if (!w->mark_names[i]) continue;
-            float t = 0.f;
-            if (hipEventElapsedTime(&t, w->ev[i - 1], w->ev[i]) != hipSuccess) t = -1.f;
-            ctx->stage_names[ctx->n_stages] = w->mark_names[i];
+    auto resolve = [&](cp_ctx *c) {
+        for (int i = 1; i < c->n_marks && ctx->n_stages < CP_MAX_STAGES; ++i) {
+            if (!c->mark_names[i]) continue;
+            float t = 0.f, b = -1.f;
+            if (hipEventElapsedTime(&t, c->ev[i - 1], c->ev[i]) != hipSuccess) t = -1.f;
+            if (begin_ms && (!epoch || hipEventElapsedTime(&b, epoch, c->ev[i - 1]) != hipSuccess)) b = -1.f;
+            ctx->stage_names[ctx->n_stages] = c->mark_names[i];
             ctx->stage_ms[ctx->n_stages] = t;
+            if (begin_ms) begin_ms[ctx->n_stages] = b;
             ++ctx->n_stages;
         }
-        w->n_marks = 0;
+        c->n_marks = 0;
+    };
+    resolve(ctx);
+    if (cp_ctx *w = ctx->pre.worker) {   // the stages of the overlapped precompute (side stream) belong to this call too
+        hipStreamSynchronize(w->stream);
+        resolve(w);
     }
     *count = ctx->n_stages;
     for (int i = 0; i < ctx->n_stages; ++i) ms[i] = ctx->stage_ms[i];
     return CP_OK;
+}
+
+extern "C" int cp_last_stage_times(cp_ctx *ctx, int *count, float *ms) {
+    return cp_last_stage_spans(ctx, nullptr, count, ms, nullptr);
 }
 
 extern "C" const char *cp_stage_name(cp_ctx *ctx, int index) {

@@ -357,6 +357,13 @@ int cp_last_stage_times(cp_ctx *ctx, int *count, float *ms /* [CP_MAX_STAGES] */
 const char *cp_stage_name(cp_ctx *ctx, int index);
 int cp_enable_stage_timing(cp_ctx *ctx, int on); /* 0 off, 1 every stage, 2 only "refit_gram_gemm" (two events per
                                                    * call: each event is one more packet in the stream) */
+/* A common clock for the stage brackets of SEVERAL contexts (the layers of a job run on their own streams): cp_stage_epoch
+ * records a reference event on ctx's stream; cp_last_stage_spans is cp_last_stage_times that also returns, per stage, when
+ * its bracket BEGAN in ms after the epoch of `epoch_of` (another context of the same device, or ctx itself): the wall window
+ * that concurrent brackets span = max(begin + ms) - min(begin).  Used by bench.py for roofline.chip_level. */
+int cp_stage_epoch(cp_ctx *ctx);
+int cp_last_stage_spans(cp_ctx *ctx, cp_ctx *epoch_of, int *count, float *ms /* [CP_MAX_STAGES] */,
+                        float *begin_ms /* [CP_MAX_STAGES] */);
 
 #ifdef __cplusplus
 }

@@ -1228,3 +1228,105 @@ def test_alpha_carry_over_the_vgg16_job_matches_the_reference_chain(ctx):
         assert relfro(wm @ cp_oracle.sketch_matrix(wm.shape[1]), g["newW2_sketch_%02d" % i]) <= REL_W
         assert relfro(newB2, g["newB2_%02d" % i]) <= REL_W
     cfgs.alpha = 1e-3
+
+
+def _chol_debug(ctx):
+    import ctypes
+    lib = ctx.lib
+    lib.cp_debug_chol_fail_flag_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cp_debug_chol_fail_flag_wait.restype = ctypes.c_int
+    lib.cp_debug_lds_hog.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.cp_debug_lds_hog.restype = ctypes.c_int
+    return lib
+
+
+@pytest.mark.parametrize("name", ["s02_c64_k3", "L02_conv3_1_conv3_2"])
+def test_chol_step_flag_wait_timeout_is_a_slower_route_not_a_failed_layer(name):
+    """k_chol_step's panel workgroups wait (bounded) for the diagonal workgroup of their own launch.  When that wait runs out
+    -- forced here: cp_debug_chol_fail_flag_wait gives the next factorisation a spin limit of 0, the real time-out path -- the
+    factorisation is reported as not trustworthy (info[0] != 0) and the refit takes its rank-revealing route, which factors
+    again: the layer still ends on the reference golden; cp_refit_info.fallback says which route produced it."""
+    from cpmi355 import capi
+    ctx = capi.default_context()
+    lib = _chol_debug(ctx)
+    g, p, X, W2, Y, B2 = load_case(name)
+    ctx._check(lib.cp_debug_chol_fail_flag_wait(ctx.h, 1), "cp_debug_chol_fail_flag_wait")
+    try:
+        got = _run_dropin(p, X, W2, Y, B2, "device", exact_ops=True)
+    finally:
+        lib.cp_debug_chol_fail_flag_wait(ctx.h, 0)
+    _check_against_golden(g, p, got)
+    assert got[5]["fallback"] != 0            # the plain normal-equation route did not produce this result
+    got = _run_dropin(p, X, W2, Y, B2, "device", exact_ops=True)
+    _check_against_golden(g, p, got)
+    assert got[5]["fallback"] == 0            # the hook was one-shot
+
+
+def test_chol_step_flag_wait_on_a_chip_saturated_with_lds_hungry_workgroups():
+    """The in-launch dependency of k_chol_step (panel workgroups spin on the flag of workgroup 0 of their own launch) while
+    the chip is held by fillers that take a whole CU's LDS each: eight streams relaunch 256 workgroups x 150 KB of LDS that
+    stay 300 us, so a 75 KB factorisation workgroup only gets a CU in the gaps between fillers, one at a time -- and twelve
+    c = 256 / c = 512 refits run on streams of their own meanwhile.  Every refit equals the one computed on the idle chip bit
+    for bit, no CP_ERR_NUMERIC, no time-out (fallback == 0)."""
+    import threading
+    import cpmi355
+    import cp_oracle
+    from cpmi355 import capi
+    main = capi.default_context()
+    lib = _chol_debug(main)
+    rs = np.random.RandomState(11)
+    cases = []
+    for c, n in ((256, 256), (512, 512), (256, 256)):
+        X, W2, Y, _ = cp_oracle.synth_layer(400 + c, 5000, c, n, 3)
+        mask = rs.rand(c) < 0.87
+        cases.append((X, W2, Y, mask))
+    workers = [cpmi355.Context(0) for _ in range(12)]
+    probs = [cpmi355.LayerProblem(cx, *cases[i % 3][:3]) for i, cx in enumerate(workers)]
+    quiet = [pr.refit(cases[i % 3][3]) for i, pr in enumerate(probs)]          # idle chip
+    hogs = [cpmi355.Context(0) for _ in range(8)]
+    stop = threading.Event()
+    errors, results = [], [None] * len(workers)
+
+    def hog(cx):
+        try:
+            while not stop.is_set():
+                cx._check(lib.cp_debug_lds_hog(cx.h, 150 * 1024, 300, 256), "cp_debug_lds_hog")
+                cx.sync()
+        except Exception as e:                # noqa: BLE001
+            errors.append(e)
+
+    def refit(i):
+        try:
+            out = []
+            for _ in range(2):
+                W, b = probs[i].refit(cases[i % 3][3])
+                out.append((W, b, int(probs[i].refit_info.fallback)))
+            results[i] = out
+        except Exception as e:                # noqa: BLE001
+            errors.append(e)
+
+    hog_threads = [threading.Thread(target=hog, args=(cx,), daemon=True) for cx in hogs]
+    for t in hog_threads:
+        t.start()
+    try:
+        threads = [threading.Thread(target=refit, args=(i,)) for i in range(len(workers))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+    finally:
+        stop.set()
+        for t in hog_threads:
+            t.join(timeout=60)
+    try:
+        assert not errors, errors
+        for i, out in enumerate(results):
+            assert out is not None
+            for W, b, fb in out:
+                assert fb == 0
+                assert np.array_equal(W, quiet[i][0]) and np.array_equal(b, quiet[i][1])
+    finally:
+        for pr in probs:
+            pr.free()
+        for cx in workers + hogs:
+            cx.close()

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 
+int cp_arena_reserve(cp_ctx *, size_t) { return CP_ERR_NOMEM; }   // only cp_debug_lds_hog wants it (not used here)
 int cp_set_error(cp_ctx *, int code, const char *fmt, ...) {
     fprintf(stderr, "cp_set_error %d: %s\n", code, fmt);
     return code;
@@ -25,7 +26,9 @@ __global__ void k_diag(const double *G, int p, double *dg0) {
     if (i < p) dg0[i] = G[size_t(i) * p + i];
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const int prio = argc > 1 ? atoi(argv[1]) : 1;
+    const int form = argc > 2 ? atoi(argv[2]) : 3;
     const int nblk = 36, p = nblk * NB;
     double *G, *U, *Lt, *TI, *TIT, *dg0;
     int *info;
@@ -43,7 +46,7 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    std::vector<unsigned long long> st(4096 * 4);
+    std::vector<unsigned long long> st(4096 * 8), st5(4096 * 8);
     for (int pass = 0; pass < 2; ++pass) {
         k_fill<<<2048, 256>>>(G, p);
         k_diag<<<(p + 255) / 256, 256>>>(G, p, dg0);
@@ -57,7 +60,7 @@ int main() {
             if (s >= 2 && !(s & 1)) tiles = n * (n + 1) / 2;
             else if ((s & 1) && n > 1) tiles += n - 1;
             hipEventRecord(e0);
-            k_chol_step<<<tiles, PT, lds>>>(G, U, Lt, p, nblk, s, dg0, 1e-12, TI, TIT, info, nullptr, 0, 0);
+            k_chol_step<<<tiles, PT, lds>>>(G, U, Lt, p, nblk, s, dg0, 1e-12, TI, TIT, info, nullptr, 0, 0, prio, 1 << 26, form);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
@@ -65,17 +68,46 @@ int main() {
             total += ms;
             if (pass && (s < 12 || s % 4 == 0)) printf("| %d | %d | %.1f |\n", s, tiles, ms * 1e3);
             if (pass && s == 4) hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(cp_chol_stamps), st.size() * 8);
+            if (pass && s == 5) hipMemcpyFromSymbol(st5.data(), HIP_SYMBOL(cp_chol_stamps), st5.size() * 8);
         }
         int h[4];
         hipMemcpy(h, info, 16, hipMemcpyDeviceToHost);
         if (pass) printf("\nall %d steps: %.3f ms (info[0] = %d)\n", nblk, total, h[0]);
+    }
+    {   // correctness of the factor this run left: U^T U against the matrix k_fill builds, U strictly upper-zero below the
+        // diagonal, TI_b U_bb = I and the operator's diagonal slots (sampled; host arithmetic)
+        std::vector<double> hU(size_t(p) * p), hTI(size_t(nblk) * NB * NB);
+        hipMemcpy(hU.data(), U, hU.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(hTI.data(), TI, hTI.size() * 8, hipMemcpyDeviceToHost);
+        double worst = 0, lower = 0, inv_err = 0;
+        unsigned rs = 12345u;
+        auto rnd = [&](int m) { rs = rs * 1664525u + 1013904223u; return int((rs >> 8) % unsigned(m)); };
+        for (int t = 0; t < 3000; ++t) {
+            int i = rnd(p), j = rnd(p);
+            if (t < 600) j = std::min(p - 1, i + rnd(40));          // near the diagonal, inside diagonal tiles
+            if (i > j) std::swap(i, j);
+            double acc = 0;
+            for (int k = 0; k <= i; ++k) acc += hU[size_t(k) * p + i] * hU[size_t(k) * p + j];
+            const double want = i == j ? 2.0 * p : sin(1e-3 * double(i + 1) * double(j + 1));
+            worst = std::max(worst, fabs(acc - want));
+            if (i != j && (i / NB) == (j / NB)) lower = std::max(lower, fabs(hU[size_t(j) * p + i]));   // inside a diagonal tile, below the diagonal
+        }
+        for (int b = 0; b < nblk; b += 7)
+            for (int t = 0; t < 400; ++t) {
+                const int i = rnd(NB), j = rnd(NB);
+                double acc = 0;
+                for (int k = 0; k < NB; ++k) acc += hTI[size_t(b) * NB * NB + size_t(i) * NB + k] * hU[size_t(b * NB + k) * p + b * NB + j];
+                inv_err = std::max(inv_err, fabs(acc - (i == j ? 1.0 : 0.0)));
+            }
+        printf("\ncheck: max |U^T U - G| = %.3e (|G_ii| = %.0f), max |U| below the diagonal inside diagonal tiles = %.3e, "
+               "max |TI_b U_bb - I| = %.3e\n", worst, 2.0 * p, lower, inv_err);
     }
     // step 4: workgroups [0, 32) are block row 4 (diagonal + panels), the rest bulk tiles with K = 256
     const int n4 = nblk - 4, tiles4 = n4 * (n4 + 1) / 2;
     std::vector<double> load, upd, store, all;
     unsigned long long first = ~0ull, last = 0;
     for (int w = n4; w < tiles4; ++w) {
-        const unsigned long long *q = &st[size_t(w) * 4];
+        const unsigned long long *q = &st[size_t(w) * 8];
         if (!q[0] || !q[3]) continue;
         load.push_back(double(q[1] - q[0]));
         upd.push_back(double(q[2] - q[1]));
@@ -90,5 +122,26 @@ int main() {
     printf("| tile load | update loop (16 chunks) | store | whole |\n|---|---|---|---|\n");
     printf("| %.0f / %.0f | %.0f / %.0f | %.0f / %.0f | %.0f / %.0f |\n", med(load), mx(load), med(upd), mx(upd), med(store),
            mx(store), med(all), mx(all));
+    // step 5 (odd: block row 5 + block row 6 riding along, no other bulk): the serial piece, phase by phase
+    {
+        const unsigned long long *d = &st5[0];
+        printf("\nstep 5, diagonal workgroup (cycles): tile load %llu | K=128 update %llu | to LDS %llu | 128x128 factorisation %llu | "
+               "output + flag %llu | inverse (off the chain) %llu\n", d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4],
+               d[6] - d[5]);
+        std::vector<double> upd, wait, opl, solve, whole;
+        const int n5 = nblk - 5;
+        for (int w = 1; w < n5; ++w) {
+            const unsigned long long *q = &st5[size_t(w) * 8];
+            if (!q[0] || !q[5]) continue;
+            upd.push_back(double(q[2] - q[0]));
+            wait.push_back(double(q[3] - q[2]));
+            opl.push_back(double(q[4] - q[3]));
+            solve.push_back(double(q[5] - q[4]));
+            whole.push_back(double(q[5] - d[0]));
+        }
+        printf("step 5, %zu panel workgroups (median / max cycles): load + update %.0f / %.0f | wait for the flag %.0f / %.0f | operator "
+               "load %.0f / %.0f | substitution + stores %.0f / %.0f | end of the panel since the start of the diagonal workgroup %.0f / %.0f\n",
+               upd.size(), med(upd), mx(upd), med(wait), mx(wait), med(opl), mx(opl), med(solve), mx(solve), med(whole), mx(whole));
+    }
     return 0;
 }
