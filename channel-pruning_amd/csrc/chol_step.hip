@@ -43,7 +43,8 @@ typedef double v2f64s __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int NB = 128, PNB = 16, NPAN = NB / PNB, PT = 512;
-constexpr int KCH = 16;                      // k-rows of an operand chunk staged through LDS (two double2 per thread and operand)
+constexpr int KCH_BASE = 16;                 // k-rows of an operand chunk staged through LDS (two double2 per thread and operand)
+constexpr int KCH = KCH_BASE;
 constexpr int SLD = NB + 16;                 // padded chunk row: the two k-rows a 32-lane half reads fall on disjoint bank halves
 constexpr int PACK = 36 * PNB * PNB;         // packed upper triangle of a 128 x 128 tile in 16 x 16 blocks
 constexpr int LDS_DOUBLES = PACK + 2 * NB;   // + dinv[128] + dref[128]
@@ -98,14 +99,14 @@ __device__ __forceinline__ double read_lane(double v, int lane) {   // lane: wav
 }
 
 // spin_limit: 1 << 26 polls of ~100 ns (seconds); 0 in the test of the time-out path (cp_debug_chol_fail_flag_wait)
-__device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_limit) {
+__device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_limit, int want = 1) {
     // RELAXED agent-scope load (global_load ... sc1: never served from this XCD's non-coherent L2 lines).  An ACQUIRE here is a
     // `buffer_inv sc1` after EVERY poll -- an invalidation of the whole L2 of the XCD, issued by ~35 panel workgroups for
     // ~45 us per step, on top of the one all their waves issued after the wait: during a job's factorisation phase every
     // XCD lost its L2 contents every microsecond or two, for every kernel running next to this one.  The operator the flag
     // announces is read with sc1 loads as well (role_panel), so no fence is needed at all.
     for (int spin = 0; spin < spin_limit; ++spin) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return;
         __builtin_amdgcn_s_sleep(2);
     }
     // Not observed outside the test: the host reads info[0] != 0 as "this factorisation is not to be trusted" and the refit
@@ -128,8 +129,11 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld
                                             int balanced = 0) {
     const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
     const int wave = SAME ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6), balanced) : __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the diagonal tile stages ONE operand, so its chunks can be twice as deep in the same LDS: 4 instead of 8 chunks (two
+    // barriers and an exposed LDS / global latency each) on the serial piece of the step
+    constexpr int KCH = SAME ? 2 * KCH_BASE : KCH_BASE;
     double *As = sm, *Bs = SAME ? sm : sm + KCH * SLD;
-    constexpr int PER = KCH * NB / 2 / PT;   // double2 loads per thread, operand and chunk (= 2)
+    constexpr int PER = KCH * NB / 2 / PT;   // double2 loads per thread, operand and chunk (2; 4 for the diagonal tile)
     v2f64s ar[PER], br[PER];
     // uniform base + 32-bit lane offset: the loads take the scalar-base form instead of a 64-bit address pair per load
     const int goff = (tid >> 6) * ld + (tid & 63) * 2;   // thread's (row, column pair) inside a chunk; +8 rows per i
@@ -274,6 +278,16 @@ __device__ __noinline__ void diag_factor_lds(double *sm, double piv_tol, int *in
 
 }
 
+#ifdef CP_CHOL_STAMPS   // diagnostic build (tools/ubench/chol_bulk.hip): where the look-ahead factorisation spends its cycles
+__device__ unsigned long long cp_chol_diag_stamps[128];
+#define CP_DSTAMP(slot, who)                                                                                  \
+    do {                                                                                                      \
+        if (threadIdx.x == (who)) cp_chol_diag_stamps[(slot)] = __builtin_readcyclecounter();                 \
+    } while (0)
+#else
+#define CP_DSTAMP(slot, who) do { } while (0)
+#endif
+
 // ---- the diagonal role, second form (round 5): look-ahead over the 16-column panels ---------------------------------------
 // What the first form leaves on the chain per panel: the 16 x 16 factorisation by ONE wave while seven wait at a barrier, the
 // U12 substitution as one thread per column (16 dependent steps of LDS broadcasts), the trailing update, three barriers; then,
@@ -299,52 +313,89 @@ __device__ __forceinline__ void store_block_global(gdp Ub, CP_GLOBAL unsigned lo
     }
 }
 
-// wave 0: v = the (fully updated) diagonal block p in the D lay-out -> U_pp (global U[s,s]), T_p (LDS slot + operator)
+// wave 0: v = the (fully updated) diagonal block p in the D lay-out -> U_pp (global U[s,s]), T_p (LDS slot + operator).
+// A lone wave issues an instruction every ~7 cycles whatever it is, so a pivot costs what its instruction count costs (the
+// first version of this function: ~60 instructions, 550 cycles per pivot, 8.8k per block).  This one keeps the block UNSCALED
+// while it eliminates -- a[i][j] -= a[k][i] a[k][j] / a[k][k] -- so that
+//   * the cross-lane fetches of row k (ds_bpermute with lane addresses computed once per call) do not wait for 1 / sqrt: they are
+//     in flight while the reciprocal of the pivot is refined;
+//   * only the rows that still change are fetched / updated (compile-time: r > k / 4; lane-dependent only for r = k / 4);
+//   * the pivot test is one vector compare after the loop (a failed pivot poisons the block with NaN / Inf, which the caller
+//     discards anyway once info[0] is set);
+// and scales the rows by 1 / sqrt(pivot) once at the end.  ~33 instructions per pivot.
+__device__ __forceinline__ double bperm(int addr, double x) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void factor_block_inreg(v4f64s v, double *sm, int p, double piv_tol, int *info, int blk, gdp Ub,
-                                                   CP_GLOBAL unsigned long long *Go, int ld, int lane, int fk, int fi) {
+                                                   CP_GLOBAL unsigned long long *Go, int ld, int lane, int fk, int fi, bool store_t) {
     const double *dref = sm + PACK + NB;
     const int k0 = p * PNB;
-    v4f64s w;                                   // the identity carried along: ends as U_pp^-T (lower triangular)
+    v4f64s w, sc;                                // w: the identity carried along (ends as U_pp^-T); sc[r]: 1 / sqrt(pivot of row fk + 4 r)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w[r] = (fk + 4 * r == fi) ? 1.0 : 0.0;
-    const double refv = dref[k0 + fi];
+    for (int r = 0; r < 4; ++r) {
+        w[r] = (fk + 4 * r == fi) ? 1.0 : 0.0;
+        sc[r] = 1.0;
+    }
+    const double thr = piv_tol * dref[k0 + fi];   // the pivot of column fi has to stay above this
+    bool bad = false;
+    int a_row[4], a_col[4][4];                    // byte addresses of the source lanes: (kq, fi) and (kq, fk + 4 r)
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        a_row[kq] = (kq * 16 + fi) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a_col[kq][r] = (kq * 16 + fk + 4 * r) * 4;
+    }
 #pragma unroll
     for (int k = 0; k < PNB; ++k) {
-        const int kr = k >> 2, kq = k & 3, src = kq * 16 + k;
-        double piv = read_lane(v[kr], src);
-        const double ref = read_lane(refv, k);
-        if (!(piv > piv_tol * ref)) {   // wave-uniform
-            if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
-            piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
-        }
-        const double inv = rsqrt_nr(piv);
-        if (fk == kq) {
-            v[kr] = fi == k ? piv * inv : v[kr] * inv;      // row k of U (columns >= k meaningful)
-            w[kr] = w[kr] * inv;                            // row k of U^-T
-        }
-        const double urow = __shfl(v[kr], kq * 16 + fi, 64);           // U[k, fi]
-        const double xrow = __shfl(w[kr], kq * 16 + fi, 64);           // U^-T[k, fi]
+        const int kr = k >> 2, kq = k & 3;
+        const double piv = read_lane(v[kr], kq * 16 + k);          // a[k][k], uniform
+        // row k (unscaled) to every lane that needs it: column fi of it, and the columns that are this lane's rows
+        const double urow = bperm(a_row[kq], v[kr]);
+        const double xrow = bperm(a_row[kq], w[kr]);
+        double ucol[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double ucol = __shfl(v[kr], kq * 16 + fk + 4 * r, 64);   // U[k, fk + 4 r]
-            if (fk + 4 * r > k) {
-                v[r] = fma(-ucol, urow, v[r]);
-                w[r] = fma(-ucol, xrow, w[r]);
-            }
+        for (int r = kr; r < 4; ++r) ucol[r] = bperm(a_col[kq][r], v[kr]);
+        // 1 / piv and 1 / sqrt(piv) meanwhile
+        const double inv = rsqrt_nr(piv);
+        const double rinv = inv * inv;
+        if (fi == k && fk == kq) bad = bad || !(piv > thr);          // lane (kq, k): thr belongs to column k
+        const double ut = urow * rinv, xt = xrow * rinv;
+        if (fk <= kq) ucol[kr] = 0.0;                                // rows fk + 4 kr <= k of this register do not change
+#pragma unroll
+        for (int r = kr; r < 4; ++r) {
+            v[r] = fma(-ucol[r], ut, v[r]);
+            w[r] = fma(-ucol[r], xt, w[r]);
         }
+        if (fk == kq) sc[kr] = inv;
+    }
+    const unsigned long long any_bad = __ballot(bad);
+    if (any_bad != 0 && lane == 0) {
+        const int first = __ffsll((long long)any_bad) - 1;            // lane (kq, k) -> column k = lane & 15
+        atomicCAS(info, 0, blk * NB + k0 + (first & 15) + 1);
     }
     double *Dp = sm + pk(p, p) * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = fk + 4 * r;
-        Dp[fi * 16 + row] = w[r];                                           // T_p[fi][row] = U^-T[row][fi]
-        Ub[(k0 + row) * ld + k0 + fi] = fi >= row ? v[r] : 0.0;             // U_pp, zeros below the diagonal
-        __hip_atomic_store(Go + (k0 + fi) * ld + k0 + row, (unsigned long long)__double_as_longlong(w[r]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);                       // operator, diagonal slot: T_p
+        const double u = v[r] * sc[r], x = w[r] * sc[r];
+        Dp[fi * 16 + row] = x;                                              // T_p[fi][row] = U^-T[row][fi]
+        Ub[(k0 + row) * ld + k0 + fi] = fi >= row ? u : 0.0;                // U_pp, zeros below the diagonal
+        if (store_t)
+            __hip_atomic_store(Go + (k0 + fi) * ld + k0 + row, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);                   // operator, diagonal slot: T_p
     }
 }
 
-__device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, int *info, int blk, double *Ub_, double *Gss_, int ld) {
+// stream != 0: the operator is PUBLISHED block column by block column -- the flag word counts the columns q whose blocks
+// (k, q), k < q, and T_q are in global memory -- so that the panel workgroups substitute behind the factorisation instead of
+// starting when it ends (role_panel).  Who stores what then: the strictly upper blocks by the waves 1 .. 7 that compute them
+// (phase A; each waits for its stores before the barrier that ends phase B), T_q by wave 7, which has no column of its own
+// from the second panel on: it copies T_q out of LDS during phase A of panel q, waits for the copy and raises the count.  Wave
+// 0 -- the chain -- issues no operator store and never waits for memory.
+__device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, int *info, int blk, double *Ub_, double *Gss_, int ld,
+                                                   int stream) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     const gdp Ub = (gdp)Ub_;
     CP_GLOBAL unsigned long long *const Go = (CP_GLOBAL unsigned long long *)Gss_;
@@ -363,13 +414,16 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
         const double *D0 = sm + pk(0, 0) * 256;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = D0[(fk + 4 * r) * 16 + fi];
-        factor_block_inreg(v, sm, 0, piv_tol, info, blk, Ub, Go, ld, lane, fk, fi);
+        CP_DSTAMP(0, 0);
+        factor_block_inreg(v, sm, 0, piv_tol, info, blk, Ub, Go, ld, lane, fk, fi, !stream);
+        CP_DSTAMP(1, 0);
     }
     __syncthreads();
 #pragma unroll 1
     for (int p = 0; p < NPAN; ++p) {
-        // phase A: U_pj = T_p^T A_pj, wave w -> block column p + 1 + w
-        const int j = p + 1 + wave;
+        CP_DSTAMP(8 + 8 * p + 0, 0);
+        // phase A: U_pj = T_p^T A_pj, wave w -> block column p + 1 + w (streaming form: waves 1 .. 7 -> columns p + 1 .. p + 7)
+        const int j = stream ? (wave == 0 ? NPAN : p + wave) : p + 1 + wave;
         if (j < NPAN) {
             const double *Tp = sm + pk(p, p) * 256;
             double *Cp = sm + pk(p, j) * 256;
@@ -381,7 +435,21 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
             for (int r = 0; r < 4; ++r) Cp[(fk + 4 * r) * 16 + fi] = y[r];
             store_block_global(Ub, Go, ld, p, j, y, fk, fi, false);
         }
+        CP_DSTAMP(8 + 8 * p + 1, 0);
         __syncthreads();
+        CP_DSTAMP(8 + 8 * p + 2, 0);
+        // publisher (wave 7, AFTER the barrier so that the chain does not wait for its store round trip): T_p out of its LDS
+        // slot, then the count -- block column p is complete
+        if (stream && wave == NPAN - 1) {
+            const double *Tp = sm + pk(p, p) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __hip_atomic_store(Go + (16 * p + fk + 4 * r) * ld + 16 * p + fi,
+                                   (unsigned long long)__double_as_longlong(Tp[(fk + 4 * r) * 16 + fi]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(info + 1 + blk, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (p + 1 >= NPAN) break;
         // phase B: wave 0 takes block (p + 1, p + 1) -- update, then factor -- the others the rest of the trailing blocks
         const int rt = NPAN - p - 1;                     // trailing grid: rt x rt blocks, upper triangle
@@ -396,7 +464,9 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
                 const double rv = Rq[(kk * 4 + fk) * 16 + fi];
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(-rv, rv, c, 0, 0, 0);
             }
-            factor_block_inreg(c, sm, p + 1, piv_tol, info, blk, Ub, Go, ld, lane, fk, fi);
+            CP_DSTAMP(8 + 8 * p + 3, 0);
+            factor_block_inreg(c, sm, p + 1, piv_tol, info, blk, Ub, Go, ld, lane, fk, fi, !stream);
+            CP_DSTAMP(8 + 8 * p + 4, 0);
         } else {
             const int ntile = rt * (rt + 1) / 2;
             for (int e = wave; e < ntile; e += PT / 64 - 1) {        // e = 0 is wave 0's block
@@ -416,13 +486,18 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Cij[(fk + 4 * r) * 16 + fi] = c[r];
             }
+            CP_DSTAMP(8 + 8 * p + 5, 64);      // wave 1 done with its share of the trailing blocks
+            // this wave's phase-A stores (the blocks (p, j) of the operator) are out before block column p + 1 is published
+            if (stream) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        CP_DSTAMP(8 + 8 * p + 6, 0);
     }
+    if (stream) return;                 // the last column was published by wave 7 in phase A of the last panel
     // every wave's stores of the operator have to be out before the flag goes up (see diag_output)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(info + 1 + blk, NPAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __noinline__ void diag_output(double *sm, double *Ub_, int ld, double *Gss_, int *info, int blk) {
@@ -473,7 +548,20 @@ __device__ __noinline__ void diag_output(double *sm, double *Ub_, int ld, double
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(info + 1 + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(info + 1 + blk, NPAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all eight block columns at once
+}
+
+// the substituted tile: U[s,j] (or Y[s,jr]) row-major and, for factor tiles, its transpose Lt[j,s]
+__device__ __forceinline__ void panel_store(v4f64s (&acc)[NPAN], gdp Usj, int ldu, gdp Ltjs, int ld) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fk = lane >> 4, fi = lane & 15;
+    const int uoff = fk * ldu + 16 * wave + fi, loff = (16 * wave + fi) * ld + fk;
+#pragma unroll
+    for (int q = 0; q < NPAN; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            (Usj + size_t(16 * q + 4 * r) * ldu)[uoff] = acc[q][r];    // row 16 q + fk + 4 r, column 16 w + fi
+            if (Ltjs) (Ltjs + (16 * q + 4 * r))[loff] = acc[q][r];     // transposed (factor tiles only)
+        }
 }
 
 // U[s,j] = U_ss^-T S for the tile in `acc`: block forward substitution over the eight 16-row blocks with the operator in
@@ -497,14 +585,7 @@ __device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *s
         for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
         acc[q] = y;
     }
-    const int uoff = fk * ldu + 16 * wave + fi, loff = (16 * wave + fi) * ld + fk;
-#pragma unroll
-    for (int q = 0; q < NPAN; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            (Usj + size_t(16 * q + 4 * r) * ldu)[uoff] = acc[q][r];    // row 16 q + fk + 4 r, column 16 w + fi
-            if (Ltjs) (Ltjs + (16 * q + 4 * r))[loff] = acc[q][r];     // transposed (factor tiles only)
-        }
+    panel_store(acc, Usj, ldu, Ltjs, ld);
 }
 
 // TI_b = U_bb^-1 (upper) and TIT_b = its transpose from the operator in LDS: what the substitution kernels of refit.hip
@@ -635,7 +716,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const 
     }
     CP_STAMP(3);
     if (form & 1) {     // look-ahead form: U[s,s], the operator and the flag leave from inside
-        diag_factor_lookahead(sm, piv_tol, info, s, Uss, t_.T, ld);
+        diag_factor_lookahead(sm, piv_tol, info, s, Uss, t_.T, ld, form & 4);
         CP_STAMP(4);
     } else {
         diag_factor_lds(sm, piv_tol, info, s);
@@ -652,12 +733,60 @@ __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const 
 __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const double *__restrict__ Ai, int ld, int s,
                                                                   double *__restrict__ out, int ldo, double *__restrict__ Ltjs,
                                                                   const double *__restrict__ Gss, int *info, int spin_limit,
-                                                                  double *sm) {
+                                                                  int stream, double *sm) {
     const int tid = threadIdx.x;
     v4f64s acc[NPAN];
     CP_STAMP(0);
     tile_load_update<false>(acc, t_, Ai, ld, sm);
-    if (tid == 0) flag_wait(info + 1 + s, info, spin_limit);  // bounded; running out is reported as a failed factorisation
+    if (stream) {
+        // Substitution BEHIND the factorisation: block column q of the operator (the blocks (k, q), k < q, and T_q) is fetched
+        // and applied as soon as the diagonal workgroup has published it (the flag word counts the published columns), so
+        // that after the last publication only the last of the eight steps is left -- not the operator load and all eight.
+        const int lane = tid & 63, fk = lane >> 4, fi = lane & 15;
+        typedef const CP_GLOBAL unsigned long long *gcup;
+        const gcup Go = (gcup)Gss;
+#pragma unroll
+        for (int q = 0; q < NPAN; ++q) {
+            if (tid == 0) flag_wait(info + 1 + s, info, spin_limit, q + 1);
+            __syncthreads();
+            if (q == NPAN - 1) CP_STAMP(3);
+            // (q + 1) blocks of 256 words: the first (q + 1) * 256 threads take one word... two rounds cover up to 8 blocks
+            constexpr int ROUNDS_MAX = (NPAN * 256 + PT - 1) / PT;
+            const int rounds = ((q + 1) * 256 + PT - 1) / PT;  // compile-time after unrolling
+            unsigned long long wv[ROUNDS_MAX];
+#pragma unroll
+            for (int i = 0; i < ROUNDS_MAX; ++i) {             // the loads of the column in flight together
+                const int e = tid + PT * i;                    // word e of the column: block k = e / 256, element (r, c)
+                if (i < rounds && e < (q + 1) * 256)
+                    wv[i] = __hip_atomic_load(Go + (16 * (e >> 8) + ((e >> 4) & 15)) * ld + 16 * q + (e & 15), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < ROUNDS_MAX; ++i) {
+                const int e = tid + PT * i;
+                if (i < rounds && e < (q + 1) * 256) sm[pk(e >> 8, q) * 256 + (e & 255)] = __longlong_as_double((long long)wv[i]);
+            }
+            __syncthreads();
+            if (q == NPAN - 1) CP_STAMP(4);
+#pragma unroll
+            for (int k = 0; k < q; ++k) {
+                const double *Ukq = sm + pk(k, q) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ukq[(4 * r + fk) * 16 + fi], acc[k][r], acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const double *Tq = sm + pk(q, q) * 256;
+            v4f64s y = {0., 0., 0., 0.};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
+            acc[q] = y;
+        }
+        panel_store(acc, (gdp)out, ldo, (gdp)Ltjs, ld);
+        CP_STAMP(5);
+        __builtin_amdgcn_endpgm();
+    }
+    if (tid == 0) flag_wait(info + 1 + s, info, spin_limit, NPAN);  // bounded; running out is reported as a failed factorisation
     __syncthreads();
     CP_STAMP(3);
     // the operator of block s, left in G[s,s] by the diagonal role of this launch: sc1 loads (see flag_wait), 18 per thread
@@ -734,9 +863,9 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
                   TIT + size_t(s) * NB * NB, info, diag_form, sm);
     else if (!rhs)
         role_panel(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB, Gss, info,
-                   spin_limit, sm);
+                   spin_limit, (diag_form & 5) == 5, sm);
     else
-        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, spin_limit, sm);
+        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, spin_limit, (diag_form & 5) == 5, sm);
 }
 
 hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explicit opt-in, once per device
@@ -765,7 +894,9 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     const int ntr = R ? n_pad / NB : 0;
     static const int prio = !(getenv("CP_CHOL_PRIO") && getenv("CP_CHOL_PRIO")[0] == '0');
     // CP_CHOL_DIAG: bit 0 = look-ahead form of the 128 x 128 factorisation, bit 1 = balanced K = 128 update of the diagonal tile
-    static const int diag_form = getenv("CP_CHOL_DIAG") ? atoi(getenv("CP_CHOL_DIAG")) : 3;
+    //               bit 2 = the operator published block column by block column, the panel workgroups substituting behind (needs bit 0)
+    static const int diag_form_env = getenv("CP_CHOL_DIAG") ? atoi(getenv("CP_CHOL_DIAG")) : 7;
+    const int diag_form = (diag_form_env & 1) ? diag_form_env : (diag_form_env & ~4);
     int spin_limit = 1 << 26;
     if (ctx->chol_test_fail_flag_waits > 0) {   // test hook: the panel workgroups of THIS factorisation give up at once
         --ctx->chol_test_fail_flag_waits;

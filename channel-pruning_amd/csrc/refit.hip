@@ -301,7 +301,58 @@ struct StripFinal {  // optional tail of k_solve_strips: what k_finalize does, f
     double *coef_host, *b_host;    // pinned host copies (may be null)
     const int *info;
     int *info_host;
+    // Banded backward substitution (chol_solve_blocked): the rows of W become final band by band, from the bottom up, and
+    // leave for the host AS THEY DO -- the launch of a band first lays out the rows the PREVIOUS band finished (rows
+    // [pre_lo, pre_hi): posted writes over PCIe that drain while this band substitutes), the launch of the top band also its
+    // own (rows [post_lo, post_hi)) and the intercept.  b accumulates sum_col xmean[col] W[col, j] across the launches (first:
+    // the launch that starts it; last: the one that turns it into ymean - sum).  All four bounds 0: the whole-matrix tail above.
+    int pre_lo = 0, pre_hi = 0, post_lo = 0, post_hi = 0;
+    int first = 0, last = 0;
 };
+
+// rows [lo, hi) of W (already final) for this strip's 16 right-hand sides: coef[j, col] = W[col, j] (device + pinned host copy),
+// their share of sum_col xmean[col] W[col, j] added to b[j] (start: written instead); finish: b[j] = ymean[j] - sum
+__device__ __forceinline__ void strip_finalize_rows(const double *R, int n_pad, const StripFinal &fin, int col0, int lo, int hi,
+                                                    bool start, bool finish, double *red /* 8 x 16 doubles of LDS */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (hi > fin.p) hi = fin.p;
+    double acc16[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) acc16[jj] = 0.0;
+    for (int col = lo + int(threadIdx.x); col < hi; col += 512) {
+        const double xm = fin.xmean[col];
+        const double *wr = R + size_t(col) * n_pad + col0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = col0 + jj;
+            if (j < fin.n) {
+                const double v = wr[jj];
+                fin.coef[size_t(j) * fin.p + col] = v;
+                if (fin.coef_host) fin.coef_host[size_t(j) * fin.p + col] = v;
+                acc16[jj] = fma(xm, v, acc16[jj]);
+            }
+        }
+    }
+    __syncthreads();      // `red` may alias the substitution's LDS
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        double v = acc16[jj];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave * 16 + jj] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && col0 + int(threadIdx.x) < fin.n) {
+        double tot = 0;
+        for (int w8 = 0; w8 < 8; ++w8) tot += red[w8 * 16 + threadIdx.x];
+        const int j = col0 + threadIdx.x;
+        if (!start) tot += fin.b[j];
+        const double bj = finish ? fin.ymean[j] - tot : tot;
+        fin.b[j] = bj;
+        if (finish && fin.b_host) fin.b_host[j] = bj;
+    }
+    __syncthreads();
+}
 
 // SWEEPS: bit 0 = forward (U^T y = r), bit 1 = backward (U w = y); 3 = both (the normal-equation solve)
 template <int SWEEPS = 3>
@@ -316,6 +367,9 @@ __device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fk = lane >> 4, fi = lane & 15;
     const int col0 = blockIdx.x * 16, row0 = wave * 16;
+    const bool banded_tail = fin.p > 0 && (fin.pre_hi > fin.pre_lo || fin.post_hi > fin.post_lo);
+    if (banded_tail && fin.pre_hi > fin.pre_lo)     // the rows the previous band finished: on their way while this band works
+        strip_finalize_rows(R, n_pad, fin, col0, fin.pre_lo, fin.pre_hi, fin.first != 0, false, &S[0][0]);
     for (int sweep = 0; sweep < 2; ++sweep) {
         if (!(SWEEPS & (1 << sweep))) continue;
         const double *Tri = sweep == 0 ? U : Lt;      // element (kk of block k, m of block b) at Tri[(k NB + kk) ld + b NB + m]
@@ -349,6 +403,14 @@ __device__ __forceinline__ void solve_strips_body(const double *__restrict__ U, 
             for (int r = 0; r < 4; ++r) Rb[size_t(fk + 4 * r) * n_pad] = o[r];
             __syncthreads();  // block b of the strip is complete (and visible) before any wave reads it
         }
+    }
+    if (banded_tail) {
+        if (fin.post_hi > fin.post_lo) {
+            if (blockIdx.x == 0 && threadIdx.x == 0 && fin.info_host && fin.last) fin.info_host[0] = fin.info[0];
+            strip_finalize_rows(R, n_pad, fin, col0, fin.post_lo, fin.post_hi, fin.first != 0 && !(fin.pre_hi > fin.pre_lo),
+                                fin.last != 0, &S[0][0]);
+        }
+        return;
     }
     if (fin.p > 0) {  // coef[j, col] = W[col, j],  b[j] = ymean[j] - sum_col xmean[col] W[col, j]  for this strip's j
         if (blockIdx.x == 0 && threadIdx.x == 0 && fin.info_host) fin.info_host[0] = fin.info[0];
@@ -438,9 +500,13 @@ constexpr int solve_blocked_min_blocks() { return 16; }   // banded substitution
 size_t chol_solve_blocked_workspace(const cp_ctx *ctx, int p_pad, int n_pad) {
     return cp_gemm_tn_workspace(ctx, p_pad, n_pad, SOLVE_OB * NB, CP_TRI_NONE);
 }
-int chol_solve_blocked(cp_ctx *ctx, const Chol &ch, double *Rm, int n_pad, int sweeps = 3) {
+// fin (optional): the coefficient lay-out / intercept ride in the launches of the BACKWARD sweep, band by band (StripFinal);
+// *fin_done tells the caller that nothing is left to finalize.
+int chol_solve_blocked(cp_ctx *ctx, const Chol &ch, double *Rm, int n_pad, int sweeps = 3, const StripFinal *fin = nullptr,
+                       bool *fin_done = nullptr) {
     const int ld = ch.p_pad, nblk = ch.nblk;
     const StripFinal none{};
+    if (fin_done) *fin_done = false;
     if (sweeps & 1) {
         for (int b0 = 0; b0 < nblk; b0 += SOLVE_OB) {
             const int b1 = std::min(nblk, b0 + SOLVE_OB);
@@ -455,13 +521,30 @@ int chol_solve_blocked(cp_ctx *ctx, const Chol &ch, double *Rm, int n_pad, int s
     if (sweeps & 2) {
         for (int b1 = nblk; b1 > 0; b1 -= SOLVE_OB) {
             const int b0 = std::max(0, b1 - SOLVE_OB);
-            k_solve_strips<2><<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ld, ch.TI, ch.TIT, nblk, Rm, n_pad, none, b0, b1);
+            StripFinal f = none;
+            if (fin && fin->p > 0) {
+                f = *fin;
+                f.first = b1 == nblk ? 0 : (b1 + SOLVE_OB >= nblk ? 1 : 0);   // the launch that lays out the first rows starts b
+                if (b1 < nblk) {                                          // the rows of the band above... below: finished by the previous launch
+                    f.pre_lo = b1 * NB;
+                    f.pre_hi = std::min(nblk, b1 + SOLVE_OB) * NB;
+                }
+                if (b0 == 0) {                                            // the top band: its own rows too, and the intercept
+                    f.post_lo = 0;
+                    f.post_hi = b1 * NB;
+                    f.last = 1;
+                    if (b1 == nblk) f.first = 1;                          // a single band: everything in this launch
+                }
+                if (f.pre_hi <= f.pre_lo && f.post_hi <= f.post_lo) f = none;   // the first of several bands: nothing final yet
+            }
+            k_solve_strips<2><<<n_pad / 16, 512, 0, ctx->stream>>>(ch.U, ch.Lt, ld, ch.TI, ch.TIT, nblk, Rm, n_pad, f, b0, b1);
             CP_LAUNCH_CHECK(ctx);
             const int above = b0 * NB;
             if (above > 0)
                 CP_TRY(cp_gemm_tn_f64(ctx, above, n_pad, (b1 - b0) * NB, -1.0, ch.Lt + size_t(b0) * NB * ld, ld,
                                       Rm + size_t(b0) * NB * n_pad, n_pad, 1.0, Rm, n_pad, CP_TRI_NONE));
         }
+        if (fin && fin->p > 0 && fin_done) *fin_done = true;
     }
     return CP_OK;
 }
@@ -762,10 +845,18 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
         cp_stage_mark(ctx, "refit_chol_begin");   // opens the bracket of the factorisation chain (timing mode 2)
         CP_TRY(chol_factor(ctx, ch, PIV_TOL, Rm, n_pad, &fwd));
         cp_stage_mark(ctx, "refit_cholesky");
-        if (nblk >= solve_blocked_min_blocks()) {   // large factor: banded substitution with GEMM updates, then the lay-out kernel
-            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3));
+        if (nblk >= solve_blocked_min_blocks()) {   // large factor: banded substitution with GEMM updates; the lay-out rides along
+            static const bool band_final = !(getenv("CP_REFIT_BAND_FINAL") && getenv("CP_REFIT_BAND_FINAL")[0] == '0');
+            StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
+            bool fin_done = false;
+            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3, band_final ? &fin : nullptr, &fin_done));
             cp_stage_mark(ctx, "refit_solve");
-            CP_TRY(finalize());
+            if (fin_done) {
+                CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything came back with the kernels
+                hinfo = *info_host;
+            } else {
+                CP_TRY(finalize());
+            }
         } else {
             StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
             CP_TRY(chol_solve(ctx, ch, Rm, Yt, n_pad, fin, fwd ? 2 : 3));  // substitution(s) + coefficient lay-out + intercept in one launch

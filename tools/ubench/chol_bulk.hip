@@ -122,6 +122,16 @@ int main(int argc, char **argv) {
     printf("| tile load | update loop (16 chunks) | store | whole |\n|---|---|---|---|\n");
     printf("| %.0f / %.0f | %.0f / %.0f | %.0f / %.0f | %.0f / %.0f |\n", med(load), mx(load), med(upd), mx(upd), med(store),
            mx(store), med(all), mx(all));
+    if (form & 1) {   // the look-ahead factorisation of the LAST step's diagonal tile, panel by panel
+        std::vector<unsigned long long> ds(128);
+        hipMemcpyFromSymbol(ds.data(), HIP_SYMBOL(cp_chol_diag_stamps), ds.size() * 8);
+        printf("\nlook-ahead factorisation (cycles): first 16 x 16 block in registers %llu\n", ds[1] - ds[0]);
+        printf("| panel | phase A: U_pj = T_p^T A_pj (wave 0) | barrier | wave 0: update of block p+1 | wave 0: factorisation of block p+1 | wave 1: its trailing blocks | whole panel |\n|---|---|---|---|---|---|---|\n");
+        for (int q = 0; q < 7; ++q) {
+            const unsigned long long *d = &ds[8 + 8 * q];
+            printf("| %d | %llu | %llu | %llu | %llu | %llu | %llu |\n", q, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[2], d[6] - d[0]);
+        }
+    }
     // step 5 (odd: block row 5 + block row 6 riding along, no other bulk): the serial piece, phase by phase
     {
         const unsigned long long *d = &st5[0];
