@@ -466,6 +466,7 @@ def bench_job(args, env, job):
     roots = [ch["ctxs"][0] for ch in rset.chunks]
 
     masks_equal = [True]
+    exchange_rounds = None if (weak or args.no_exchange_rounds) else shard.plan_rounds(specs, owner)
 
     def one_job():
         if weak:
@@ -478,8 +479,10 @@ def bench_job(args, env, job):
                 shard.LAST_EXCHANGE_MS.clear()
                 shard.LAST_EXCHANGE_MS.update(total=(time.perf_counter() - t_x) * 1e3, bytes_sent=sum(s["c"] for s in specs))
             return res
+        # N > 1: the results of the light layers are exchanged while the heavy ones are still being pruned (shard.plan_rounds)
         return shard.prune_sharded(specs, compute_many=rset, dist=env.dist, owner=owner,
-                                   staging="device" if env.dist is not None else None)
+                                   staging="device" if env.dist is not None else None,
+                                   rounds=exchange_rounds if env.dist is not None else None)
 
     def sync_all():
         for cx in roots:
@@ -728,9 +731,11 @@ def bench_job(args, env, job):
                        "streams_per_gpu": len(rset.chunks), "layers_in_flight_per_gpu": len(own),
                        "layers_per_call": sorted({len(ch["members"]) for ch in rset.chunks}),
                        "owner_rank_of_layer": None if weak else owner,
+                       "exchange_round_of_layer": exchange_rounds if env.dist is not None else None,
                        "parallelism": ("one job instance per GPU x%d, uint8 all_gather of the channel masks per job" % env.world)
-                       if weak else ("layers of one instance sharded x%d (LPT), masks all_gather + ONE all_gather of the "
-                                     "packed (W,b)" % env.world)},
+                       if weak else ("layers of one instance sharded x%d (LPT), masks all_gather + all_gather of the "
+                                     "packed (W,b) -- in two rounds: the light layers' results travel while the heavy "
+                                     "layers are still being pruned" % env.world)},
             "job_ms": round(job_ms, 3),
             "exchange_rank0": None if not exch_ms else dict(
                 {k: (round(v, 3) if isinstance(v, float) else v) for k, v in shard.LAST_EXCHANGE_MS.items()},
@@ -1334,6 +1339,8 @@ def main():
     ap.add_argument("--precompute-heaviest", type=int, default=None,
                     help="layers whose full normal equations are computed under their alpha search (default: the library's 2)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-jobs-in-flight leg (N = 1)")
+    ap.add_argument("--no-exchange-rounds", action="store_true",
+                    help="N > 1, strong: ONE exchange after all layers instead of the light layers' results travelling early")
     ap.add_argument("--no-gather", action="store_true", help="skip the sampled-point im2col (extract_XY) measurement")
     ap.add_argument("--no-pcie-f64", action="store_true", help="skip the float64-X variant of the PCIe-inclusive pass")
     ap.add_argument("--profile-mode", action="store_true",

@@ -201,20 +201,47 @@ class ResidentLayerSet:
                 ch["error"] = e
             ch["done"].set()
 
-    def run(self):
+    def start(self):
+        """every chunk begins its layers now; collect with wait() (some of the layers, as they finish) and / or finish()"""
         for ch in self.chunks:
             ch["done"].clear()
             ch["error"] = None
             ch["go"].set()
+
+    def wait(self, indices):
+        """blocks until the layers `indices` (positions in the constructor's specs) are done -> {index: (idxs, W, b, alpha)}.
+        The chunks of the other layers keep running."""
+        want = set(int(i) for i in indices)
+        out = {}
+        for ch in self.chunks:
+            if want.isdisjoint(ch["members"]):
+                continue
+            ch["done"].wait()
+            if ch["error"] is not None:
+                self.finish(raise_errors=False)      # nothing may still be inside its foreign call when this propagates
+                raise ch["error"]
+            for i, r in zip(ch["members"], ch["out"]):
+                if i in want:
+                    out[i] = r
+        return out
+
+    def finish(self, raise_errors=True):
+        """every chunk is done -> all results in layer order"""
         out = [None] * len(self.specs)
         for ch in self.chunks:          # every chunk finishes before anything is raised: a chunk still inside its foreign
             ch["done"].wait()           # call must not see its events re-armed or its contexts freed
         for ch in self.chunks:
             if ch["error"] is not None:
-                raise ch["error"]
+                if raise_errors:
+                    raise ch["error"]
+                continue
             for i, r in zip(ch["members"], ch["out"]):
                 out[i] = r
         return out
+
+    def run(self):
+        self.start()
+        return self.finish()
 
     def __call__(self, specs=None):
         """compute_many of prune_sharded (the specs are the ones given to the constructor)."""
@@ -366,7 +393,7 @@ def exchange_results(specs, owner, mine, dist, device=None, staging=None):
 
 
 def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None, owner=None, staging=None,
-                  force_exchange=False):
+                  force_exchange=False, rounds=None):
     """specs: list of dicts with at least N, c, n, k, rank; compute_fn(spec) -> (idxs, W, b), or
     compute_many(list of this rank's specs) -> list of (idxs, W, b) (a GpuLayerBatches or a ResidentLayerSet).
     Every rank returns the full list of results in layer order.  `dist` is an initialised
@@ -377,6 +404,11 @@ def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=N
     rank = dist.get_rank() if dist is not None else 0
     if owner is None:
         owner = plan_owners(specs, world)
+    # rounds (plan_rounds): the exchange of the early layers overlaps the pruning of the heavy ones -- needs a compute_many
+    # with start() / wait() / finish() (ResidentLayerSet, ThreadedLayerSet)
+    if rounds is not None and len(set(rounds)) > 1 and dist is not None and (world > 1 or force_exchange) and \
+            compute_many is not None and hasattr(compute_many, "wait"):
+        return prune_sharded_rounds(specs, compute_many, dist, owner, rounds, device, staging)
     mine = {}
     own = [i for i in range(len(specs)) if owner[i] == rank]
     if compute_many is not None:
@@ -388,6 +420,99 @@ def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=N
     if dist is None or (world == 1 and not force_exchange):
         return [mine[i] for i in range(len(specs))]
     return exchange_results(specs, owner, mine, dist, device, staging)
+
+
+def plan_rounds(specs, owner=None, heavy_fraction=0.5):
+    """Exchange round of every layer for prune_sharded(..., rounds=...): 0 for the layers that finish early, 1 for the heavy
+    ones (cost above heavy_fraction of the job's most expensive layer).  The results of round 0 travel -- one mask all_gather
+    + one all_gather of the packed (W, b), as always -- while the heavy layers are still being pruned; the job then ends with
+    the exchange of the heavy layers alone.  Every rank computes the same table (costs are part of the specs)."""
+    costs = [s.get("cost", layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"])) for s in specs]
+    top = max(costs) if costs else 0.0
+    rounds = [1 if c > heavy_fraction * top else 0 for c in costs]
+    if len(set(rounds)) < 2:
+        rounds = [0] * len(specs)
+    return rounds
+
+
+class ThreadedLayerSet:
+    """The start() / wait() / finish() protocol of ResidentLayerSet around a plain compute_fn(spec) -> (idxs, W, b), one
+    host thread per layer: what prune_sharded(rounds=...) needs from its compute_many.  (CPU tests; any engine that prunes
+    a layer per call.)"""
+
+    def __init__(self, specs, compute_fn):
+        self.specs, self.compute_fn = list(specs), compute_fn
+        self._threads, self._out, self._err = [], {}, {}
+
+    def start(self):
+        import threading
+        self._out, self._err = {}, {}
+
+        def work(i):
+            try:
+                self._out[i] = self.compute_fn(self.specs[i])
+            except BaseException as e:   # noqa
+                self._err[i] = e
+
+        self._threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(self.specs))]
+        for t in self._threads:
+            t.start()
+
+    def wait(self, indices):
+        out = {}
+        for i in indices:
+            self._threads[i].join()
+            if i in self._err:
+                self.finish(raise_errors=False)
+                raise self._err[i]
+            out[i] = self._out[i] + (None,) if len(self._out[i]) == 3 else self._out[i]
+        return out
+
+    def finish(self, raise_errors=True):
+        for t in self._threads:
+            t.join()
+        if raise_errors and self._err:
+            raise next(iter(self._err.values()))
+        return [self._out.get(i) for i in range(len(self.specs))]
+
+    def __call__(self, specs=None):
+        self.start()
+        return [r[:3] for r in self.finish()]
+
+
+def prune_sharded_rounds(specs, layer_set, dist, owner, rounds, device=None, staging=None):
+    """prune_sharded with the exchange OVERLAPPED with the pruning: `layer_set` (a ResidentLayerSet / ThreadedLayerSet over
+    THIS rank's layers, in layer order) is started, and for every round r = 0, 1, ... this rank waits for ITS layers of
+    that round only and joins the exchange of that round's layers (exchange_results on the sub-list: the same two
+    collectives, the same packed lay-out) while its later rounds are still running on the GPU.  Every rank walks the
+    rounds in the same order, so the collectives match.  -> every layer's (mask, W, b) in layer order, on every rank.
+    LAST_EXCHANGE_MS: the last round's figures + "rounds": [ms per round]."""
+    import time
+    world, rank = dist.get_world_size(), dist.get_rank()
+    own = [i for i in range(len(specs)) if owner[i] == rank]
+    pos = {i: k for k, i in enumerate(own)}              # layer index -> position in layer_set
+    layer_set.start()
+    results = [None] * len(specs)
+    per_round = []
+    try:
+        for r in sorted(set(rounds)):
+            members = [i for i in range(len(specs)) if rounds[i] == r]
+            got = layer_set.wait([pos[i] for i in members if i in pos])
+            mine = {}
+            for k, i in enumerate(members):
+                if i in pos:
+                    idxs, W, b = got[pos[i]][:3]
+                    mine[k] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
+            t0 = time.perf_counter()
+            sub = exchange_results([specs[i] for i in members], [owner[i] for i in members], mine, dist, device, staging)
+            per_round.append((time.perf_counter() - t0) * 1e3)
+            for k, i in enumerate(members):
+                results[i] = sub[k]
+    finally:
+        layer_set.finish(raise_errors=False)
+    LAST_EXCHANGE_MS["rounds"] = [round(v, 3) for v in per_round]
+    LAST_EXCHANGE_MS["total"] = float(sum(per_round))
+    return results
 
 
 def plan_owners(specs, world):

@@ -1118,9 +1118,11 @@ def _nccl_worker(rank, world, port, q, backend="nccl", force_exchange=False):
     own = [s for s, o in zip(specs, owner) if o == rank]
     rset = shard.ResidentLayerSet(gpu, own, lambda s: data[s["layer_id"]], per_stream=2, flags=3, borrow_results=True)
     ok = True
-    for _ in range(2):                                # twice: the lent result blocks and the staging buffers are reused
+    for it in range(2):                               # twice: the lent result blocks and the staging buffers are reused
+        # the second time with the exchange in rounds: the light layers' results travel while the heavy ones are pruned
         res = shard.prune_sharded(specs, compute_many=rset, dist=dist, owner=owner, staging="device",
-                                  force_exchange=force_exchange)
+                                  force_exchange=force_exchange, rounds=shard.plan_rounds(specs, owner) if it else None)
+        ok = ok and (it == 0 or len(shard.LAST_EXCHANGE_MS.get("rounds", [])) == 2)
         for s, (idxs, W, b) in zip(specs, res):
             g = np.load(os.path.join(GOLDEN_DIR, s["name"] + ".npz"))
             ok = ok and np.array_equal(idxs, g["idxs"]) and W.shape == g["newW2"].shape

@@ -248,6 +248,73 @@ def test_exchange_results_world_size_8_with_the_vgg16_owner_table(case):
     assert all((sent[r] == 0) == (loads[r] == 0) for r in range(8))
 
 
+def _rounds_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import hashlib
+    import time
+
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # six layers: two heavy (0.6 s of "pruning" each), four light (0.05 s); costs in the specs, as bench.py carries them
+    shapes = [(24, 6, 3, 0.6), (8, 4, 1, 0.05), (12, 5, 3, 0.05), (24, 6, 3, 0.6), (8, 3, 3, 0.05), (10, 4, 1, 0.05)]
+    specs = [dict(layer_id=i, N=10, c=c, n=n, k=k, rank=1, cost=cost) for i, (c, n, k, cost) in enumerate(shapes)]
+    owner = shard.plan_owners(specs, world)
+    rounds = shard.plan_rounds(specs)
+    ended = {}
+
+    def compute(s):
+        time.sleep(s["cost"])
+        rs = np.random.RandomState(90 + s["layer_id"])
+        idxs = rs.rand(s["c"]) < 0.7
+        idxs[0] = True
+        ended[s["layer_id"]] = time.perf_counter()
+        return idxs, rs.randn(s["n"], int(idxs.sum()), s["k"], s["k"]), rs.randn(s["n"])
+
+    own = [s for s, o in zip(specs, owner) if o == rank]
+    exchanged = []
+    real = shard.exchange_results
+
+    def logged(*a, **kw):
+        out = real(*a, **kw)
+        exchanged.append(time.perf_counter())
+        return out
+
+    shard.exchange_results = logged
+    res = shard.prune_sharded(specs, dist=dist, owner=owner, compute_many=shard.ThreadedLayerSet(own, compute), rounds=rounds)
+    shard.exchange_results = real
+    plain = shard.prune_sharded(specs, dist=dist, owner=owner, compute_many=shard.ThreadedLayerSet(own, compute))
+    same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) for a, b in zip(res, plain))
+    heavy_end = max([ended[s["layer_id"]] for s in own if s["cost"] > 0.3], default=None)
+    q.put((rank, owner, rounds, same, len(exchanged), (exchanged[0] < heavy_end) if heavy_end is not None else None,
+           [hashlib.sha1(np.ascontiguousarray(r[1]).tobytes()).hexdigest() for r in res], list(shard.LAST_EXCHANGE_MS.get("rounds", []))))
+    dist.destroy_process_group()
+
+
+def test_exchange_in_rounds_overlaps_the_heavy_layers_world_size_3_gloo():
+    """prune_sharded(rounds=plan_rounds(...)): the results of the light layers are exchanged (mask all_gather + packed
+    all_gather, as always) while the heavy layers are still being pruned, the heavy layers' afterwards.  Three ranks, six
+    layers (two heavy): every rank ends with exactly what the one-exchange path gives, two exchanges ran, and on the ranks
+    that own a heavy layer the first exchange was over before that layer finished."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rounds_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][2] == [1, 0, 0, 1, 0, 0]
+    assert all(g[3] for g in got) and all(g[4] == 2 for g in got) and all(len(g[7]) == 2 for g in got)
+    assert got[0][6] == got[1][6] == got[2][6]
+    overl = [g[5] for g in got if g[5] is not None]
+    assert len(overl) == 2 and all(overl)          # the two heavy layers sit on two different ranks (LPT)
+
+
 def test_sharded_pruning_world_size_2_gloo():
     """Two ranks split four layers, then every rank holds every layer's (mask, W, b); the union of
     the work is exactly one call per layer and the results equal a single-process run."""
