@@ -501,8 +501,10 @@ def bench_job(args, env, job):
     reps = args.jobs_per_step or max(1, int(np.ceil(MIN_TIMED_SECONDS / max(job_s * args.steps, 1e-9))))
     reps = env.bcast_int(reps)
 
-    for cx in ctxs:
-        cx.enable_stage_timing(2)      # timed region: only the two events around the roofline kernel
+    # The stage brackets (HIP events on the launch streams, cp_enable_stage_timing mode 2) are taken during the TIMED jobs, on
+    # every STAGE_SAMPLE-th of them: reading them back costs ~1 ms of host time per job (12 layers x ~8 brackets x two
+    # hipEventElapsedTime each), which is measurement, not pruning work -- with every job instrumented it was 4 % of `value`
+    STAGE_SAMPLE = 4
     g_ms, g_fl, exch_ms = [], [], []
     cls_ms = {"alpha_search": [], "refit_gram": [], "cholesky_chain": [], "backward_substitution": []}   # per launch / bracket, in the job
     chol_fl = []
@@ -512,13 +514,21 @@ def bench_job(args, env, job):
     epoch0 = time.time()
     windows = {"refit_gram": [], "cholesky_chain": []}     # per job: wall window the concurrent brackets of a class span (ms)
     cd_steps_ns = {}                                        # channel count -> [ns per coordinate step, in the job]
+    job_no = 0
     for _ in range(args.steps):
         for _ in range(reps):
-            if roots:
-                roots[0].stage_epoch()       # one clock for the brackets of all the layers' streams (cp_last_stage_spans)
+            sampled = job_no % STAGE_SAMPLE == 0
+            job_no += 1
+            if sampled:
+                for cx in ctxs:
+                    cx.enable_stage_timing(2)      # only the events around the roofline kernels and the two chains
+                if roots:
+                    roots[0].stage_epoch()       # one clock for the brackets of all the layers' streams (cp_last_stage_spans)
             results = one_job()
             if env.dist is not None:
                 exch_ms.append(shard.LAST_EXCHANGE_MS.get("total", 0.0))
+            if not sampled:
+                continue
             span = {"refit_gram": [], "cholesky_chain": []}
             for j, pr in probs.items():
                 for name, ms, begin in pr.ctx.last_stage_spans(roots[0]):
@@ -542,6 +552,8 @@ def bench_job(args, env, job):
             for k_, v_ in span.items():
                 if v_ and min(b for b, _ in v_) >= 0:
                     windows[k_].append(max(e for _, e in v_) - min(b for b, _ in v_))
+            for cx in ctxs:
+                cx.enable_stage_timing(0)
     sync_all()
     env.barrier()
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
@@ -702,7 +714,10 @@ def bench_job(args, env, job):
         fl = [layer_flops(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         by = [algorithmic_bytes(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
-        roof = roofline_object(cls_ms, g_fl, chol_fl, jobs, roots[0], PROFILE_TAG, job, windows=windows, cd_steps_ns=cd_steps_ns)
+        n_sampled = (jobs + STAGE_SAMPLE - 1) // STAGE_SAMPLE       # the jobs whose stage brackets were read
+        roof = roofline_object(cls_ms, g_fl, chol_fl, n_sampled, roots[0], PROFILE_TAG, job, windows=windows, cd_steps_ns=cd_steps_ns)
+        if roof is not None:
+            roof["jobs_with_stage_brackets"] = n_sampled
         if roof is not None and alone_g_ms:
             a1 = sum(alone_g_fl) / (sum(alone_g_ms) * 1e-3) / 1e12
             roof["alone"] = {"refit_gram": {"achieved": round(a1, 3), "frac": round(a1 / F64_MFMA_PEAK_TFLOPS, 4),
