@@ -164,6 +164,9 @@ class ResidentLayerSet:
         self._latency_kind = "gram" if len(self.chunks) > 2 else True
         self._stop = False
         self._threads = []
+        self._t_go = 0.0
+        for ch, nxt in zip(self.chunks, self.chunks[1:] + [None]):
+            ch["next"] = nxt
         for ch in self.chunks:
             t = threading.Thread(target=self._worker, args=(ch,), daemon=True)
             t.start()
@@ -173,6 +176,7 @@ class ResidentLayerSet:
         import time
 
         from .pruner import prune_layer, prune_layers_batched, rng_rewind
+        ch["lag_ms"] = (time.perf_counter() - self._t_go) * 1e3     # from start() to this chunk's thread getting going
         for r, m in zip(ch["rngs"], ch["marks"]):          # every run starts from the layer's own seed
             rng_rewind(r, m)
         specs = [self.specs[i] for i in ch["members"]]
@@ -187,6 +191,7 @@ class ResidentLayerSet:
                                        [s.get("alpha_in", self.alpha_in) for s in specs], ch["rngs"],
                                        rank_tol=self.rank_tol)
         ch["ms"] = (time.perf_counter() - t0) * 1e3
+        ch["end_ms"] = (time.perf_counter() - self._t_go) * 1e3
         return out
 
     def _worker(self, ch):
@@ -195,6 +200,13 @@ class ResidentLayerSet:
             ch["go"].clear()
             if self._stop:
                 return
+            # The chunks start as a CHAIN, widest layers first: a thread hands the baton to the next chunk before its own
+            # host-side preamble (RNG draws, argument marshalling: ~70 us under the interpreter lock), so the next thread gets
+            # the lock the moment this one enters its foreign call.  With all twelve woken at once the order in which they got
+            # the lock was arbitrary and a 512-channel layer -- the job's critical path -- started up to 0.9 ms late.
+            nxt = ch.get("next")
+            if nxt is not None and not self._stop:
+                nxt["go"].set()
             try:
                 ch["out"] = self._prune_chunk(ch)
             except BaseException as e:   # noqa
@@ -203,10 +215,13 @@ class ResidentLayerSet:
 
     def start(self):
         """every chunk begins its layers now; collect with wait() (some of the layers, as they finish) and / or finish()"""
+        import time
+        self._t_go = time.perf_counter()
         for ch in self.chunks:
             ch["done"].clear()
             ch["error"] = None
-            ch["go"].set()
+        if self.chunks:
+            self.chunks[0]["go"].set()          # the others follow as a chain (see _worker)
 
     def wait(self, indices):
         """blocks until the layers `indices` (positions in the constructor's specs) are done -> {index: (idxs, W, b, alpha)}.
@@ -249,7 +264,8 @@ class ResidentLayerSet:
 
     def chunk_report(self):
         return [dict(layers=[self.specs[i].get("name", self.specs[i].get("layer_id", i)) for i in ch["members"]],
-                     c=int(self.specs[ch["members"][0]]["c"]), ms=round(ch["ms"], 3)) for ch in self.chunks]
+                     c=int(self.specs[ch["members"][0]]["c"]), ms=round(ch["ms"], 3), start_lag_ms=round(ch.get("lag_ms", 0.0), 3),
+                     end_ms=round(ch.get("end_ms", 0.0), 3)) for ch in self.chunks]
 
     def problems(self):
         """{index in specs: LayerProblem} (fit logs, refit_info of the last run)"""
