@@ -623,10 +623,13 @@ def bench_job(args, env, job):
                             "note": "one GPU already overlaps the layers of a job (job_ms at N = 1 against sum_of_layers_alone_ms); "
                                     "more GPUs cannot push ONE job below its longest layer alone + the exchange.  The >= 6x of "
                                     "north_star at 8 GPUs exists only as throughput over independent jobs: replica_throughput",
-                            "row_sharding": "cpmi355.shard.prune_layer_rows (rows of one layer over several ranks: two all-reduces, "
-                                            "Gram p^2 doubles) divides a layer's Gram, not its search; it pays when N p^2 / 68 TFLOP/s "
-                                            "exceeds 2 x 8 p^2 B / link bandwidth, i.e. N > ~5000 rows per rank at 150 GB/s: not at "
-                                            "the 5000-sample jobs, marginal at vgg16_5x (N = 20000); tools/rowshard_bench.py"}
+                            "row_sharding": {
+                                "note": "cpmi355.shard.prune_layer_rows (the rows of one layer over two ranks: all-reduces of the "
+                                        "normal equations) divides a layer's Gram and X^T Y, not its alpha search; cost test per "
+                                        "layer (shard.row_shard_cost_test: GEMM at 50 TFLOP/s in a job, 150 GB/s per xGMI link); "
+                                        "taken only where the saving exceeds 1.5 x the cost",
+                                "layers": {s_["name"]: shard.row_shard_cost_test(s_) for s_ in specs if s_["c"] >= 256},
+                                "layers_that_take_it": [s_["name"] for s_ in specs if shard.row_shard_cost_test(s_)["pays"]]}}
         if env.world > 1 and not args.profile_mode:
             # every rank prunes its OWN instance of the whole job (weak scaling, what --scaling weak times as `value`)
             rset.close()

@@ -540,6 +540,22 @@ def plan_owners(specs, world):
 # ---------------------------------------------------------------------------------------------------------
 # one layer, rows sharded over the ranks
 # ---------------------------------------------------------------------------------------------------------
+def row_shard_cost_test(spec, ranks=2, gemm_tflops=50.0, link_gb_s=150.0):
+    """Does spreading the ROWS of this layer over `ranks` GPUs (prune_layer_rows) pay?  -> dict(saved_ms, cost_ms, pays).
+    What it divides is the refit's Gram and X^T Y (N p^2 + 2 N p n flop at the rate the GEMM sustains in a job); what it
+    costs is the two all-reduces of the normal equations (8 p^2 + 8 p n bytes each way over one xGMI link per pair of ranks:
+    a ring all-reduce moves 2 (r - 1) / r of the buffer) plus one of the column sums; the alpha search -- the larger part of
+    a layer -- is not divided.  p = kept channels x k^2 (5 % slack on the requested rank, as layer_cost)."""
+    kk = spec["k"] ** 2
+    p = spec["rank"] * kk * 1.05
+    N, n = spec["N"], spec["n"]
+    flops = N * p * p + 2.0 * N * p * n
+    saved_ms = flops * (1.0 - 1.0 / ranks) / (gemm_tflops * 1e12) * 1e3
+    bytes_ar = (8.0 * p * p + 8.0 * p * n) * 2.0 * (ranks - 1) / ranks
+    cost_ms = bytes_ar / (link_gb_s * 1e9) * 1e3 + 0.05       # + the launch / rendezvous of three collectives
+    return dict(saved_ms=round(saved_ms, 3), cost_ms=round(cost_ms, 3), pays=bool(saved_ms > 1.5 * cost_ms))
+
+
 def row_range(N, world, rank):
     """[lo, hi) of `rank` when N rows are split into `world` contiguous, balanced slices."""
     base, extra = divmod(int(N), int(world))
@@ -547,22 +563,22 @@ def row_range(N, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def allreduce_sum(dist, t):
-    """In-place sum over the ranks of a torch tensor.  RCCL ("nccl") reduces device tensors in place over xGMI;
-    with "gloo" (CPU tests, or several ranks on one GPU) a device tensor is staged through the host."""
+def allreduce_sum(dist, t, group=None):
+    """In-place sum over the ranks (of `group`, default: all) of a torch tensor.  RCCL ("nccl") reduces device tensors in
+    place over xGMI; with "gloo" (CPU tests, or several ranks on one GPU) a device tensor is staged through the host."""
     if dist is None or dist.get_world_size() == 1:
         return t
     if t.is_cuda and dist.get_backend() != "nccl":
         h = t.cpu()
-        dist.all_reduce(h)
+        dist.all_reduce(h, group=group)
         t.copy_(h)
     elif not t.is_cuda and dist.get_backend() == "nccl":
         import torch
         d = t.to(torch.device("cuda", torch.cuda.current_device()))
-        dist.all_reduce(d)
+        dist.all_reduce(d, group=group)
         t.copy_(d.cpu())
     else:
-        dist.all_reduce(t)
+        dist.all_reduce(t, group=group)
     if t.is_cuda:
         import torch
         torch.cuda.synchronize(t.device)   # the library runs on its own stream
@@ -707,4 +723,94 @@ def prune_layer_rows(engine, X_local, W2, Y_local, row0, N_total, rank, alpha_in
     finally:
         if own_rows:
             engine.free()
+    return idxs, W.reshape((n, kept, k, k)), b, alpha
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one layer whose OWNER is helped by a rank with slack: the rows of the refit split over the two
+# ---------------------------------------------------------------------------------------------------------
+def plan_assists(specs, owner, world, min_gain_ms=0.3):
+    """{layer index: helper rank} for a job sharded by `owner`: the layers for which splitting the refit's rows over two ranks
+    pays (row_shard_cost_test) get, heaviest first, the least-loaded rank that (a) is not the owner, (b) helps nobody else
+    and (c) has its own layers done well before the owner's alpha search ends (own load <= half the layer's cost) -- the
+    helper joins when the owner broadcasts the mask, so it must be idle by then.  Every rank computes the same plan."""
+    costs = [s.get("cost", layer_cost(s["N"], s["c"], s["n"], s["k"], s["rank"])) for s in specs]
+    load = [0.0] * world
+    for c_, o in zip(costs, owner):
+        load[o] += c_
+    assists, taken = {}, set()
+    cand = sorted(range(len(specs)), key=lambda i: -costs[i])
+    for i in cand:
+        t = row_shard_cost_test(specs[i])
+        if not t["pays"] or t["saved_ms"] - t["cost_ms"] < min_gain_ms:
+            continue
+        free = [r for r in range(world) if r != owner[i] and r not in taken and load[r] <= 0.5 * costs[i]]
+        if not free:
+            continue
+        h = min(free, key=lambda r: (load[r], r))
+        assists[i] = h
+        taken.add(h)
+    return assists
+
+
+def _bcast_mask(dist, mask_u8, src, group):
+    """mask uint8[c] from global rank `src` to the ranks of `group` (a device tensor with RCCL, a host tensor otherwise)"""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(mask_u8, dtype=np.uint8))
+    if dist.get_backend() == "nccl":
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    dist.broadcast(t, src=src, group=group)
+    return t.cpu().numpy()
+
+
+def prune_layer_assisted(engine, role, dist, group, owner_rank, c, W2, N_total, rank, alpha_in, X=None, Y=None, rank_tol=.1,
+                         rng=None, ridge=0.0, alpha_arg=1e-4, timings=None):
+    """dictionary() (lib/decompose.py:386-634) on a layer whose owner is HELPED by a second rank for the refit.
+
+    role "owner": X / Y are the layer's host arrays (all N_total rows: the sample subset of decompose.py:425 is drawn from
+    them), the engine holds the owner's share of the rows (engine.load_rows, any contiguous part); it runs the alpha search
+    alone -- the one step no second GPU can divide -- broadcasts the mask, and both ranks then sum their rows' column sums
+    and normal equations (two all-reduces inside `group`); the owner solves.  -> (idxs, newW2[n, nnz, k, k], newB2, alpha).
+    role "helper": the engine holds the other rows; waits for the mask, contributes its sums and Gram, returns None.  It
+    draws nothing from any RNG.  The reference's RNG stream on the owner is consumed exactly as dictionary() does."""
+    import time
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + now - t_last[0]
+            t_last[0] = now
+
+    if role == "owner":
+        rng = np.random if rng is None else rng
+        X = np.asarray(X)
+        Y = np.asarray(Y, dtype=np.float64)
+        k = X.shape[2] if X.ndim > 2 else 1
+        n = W2.shape[0]
+        samples = rng.randint(0, N_total, min(400, N_total // 20))               # decompose.py:425
+        if rank == c:                                                             # decompose.py:487-488
+            idxs, alpha = np.array([True] * rank), alpha_arg
+        else:
+            idxs, alpha = engine.select(np.ascontiguousarray(X[samples]), W2, np.ascontiguousarray(Y[samples]), rank, alpha_in,
+                                        rank_tol, rng)
+        lap("alpha_search")
+        mask = idxs.astype(np.uint8)
+        _bcast_mask(dist, mask, owner_rank, group)
+    else:
+        mask = _bcast_mask(dist, np.zeros(c, dtype=np.uint8), owner_rank, group)
+    lap("mask_broadcast")
+    kept = int(mask.sum())
+    sums_elems, gram_elems = engine.layout(kept)
+    sums, gram = engine.buffer(sums_elems), engine.buffer(gram_elems)
+    engine.sums(mask, sums)
+    allreduce_sum(dist, sums, group)
+    lap("refit_sums")
+    engine.gram(mask, N_total, sums, gram)
+    allreduce_sum(dist, gram, group)
+    lap("refit_gram")
+    if role != "owner":
+        return None
+    W, b = engine.solve(kept, N_total, ridge, sums, gram)
+    lap("refit_solve")
     return idxs, W.reshape((n, kept, k, k)), b, alpha

@@ -781,8 +781,18 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
             acc[q] = y;
+            // rows 16 q .. 16 q + 15 of the tile are final: on their way while the next block column is waited for
+            {
+                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const int uoff = fk * ldo + 16 * wv + fi, loff = (16 * wv + fi) * ld + fk;
+                const gdp Uo = (gdp)out, Lo = (gdp)Ltjs;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    (Uo + size_t(16 * q + 4 * r) * ldo)[uoff] = y[r];
+                    if (Ltjs) (Lo + (16 * q + 4 * r))[loff] = y[r];
+                }
+            }
         }
-        panel_store(acc, (gdp)out, ldo, (gdp)Ltjs, ld);
         CP_STAMP(5);
         __builtin_amdgcn_endpgm();
     }

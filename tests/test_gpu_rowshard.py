@@ -116,6 +116,67 @@ def test_row_sharded_world_matches_reference_golden(world):
         assert len({got[r][name]["digest"] for r in range(world)}) == 1, name + ": ranks disagree"
 
 
+def _assist_worker(rank, world, port, names, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for sub in ("channel-pruning_amd", "oracle"):
+        sys.path.insert(0, os.path.join(ROOT, sub))
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpmi355 import capi
+    from cpmi355.shard import RowShardEngine, prune_layer_assisted
+    group = dist.new_group(ranks=[0, 1])
+    out = {}
+    try:
+        for name in names:
+            g, p, X, W2, Y = _load(name)
+            cut = p["N"] // 2
+            ctx = capi.Context(0)
+            eng = RowShardEngine(ctx, flags=0)
+            if rank == 0:
+                eng.load_rows(X[:cut], Y[:cut])
+                rng = np.random.RandomState(1234 + p["layer_id"])
+                idxs, W, b, alpha = prune_layer_assisted(eng, "owner", dist, group, 0, p["c"], W2, p["N"], p["rank"],
+                                                         p.get("alpha_in", 1e-3), X=X, Y=Y, rank_tol=p.get("rank_tol", .1), rng=rng)
+                out[name] = dict(mask_equal=bool(np.array_equal(idxs, g["idxs"])), alpha_equal=bool(alpha == float(g["alpha_out"])),
+                                 fits_equal=bool(np.array_equal(np.array(eng.fits, dtype=np.float64).reshape(-1, 3), g["fits"])),
+                                 rng_equal=bool(int(rng.randint(0, 2147483647)) == int(g["rng_next"])),
+                                 shape_equal=bool(W.shape == g["newW2"].shape),
+                                 errW=float(_relfro(W, g["newW2"])) if W.shape == g["newW2"].shape else 1.0,
+                                 errb=float(_relfro(b, g["newB2"])))
+            else:
+                eng.load_rows(X[cut:], Y[cut:])
+                assert prune_layer_assisted(eng, "helper", dist, group, 0, p["c"], W2, p["N"], p["rank"], 1e-3) is None
+            eng.free()
+            ctx.close()
+        q.put((rank, out))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_layer_whose_owner_is_helped_by_a_second_rank_matches_reference_golden():
+    """prune_layer_assisted on the GPU: the owner (rank 0) searches alone and broadcasts the mask, the helper (rank 1, the other
+    half of the rows; both on this one GPU, gloo) contributes its column sums and its share of the normal equations, the owner
+    solves: masks, per-fit logs, alpha and the RNG stream identical to the reference, weights within 1e-5."""
+    import multiprocessing as mp
+    names = ["s01_c32_k3", "s08_resid_k1", "L02_conv3_1_conv3_2"]
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 29300 + (os.getpid() % 2000)
+    procs = [mpc.Process(target=_assist_worker, args=(r, 2, port, names, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for name in names:
+        _check(name, got[0][name])
+    assert got[1] == {}
+
+
 def test_row_shard_engine_explains_the_load_order(ctx):
     """In THIS process the library came first (session fixture), so torch.cuda cannot start: the engine says why."""
     from cpmi355.shard import RowShardEngine

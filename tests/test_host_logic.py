@@ -434,6 +434,76 @@ def _row_shard_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _assist_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cp_oracle
+    from cpmi355.shard import prune_layer_assisted
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = dist.new_group(ranks=[0, 2])              # every rank creates it; rank 1 stands by
+    out = []
+    for lid, (N, c, n, k, r) in enumerate([(600, 16, 12, 3, 8), (500, 24, 16, 1, 10), (400, 12, 12, 3, 12)], start=1):
+        X, W2, Y, B2 = cp_oracle.synth_layer(lid, N, c, n, k)
+        cut = N // 2 + 7                               # the owner keeps the first rows, the helper the rest (uneven on purpose)
+        if rank == 0:
+            eng = _NumpyRowEngine()
+            eng.load_rows(X[:cut], Y[:cut])
+            rng = np.random.RandomState(1234 + lid)
+            idxs, W, b, alpha = prune_layer_assisted(eng, "owner", dist, group, 0, c, W2, N, r, 1e-3, X=X, Y=Y, rng=rng)
+            out.append((idxs.tolist(), W, b, alpha, int(rng.randint(0, 2147483647))))
+        elif rank == 2:
+            eng = _NumpyRowEngine()
+            eng.load_rows(X[cut:], Y[cut:])
+            assert prune_layer_assisted(eng, "helper", dist, group, 0, c, W2, N, r, 1e-3) is None
+    dist.barrier()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_layer_whose_owner_is_helped_by_a_second_rank_world_size_3_gloo():
+    """prune_layer_assisted: the owner runs the alpha search alone and broadcasts the mask; owner and helper then sum the column
+    sums and the normal equations of their rows (two all-reduces inside their own group, a third rank standing by); the owner
+    solves.  Mask, alpha and the reference's RNG stream exactly as a single process gives them, W / b to 1e-9 (NumPy stand-in
+    for the GPU engine: the exchange logic is what runs here)."""
+    import multiprocessing as mp
+    import cp_oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_assist_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] == [] and got[2] == [] and len(got[0]) == 3
+    for lid, (N, c, n, k, r) in enumerate([(600, 16, 12, 3, 8), (500, 24, 16, 1, 10), (400, 12, 12, 3, 12)], start=1):
+        X, W2, Y, B2 = cp_oracle.synth_layer(lid, N, c, n, k)
+        rng = np.random.RandomState(1234 + lid)
+        ref = cp_oracle.dictionary_oracle(X.astype(np.float64), W2, Y, r, B2, rng=rng, lasso="c_gram", ls="numpy")
+        idxs, W, b, alpha, nxt = got[0][lid - 1]
+        assert idxs == ref[0].tolist() and alpha == ref[3] and nxt == int(rng.randint(0, 2147483647))
+        assert np.linalg.norm(W - ref[1]) <= 1e-9 * np.linalg.norm(ref[1]) and np.linalg.norm(b - ref[2]) <= 1e-9 * max(1.0, np.linalg.norm(ref[2]))
+
+
+def test_plan_assists_uses_ranks_with_slack_only():
+    """plan_assists: a helper for the layers whose cost test pays (N = 20000), never at the 5000-sample job; a rank helps at most
+    one layer, never its own, and only if its own load is at most half the helped layer's cost."""
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import jobs, shard
+    s5 = jobs.vgg16_5x()
+    owner = shard.plan_owners(s5, 8)
+    a = shard.plan_assists(s5, owner, 8)
+    assert a and all(s5[i]["c"] == 512 for i in a) and len(set(a.values())) == len(a)
+    assert all(h != owner[i] for i, h in a.items())
+    assert shard.plan_assists(jobs.vgg16_4x(), shard.plan_owners(jobs.vgg16_4x(), 8), 8) == {}
+    assert shard.plan_assists(s5, [0] * len(s5), 1) == {}
+
+
 def test_row_sharded_layer_world_size_2_gloo():
     """prune_layer_rows with the rows of each layer split over two ranks: the sampled-row exchange and the two
     all-reduces reproduce the single-process result (mask, alpha and RNG stream exactly; W, b to 1e-9) on both
