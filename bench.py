@@ -393,6 +393,15 @@ def bench_job(args, env, job):
     weak = args.scaling == "weak"
     owner = [env.rank] * len(specs) if weak else shard.plan_owners(specs, env.world)
     own = [i for i in range(len(specs)) if owner[i] == env.rank]
+    # N > 1, strong: the layers for which splitting the refit's rows over two ranks pays (shard.row_shard_cost_test: the
+    # N = 20000 job's wide layers, never the 5000-sample jobs) get a helper among the ranks with slack (shard.plan_assists):
+    # the owner searches and solves, the helper contributes half of the column sums and of the normal equations
+    assists = {}
+    if not weak and env.dist is not None and not args.no_row_assist:
+        assists = shard.plan_assists(specs, owner, env.world)
+        if os.environ.get("CP_BENCH_ASSISTS"):      # flow tests on a small box: "layer index:helper rank,..." instead of the plan
+            assists = {int(a.split(":")[0]): int(a.split(":")[1]) for a in os.environ["CP_BENCH_ASSISTS"].split(",")}
+    rset_index = [i for i in own if i not in assists]
     host_data = {}
 
     def operands(spec):
@@ -459,9 +468,17 @@ def bench_job(args, env, job):
         for item in os.environ["CP_BENCH_PER_STREAM_BY_WIDTH"].split(","):
             k_, v_ = item.split(":")
             per_stream[int(k_)] = int(v_)
-    rset = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in own], operands, per_stream=per_stream,
+    rset = shard.ResidentLayerSet(env.local_rank, [specs[i] for i in rset_index], operands, per_stream=per_stream,
                                   flags=CD_FLAGS, borrow_results=True, precompute_heaviest=args.precompute_heaviest)
-    probs = rset.problems()           # index in `own` order -> LayerProblem
+    probs = rset.problems()           # index in `rset_index` order -> LayerProblem
+    job_set = rset
+    if assists:
+        def make_engine():
+            cx_ = cpmi355.Context(env.local_rank)
+            eng_ = shard.RowShardEngine(cx_, flags=CD_FLAGS)
+            eng_.owned_ctx = cx_
+            return eng_
+        job_set = shard.AssistedJob(specs, owner, assists, env.dist, operands, make_engine, rset, rset_index)
     ctxs = [cx for ch in rset.chunks for cx in ch["ctxs"]]
     roots = [ch["ctxs"][0] for ch in rset.chunks]
 
@@ -480,9 +497,9 @@ def bench_job(args, env, job):
                 shard.LAST_EXCHANGE_MS.update(total=(time.perf_counter() - t_x) * 1e3, bytes_sent=sum(s["c"] for s in specs))
             return res
         # N > 1: the results of the light layers are exchanged while the heavy ones are still being pruned (shard.plan_rounds)
-        return shard.prune_sharded(specs, compute_many=rset, dist=env.dist, owner=owner,
+        return shard.prune_sharded(specs, compute_many=job_set, dist=env.dist, owner=owner,
                                    staging="device" if env.dist is not None else None,
-                                   rounds=exchange_rounds if env.dist is not None else None)
+                                   rounds=exchange_rounds if (env.dist is not None and not assists) else None)
 
     def sync_all():
         for cx in roots:
@@ -571,7 +588,7 @@ def bench_job(args, env, job):
     alone_c_ms, alone_c_fl = [], []
     stage_by_c = {}
     for j, pr in ([] if args.profile_mode else probs.items()):
-        spec = specs[own[j]]
+        spec = specs[rset_index[j]]
         kk = spec["k"] ** 2
         pr.ctx.enable_stage_timing(1)
         ch = [c_ for c_ in rset.chunks if j in c_["members"]][0]
@@ -632,6 +649,8 @@ def bench_job(args, env, job):
                                 "layers_that_take_it": [s_["name"] for s_ in specs if shard.row_shard_cost_test(s_)["pays"]]}}
         if env.world > 1 and not args.profile_mode:
             # every rank prunes its OWN instance of the whole job (weak scaling, what --scaling weak times as `value`)
+            if assists:
+                job_set.close()
             rset.close()
             host_data.clear()
             rset = shard.ResidentLayerSet(env.local_rank, specs, lambda sp: cpjobs.synth(sp)[:3], per_stream=per_stream,
@@ -718,7 +737,8 @@ def bench_job(args, env, job):
         by = [algorithmic_bytes(s["c"], s["n"], int(r[0].sum()) * s["k"] ** 2, N=s["N"], kk=s["k"] ** 2) for s, r in zip(specs, results)]
         alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
         n_sampled = (jobs + STAGE_SAMPLE - 1) // STAGE_SAMPLE       # the jobs whose stage brackets were read
-        roof = roofline_object(cls_ms, g_fl, chol_fl, n_sampled, roots[0], PROFILE_TAG, job, windows=windows, cd_steps_ns=cd_steps_ns)
+        roof = roofline_object(cls_ms, g_fl, chol_fl, n_sampled, roots[0] if roots else None, PROFILE_TAG, job, windows=windows,
+                               cd_steps_ns=cd_steps_ns)
         if roof is not None:
             roof["jobs_with_stage_brackets"] = n_sampled
         if roof is not None and alone_g_ms:
@@ -749,7 +769,9 @@ def bench_job(args, env, job):
                        "streams_per_gpu": len(rset.chunks), "layers_in_flight_per_gpu": len(own),
                        "layers_per_call": sorted({len(ch["members"]) for ch in rset.chunks}),
                        "owner_rank_of_layer": None if weak else owner,
-                       "exchange_round_of_layer": exchange_rounds if env.dist is not None else None,
+                       "exchange_round_of_layer": exchange_rounds if (env.dist is not None and not assists) else None,
+                       "row_assisted_layers": {specs[i]["name"]: {"owner": owner[i], "helper": h} for i, h in sorted(assists.items())},
+                       "row_assist_timings_rank0_ms": getattr(job_set, "last_timings", None) if assists else None,
                        "parallelism": ("one job instance per GPU x%d, uint8 all_gather of the channel masks per job" % env.world)
                        if weak else ("layers of one instance sharded x%d (LPT), masks all_gather + all_gather of the "
                                      "packed (W,b) -- in two rounds: the light layers' results travel while the heavy "
@@ -796,6 +818,8 @@ def bench_job(args, env, job):
             # layers/s of the same job and job_speedup_wall_clock is observed, not extrapolated; --cpu-sample: the five cheapest
             full = args.cpu_full or (job == "vgg16" and not args.cpu_sample)
             out["cpu_baseline"] = cpu_baseline_object(specs, specs if full else small, per_layer, job_ms, full)
+    if assists and not (env.world > 1 and not args.profile_mode and not weak):     # (closed above before the replica leg)
+        job_set.close()
     rset.close()
     return out
 
@@ -1357,6 +1381,8 @@ def main():
     ap.add_argument("--precompute-heaviest", type=int, default=None,
                     help="layers whose full normal equations are computed under their alpha search (default: the library's 2)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-jobs-in-flight leg (N = 1)")
+    ap.add_argument("--no-row-assist", action="store_true",
+                    help="N > 1, strong: never split a layer's refit rows over its owner and a helper rank (shard.plan_assists)")
     ap.add_argument("--no-exchange-rounds", action="store_true",
                     help="N > 1, strong: ONE exchange after all layers instead of the light layers' results travelling early")
     ap.add_argument("--no-gather", action="store_true", help="skip the sampled-point im2col (extract_XY) measurement")

@@ -814,3 +814,84 @@ def prune_layer_assisted(engine, role, dist, group, owner_rank, c, W2, N_total, 
     W, b = engine.solve(kept, N_total, ridge, sums, gram)
     lap("refit_solve")
     return idxs, W.reshape((n, kept, k, k)), b, alpha
+
+
+class AssistedJob:
+    """compute_many for prune_sharded when some layers of a job are row-assisted (plan_assists): this rank's other layers
+    run on its ResidentLayerSet as always; every assisted layer it OWNS and every layer it HELPS runs prune_layer_assisted
+    on a host thread of its own with a RowShardEngine (own context = own stream) -- the helper thread blocks on the owner's
+    mask broadcast, i.e. it starts working when the owner's search ends, by which time the helper's own (light) layers are
+    done.  One process group per (owner, helper) pair, created by every rank in the same order.
+
+        specs, owner, assists   the job, its owner table, {layer index: helper rank}
+        operands(spec)          host arrays (X, W2, Y) of a layer, as for ResidentLayerSet
+        make_engine()           -> a fresh RowShardEngine (the GPU one, or a stand-in with the same methods)
+    """
+
+    def __init__(self, specs, owner, assists, dist, operands, make_engine, rset, rset_index, seed=lambda s: 1234 + s["layer_id"],
+                 alpha_in=1e-3, rank_tol=.1):
+        self.specs, self.owner, self.assists, self.dist = specs, owner, dict(assists), dist
+        self.rset, self.rset_index = rset, list(rset_index)           # rset over specs[i] for i in rset_index (this rank's other layers)
+        self.alpha_in, self.rank_tol, self.seed = alpha_in, rank_tol, seed
+        rank = dist.get_rank()
+        self.groups, self.mine, self.helped = {}, {}, {}
+        for i in sorted(self.assists):                                # every rank, same order: collective
+            self.groups[i] = dist.new_group(ranks=sorted({owner[i], self.assists[i]}))
+        for i, h in sorted(self.assists.items()):
+            s = specs[i]
+            cut = s["N"] // 2
+            if owner[i] == rank:
+                X, W2, Y = operands(s)
+                eng = make_engine()
+                eng.load_rows(X[:cut], Y[:cut])
+                self.mine[i] = dict(engine=eng, X=X, W2=W2, Y=Y)
+            elif h == rank:
+                X, W2, Y = operands(s)
+                eng = make_engine()
+                eng.load_rows(X[cut:], Y[cut:])
+                self.helped[i] = dict(engine=eng, W2=W2)
+        self.last_timings = {}
+
+    def __call__(self, own_specs=None):
+        import threading
+        rank = self.dist.get_rank()
+        out, errors = {}, []
+
+        def own_layer(i):
+            try:
+                s, m = self.specs[i], self.mine[i]
+                tm = {}
+                out[i] = prune_layer_assisted(m["engine"], "owner", self.dist, self.groups[i], rank, s["c"], m["W2"], s["N"], s["rank"],
+                                              s.get("alpha_in", self.alpha_in), X=m["X"], Y=m["Y"], rank_tol=self.rank_tol,
+                                              rng=np.random.RandomState(self.seed(s)), timings=tm)[:3]
+                self.last_timings[s.get("name", i)] = {k: round(v * 1e3, 3) for k, v in tm.items()}
+            except BaseException as e:   # noqa
+                errors.append(e)
+
+        def help_layer(i):
+            try:
+                s, m = self.specs[i], self.helped[i]
+                prune_layer_assisted(m["engine"], "helper", self.dist, self.groups[i], self.owner[i], s["c"], m["W2"], s["N"], s["rank"],
+                                     s.get("alpha_in", self.alpha_in))
+            except BaseException as e:   # noqa
+                errors.append(e)
+
+        threads = [threading.Thread(target=own_layer, args=(i,)) for i in self.mine] + \
+                  [threading.Thread(target=help_layer, args=(i,)) for i in self.helped]
+        for t in threads:
+            t.start()
+        rest = self.rset() if self.rset is not None else []
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        for i, r in zip(self.rset_index, rest):
+            out[i] = r
+        return [out[i] for i in sorted(out)]           # this rank's layers in layer order, as prune_sharded expects
+
+    def close(self):
+        for m in list(self.mine.values()) + list(self.helped.values()):
+            m["engine"].free()
+            cx = getattr(m["engine"], "owned_ctx", None)
+            if cx is not None:
+                cx.close()
