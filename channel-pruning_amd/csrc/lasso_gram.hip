@@ -218,6 +218,17 @@ __global__ void __launch_bounds__(ZT) k_hadamard_q(const double *__restrict__ GX
 
 }  // namespace
 
+namespace {
+constexpr int SAMPLE_ARG_MAX = 400;     // min(400, N // 20) of decompose.py:425
+struct SampleArg {
+    int v[SAMPLE_ARG_MAX];
+};
+__global__ void __launch_bounds__(512) k_samples_from_arg(SampleArg sa, int S, int64_t *__restrict__ out) {
+    const int s = threadIdx.x;
+    if (s < S) out[s] = sa.v[s];
+}
+}  // namespace
+
 extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const void *W2,
                              int w_dtype, int n, const double *Y, const int64_t *samples, int S, double *Q, double *q,
                              double *stats) {
@@ -256,7 +267,16 @@ extern "C" int cp_lasso_gram(cp_ctx *ctx, const void *X, int x_dtype, int64_t N,
         return cp_set_error(ctx, CP_ERR_NOMEM, "lasso_gram: arena");
 
     cp_stage_begin(ctx);
-    CP_HIP(ctx, hipMemcpyAsync(dsamples, samples, size_t(S) * 8, hipMemcpyHostToDevice, ctx->stream));
+    // the sample subset (S <= 400 row indices, decompose.py:425) as a kernel argument: the first thing on a layer's stream is a
+    // one-workgroup launch instead of a copy out of pageable host memory that the runtime stages through a buffer of its own
+    if (S <= SAMPLE_ARG_MAX && N <= 0x7fffffffLL) {
+        SampleArg sa;
+        for (int s = 0; s < S; ++s) sa.v[s] = int(samples[s]);
+        k_samples_from_arg<<<1, 512, 0, ctx->stream>>>(sa, S, dsamples);
+        CP_LAUNCH_CHECK(ctx);
+    } else {
+        CP_HIP(ctx, hipMemcpyAsync(dsamples, samples, size_t(S) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     {
         const unsigned nblk = unsigned(S_pad + n_pad + (S_pad / 32) * (n_pad / 32) + YB);
         const float *Xf = static_cast<const float *>(X), *Wf32 = static_cast<const float *>(W2);
