@@ -26,7 +26,6 @@
 // from every product with <= 8 chunks.
 #include <algorithm>
 #include <cstdlib>
-#include <mutex>
 
 #include "cp_common.h"
 
@@ -567,17 +566,6 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
     } while (0)
     const int tag = ctx->gemm_tag;
     ctx->gemm_tag = CP_GEMM_GENERIC;
-    // CP_GEMM_SERIALIZE=1 (experiment, default off): the chip-filling products of ALL streams of the device take turns -- each
-    // waits for the event the previous one recorded -- instead of interleaving their workgroups on the same CUs and L2s.
-    static const bool serialize = getenv("CP_GEMM_SERIALIZE") && getenv("CP_GEMM_SERIALIZE")[0] == '1';
-    const bool big = serialize && !p.small && p.n_tiles >= 2 * ctx->cu_count;
-    static std::mutex ser_mu;
-    static hipEvent_t ser_ring[64];
-    static int ser_next = 0, ser_last = -1;
-    if (big) {
-        ser_mu.lock();
-        if (ser_last >= 0) (void)hipStreamWaitEvent(ctx->stream, ser_ring[ser_last], 0);
-    }
     if (tri == CP_TRI_NONE) {
         if (tag == CP_GEMM_REFIT_XTY)
             CP_GEMM_LAUNCH(CP_TRI_NONE, CP_GEMM_REFIT_XTY);
@@ -594,13 +582,6 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
         CP_GEMM_LAUNCH(CP_TRI_UPPER, CP_GEMM_GENERIC);
     }
 #undef CP_GEMM_LAUNCH
-    if (big) {
-        if (!ser_ring[ser_next]) (void)hipEventCreateWithFlags(&ser_ring[ser_next], hipEventDisableTiming);
-        (void)hipEventRecord(ser_ring[ser_next], ctx->stream);
-        ser_last = ser_next;
-        ser_next = (ser_next + 1) % 64;
-        ser_mu.unlock();
-    }
     CP_LAUNCH_CHECK(ctx);
     if (ctx->gemm_mark) {
         cp_stage_mark(ctx, ctx->gemm_mark);
