@@ -521,7 +521,7 @@ def bench_job(args, env, job):
     # The stage brackets (HIP events on the launch streams, cp_enable_stage_timing mode 2) are taken during the TIMED jobs, on
     # every STAGE_SAMPLE-th of them: reading them back costs ~1 ms of host time per job (12 layers x ~8 brackets x two
     # hipEventElapsedTime each), which is measurement, not pruning work -- with every job instrumented it was 4 % of `value`
-    STAGE_SAMPLE = 4
+    STAGE_SAMPLE = 8
     g_ms, g_fl, exch_ms = [], [], []
     cls_ms = {"alpha_search": [], "refit_gram": [], "cholesky_chain": [], "backward_substitution": []}   # per launch / bracket, in the job
     chol_fl = []
