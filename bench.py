@@ -923,7 +923,7 @@ def run_passes(groups, passes):
             raise w.error
 
 
-def block_single_instance(device, passes=5):
+def block_single_instance(device, passes=7):
     """ONE instance of the conv3_x block: its three (independent) layers side by side on three streams through
     cp_prune_layer, nothing else on the chip.  -> dict (ms per pass, layers/s, per-stage ms, fits, CD steps)"""
     group = [LayerWorker(device, lid, c, n, r, batch=1) for lid, c, n, r in BLOCK_LAYERS]
@@ -934,10 +934,12 @@ def block_single_instance(device, passes=5):
         for cx in (w.ctx for w in group):
             cx.enable_stage_timing(1)
         ts = []
-        for i in range(passes + 1):
+        WARM = 4      # untimed passes first: this leg follows ~45 s of CPU baseline with an idle GPU, and the first passes after
+                      # that ran 2x slower in one run out of three (clocks / runtime state coming back up)
+        for i in range(passes + WARM):
             t1 = time.perf_counter()
             for w in group:                      # the three layers of ONE block instance, concurrently (own streams)
-                w.collect = i > 0
+                w.collect = i >= WARM
                 w.todo = 1
                 w.done.clear()
                 w.go.set()
@@ -945,7 +947,7 @@ def block_single_instance(device, passes=5):
                 w.done.wait()
                 if w.error is not None:
                     raise w.error
-            if i > 0:
+            if i >= WARM:
                 ts.append((time.perf_counter() - t1) * 1e3)
         stages = {}
         for w in group:
