@@ -114,7 +114,7 @@ class ResidentLayerSet:
         operands(spec) -> (X[N,c,k,k], W2[n,c,k,k], Y[N,n]) host arrays, called once per layer."""
 
     def __init__(self, device, specs, operands, seed=lambda s: 1234 + s["layer_id"], per_stream=2, alpha_in=1e-3,
-                 rank_tol=.1, flags=None, precompute_heaviest=None, borrow_results=False, low_priority_below=None):
+                 rank_tol=.1, flags=None, precompute_heaviest=None, borrow_results=False):
         import threading
 
         from . import capi
@@ -122,8 +122,6 @@ class ResidentLayerSet:
         self.specs = list(specs)
         self.alpha_in, self.rank_tol = alpha_in, rank_tol
         flags = 0 if flags is None else flags           # 0 = sklearn's operation order (capi.CP_CD_* trade it for speed)
-        if low_priority_below is None and os.environ.get("CP_RSET_LOW_PRIO_BELOW"):
-            low_priority_below = int(os.environ["CP_RSET_LOW_PRIO_BELOW"])
         by_width = {}
         for i, s in enumerate(self.specs):
             by_width.setdefault(int(s["c"]), []).append(i)
@@ -134,13 +132,9 @@ class ResidentLayerSet:
             per = max(1, min(int(per), capi_max_jobs()))
             for g0 in range(0, len(members), per):
                 group = members[g0:g0 + per]
-                # (the widest layers' streams at the higher HIP priority -- capi.Context(device, priority=-1) -- was
-                #  measured: vgg16 job 29.5 against 28.0 ms; not used)
-                # low_priority_below: the streams of the layers narrower than that many channels get the LOWER HIP priority
-                # (their products then yield to the wide layers', which own the job's critical path; their own chains are
-                # short and fit into the idle tail of the job)
-                low = low_priority_below is not None and c < int(low_priority_below)
-                root = capi.Context(device, priority=1) if low else capi.Context(device)
+                # (stream priorities were measured both ways -- the widest layers' streams higher: vgg16 job 29.5 against
+                #  28.0 ms; the narrow layers' lower: no change -- and are not used)
+                root = capi.Context(device)
                 ctxs = [root] + [root.sibling() for _ in group[1:]]
                 probs, rngs = [], []
                 for cx, i in zip(ctxs, group):

@@ -14,8 +14,10 @@
 //                                                           r = s - 2 and s - 1 (K = 256); at odd s only block row s + 1
 //                                                           rides along and takes r = s - 1 early, so that the serial piece
 //                                                           of every step stays at K = 128
-//     (s, s)       S = U_ss^T U_ss in LDS, T_q = (16 x 16 diagonal blocks)^-1, flag, U_ss^-1  -> U[s,s], operator, TI_s, TIT_s
-//     (s, j > s)   wait for the flag, U[s,j] = U_ss^-T S by block forward substitution          -> U[s,j], Lt[j,s]
+//     (s, s)       S = U_ss^T U_ss in LDS with look-ahead over its 16-column panels, T_q = (16 x 16 diagonal blocks)^-1, each block
+//                  column published (flag word = columns out) as it becomes final; then U_ss^-1  -> U[s,s], operator, TI_s, TIT_s
+//     (s, j > s)   U[s,j] = U_ss^-T S by block forward substitution, block column by block column BEHIND the publication
+//                                                                                                -> U[s,j], Lt[j,s]
 //     (i > s, j)   G[i,j] = S
 //   The right-hand sides R of the solve that follows ride along as extra tile columns of every block row (B operand: block
 //   row s - 1 of Y instead of U): when the last step ends, R holds Y = U^-T R -- the forward substitution costs no launch.
@@ -50,24 +52,6 @@ constexpr int PACK = 36 * PNB * PNB;         // packed upper triangle of a 128 x
 constexpr int LDS_DOUBLES = PACK + 2 * NB;   // + dinv[128] + dref[128]
 static_assert(2 * KCH * SLD <= PACK, "the operand chunks and the packed tile share the same LDS");
 
-// (bi, bj) of packed slot 0 .. 35 (row-major upper triangle of the 8 x 8 block grid), three bits each, packed in two 64-bit
-// constants per table: a few scalar / vector ALU operations instead of a dependent table load from memory on the chain
-__host__ __device__ constexpr unsigned long long pk_pack(bool want_j, int first, int last) {
-    unsigned long long v = 0;
-    int slot = 0;
-    for (int bi = 0; bi < 8; ++bi)
-        for (int bj = bi; bj < 8; ++bj, ++slot)
-            if (slot >= first && slot < last) v |= (unsigned long long)(want_j ? bj : bi) << (3 * (slot - first));
-    return v;
-}
-__device__ __forceinline__ int pk_bi(int b) {
-    constexpr unsigned long long lo = pk_pack(false, 0, 21), hi = pk_pack(false, 21, 36);
-    return int(((b < 21 ? lo >> (3 * b) : hi >> (3 * (b - 21)))) & 7);
-}
-__device__ __forceinline__ int pk_bj(int b) {
-    constexpr unsigned long long lo = pk_pack(true, 0, 21), hi = pk_pack(true, 21, 36);
-    return int(((b < 21 ? lo >> (3 * b) : hi >> (3 * (b - 21)))) & 7);
-}
 // slot of block (bi, bj), bi <= bj, in the packed upper triangle (row-major)
 __device__ __forceinline__ constexpr int pk(int bi, int bj) { return bi * NPAN - bi * (bi - 1) / 2 + (bj - bi); }
 // element (r, c) of the tile, block row <= block column
@@ -122,13 +106,12 @@ __device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_l
 // Block column of the DIAGONAL tile a wave owns.  Column w has w + 1 upper blocks, and waves w and w + 4 share a SIMD: with
 // column = wave the four SIMDs carry 6 / 8 / 10 / 12 blocks of the K = 128 update (the serial piece of a step waits for the
 // last); with the columns handed out as 7, 6, 5, 4 | 0, 1, 2, 3 every SIMD carries 9.
-__device__ __forceinline__ int diag_col(int wave, int balanced) { return balanced ? (wave < 4 ? 7 - wave : wave - 4) : wave; }
+__device__ __forceinline__ int diag_col(int wave) { return wave < 4 ? 7 - wave : wave - 4; }
 
 template <bool SAME>
-__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld, gcdp Bb, int ldb, int kcnt, double *sm,
-                                            int balanced = 0) {
+__device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld, gcdp Bb, int ldb, int kcnt, double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
-    const int wave = SAME ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6), balanced) : __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = SAME ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6)) : __builtin_amdgcn_readfirstlane(tid >> 6);
     // the diagonal tile stages ONE operand, so its chunks can be twice as deep in the same LDS: 4 instead of 8 chunks (two
     // barriers and an exposed LDS / global latency each) on the serial piece of the step
     constexpr int KCH = SAME ? 2 * KCH_BASE : KCH_BASE;
@@ -172,15 +155,15 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld
     }
 }
 
-// The diagonal role in three phases, each a function of its own (not inlined: the register allocator then sees one phase at
-// a time -- as one function the 16 x 16 in-register factorisation spilled on the chain at 128 VGPRs):
-//   diag_to_lds      the tile (upper blocks t <= w of `acc`) into the packed LDS tile, pivot references
-//   diag_factor_lds  U_ss^T U_ss = S in LDS.  The 16-column panel loop is the one of rounds 1-3 (wave 0 factors the 16 x 16
-//                    diagonal block in registers, one thread per column solves U12, all waves apply the rank-16 update on MFMA)
-//   diag_output      U[s,s] (upper, zeros below), T_p = U_pp^-1 into the diagonal slots, the operator P[s], the flag
-__device__ __forceinline__ void diag_to_lds(v4f64s (&acc)[NPAN], double *sm, gcdp dg0_blk, int balanced) {
+// The diagonal role in phases, the long ones functions of their own (not inlined: the register allocator then sees one phase
+// at a time -- as one function the 16 x 16 in-register factorisation spilled on the chain at 128 VGPRs):
+//   diag_to_lds            the tile (upper blocks t <= column of `acc`) into the packed LDS tile, pivot references
+//   diag_factor_lookahead  U_ss^T U_ss = S in LDS with look-ahead over the 16-column panels; U[s,s] and the operator of block s
+//                          leave for global memory as they become final, the flag word counts the published block columns
+//   diag_inverse           TI_s / TIT_s, after the last publication
+__device__ __forceinline__ void diag_to_lds(v4f64s (&acc)[NPAN], double *sm, gcdp dg0_blk) {
     const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
-    const int wave = diag_col(__builtin_amdgcn_readfirstlane(tid >> 6), balanced);
+    const int wave = diag_col(__builtin_amdgcn_readfirstlane(tid >> 6));
     double *dref = sm + PACK + NB;
 #pragma unroll
     for (int t = 0; t < NPAN; ++t) {
@@ -190,92 +173,6 @@ __device__ __forceinline__ void diag_to_lds(v4f64s (&acc)[NPAN], double *sm, gcd
     }
     if (tid < NB) dref[tid] = dg0_blk[tid];
     __syncthreads();
-}
-
-__device__ __noinline__ void diag_factor_lds(double *sm, double piv_tol, int *info, int blk) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
-    double *dinv = sm + PACK, *dref = dinv + NB;
-#pragma unroll 1
-    for (int p = 0; p < NPAN; ++p) {
-        const int k0 = p * PNB;
-        // (1) 16 x 16 diagonal block on wave 0, in registers, in the D lay-out of the MFMA tiles: lane (fk, fi) holds rows
-        // fk + 4 r of column fi (4 doubles).  Per pivot: the pivot to an SGPR pair (v_readlane), 1 / sqrt on every lane, row k
-        // scaled in the lanes that hold it, then U[k, fi] and the four U[k, fk + 4 r] fetched across lanes (ds_bpermute) and
-        // a[i, j] -= U[k, i] U[k, j] on the rows below.  (The column-per-lane form of rounds 1-3 -- 16 doubles per lane and 15
-        // row broadcasts in flight per pivot -- did not fit 128 VGPRs: it spilled on the chain.)
-        if (wave == 0) {
-            double *Dp = sm + pk(p, p) * 256;
-            double v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = Dp[(fk + 4 * r) * 16 + fi];
-            const double refv = dref[k0 + fi];
-#pragma unroll
-            for (int k = 0; k < PNB; ++k) {
-                const int kr = k >> 2, kq = k & 3, src = kq * 16 + k;
-                double piv = read_lane(v[kr], src);
-                const double ref = read_lane(refv, k);
-                if (!(piv > piv_tol * ref)) {   // wave-uniform
-                    if (lane == 0) atomicCAS(info, 0, blk * NB + k0 + k + 1);
-                    piv = ref > 0 ? ref : 1.0;  // harmless pivot; the result is discarded by the caller
-                }
-                const double inv = rsqrt_nr(piv);
-                if (fk == kq) v[kr] = fi == k ? piv * inv : v[kr] * inv;      // row k of U (columns >= k meaningful)
-                const double urow = __shfl(v[kr], kq * 16 + fi, 64);           // U[k, fi]
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double ucol = __shfl(v[kr], kq * 16 + fk + 4 * r, 64);   // U[k, fk + 4 r]
-                    if (fk + 4 * r > k) v[r] = fma(-ucol, urow, v[r]);
-                }
-                if (lane == 0) dinv[k0 + k] = inv;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (fi >= fk + 4 * r) Dp[(fk + 4 * r) * 16 + fi] = v[r];
-        }
-        __syncthreads();
-        // (2) U12 = U11^-T A12: thread t owns column k0 + 16 + t
-        const int rest = NB - k0 - PNB;
-        if (tid < rest) {
-            const int col = k0 + PNB + tid;
-            const double *Dp = sm + pk(p, p) * 256;
-            double *Cp = sm + pk(p, col >> 4) * 256 + (col & 15);
-            double x[PNB];
-#pragma unroll
-            for (int i = 0; i < PNB; ++i) x[i] = Cp[i * 16];
-#pragma unroll
-            for (int i = 0; i < PNB; ++i) {
-                double sacc = x[i];
-#pragma unroll
-                for (int k = 0; k < i; ++k) sacc = fma(-Dp[k * 16 + i], x[k], sacc);
-                x[i] = sacc * dinv[k0 + i];
-                __builtin_amdgcn_sched_barrier(0);   // the 120 broadcast reads of U11 stay next to their uses (registers)
-            }
-#pragma unroll
-            for (int i = 0; i < PNB; ++i) Cp[i * 16] = x[i];
-        }
-        __syncthreads();
-        // (3) A22 -= U12^T U12 on the upper 16 x 16 blocks (b <= a) of the trailing grid
-        const int rt = rest / PNB, ntile = rt * (rt + 1) / 2;
-        for (int e = wave; e < ntile; e += PT / 64) {
-            int a = int((sqrtf(8.f * float(e) + 1.f) - 1.f) * 0.5f);
-            while ((a + 1) * (a + 2) / 2 <= e) ++a;
-            while (a * (a + 1) / 2 > e) --a;
-            const int b = e - a * (a + 1) / 2;  // b <= a
-            const int bi = p + 1 + b, bj = p + 1 + a;
-            double *Cij = sm + pk(bi, bj) * 256;
-            const double *Ri = sm + pk(p, bi) * 256, *Rj = sm + pk(p, bj) * 256;
-            v4f64s c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] = Cij[(fk + 4 * r) * 16 + fi];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ri[(kk * 4 + fk) * 16 + fi], Rj[(kk * 4 + fk) * 16 + fi], c, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cij[(fk + 4 * r) * 16 + fi] = c[r];
-        }
-        __syncthreads();
-    }
-
 }
 
 #ifdef CP_CHOL_STAMPS   // diagnostic build (tools/ubench/chol_bulk.hip): where the look-ahead factorisation spends its cycles
@@ -288,11 +185,11 @@ __device__ unsigned long long cp_chol_diag_stamps[128];
 #define CP_DSTAMP(slot, who) do { } while (0)
 #endif
 
-// ---- the diagonal role, second form (round 5): look-ahead over the 16-column panels ---------------------------------------
-// What the first form leaves on the chain per panel: the 16 x 16 factorisation by ONE wave while seven wait at a barrier, the
-// U12 substitution as one thread per column (16 dependent steps of LDS broadcasts), the trailing update, three barriers; then,
-// after the last panel, the inversion of the eight diagonal blocks, U[s,s] and the operator to global memory, the flag.
-// Here:
+// ---- the diagonal role: look-ahead over the 16-column panels -------------------------------------------------------------
+// What a plain right-looking sweep over the panels (rounds 1-4, HISTORY.md) leaves on the chain per panel: the 16 x 16
+// factorisation by ONE wave while seven wait at a barrier, the U12 substitution as one thread per column (16 dependent steps of
+// LDS broadcasts), the trailing update, three barriers; then, after the last panel, the inversion of the eight diagonal blocks,
+// U[s,s] and the operator to global memory, the flag.  Here:
 //   * the in-register factorisation of a diagonal block carries the identity along (the same row operations): it ends with
 //     U_pp AND U_pp^-T = T_p^T in registers, so T_p goes straight to its slot of the operator and no inversion pass is left;
 //   * U_pj = T_p^T A_pj is four MFMAs per 16 x 16 block (wave per block column) instead of a thread per column;
@@ -313,7 +210,8 @@ __device__ __forceinline__ void store_block_global(gdp Ub, CP_GLOBAL unsigned lo
     }
 }
 
-// wave 0: v = the (fully updated) diagonal block p in the D lay-out -> U_pp (global U[s,s]), T_p (LDS slot + operator).
+// wave 0: v = the (fully updated) diagonal block p in the D lay-out -> U_pp (global U[s,s]), T_p (its LDS slot; wave 7 copies it
+// into the operator).
 // A lone wave issues an instruction every ~7 cycles whatever it is, so a pivot costs what its instruction count costs (the
 // first version of this function: ~60 instructions, 550 cycles per pivot, 8.8k per block).  This one keeps the block UNSCALED
 // while it eliminates -- a[i][j] -= a[k][i] a[k][j] / a[k][k] -- so that
@@ -329,7 +227,7 @@ __device__ __forceinline__ double bperm(int addr, double x) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ void factor_block_inreg(v4f64s v, double *sm, int p, double piv_tol, int *info, int blk, gdp Ub,
-                                                   CP_GLOBAL unsigned long long *Go, int ld, int lane, int fk, int fi, bool store_t) {
+                                                   int ld, int lane, int fk, int fi) {
     const double *dref = sm + PACK + NB;
     const int k0 = p * PNB;
     v4f64s w, sc;                                // w: the identity carried along (ends as U_pp^-T); sc[r]: 1 / sqrt(pivot of row fk + 4 r)
@@ -382,20 +280,16 @@ __device__ __forceinline__ void factor_block_inreg(v4f64s v, double *sm, int p, 
         const double u = v[r] * sc[r], x = w[r] * sc[r];
         Dp[fi * 16 + row] = x;                                              // T_p[fi][row] = U^-T[row][fi]
         Ub[(k0 + row) * ld + k0 + fi] = fi >= row ? u : 0.0;                // U_pp, zeros below the diagonal
-        if (store_t)
-            __hip_atomic_store(Go + (k0 + fi) * ld + k0 + row, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);                   // operator, diagonal slot: T_p
     }
 }
 
-// stream != 0: the operator is PUBLISHED block column by block column -- the flag word counts the columns q whose blocks
-// (k, q), k < q, and T_q are in global memory -- so that the panel workgroups substitute behind the factorisation instead of
-// starting when it ends (role_panel).  Who stores what then: the strictly upper blocks by the waves 1 .. 7 that compute them
-// (phase A; each waits for its stores before the barrier that ends phase B), T_q by wave 7, which has no column of its own
-// from the second panel on: it copies T_q out of LDS during phase A of panel q, waits for the copy and raises the count.  Wave
-// 0 -- the chain -- issues no operator store and never waits for memory.
-__device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, int *info, int blk, double *Ub_, double *Gss_, int ld,
-                                                   int stream) {
+// The operator is PUBLISHED block column by block column -- the flag word counts the columns q whose blocks (k, q), k < q, and
+// T_q are in global memory -- so that the panel workgroups substitute behind the factorisation instead of starting when it
+// ends (role_panel).  Who stores what: the strictly upper blocks by the waves 1 .. 7 that compute them (phase A; each waits for
+// its stores before the barrier that ends phase B), T_q by wave 7, after the barrier that opens phase B of panel q: it copies
+// T_q out of LDS, waits for the copy and raises the count.  Wave 0 -- the chain -- issues no operator store and never waits for
+// memory.
+__device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, int *info, int blk, double *Ub_, double *Gss_, int ld) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     const gdp Ub = (gdp)Ub_;
     CP_GLOBAL unsigned long long *const Go = (CP_GLOBAL unsigned long long *)Gss_;
@@ -415,15 +309,15 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = D0[(fk + 4 * r) * 16 + fi];
         CP_DSTAMP(0, 0);
-        factor_block_inreg(v, sm, 0, piv_tol, info, blk, Ub, Go, ld, lane, fk, fi, !stream);
+        factor_block_inreg(v, sm, 0, piv_tol, info, blk, Ub, ld, lane, fk, fi);
         CP_DSTAMP(1, 0);
     }
     __syncthreads();
 #pragma unroll 1
     for (int p = 0; p < NPAN; ++p) {
         CP_DSTAMP(8 + 8 * p + 0, 0);
-        // phase A: U_pj = T_p^T A_pj, wave w -> block column p + 1 + w (streaming form: waves 1 .. 7 -> columns p + 1 .. p + 7)
-        const int j = stream ? (wave == 0 ? NPAN : p + wave) : p + 1 + wave;
+        // phase A: U_pj = T_p^T A_pj, waves 1 .. 7 -> block columns p + 1 .. p + 7 (wave 0 issues no global store)
+        const int j = wave == 0 ? NPAN : p + wave;
         if (j < NPAN) {
             const double *Tp = sm + pk(p, p) * 256;
             double *Cp = sm + pk(p, j) * 256;
@@ -440,7 +334,7 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
         CP_DSTAMP(8 + 8 * p + 2, 0);
         // publisher (wave 7, AFTER the barrier so that the chain does not wait for its store round trip): T_p out of its LDS
         // slot, then the count -- block column p is complete
-        if (stream && wave == NPAN - 1) {
+        if (wave == NPAN - 1) {
             const double *Tp = sm + pk(p, p) * 256;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -465,7 +359,7 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(-rv, rv, c, 0, 0, 0);
             }
             CP_DSTAMP(8 + 8 * p + 3, 0);
-            factor_block_inreg(c, sm, p + 1, piv_tol, info, blk, Ub, Go, ld, lane, fk, fi, !stream);
+            factor_block_inreg(c, sm, p + 1, piv_tol, info, blk, Ub, ld, lane, fk, fi);
             CP_DSTAMP(8 + 8 * p + 4, 0);
         } else {
             const int ntile = rt * (rt + 1) / 2;
@@ -488,104 +382,12 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
             }
             CP_DSTAMP(8 + 8 * p + 5, 64);      // wave 1 done with its share of the trailing blocks
             // this wave's phase-A stores (the blocks (p, j) of the operator) are out before block column p + 1 is published
-            if (stream) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         CP_DSTAMP(8 + 8 * p + 6, 0);
     }
-    if (stream) return;                 // the last column was published by wave 7 in phase A of the last panel
-    // every wave's stores of the operator have to be out before the flag goes up (see diag_output)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(info + 1 + blk, NPAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __noinline__ void diag_output(double *sm, double *Ub_, int ld, double *Gss_, int *info, int blk) {
-    const gdp Ub = (gdp)Ub_, Gss = (gdp)Gss_;
-    const int tid = threadIdx.x;
-    const double *dinv = sm + PACK;
-    // U[s,s] -> global (upper; the lower part zeroed)
-    for (int e = tid; e < NB * NB; e += PT) {
-        const int r = e >> 7, cc = e & (NB - 1);
-        Ub[size_t(r) * ld + cc] = cc >= r ? CP_PK(r, cc) : 0.0;
-    }
-    // T_p = U_pp^-1 (upper 16 x 16): thread (p, j) runs the back substitution of column j in registers
-    double tcol[PNB];
-    if (tid < NB) {
-        const int p = tid >> 4, j = tid & 15;
-        const double *Dp = sm + pk(p, p) * 256;
-#pragma unroll
-        for (int i = PNB - 1; i >= 0; --i) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int k = i + 1; k < PNB; ++k) sacc = fma(Dp[i * 16 + k], tcol[k], sacc);   // tcol[k] = 0 for k > j
-            tcol[i] = i <= j ? ((i == j ? 1.0 : 0.0) - sacc) * dinv[p * PNB + i] : 0.0;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __syncthreads();
-    if (tid < NB) {
-        const int p = tid >> 4, j = tid & 15;
-        double *Dp = sm + pk(p, p) * 256;
-#pragma unroll
-        for (int i = 0; i < PNB; ++i) Dp[i * 16 + j] = tcol[i];
-    }
-    __syncthreads();
-    // the operator goes where the tile came from: block (bi, bj) of G[s,s] (dead from here on) -- 16 lanes per 128-byte row.
-    // Hand-off to the panel workgroups (other CUs, other XCDs = other L2s) without fences: the operator is written with
-    // relaxed agent-scope atomics (global_store ... sc1: write-through) and read with sc1 loads (role_panel); every wave
-    // waits for ITS stores (vmcnt) before the barrier, then thread 0 raises the flag the same way.  An agent-scope release /
-    // acquire pair would be a write-back / invalidation of the whole L2 of the XCD (gemm_f64.hip tells what that costs).
-    {
-        typedef CP_GLOBAL unsigned long long *gup;
-        const gup Go = (gup)Gss_;
-#pragma unroll
-        for (int i = 0; i < PACK / PT; ++i) {
-            const int e = tid + PT * i, b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-            __hip_atomic_store(Go + (16 * pk_bi(b) + r) * ld + 16 * pk_bj(b) + c, (unsigned long long)__double_as_longlong(sm[e]),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(info + 1 + blk, NPAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all eight block columns at once
-}
-
-// the substituted tile: U[s,j] (or Y[s,jr]) row-major and, for factor tiles, its transpose Lt[j,s]
-__device__ __forceinline__ void panel_store(v4f64s (&acc)[NPAN], gdp Usj, int ldu, gdp Ltjs, int ld) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fk = lane >> 4, fi = lane & 15;
-    const int uoff = fk * ldu + 16 * wave + fi, loff = (16 * wave + fi) * ld + fk;
-#pragma unroll
-    for (int q = 0; q < NPAN; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            (Usj + size_t(16 * q + 4 * r) * ldu)[uoff] = acc[q][r];    // row 16 q + fk + 4 r, column 16 w + fi
-            if (Ltjs) (Ltjs + (16 * q + 4 * r))[loff] = acc[q][r];     // transposed (factor tiles only)
-        }
-}
-
-// U[s,j] = U_ss^-T S for the tile in `acc`: block forward substitution over the eight 16-row blocks with the operator in
-// LDS; a wave owns 16 columns of the tile, so the eight steps are register-to-register (the D lay-out of one MFMA is the B
-// operand of the next).  Also writes the transposed tile Lt[j,s] (what the backward substitution reads).
-__device__ __forceinline__ void panel_solve(v4f64s (&acc)[NPAN], const double *sm, gdp Usj, int ldu, gdp Ltjs, int ld) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fk = lane >> 4, fi = lane & 15;
-#pragma unroll
-    for (int q = 0; q < NPAN; ++q) {
-#pragma unroll
-        for (int k = 0; k < q; ++k) {
-            const double *Ukq = sm + pk(k, q) * 256;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ukq[(4 * r + fk) * 16 + fi], acc[k][r], acc[q], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // keep the 36 blocks' operand reads from being hoisted into 300 live registers
-        }
-        const double *Tq = sm + pk(q, q) * 256;
-        v4f64s y = {0., 0., 0., 0.};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
-        acc[q] = y;
-    }
-    panel_store(acc, Usj, ldu, Ltjs, ld);
+    // (the last column was published by wave 7 after the barrier of the last panel)
 }
 
 // TI_b = U_bb^-1 (upper) and TIT_b = its transpose from the operator in LDS: what the substitution kernels of refit.hip
@@ -666,11 +468,10 @@ struct Tile {
 
 // acc <- the tile, then the pending updates (see the head of the file)
 template <bool DIAG>
-__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *Ai_, int ld, double *sm,
-                                                 int balanced = 0) {
+__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *Ai_, int ld, double *sm) {
     const gcdp T = (gcdp)t_.T, Bop = (gcdp)t_.B, Ai = (gcdp)Ai_;
     const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
-    const int wave = DIAG ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6), balanced) : __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = DIAG ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6)) : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int toff = fk * t_.ldt + 16 * wave + fi;   // lane's offset inside a (16 t + 4 r)-row band of the tile: scalar base + 32-bit offset
 #pragma unroll
     for (int t = 0; t < NPAN; ++t) {
@@ -682,7 +483,7 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile
         for (int r = 0; r < 4; ++r) acc[t][r] = (T + size_t(16 * t + 4 * r) * t_.ldt)[toff];
     }
     CP_STAMP(1);
-    if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm, balanced);
+    if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm);
     CP_STAMP(2);
 }
 
@@ -707,22 +508,16 @@ __device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const 
 __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const double *__restrict__ Ai, double *__restrict__ Uss,
                                                                  int ld, int s, const double *__restrict__ dg0, double piv_tol,
                                                                  double *__restrict__ TIb, double *__restrict__ TITb, int *info,
-                                                                 int form, double *sm) {
+                                                                 double *sm) {
     CP_STAMP(0);
     {
         v4f64s acc[NPAN];
-        tile_load_update<true>(acc, t_, Ai, ld, sm, form & 2);
-        diag_to_lds(acc, sm, (gcdp)dg0 + size_t(s) * NB, form & 2);
+        tile_load_update<true>(acc, t_, Ai, ld, sm);
+        diag_to_lds(acc, sm, (gcdp)dg0 + size_t(s) * NB);
     }
     CP_STAMP(3);
-    if (form & 1) {     // look-ahead form: U[s,s], the operator and the flag leave from inside
-        diag_factor_lookahead(sm, piv_tol, info, s, Uss, t_.T, ld, form & 4);
-        CP_STAMP(4);
-    } else {
-        diag_factor_lds(sm, piv_tol, info, s);
-        CP_STAMP(4);
-        diag_output(sm, Uss, ld, t_.T, info, s);     // ... and the flag: the panel workgroups go on from here
-    }
+    diag_factor_lookahead(sm, piv_tol, info, s, Uss, t_.T, ld);   // U[s,s], the operator and the flag leave from inside
+    CP_STAMP(4);
     CP_STAMP(5);
     diag_inverse(sm, TIb, TITb);
     CP_STAMP(6);
@@ -733,89 +528,65 @@ __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const 
 __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const double *__restrict__ Ai, int ld, int s,
                                                                   double *__restrict__ out, int ldo, double *__restrict__ Ltjs,
                                                                   const double *__restrict__ Gss, int *info, int spin_limit,
-                                                                  int stream, double *sm) {
-    const int tid = threadIdx.x;
+                                                                  double *sm) {
+    const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
     v4f64s acc[NPAN];
     CP_STAMP(0);
     tile_load_update<false>(acc, t_, Ai, ld, sm);
-    if (stream) {
-        // Substitution BEHIND the factorisation: block column q of the operator (the blocks (k, q), k < q, and T_q) is fetched
-        // and applied as soon as the diagonal workgroup has published it (the flag word counts the published columns), so
-        // that after the last publication only the last of the eight steps is left -- not the operator load and all eight.
-        const int lane = tid & 63, fk = lane >> 4, fi = lane & 15;
-        typedef const CP_GLOBAL unsigned long long *gcup;
-        const gcup Go = (gcup)Gss;
+    // Substitution BEHIND the factorisation: block column q of the operator (the blocks (k, q), k < q, and T_q) is fetched and
+    // applied as soon as the diagonal workgroup has published it (the flag word counts the published columns), so that after
+    // the last publication only the last of the eight steps is left -- not the operator load and all eight.
+    typedef const CP_GLOBAL unsigned long long *gcup;
+    const gcup Go = (gcup)Gss;
 #pragma unroll
-        for (int q = 0; q < NPAN; ++q) {
-            if (tid == 0) flag_wait(info + 1 + s, info, spin_limit, q + 1);
-            __syncthreads();
-            if (q == NPAN - 1) CP_STAMP(3);
-            // (q + 1) blocks of 256 words: the first (q + 1) * 256 threads take one word... two rounds cover up to 8 blocks
-            constexpr int ROUNDS_MAX = (NPAN * 256 + PT - 1) / PT;
-            const int rounds = ((q + 1) * 256 + PT - 1) / PT;  // compile-time after unrolling
-            unsigned long long wv[ROUNDS_MAX];
+    for (int q = 0; q < NPAN; ++q) {
+        if (tid == 0) flag_wait(info + 1 + s, info, spin_limit, q + 1);  // bounded; running out is reported as a failed factorisation
+        __syncthreads();
+        if (q == NPAN - 1) CP_STAMP(3);
+        // (q + 1) blocks of 256 words, a word per thread and round: sc1 loads (see flag_wait), all in flight together
+        constexpr int ROUNDS_MAX = (NPAN * 256 + PT - 1) / PT;
+        const int rounds = ((q + 1) * 256 + PT - 1) / PT;  // compile-time after unrolling
+        unsigned long long wv[ROUNDS_MAX];
 #pragma unroll
-            for (int i = 0; i < ROUNDS_MAX; ++i) {             // the loads of the column in flight together
-                const int e = tid + PT * i;                    // word e of the column: block k = e / 256, element (r, c)
-                if (i < rounds && e < (q + 1) * 256)
-                    wv[i] = __hip_atomic_load(Go + (16 * (e >> 8) + ((e >> 4) & 15)) * ld + 16 * q + (e & 15), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int i = 0; i < ROUNDS_MAX; ++i) {
-                const int e = tid + PT * i;
-                if (i < rounds && e < (q + 1) * 256) sm[pk(e >> 8, q) * 256 + (e & 255)] = __longlong_as_double((long long)wv[i]);
-            }
-            __syncthreads();
-            if (q == NPAN - 1) CP_STAMP(4);
-#pragma unroll
-            for (int k = 0; k < q; ++k) {
-                const double *Ukq = sm + pk(k, q) * 256;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ukq[(4 * r + fk) * 16 + fi], acc[k][r], acc[q], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const double *Tq = sm + pk(q, q) * 256;
-            v4f64s y = {0., 0., 0., 0.};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
-            acc[q] = y;
-            // rows 16 q .. 16 q + 15 of the tile are final: on their way while the next block column is waited for
-            {
-                const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-                const int uoff = fk * ldo + 16 * wv + fi, loff = (16 * wv + fi) * ld + fk;
-                const gdp Uo = (gdp)out, Lo = (gdp)Ltjs;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    (Uo + size_t(16 * q + 4 * r) * ldo)[uoff] = y[r];
-                    if (Ltjs) (Lo + (16 * q + 4 * r))[loff] = y[r];
-                }
-            }
-        }
-        CP_STAMP(5);
-        __builtin_amdgcn_endpgm();
-    }
-    if (tid == 0) flag_wait(info + 1 + s, info, spin_limit, NPAN);  // bounded; running out is reported as a failed factorisation
-    __syncthreads();
-    CP_STAMP(3);
-    // the operator of block s, left in G[s,s] by the diagonal role of this launch: sc1 loads (see flag_wait), 18 per thread
-    {
-        static_assert(PACK % PT == 0, "operator words per thread");
-        typedef const CP_GLOBAL unsigned long long *gcup;
-        const gcup Go = (gcup)Gss;
-        unsigned long long w[PACK / PT];
-#pragma unroll
-        for (int i = 0; i < PACK / PT; ++i) {      // all the loads in flight together
-            const int e = tid + PT * i, b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-            w[i] = __hip_atomic_load(Go + (16 * pk_bi(b) + r) * ld + 16 * pk_bj(b) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < ROUNDS_MAX; ++i) {
+            const int e = tid + PT * i;                    // word e of the column: block k = e / 256, element (r, c)
+            if (i < rounds && e < (q + 1) * 256)
+                wv[i] = __hip_atomic_load(Go + (16 * (e >> 8) + ((e >> 4) & 15)) * ld + 16 * q + (e & 15), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int i = 0; i < PACK / PT; ++i) sm[tid + PT * i] = __longlong_as_double((long long)w[i]);
+        for (int i = 0; i < ROUNDS_MAX; ++i) {
+            const int e = tid + PT * i;
+            if (i < rounds && e < (q + 1) * 256) sm[pk(e >> 8, q) * 256 + (e & 255)] = __longlong_as_double((long long)wv[i]);
+        }
+        __syncthreads();
+        if (q == NPAN - 1) CP_STAMP(4);
+        // block row q of the tile: acc[q] <- T_q^T (acc[q] - sum_{k < q} U_kq^T acc[k]); a finished block in the D lay-out is
+        // the B operand of the next product as it is
+#pragma unroll
+        for (int k = 0; k < q; ++k) {
+            const double *Ukq = sm + pk(k, q) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ukq[(4 * r + fk) * 16 + fi], acc[k][r], acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const double *Tq = sm + pk(q, q) * 256;
+        v4f64s y = {0., 0., 0., 0.};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
+        acc[q] = y;
+        // rows 16 q .. 16 q + 15 of the tile are final: on their way (U[s,j] or Y[s,jr] row-major and, for a factor tile, the
+        // transpose Lt[j,s]) while the next block column is waited for
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int uoff = fk * ldo + 16 * wave + fi, loff = (16 * wave + fi) * ld + fk;
+        const gdp Uo = (gdp)out, Lo = (gdp)Ltjs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            (Uo + size_t(16 * q + 4 * r) * ldo)[uoff] = y[r];
+            if (Ltjs) (Lo + (16 * q + 4 * r))[loff] = y[r];
+        }
     }
-    __syncthreads();
-    CP_STAMP(4);
-    panel_solve(acc, sm, (gdp)out, ldo, (gdp)Ltjs, ld);
     CP_STAMP(5);
     __builtin_amdgcn_endpgm();
 }
@@ -826,7 +597,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
 __global__ void __launch_bounds__(PT, 4)
 k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int s,
             const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, double *__restrict__ TIT, int *info,
-            double *__restrict__ R, int ldr, int ntr, int prio, int spin_limit, int diag_form) {
+            double *__restrict__ R, int ldr, int ntr, int spin_limit) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     int i = s, jt;
     {   // tile -> (i, jt): block row i holds nblk - i factor tiles, then ntr right-hand-side tiles; row s first.
@@ -864,18 +635,18 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
     }
     const double *Gss = G + size_t(s) * NB * ld + size_t(s) * NB;   // where the diagonal role leaves the operator of block s
     // The workgroups of block row s are the serial piece of the step: their waves get the higher issue priority over the
-    // bulk workgroups (of this or any other layer's launch) that share their SIMDs (CP_CHOL_PRIO, default on).
-    if (prio && i == s) __builtin_amdgcn_s_setprio(3);
+    // bulk workgroups (of this or any other layer's launch) that share their SIMDs.
+    if (i == s) __builtin_amdgcn_s_setprio(3);
     if (i > s)            // below the block row of this step: the updated tile goes back
         role_bulk(t_, Ai, ld, s, sm);
     else if (!rhs && j == s)
         role_diag(t_, Ai, U + size_t(s) * NB * ld + size_t(s) * NB, ld, s, dg0, piv_tol, TI + size_t(s) * NB * NB,
-                  TIT + size_t(s) * NB * NB, info, diag_form, sm);
+                  TIT + size_t(s) * NB * NB, info, sm);
     else if (!rhs)
         role_panel(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB, Gss, info,
-                   spin_limit, (diag_form & 5) == 5, sm);
+                   spin_limit, sm);
     else
-        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, spin_limit, (diag_form & 5) == 5, sm);
+        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, spin_limit, sm);
 }
 
 hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explicit opt-in, once per device
@@ -902,11 +673,6 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     CP_HIP(ctx, lds_opt_in(ctx->device));
     const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
     const int ntr = R ? n_pad / NB : 0;
-    static const int prio = !(getenv("CP_CHOL_PRIO") && getenv("CP_CHOL_PRIO")[0] == '0');
-    // CP_CHOL_DIAG: bit 0 = look-ahead form of the 128 x 128 factorisation, bit 1 = balanced K = 128 update of the diagonal tile
-    //               bit 2 = the operator published block column by block column, the panel workgroups substituting behind (needs bit 0)
-    static const int diag_form_env = getenv("CP_CHOL_DIAG") ? atoi(getenv("CP_CHOL_DIAG")) : 7;
-    const int diag_form = (diag_form_env & 1) ? diag_form_env : (diag_form_env & ~4);
     int spin_limit = 1 << 26;
     if (ctx->chol_test_fail_flag_waits > 0) {   // test hook: the panel workgroups of THIS factorisation give up at once
         --ctx->chol_test_fail_flag_waits;
@@ -918,7 +684,7 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
         int tiles = n + ntr;
         if (s >= 2 && !(s & 1)) tiles = n * (n + 1) / 2 + n * ntr;
         else if ((s & 1) && n > 1) tiles += (n - 1) + ntr;
-        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, TIT, info, R, n_pad, ntr, prio, spin_limit, diag_form);
+        k_chol_step<<<tiles, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, s, dg0, piv_tol, TI, TIT, info, R, n_pad, ntr, spin_limit);
         CP_LAUNCH_CHECK(ctx);
     }
     return CP_OK;

@@ -49,7 +49,6 @@ struct cp_precompute {
     double *Gw = nullptr, *U = nullptr, *Lt = nullptr, *TI = nullptr, *TIT = nullptr, *F = nullptr, *dg0 = nullptr, *gmax = nullptr;
     int *finfo = nullptr;
     hipStream_t chain_stream = nullptr;   // this context's own stream for the (latency-bound) factorisation chain
-    hipStream_t own_side = nullptr;       // CP_SIDE_STREAM_PER_CTX: this context's own side stream instead of the device's shared one
     hipEvent_t gram_done = nullptr;
 };
 

@@ -846,10 +846,9 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
         CP_TRY(chol_factor(ctx, ch, PIV_TOL, Rm, n_pad, &fwd));
         cp_stage_mark(ctx, "refit_cholesky");
         if (nblk >= solve_blocked_min_blocks()) {   // large factor: banded substitution with GEMM updates; the lay-out rides along
-            static const bool band_final = !(getenv("CP_REFIT_BAND_FINAL") && getenv("CP_REFIT_BAND_FINAL")[0] == '0');
             StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
             bool fin_done = false;
-            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3, band_final ? &fin : nullptr, &fin_done));
+            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3, &fin, &fin_done));
             cp_stage_mark(ctx, "refit_solve");
             if (fin_done) {
                 CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything came back with the kernels
@@ -978,13 +977,9 @@ __global__ void __launch_bounds__(256) k_chan_from_bits(ChanBits bits, int c, in
     for (int b = 0; b < 8 && c0 + b < c; ++b)
         if (m & (1u << b)) chan[pos++] = c0 + b;
 }
-bool chan_kernarg_wanted() {
-    static const bool on = !(getenv("CP_REFIT_CHAN_KERNARG") && getenv("CP_REFIT_CHAN_KERNARG")[0] == '0');
-    return on;
-}
 // the kept-channel list on the device, ordered on ctx->stream
 int upload_chan(cp_ctx *ctx, const std::vector<int> &chan, int c, int *dchan) {
-    if (c <= CHAN_BITS_MAX && chan_kernarg_wanted()) {
+    if (c <= CHAN_BITS_MAX) {
         ChanBits bits;
         memset(&bits, 0, sizeof(bits));
         for (int ch : chan) bits.w[ch >> 6] |= 1ull << (ch & 63);
@@ -1053,7 +1048,6 @@ void cp_precompute_release(cp_ctx *ctx) {
         hipStreamSynchronize(pc.chain_stream);
         hipStreamDestroy(pc.chain_stream);
     }
-    if (pc.own_side) hipStreamDestroy(pc.own_side);
     if (pc.buf) hipFree(pc.buf);
     if (pc.fbuf) hipFree(pc.fbuf);
     if (pc.done) hipEventDestroy(pc.done);
@@ -1093,10 +1087,6 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
         w->cu_count = ctx->cu_count;
         w->own_stream = nullptr;
         w->stream = cp_side_stream(ctx);
-        // CP_SIDE_STREAM_PER_CTX=1: a side stream per context, so that several layers' normal equations run side by side
-        // under their searches instead of taking turns on the device's one shared stream
-        static const bool per_ctx = getenv("CP_SIDE_STREAM_PER_CTX") && getenv("CP_SIDE_STREAM_PER_CTX")[0] == '1';
-        if (per_ctx && hipStreamCreateWithFlags(&pc.own_side, hipStreamNonBlocking) == hipSuccess) w->stream = pc.own_side;
         for (int i = 0; i < 2 * CP_MAX_STAGES; ++i) hipEventCreate(&w->ev[i]);
         w->timing = ctx->timing;
         w->timing_gram_only = ctx->timing_gram_only;

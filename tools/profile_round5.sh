@@ -29,5 +29,5 @@ for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; do
   DB=$(find /tmp/pm_$C -name '*.db' | head -1)
   [ -n "$DB" ] && python $R/tools/rocpd_pmc.py $DB $C k_ > $OUT/pmc_mfma_$C.md 2>&1
 done
-timeout -k 5 120 $R/tools/ubench/chol_bulk 1 7 > $OUT/chol_bulk.md 2>&1
+timeout -k 5 120 $R/tools/ubench/chol_bulk > $OUT/chol_bulk.md 2>&1
 ls -la $OUT

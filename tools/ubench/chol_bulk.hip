@@ -27,8 +27,7 @@ __global__ void k_diag(const double *G, int p, double *dg0) {
 }
 
 int main(int argc, char **argv) {
-    const int prio = argc > 1 ? atoi(argv[1]) : 1;
-    const int form = argc > 2 ? atoi(argv[2]) : 3;
+    (void)argc, (void)argv;
     const int nblk = 36, p = nblk * NB;
     double *G, *U, *Lt, *TI, *TIT, *dg0;
     int *info;
@@ -60,7 +59,7 @@ int main(int argc, char **argv) {
             if (s >= 2 && !(s & 1)) tiles = n * (n + 1) / 2;
             else if ((s & 1) && n > 1) tiles += n - 1;
             hipEventRecord(e0);
-            k_chol_step<<<tiles, PT, lds>>>(G, U, Lt, p, nblk, s, dg0, 1e-12, TI, TIT, info, nullptr, 0, 0, prio, 1 << 26, form);
+            k_chol_step<<<tiles, PT, lds>>>(G, U, Lt, p, nblk, s, dg0, 1e-12, TI, TIT, info, nullptr, 0, 0, 1 << 26);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
@@ -122,7 +121,7 @@ int main(int argc, char **argv) {
     printf("| tile load | update loop (16 chunks) | store | whole |\n|---|---|---|---|\n");
     printf("| %.0f / %.0f | %.0f / %.0f | %.0f / %.0f | %.0f / %.0f |\n", med(load), mx(load), med(upd), mx(upd), med(store),
            mx(store), med(all), mx(all));
-    if (form & 1) {   // the look-ahead factorisation of the LAST step's diagonal tile, panel by panel
+    {   // the look-ahead factorisation of the LAST step's diagonal tile, panel by panel
         std::vector<unsigned long long> ds(128);
         hipMemcpyFromSymbol(ds.data(), HIP_SYMBOL(cp_chol_diag_stamps), ds.size() * 8);
         printf("\nlook-ahead factorisation (cycles): first 16 x 16 block in registers %llu\n", ds[1] - ds[0]);
@@ -138,7 +137,7 @@ int main(int argc, char **argv) {
         printf("\nstep 5, diagonal workgroup (cycles): tile load %llu | K=128 update %llu | to LDS %llu | 128x128 factorisation %llu | "
                "output + flag %llu | inverse (off the chain) %llu\n", d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4],
                d[6] - d[5]);
-        std::vector<double> upd, wait, opl, solve, whole;
+        std::vector<double> upd, wait, opl, solve;   // (stamps of different CUs are not comparable: no cross-workgroup column)
         const int n5 = nblk - 5;
         for (int w = 1; w < n5; ++w) {
             const unsigned long long *q = &st5[size_t(w) * 8];
@@ -147,11 +146,10 @@ int main(int argc, char **argv) {
             wait.push_back(double(q[3] - q[2]));
             opl.push_back(double(q[4] - q[3]));
             solve.push_back(double(q[5] - q[4]));
-            whole.push_back(double(q[5] - d[0]));
         }
         printf("step 5, %zu panel workgroups (median / max cycles): load + update %.0f / %.0f | wait for the flag %.0f / %.0f | operator "
-               "load %.0f / %.0f | substitution + stores %.0f / %.0f | end of the panel since the start of the diagonal workgroup %.0f / %.0f\n",
-               upd.size(), med(upd), mx(upd), med(wait), mx(wait), med(opl), mx(opl), med(solve), mx(solve), med(whole), mx(whole));
+               "load %.0f / %.0f | substitution + stores %.0f / %.0f\n",
+               upd.size(), med(upd), mx(upd), med(wait), mx(wait), med(opl), mx(opl), med(solve), mx(solve));
     }
     return 0;
 }
