@@ -17,6 +17,7 @@ for W in vgg16 resnet50 vgg16_5x; do
   [ -n "$DB" ] && python $R/tools/rocpd_kernels.py $DB 10 > $OUT/kernels_$W.md
   if [ "$W" = vgg16 ] && [ -n "$DB" ]; then python $R/tools/rocpd_timeline.py $DB --anchor=k_lasso_prep:12 --streams=14 > $OUT/timeline_vgg16.md 2>&1; fi
 done
+if [ "${CP_PROFILE_PMC:-1}" = 1 ]; then
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$C
   timeout -k 5 300 rocprofv3 --pmc $C --kernel-trace -d /tmp/p_$C -o r -- python $R/bench.py --profile-mode --steps 1 --warmup 1 --jobs-per-step 1 > /dev/null 2> $OUT/p_$C.err
@@ -29,5 +30,6 @@ for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; do
   DB=$(find /tmp/pm_$C -name '*.db' | head -1)
   [ -n "$DB" ] && python $R/tools/rocpd_pmc.py $DB $C k_ > $OUT/pmc_mfma_$C.md 2>&1
 done
+fi
 timeout -k 5 120 $R/tools/ubench/chol_bulk > $OUT/chol_bulk.md 2>&1
 ls -la $OUT
