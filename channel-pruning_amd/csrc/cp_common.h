@@ -38,11 +38,6 @@ struct cp_precompute {
     size_t buf_bytes = 0;
     double *xmean = nullptr, *ymean = nullptr, *G = nullptr, *R = nullptr;
     hipEvent_t done = nullptr;
-    // means_only: only xmean (all P columns) and ymean were computed (cp_refit_premeans_enqueue, on the device's auxiliary
-    // stream): the two dependent launches of the column means leave the critical path behind the search
-    bool means_only = false;
-    char *mbuf = nullptr;          // persistent: xmean [P_pad] | ymean [n_pad] | row-block partials
-    size_t mbuf_bytes = 0;
     cp_ctx *worker = nullptr;      // own arena, bound to the side stream
     // The factorisation of the FULL Gram and the forward-substituted right-hand side, also computed during the search
     // (rank hint >= 0.8 c): the refit then solves the kept-channel problem as an equality-constrained one with this
@@ -128,14 +123,12 @@ int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
 
 #define CP_LAUNCH_CHECK(ctx) CP_HIP(ctx, hipGetLastError())
 
-hipStream_t cp_aux_stream(cp_ctx *ctx);    // the device's second shared stream: short mask-independent kernels only (never null)
 hipStream_t cp_side_stream(cp_ctx *ctx);   // the device's shared stream for work that overlaps a context's own chain (never null)
 // A pending precompute that nobody will consume (error exit, an unrelated refit, new contents in its buffers): wait for the
 // side / chain stream work that still reads X / Y, then forget it.
 void cp_precompute_void(cp_ctx *ctx);
 int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n,
                                 double rank_hint = 0.0, bool fork_recorded = false);
-int cp_refit_premeans_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n);
 void cp_precompute_release(cp_ctx *ctx);
 // hipStreamSynchronize(ctx->stream), with the time spent blocked added to ctx->wait_ms
 hipError_t cp_stream_wait(cp_ctx *ctx);

@@ -59,19 +59,6 @@ hipStream_t cp_side_stream(cp_ctx *ctx) {
     return streams[ctx->device];
 }
 
-hipStream_t cp_aux_stream(cp_ctx *ctx) {
-    static std::mutex mu;
-    static hipStream_t streams[64] = {};
-    if (ctx->device < 0 || ctx->device >= 64) return ctx->stream;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!streams[ctx->device]) {
-        hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return ctx->stream;
-        streams[ctx->device] = st;
-    }
-    return streams[ctx->device];
-}
-
 extern "C" int cp_ctx_create(int device, cp_ctx **out) {
     // CP_CTX_PRIORITY (read, never written, by the library): the default HIP priority of a context's stream
     int prio = 0;

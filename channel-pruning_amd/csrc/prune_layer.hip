@@ -181,13 +181,6 @@ int prune_layer_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, 
         double alpha = 0.0;
         int rc;
         if (!streamed) {
-            // The column means of the refit do not depend on the mask: on the auxiliary stream from the very start of the call
-            // (behind whatever this stream was given before it, not behind the LASSO operands below).  Wide layers only: the
-            // searches of the narrow ones end before the auxiliary stream has worked through every layer's means (all layers:
-            // vgg16 job 24.25 ms, c >= 256: 23.89, none: 24.05; tools/README.md, call 17).
-            constexpr int PREMEANS_MIN_C = 256;
-            if (!precompute && ridge == 0.0 && c >= PREMEANS_MIN_C)
-                CP_TRY(cp_refit_premeans_enqueue(ctx, X, x_dtype, N, c, kk, Y, n));
             CP_TRY(cp_lasso_gram(ctx, X, x_dtype, N, c, kk, W2, w_dtype, n, Y, samples, S, Q, q, stats));
             if (precompute) CP_TRY(cp_refit_precompute_enqueue(ctx, X, x_dtype, N, c, kk, Y, n, (flags & CP_REFIT_PREFACTOR) ? rank : 0.0));
             ctx->host_ms[0] = now_ms() - t0;

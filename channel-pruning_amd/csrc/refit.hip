@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(RT) k_colsum_xy(const TX *__restrict__ X, cons
         const int col = blockIdx.x * RT + threadIdx.x;
         if (col >= p) return;
         const int a = col / kk, t = col - a * kk;
-        const size_t src = size_t(chan ? chan[a] : a) * kk + t, stride = size_t(c) * kk;   // null: all channels
+        const size_t src = size_t(chan[a]) * kk + t, stride = size_t(c) * kk;
         // eight independent row loads in flight per thread, summed in row order (one dependent load per iteration left the
         // pass at 6 % of the HBM rate)
         int64_t r = r0;
@@ -119,9 +119,9 @@ __global__ void __launch_bounds__(RT) k_gather_center_xy(const TX *__restrict__ 
         Yc[size_t(r) * n_pad + col] = (r < N && col < n) ? Y[size_t(r) * n + col] - ymean[col] : 0.0;
 }
 
-// The same with the kept-channel list as a bit mask in the kernel arguments (every workgroup unpacks it into LDS: no list
-// upload, no launch that builds one) and the column means taken from the means of ALL columns (cp_refit_premeans_enqueue);
-// row 0 leaves the kept columns' means in xmean for the intercept.
+// The kept-channel list as a bit mask in the kernel arguments (c <= 2048 -> 256 B of kernarg), unpacked by the kernel that
+// needs the list: no upload, no launch that builds it (k_chan_from_bits for the kernels that read a list from memory,
+// k_gather_normal_eq<true> into LDS).
 constexpr int CHAN_BITS_MAX = 2048;
 struct ChanBits {
     unsigned long long w[CHAN_BITS_MAX / 64];
@@ -136,32 +136,6 @@ __device__ __forceinline__ void chan_from_bits(const ChanBits &bits, int c, int 
     const unsigned m = unsigned(bits.w[wi] >> sh) & 0xffu;
     for (int b = 0; b < 8 && c0 + b < c; ++b)
         if (m & (1u << b)) chan[pos++] = c0 + b;
-}
-template <typename TX>
-__global__ void __launch_bounds__(RT) k_gather_center_bits(const TX *__restrict__ X, const double *__restrict__ Y, int64_t N,
-                                                           int c, int kk, int n, ChanBits bits, int p, int p_pad, int n_pad,
-                                                           const double *__restrict__ xmean_all,
-                                                           const double *__restrict__ ymean, double *__restrict__ xmean,
-                                                           double *__restrict__ Xs, double *__restrict__ Yc) {
-    static_assert(RT * 8 >= CHAN_BITS_MAX, "a thread unpacks 8 channels");
-    __shared__ int chan[CHAN_BITS_MAX];
-    chan_from_bits(bits, c, chan);
-    __syncthreads();
-    const int64_t r = blockIdx.x;
-    const size_t stride = size_t(c) * kk;
-    for (int col = threadIdx.x; col < p_pad; col += RT) {
-        double v = 0.0;
-        if (col < p) {
-            const int a = col / kk, t = col - a * kk;
-            const size_t src = size_t(chan[a]) * kk + t;
-            const double m = xmean_all[src];
-            if (r == 0) xmean[col] = m;
-            if (r < N) v = ldv(X, size_t(r) * stride + src) - m;
-        }
-        Xs[size_t(r) * p_pad + col] = v;
-    }
-    for (int col = threadIdx.x; col < n_pad; col += RT)
-        Yc[size_t(r) * n_pad + col] = (r < N && col < n) ? Y[size_t(r) * n + col] - ymean[col] : 0.0;
 }
 
 // ---- diagonal handling -------------------------------------------------------------------
@@ -1063,15 +1037,12 @@ __global__ void __launch_bounds__(RT) k_gather_normal_eq(const double *__restric
 
 void cp_precompute_void(cp_ctx *ctx) {
     cp_precompute &pc = ctx->pre;
-    if (pc.ready && pc.means_only) {
-        if (pc.done) hipEventSynchronize(pc.done);
-    } else if (pc.ready || pc.factored) {
+    if (pc.ready || pc.factored) {
         if (pc.worker) hipStreamSynchronize(pc.worker->stream);
         if (pc.chain_stream) hipStreamSynchronize(pc.chain_stream);
     }
     pc.ready = false;
     pc.factored = false;
-    pc.means_only = false;
 }
 
 void cp_precompute_release(cp_ctx *ctx) {
@@ -1098,10 +1069,6 @@ void cp_precompute_release(cp_ctx *ctx) {
         hipStreamDestroy(pc.chain_stream);
     }
     if (pc.buf) hipFree(pc.buf);
-    if (pc.mbuf) {
-        hipStreamSynchronize(cp_aux_stream(ctx));
-        hipFree(pc.mbuf);
-    }
     if (pc.fbuf) hipFree(pc.fbuf);
     if (pc.done) hipEventDestroy(pc.done);
     if (pc.gram_done) hipEventDestroy(pc.gram_done);
@@ -1130,7 +1097,6 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
     cp_precompute &pc = ctx->pre;
     pc.ready = false;
     pc.factored = false;
-    pc.means_only = false;
     const int P = c * kk;
     if (N - 1 < P) return CP_OK;
     const int P_pad = int(cp_align_up(size_t(P), NB)), n_pad = int(cp_align_up(size_t(n), 128));
@@ -1283,61 +1249,6 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
     }
     pc.X = X; pc.Y = Y; pc.N = N; pc.c = c; pc.kk = kk; pc.n = n; pc.x_dtype = x_dtype;
     pc.P = P; pc.P_pad = P_pad; pc.n_pad = n_pad;
-    pc.ready = true;
-    return CP_OK;
-}
-
-// The column means of ALL P = c kk columns of X and of Y on the device's auxiliary stream, while the layer's alpha search runs:
-// they do not depend on the mask, and after the search their two dependent launches (row-block sums, then the means) each
-// wait for a free wave slot on a chip full of other layers' products -- 0.47 + 0.53 ms on the critical layer of the vgg16
-// job (profiles/r05_timeline_vgg16.md).  Column by column the sums are the ones the refit's own launches would form (same
-// kernels, same row blocks, same order), so the result does not change by a bit.  The refit waits for the event and takes
-// the kept columns' means while it gathers (k_gather_center_bits).
-int cp_refit_premeans_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, int kk, const double *Y, int n) {
-    cp_precompute &pc = ctx->pre;
-    pc.ready = false;
-    pc.factored = false;
-    pc.means_only = false;
-    if (c > CHAN_BITS_MAX) return CP_OK;
-    const int P = c * kk;
-    const int P_pad = int(cp_align_up(size_t(P), NB)), n_pad = int(cp_align_up(size_t(n), 128));
-    const int RB = 64, rows_per_block = int((N + RB - 1) / RB);
-    hipStream_t aux = cp_aux_stream(ctx);
-    const size_t bytes = (size_t(P_pad) + n_pad) * (1 + RB) * 8;
-    if (bytes > pc.mbuf_bytes) {
-        CP_HIP(ctx, hipStreamSynchronize(aux));
-        CP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (pc.mbuf) CP_HIP(ctx, hipFree(pc.mbuf));
-        pc.mbuf = nullptr;
-        pc.mbuf_bytes = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&pc.mbuf), bytes) != hipSuccess)
-            return cp_set_error(ctx, CP_ERR_NOMEM, "refit premeans: hipMalloc(%zu)", bytes);
-        pc.mbuf_bytes = bytes;
-    }
-    if (!pc.done) CP_HIP(ctx, hipEventCreateWithFlags(&pc.done, hipEventDisableTiming));
-    if (!ctx->ev_fork) {
-        CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
-    pc.xmean = reinterpret_cast<double *>(pc.mbuf);
-    pc.ymean = pc.xmean + P_pad;
-    double *part_x = pc.ymean + n_pad, *part_y = part_x + size_t(RB) * P_pad;
-    CP_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));      // X and Y are whatever this stream has made of them so far
-    CP_HIP(ctx, hipStreamWaitEvent(aux, ctx->ev_fork, 0));
-    const int gx = (P + RT - 1) / RT, gy = (n + RT - 1) / RT;
-    if (x_dtype == CP_F32)
-        k_colsum_xy<float><<<dim3(gx + gy, RB), RT, 0, aux>>>(static_cast<const float *>(X), Y, N, c, kk, n, nullptr, P, gx,
-                                                              rows_per_block, part_x, P_pad, part_y, n_pad);
-    else
-        k_colsum_xy<double><<<dim3(gx + gy, RB), RT, 0, aux>>>(static_cast<const double *>(X), Y, N, c, kk, n, nullptr, P, gx,
-                                                               rows_per_block, part_x, P_pad, part_y, n_pad);
-    CP_LAUNCH_CHECK(ctx);
-    k_mean_finish_xy<<<gx + gy, RT, 0, aux>>>(part_x, P_pad, P, part_y, n_pad, n, gx, RB, 1.0 / double(N), pc.xmean, pc.ymean);
-    CP_LAUNCH_CHECK(ctx);
-    CP_HIP(ctx, hipEventRecord(pc.done, aux));
-    pc.X = X; pc.Y = Y; pc.N = N; pc.c = c; pc.kk = kk; pc.n = n; pc.x_dtype = x_dtype;
-    pc.P = P; pc.P_pad = P_pad; pc.n_pad = n_pad;
-    pc.means_only = true;
     pc.ready = true;
     return CP_OK;
 }
@@ -1528,16 +1439,12 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     double *b_host = host_out ? reinterpret_cast<double *>(ctx->pinned + 64) : nullptr;
     double *W_host = host_out ? b_host + n : nullptr;
     cp_stage_begin(ctx);
-    // full normal equations (or the means of all columns) already under way (cp_refit_precompute_enqueue /
-    // cp_refit_premeans_enqueue): one shot
+    // full normal equations already under way on the side stream (cp_refit_precompute_enqueue): one shot
     cp_precompute &pc = ctx->pre;
-    const bool pre_any = pc.armed && pc.ready && pc.X == X && pc.Y == Y && pc.N == N && pc.c == c && pc.kk == kk && pc.n == n &&
-                         pc.x_dtype == x_dtype && pc.n_pad == n_pad && ridge == 0.0;
-    const bool from_pre = pre_any && !pc.means_only, from_means = pre_any && pc.means_only;
-    if (!pre_any) cp_precompute_void(ctx);   // a leftover nobody may consume: its side-stream work still reads its X / Y
+    const bool from_pre = pc.armed && pc.ready && pc.X == X && pc.Y == Y && pc.N == N && pc.c == c && pc.kk == kk && pc.n == n &&
+                          pc.x_dtype == x_dtype && pc.n_pad == n_pad && ridge == 0.0;
+    if (!from_pre) cp_precompute_void(ctx);   // a leftover nobody may consume: its side-stream work still reads its X / Y
     pc.ready = false;
-    pc.means_only = false;
-    const double *xmean_all = nullptr;
     // the kept-channel list in device memory: only for the kernels that do not take it as a bit mask in their arguments
     bool chan_uploaded = false;
     auto need_chan = [&]() -> int {
@@ -1545,10 +1452,9 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         chan_uploaded = true;
         return CP_OK;
     };
-    if (pre_any) {
+    if (from_pre) {
         CP_HIP(ctx, hipStreamWaitEvent(ctx->stream, pc.done, 0));
         ymean = pc.ymean;                  // persistent until the next enqueue on this context, i.e. beyond this call
-        if (from_means) xmean_all = pc.xmean;
     } else {   // column means, then gather + centre (three launches)
         CP_TRY(need_chan());
         const int gx = (p + RT - 1) / RT, gy = (n + RT - 1) / RT;
@@ -1572,22 +1478,13 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     bool staged = false;
     auto stage_rows = [&]() -> int {
         if (staged) return CP_OK;
-        if (xmean_all) {   // means of all columns at hand: the list travels as a bit mask, row 0 leaves the kept columns' means
-            if (x_dtype == CP_F32)
-                k_gather_center_bits<float><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
-                    static_cast<const float *>(X), Y, N, c, kk, n, chan_bits(chan), p, p_pad, n_pad, xmean_all, ymean, xmean, Xs, Yc);
-            else
-                k_gather_center_bits<double><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
-                    static_cast<const double *>(X), Y, N, c, kk, n, chan_bits(chan), p, p_pad, n_pad, xmean_all, ymean, xmean, Xs, Yc);
-        } else {
-            CP_TRY(need_chan());
-            if (x_dtype == CP_F32)
-                k_gather_center_xy<float><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
-                    static_cast<const float *>(X), Y, N, c, kk, n, dchan, p, p_pad, n_pad, xmean, ymean, Xs, Yc);
-            else
-                k_gather_center_xy<double><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
-                    static_cast<const double *>(X), Y, N, c, kk, n, dchan, p, p_pad, n_pad, xmean, ymean, Xs, Yc);
-        }
+        CP_TRY(need_chan());
+        if (x_dtype == CP_F32)
+            k_gather_center_xy<float><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
+                static_cast<const float *>(X), Y, N, c, kk, n, dchan, p, p_pad, n_pad, xmean, ymean, Xs, Yc);
+        else
+            k_gather_center_xy<double><<<unsigned(N_pad), RT, 0, ctx->stream>>>(
+                static_cast<const double *>(X), Y, N, c, kk, n, dchan, p, p_pad, n_pad, xmean, ymean, Xs, Yc);
         CP_LAUNCH_CHECK(ctx);
         staged = true;
         return CP_OK;

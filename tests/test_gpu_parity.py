@@ -498,30 +498,6 @@ def test_refit_with_the_prefactored_full_gram_matches_the_kept_submatrix_route(c
             prob.free()
 
 
-def test_column_means_taken_during_the_search_leave_the_refit_bit_identical(ctx):
-    """c >= 256 without the overlapped normal equations: the means of ALL columns are formed on the auxiliary stream while the
-    search runs (cp_refit_premeans_enqueue) and the gather takes the kept columns' means from them, the channel list
-    travelling as a bit mask.  Column by column those are the sums the refit's own launches form: W and b equal a refit
-    called directly with the same mask (no search in front of it, so nothing was prepared) bit for bit; the stage list
-    shows which route ran."""
-    import cp_oracle
-    from cpmi355 import LayerProblem, prune_layer
-    for c, xdt in ((256, np.float32), (320, np.float64)):
-        X, W2, Y, B2 = cp_oracle.synth_layer(31, 2600, c, 40, 3)
-        prob = LayerProblem(ctx, X.astype(xdt), W2, Y)
-        try:
-            ctx.enable_stage_timing(1)
-            idxs, W, b, alpha = prune_layer(prob, c // 2, 1e-3, rng=np.random.RandomState(5), mode="device", latency_mode=False)
-            stages = [nm for nm, _ in ctx.last_stage_times()]
-            assert "refit_means" not in stages and "refit_gather_center" in stages
-            W_direct, b_direct = prob.refit(idxs)
-            assert "refit_means" in [nm for nm, _ in ctx.last_stage_times()]
-            assert np.array_equal(W, W_direct) and np.array_equal(b, b_direct)
-        finally:
-            ctx.enable_stage_timing(0)
-            prob.free()
-
-
 def test_f32_and_f64_storage_agree(ctx):
     """X / W2 handed over as float32 (exactly representable) or float64 give bit-identical results."""
     import cp_oracle
