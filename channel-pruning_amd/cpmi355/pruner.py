@@ -223,10 +223,11 @@ class LayerProblem:
                                                    borrow=getattr(self, "borrow_results", False),
                                                    X_host=pending[0] if pending else None,
                                                    Y_host=pending[1] if pending else None)
-        except capi.CpError as e:
+        except BaseException as e:   # noqa
             # an error return that came before the streamed upload was enqueued (bad argument, allocation failure ...)
             # leaves Xd / Yd empty: the host arrays stay pending, so a later refit() / lasso_gram() uploads them instead
-            # of reading uninitialised device memory (cp_prune_result.uploaded)
+            # of reading uninitialised device memory (cp_prune_result.uploaded).  The same for anything that is not an
+            # error return of the library (a ctypes.ArgumentError, KeyboardInterrupt ...): nothing says the arrays arrived
             if pending is not None and not getattr(e, "uploaded", False):
                 self._pending = pending
             rng_rewind(rng, mark)

@@ -331,18 +331,55 @@ def gather_masks(specs, results, dist, device=None):
     return [[g[r, i, : specs[i]["c"]].astype(bool) for i in range(len(specs))] for r in range(g.shape[0])]
 
 
-def exchange_results(specs, owner, mine, dist, device=None, staging=None):
-    """Every rank ends with every layer's (mask, W, b) on the host.  Two collectives on the data the job produces:
-    (1) ONE fixed-size uint8 all_gather of the channel masks (the "trivial gather of selected-channel masks"); the
-    sizes of everything else follow from them, so nothing has to be negotiated;
-    (2) ONE all_gather of the owners' packed float64 results (result_segments), padded to the longest segment.
-    staging "device" (default with backend "nccl" = RCCL over xGMI): this rank's (W, b) go host -> HBM once (a DMA
-    straight out of the page-locked result blocks when the ResidentLayerSet lends them: borrow_results), the gather
-    runs between the GPUs, and the other ranks' segments come back through ONE page-locked host buffer whose slices
-    are the returned arrays.  staging "host" (default otherwise): NumPy buffers through the backend."""
+class ShardPeerError(RuntimeError):
+    """a rank of the job failed before the exchange; raised on EVERY rank by exchange_results (ranks: who)"""
+
+    def __init__(self, ranks):
+        super().__init__("cpmi355.shard: rank(s) %s failed before the exchange of the results" % ", ".join(map(str, ranks)))
+        self.ranks = list(ranks)
+
+
+RANK_FAILED = 0xFF       # every byte of a rank's row block in the mask all_gather: "my layers are not coming" (a mask holds 0 / 1)
+
+
+XGMI_LINK_GBPS = 153.0      # one xGMI link of an MI355X (the GPUs of a node are fully connected: one link per pair)
+PCIE_GBPS = 50.0            # device -> page-locked host memory
+
+
+def exchange_model_ms(seg_bytes, mode, root=0):
+    """What the exchange of the packed (W, b) segments costs on an 8-GPU MI355X node, modelled (no such node was available to
+    measure on): every pair of GPUs has its own xGMI link, so both a gather to `root` and a full all_gather are bounded by
+    the LARGEST segment crossing ONE link (all links run at once); what differs is the copy back to host memory -- the root
+    alone (gather) or every rank (allgather) pulls the others' segments over PCIe.  -> dict(xgmi_ms, d2h_ms)."""
+    seg_bytes = [float(b) for b in seg_bytes]
+    if mode == "masks" or len(seg_bytes) < 2:
+        return dict(xgmi_ms=0.0, d2h_ms=0.0)
+    others = [b for r, b in enumerate(seg_bytes) if r != root] if mode == "gather" else seg_bytes
+    xgmi = max(others) / (XGMI_LINK_GBPS * 1e9) * 1e3 + 0.02
+    recv = (sum(seg_bytes) - seg_bytes[root]) if mode == "gather" else (sum(seg_bytes) - min(seg_bytes))
+    return dict(xgmi_ms=round(xgmi, 3), d2h_ms=round(recv / (PCIE_GBPS * 1e9) * 1e3, 3))
+
+
+def exchange_results(specs, owner, mine, dist, device=None, staging=None, failed=False, mode="gather", root=0):
+    """north_star's split of the exchange: (1) ONE fixed-size uint8 all_gather of the channel masks -- every rank ends with
+    every layer's mask, and the sizes of everything else follow from them, so nothing has to be negotiated; (2) the owners'
+    packed float64 results (result_segments), by `mode`:
+        "gather" (default)   to rank `root` only, every owner's segment at its exact length (point-to-point sends, one per
+                             owner: a gather of uneven parts), so that `root` ends with every layer's (mask, W, b) and the
+                             other ranks with (mask, None, None) for the layers they do not own;
+        "allgather"          ONE all_gather padded to the longest segment: every rank ends with everything;
+        "masks"              nothing travels but the masks (the weights stay with their owner).
+    staging "device" (default with backend "nccl" = RCCL over xGMI): this rank's (W, b) go host -> HBM once (a DMA straight
+    out of the page-locked result blocks when the ResidentLayerSet lends them: borrow_results), the collective runs between
+    the GPUs, and what arrives comes back through ONE page-locked host buffer whose slices are the returned arrays.
+    staging "host" (default otherwise): NumPy buffers through the backend.
+    failed: this rank could not prune its layers.  It still joins collective (1) -- with its block filled with RANK_FAILED --
+    so that nobody is left waiting in it; every rank then raises ShardPeerError before step (2)."""
     import time
 
     import torch
+    if mode not in ("gather", "allgather", "masks"):
+        raise ValueError("exchange_results: mode %r" % (mode,))
     t_begin = time.perf_counter()
     world, rank = dist.get_world_size(), dist.get_rank()
     if staging is None:
@@ -351,62 +388,97 @@ def exchange_results(specs, owner, mine, dist, device=None, staging=None):
     dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
     cmax = max(s["c"] for s in specs)
     local = np.zeros((len(specs), cmax), dtype=np.uint8)
-    for i, (idxs, _, _) in mine.items():
-        local[i, : idxs.shape[0]] = idxs
+    if failed:
+        local[:] = RANK_FAILED
+    else:
+        for i, (idxs, _, _) in mine.items():
+            local[i, : idxs.shape[0]] = idxs
     gathered = _all_gather_rows(dist, torch.from_numpy(local).to(dev)).cpu().numpy()
+    bad = [r for r in range(world) if gathered[r].size and int(gathered[r].max()) == RANK_FAILED]
+    if bad:
+        raise ShardPeerError(bad)
     masks = [gathered[owner[i], i, : specs[i]["c"]].astype(bool) for i in range(len(specs))]
     shapes, offs, seg = result_segments(specs, owner, masks, world)
     maxseg = max(1, max(seg))
     t_masks = time.perf_counter()
     t_gather = t_masks
-    if on_gpu:
-        send = torch.empty(maxseg, dtype=torch.float64, device=dev)
-        for i, (_, W, b) in mine.items():
-            nw = int(np.prod(shapes[i]))
-            send[offs[i]:offs[i] + nw].copy_(torch.from_numpy(np.ascontiguousarray(W).reshape(-1)), non_blocking=True)
-            send[offs[i] + nw:offs[i] + nw + specs[i]["n"]].copy_(torch.from_numpy(np.ascontiguousarray(b)), non_blocking=True)
-        every = _all_gather_rows(dist, send)
+    receives = (mode == "allgather" and world > 1) or (mode == "gather" and rank == root)
+    sends = mode == "allgather" or (mode == "gather" and rank != root and seg[rank] > 0)
+    starts, flat = {}, None                      # starts[r]: where rank r's segment begins in `flat`
+    if mode != "masks" and (sends or receives):
+        if on_gpu:
+            send = torch.empty(maxseg if mode == "allgather" else max(1, seg[rank]), dtype=torch.float64, device=dev)
+        else:
+            send = np.zeros(maxseg if mode == "allgather" else max(1, seg[rank]), dtype=np.float64)
+        if sends:
+            for i, (_, W, b) in mine.items():
+                nw = int(np.prod(shapes[i]))
+                if on_gpu:
+                    send[offs[i]:offs[i] + nw].copy_(torch.from_numpy(np.ascontiguousarray(W).reshape(-1)), non_blocking=True)
+                    send[offs[i] + nw:offs[i] + nw + specs[i]["n"]].copy_(torch.from_numpy(np.ascontiguousarray(b)),
+                                                                         non_blocking=True)
+                else:
+                    send[offs[i]:offs[i] + nw] = np.asarray(W).reshape(-1)
+                    send[offs[i] + nw:offs[i] + nw + specs[i]["n"]] = b
+        if mode == "allgather":
+            every = _all_gather_rows(dist, send if on_gpu else torch.from_numpy(send))
+            parts = {r: every[r, :seg[r]] for r in range(world) if r != rank and seg[r]}
+        else:
+            # a gather of uneven parts: the root posts one receive per owner, every other owner one send
+            ops, parts = [], {}
+            if rank == root:
+                for r in range(world):
+                    if r != root and seg[r]:
+                        parts[r] = torch.empty(seg[r], dtype=torch.float64, device=dev)
+                        ops.append(dist.P2POp(dist.irecv, parts[r], r))
+            elif sends:
+                ops.append(dist.P2POp(dist.isend, send if on_gpu else torch.from_numpy(send), root))
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
         t_gather = time.perf_counter()
-        starts, total = {}, 0
-        for r in range(world):
-            if r != rank and seg[r]:
-                starts[r] = total
-                total += seg[r]
-        back = torch.empty(max(1, total), dtype=torch.float64, pin_memory=True)
-        for r, st in starts.items():
-            back[st:st + seg[r]].copy_(every[r, :seg[r]], non_blocking=True)
-        torch.cuda.current_stream(dev).synchronize()
-        flat = back.numpy()
-    else:
-        send = np.zeros(maxseg, dtype=np.float64)
-        for i, (_, W, b) in mine.items():
-            nw = int(np.prod(shapes[i]))
-            send[offs[i]:offs[i] + nw] = np.asarray(W).reshape(-1)
-            send[offs[i] + nw:offs[i] + nw + specs[i]["n"]] = b
-        every = _all_gather_rows(dist, torch.from_numpy(send)).numpy()
-        starts = {r: r * maxseg for r in range(world)}
-        flat = every.reshape(-1)
+        total = 0
+        for r in sorted(parts):
+            starts[r] = total
+            total += seg[r]
+        if on_gpu:
+            back = torch.empty(max(1, total), dtype=torch.float64, pin_memory=True)
+            for r, st in starts.items():
+                back[st:st + seg[r]].copy_(parts[r], non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            flat = back.numpy()
+        else:
+            flat = np.empty(max(1, total), dtype=np.float64)
+            for r, st in starts.items():
+                flat[st:st + seg[r]] = parts[r].numpy() if hasattr(parts[r], "numpy") else parts[r]
     results = [None] * len(specs)
     for i, s in enumerate(specs):
         if owner[i] == rank:
             results[i] = (masks[i], np.asarray(mine[i][1]).reshape(shapes[i]), np.asarray(mine[i][2]))
-            continue
-        o = starts[owner[i]] + offs[i]
-        nw = int(np.prod(shapes[i]))
-        results[i] = (masks[i], flat[o:o + nw].reshape(shapes[i]), flat[o + nw:o + nw + s["n"]])
+        elif owner[i] in starts:
+            o = starts[owner[i]] + offs[i]
+            nw = int(np.prod(shapes[i]))
+            results[i] = (masks[i], flat[o:o + nw].reshape(shapes[i]), flat[o + nw:o + nw + s["n"]])
+        else:
+            results[i] = (masks[i], None, None)      # "gather" on a rank that is not the root, or "masks"
     t_end = time.perf_counter()
+    sent = int(seg[rank]) * 8 if sends else 0                    # this rank's segment (what it contributes)
+    link_out = sent * ((world - 1) if mode == "allgather" else 1)    # ... and what leaves it over its xGMI links
+    model = exchange_model_ms([v * 8 for v in seg], mode, root)
     LAST_EXCHANGE_MS.update(total=(t_end - t_begin) * 1e3, masks=(t_masks - t_begin) * 1e3,
-                            pack_and_gather=(t_gather - t_masks) * 1e3, back_to_host=(t_end - t_gather) * 1e3,
-                            bytes_sent=int(seg[rank]) * 8, bytes_received=int(sum(seg) - seg[rank]) * 8,
-                            padded_segment_bytes=int(maxseg) * 8)
+                            pack_and_gather=(t_gather - t_masks) * 1e3, back_to_host=(t_end - t_gather) * 1e3, mode=mode,
+                            bytes_sent=sent, link_bytes_out=link_out, bytes_received=int(sum(seg[r] for r in starts)) * 8,
+                            mask_bytes_sent=int(local.size), padded_segment_bytes=int(maxseg) * 8,
+                            xgmi_model_ms=model["xgmi_ms"], d2h_model_ms=model["d2h_ms"])
     return results
 
 
 def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=None, owner=None, staging=None,
-                  force_exchange=False, rounds=None):
+                  force_exchange=False, rounds=None, exchange="gather"):
     """specs: list of dicts with at least N, c, n, k, rank; compute_fn(spec) -> (idxs, W, b), or
     compute_many(list of this rank's specs) -> list of (idxs, W, b) (a GpuLayerBatches or a ResidentLayerSet).
-    Every rank returns the full list of results in layer order.  `dist` is an initialised
+    Every rank returns the list of results in layer order -- every layer's mask everywhere; the weights where `exchange` puts
+    them ("gather", the default: all of them on rank 0, (mask, None, None) elsewhere for foreign layers; "allgather":
+    everything everywhere; "masks": only the owner has them; see exchange_results).  `dist` is an initialised
     torch.distributed module (None = single process); owner[i] (default: LPT over layer_cost) says which rank
     prunes layer i.  force_exchange: run the two collectives even in a process group of ONE rank (the RCCL path on a
     one-GPU box: all_gather_into_tensor on device tensors, the page-locked return buffer)."""
@@ -418,18 +490,27 @@ def prune_sharded(specs, compute_fn=None, dist=None, device=None, compute_many=N
     # with start() / wait() / finish() (ResidentLayerSet, ThreadedLayerSet)
     if rounds is not None and len(set(rounds)) > 1 and dist is not None and (world > 1 or force_exchange) and \
             compute_many is not None and hasattr(compute_many, "wait"):
-        return prune_sharded_rounds(specs, compute_many, dist, owner, rounds, device, staging)
+        return prune_sharded_rounds(specs, compute_many, dist, owner, rounds, device, staging, exchange)
     mine = {}
     own = [i for i in range(len(specs)) if owner[i] == rank]
-    if compute_many is not None:
-        got = compute_many([specs[i] for i in own])
-    else:
-        got = [compute_fn(specs[i]) for i in own]
-    for i, (idxs, W, b) in zip(own, got):
-        mine[i] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
-    if dist is None or (world == 1 and not force_exchange):
+    exchanging = dist is not None and (world > 1 or force_exchange)
+    try:
+        if compute_many is not None:
+            got = compute_many([specs[i] for i in own])
+        else:
+            got = [compute_fn(specs[i]) for i in own]
+        for i, (idxs, W, b) in zip(own, got):
+            mine[i] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
+    except BaseException as e:   # noqa
+        if exchanging:           # the other ranks are on their way into the mask all_gather: tell them there, then raise here
+            try:
+                exchange_results(specs, owner, {}, dist, device, staging, failed=True, mode=exchange)
+            except ShardPeerError:
+                pass
+        raise e
+    if not exchanging:
         return [mine[i] for i in range(len(specs))]
-    return exchange_results(specs, owner, mine, dist, device, staging)
+    return exchange_results(specs, owner, mine, dist, device, staging, mode=exchange)
 
 
 def plan_rounds(specs, owner=None, heavy_fraction=0.5):
@@ -490,7 +571,7 @@ class ThreadedLayerSet:
         return [r[:3] for r in self.finish()]
 
 
-def prune_sharded_rounds(specs, layer_set, dist, owner, rounds, device=None, staging=None):
+def prune_sharded_rounds(specs, layer_set, dist, owner, rounds, device=None, staging=None, exchange="gather"):
     """prune_sharded with the exchange OVERLAPPED with the pruning: `layer_set` (a ResidentLayerSet / ThreadedLayerSet over
     THIS rank's layers, in layer order) is started, and for every round r = 0, 1, ... this rank waits for ITS layers of
     that round only and joins the exchange of that round's layers (exchange_results on the sub-list: the same two
@@ -503,25 +584,37 @@ def prune_sharded_rounds(specs, layer_set, dist, owner, rounds, device=None, sta
     pos = {i: k for k, i in enumerate(own)}              # layer index -> position in layer_set
     layer_set.start()
     results = [None] * len(specs)
-    per_round = []
+    per_round, totals = [], {}
     try:
         for r in sorted(set(rounds)):
             members = [i for i in range(len(specs)) if rounds[i] == r]
-            got = layer_set.wait([pos[i] for i in members if i in pos])
+            try:
+                got = layer_set.wait([pos[i] for i in members if i in pos])
+            except BaseException as e:   # noqa   (as prune_sharded: the other ranks learn it in this round's mask all_gather)
+                try:
+                    exchange_results([specs[i] for i in members], [owner[i] for i in members], {}, dist, device, staging,
+                                     failed=True, mode=exchange)
+                except ShardPeerError:
+                    pass
+                raise e
             mine = {}
             for k, i in enumerate(members):
                 if i in pos:
                     idxs, W, b = got[pos[i]][:3]
                     mine[k] = (np.asarray(idxs, dtype=bool), np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64))
             t0 = time.perf_counter()
-            sub = exchange_results([specs[i] for i in members], [owner[i] for i in members], mine, dist, device, staging)
+            sub = exchange_results([specs[i] for i in members], [owner[i] for i in members], mine, dist, device, staging,
+                                   mode=exchange)
             per_round.append((time.perf_counter() - t0) * 1e3)
+            for k_ in ("bytes_sent", "link_bytes_out", "bytes_received", "xgmi_model_ms", "d2h_model_ms"):
+                totals[k_] = totals.get(k_, 0) + LAST_EXCHANGE_MS.get(k_, 0)
             for k, i in enumerate(members):
                 results[i] = sub[k]
     finally:
         layer_set.finish(raise_errors=False)
     LAST_EXCHANGE_MS["rounds"] = [round(v, 3) for v in per_round]
     LAST_EXCHANGE_MS["total"] = float(sum(per_round))
+    LAST_EXCHANGE_MS.update(totals)             # bytes and modelled times: the sum over the rounds
     return results
 
 
@@ -557,9 +650,22 @@ def row_range(N, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def allreduce_sum(dist, t, group=None):
+def _collective_device(device=None):
+    """The GPU a host tensor is staged on for an RCCL collective.  Callers on worker threads MUST name it: torch's current
+    device is per thread (a fresh thread starts on device 0 whatever the main thread set), so falling back to
+    torch.cuda.current_device() from AssistedJob's threads would put rank r's tensor on cuda:0 -- a duplicate-GPU error or a
+    hang inside the communicator of cuda:r."""
+    import torch
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return device if isinstance(device, torch.device) else torch.device("cuda", int(device))
+
+
+def allreduce_sum(dist, t, group=None, device=None):
     """In-place sum over the ranks (of `group`, default: all) of a torch tensor.  RCCL ("nccl") reduces device tensors in
-    place over xGMI; with "gloo" (CPU tests, or several ranks on one GPU) a device tensor is staged through the host."""
+    place over xGMI; with "gloo" (CPU tests, or several ranks on one GPU) a device tensor is staged through the host.
+    device: where a HOST tensor is staged with RCCL (default: the calling thread's current device -- name it on worker
+    threads, see _collective_device)."""
     if dist is None or dist.get_world_size() == 1:
         return t
     if t.is_cuda and dist.get_backend() != "nccl":
@@ -567,8 +673,7 @@ def allreduce_sum(dist, t, group=None):
         dist.all_reduce(h, group=group)
         t.copy_(h)
     elif not t.is_cuda and dist.get_backend() == "nccl":
-        import torch
-        d = t.to(torch.device("cuda", torch.cuda.current_device()))
+        d = t.to(_collective_device(device))
         dist.all_reduce(d, group=group)
         t.copy_(d.cpu())
     else:
@@ -747,18 +852,26 @@ def plan_assists(specs, owner, world, min_gain_ms=0.3):
     return assists
 
 
-def _bcast_mask(dist, mask_u8, src, group):
-    """mask uint8[c] from global rank `src` to the ranks of `group` (a device tensor with RCCL, a host tensor otherwise)"""
+OWNER_FAILED = 0xFF      # every byte of the broadcast mask: "the owner's search failed, nothing follows" (a mask holds 0 / 1)
+
+
+class AssistPeerError(RuntimeError):
+    """the OTHER rank of an (owner, helper) pair reported a failure; this rank's own work was fine"""
+
+
+def _bcast_mask(dist, mask_u8, src, group, device=None):
+    """mask uint8[c] from global rank `src` to the ranks of `group` (a device tensor with RCCL -- on `device`, see
+    _collective_device --, a host tensor otherwise)"""
     import torch
     t = torch.from_numpy(np.ascontiguousarray(mask_u8, dtype=np.uint8))
     if dist.get_backend() == "nccl":
-        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        t = t.to(_collective_device(device))
     dist.broadcast(t, src=src, group=group)
     return t.cpu().numpy()
 
 
 def prune_layer_assisted(engine, role, dist, group, owner_rank, c, W2, N_total, rank, alpha_in, X=None, Y=None, rank_tol=.1,
-                         rng=None, ridge=0.0, alpha_arg=1e-4, timings=None):
+                         rng=None, ridge=0.0, alpha_arg=1e-4, timings=None, before_collectives=None):
     """dictionary() (lib/decompose.py:386-634) on a layer whose owner is HELPED by a second rank for the refit.
 
     role "owner": X / Y are the layer's host arrays (all N_total rows: the sample subset of decompose.py:425 is drawn from
@@ -766,9 +879,23 @@ def prune_layer_assisted(engine, role, dist, group, owner_rank, c, W2, N_total, 
     alone -- the one step no second GPU can divide -- broadcasts the mask, and both ranks then sum their rows' column sums
     and normal equations (two all-reduces inside `group`); the owner solves.  -> (idxs, newW2[n, nnz, k, k], newB2, alpha).
     role "helper": the engine holds the other rows; waits for the mask, contributes its sums and Gram, returns None.  It
-    draws nothing from any RNG.  The reference's RNG stream on the owner is consumed exactly as dictionary() does."""
+    draws nothing from any RNG.  The reference's RNG stream on the owner is consumed exactly as dictionary() does.
+
+    Failure on either side never leaves the other one blocked in a collective: the sequence broadcast -> all-reduce ->
+    all-reduce is walked by BOTH ranks whatever happens.  An owner whose search raises broadcasts the sentinel mask
+    (every byte OWNER_FAILED) and re-raises; the helper raises AssistPeerError on it; nothing follows.  After a good mask,
+    a rank whose sums / Gram stage raises keeps joining the two all-reduces with whatever its buffers hold and raises its
+    own error afterwards; the last element of the Gram all-reduce is a failure count, so the other rank raises
+    AssistPeerError instead of solving with half the rows.
+    before_collectives: optional callable run after the (collective-free) alpha search and before the first collective --
+    AssistedJob's ticket that serialises the collective phases of a rank's assisted layers in layer order."""
     import time
+
+    import torch
     t_last = [time.perf_counter()]
+    device = getattr(engine, "device", None)
+    if device is not None and getattr(device, "type", "cpu") == "cuda":
+        torch.cuda.set_device(device)        # worker threads start on device 0: collectives and staging follow the engine
 
     def lap(name):
         if timings is not None:
@@ -776,33 +903,65 @@ def prune_layer_assisted(engine, role, dist, group, owner_rank, c, W2, N_total, 
             timings[name] = timings.get(name, 0.0) + now - t_last[0]
             t_last[0] = now
 
+    failure = None
     if role == "owner":
-        rng = np.random if rng is None else rng
-        X = np.asarray(X)
-        Y = np.asarray(Y, dtype=np.float64)
-        k = X.shape[2] if X.ndim > 2 else 1
-        n = W2.shape[0]
-        samples = rng.randint(0, N_total, min(400, N_total // 20))               # decompose.py:425
-        if rank == c:                                                             # decompose.py:487-488
-            idxs, alpha = np.array([True] * rank), alpha_arg
-        else:
-            idxs, alpha = engine.select(np.ascontiguousarray(X[samples]), W2, np.ascontiguousarray(Y[samples]), rank, alpha_in,
-                                        rank_tol, rng)
+        idxs = alpha = None
+        try:
+            rng = np.random if rng is None else rng
+            X = np.asarray(X)
+            Y = np.asarray(Y, dtype=np.float64)
+            k = X.shape[2] if X.ndim > 2 else 1
+            n = W2.shape[0]
+            samples = rng.randint(0, N_total, min(400, N_total // 20))               # decompose.py:425
+            if rank == c:                                                             # decompose.py:487-488
+                idxs, alpha = np.array([True] * rank), alpha_arg
+            else:
+                idxs, alpha = engine.select(np.ascontiguousarray(X[samples]), W2, np.ascontiguousarray(Y[samples]), rank,
+                                            alpha_in, rank_tol, rng)
+            mask = idxs.astype(np.uint8)
+        except BaseException as e:   # noqa
+            failure, mask = e, np.full(c, OWNER_FAILED, dtype=np.uint8)
         lap("alpha_search")
-        mask = idxs.astype(np.uint8)
-        _bcast_mask(dist, mask, owner_rank, group)
+        if before_collectives is not None:
+            before_collectives()
+        _bcast_mask(dist, mask, owner_rank, group, device)
+        if failure is not None:
+            raise failure
     else:
-        mask = _bcast_mask(dist, np.zeros(c, dtype=np.uint8), owner_rank, group)
+        if before_collectives is not None:
+            before_collectives()
+        mask = _bcast_mask(dist, np.zeros(c, dtype=np.uint8), owner_rank, group, device)
+        if mask.size and int(mask.max()) == OWNER_FAILED:
+            raise AssistPeerError("prune_layer_assisted: the owner (rank %d) failed before it had a channel mask" % owner_rank)
     lap("mask_broadcast")
     kept = int(mask.sum())
-    sums_elems, gram_elems = engine.layout(kept)
-    sums, gram = engine.buffer(sums_elems), engine.buffer(gram_elems)
-    engine.sums(mask, sums)
-    allreduce_sum(dist, sums, group)
+    sums_elems, gram_elems = engine.layout(kept)       # pure arithmetic on (kept, k^2, n): the same on both ranks, or raises on both
+    sums = gram_all = None
+    try:
+        sums = engine.buffer(sums_elems)
+        gram_all = engine.buffer(gram_elems + 1)           # + the failure count of the pair
+        engine.sums(mask, sums)
+    except BaseException as e:   # noqa
+        failure = e
+        # not even the buffers: join the collectives with host stand-ins of the same length
+        sums = sums if sums is not None else torch.zeros(int(sums_elems), dtype=torch.float64)
+        gram_all = gram_all if gram_all is not None else torch.zeros(int(gram_elems) + 1, dtype=torch.float64)
+    gram = gram_all[:gram_elems]
+    allreduce_sum(dist, sums, group, device)
     lap("refit_sums")
-    engine.gram(mask, N_total, sums, gram)
-    allreduce_sum(dist, gram, group)
+    if failure is None:
+        try:
+            engine.gram(mask, N_total, sums, gram)
+        except BaseException as e:   # noqa
+            failure = e
+    if failure is not None:
+        gram_all[-1] = 1.0
+    allreduce_sum(dist, gram_all, group, device)
     lap("refit_gram")
+    if failure is not None:
+        raise failure
+    if float(gram_all[-1]) != 0.0:
+        raise AssistPeerError("prune_layer_assisted: the other rank of the pair failed in its sums / Gram stage")
     if role != "owner":
         return None
     W, b = engine.solve(kept, N_total, ridge, sums, gram)
@@ -850,6 +1009,16 @@ class AssistedJob:
         import threading
         rank = self.dist.get_rank()
         out, errors = {}, []
+        # One thread per assisted layer this rank owns or helps: the alpha searches (no collective) run side by side, but the
+        # collective phases of a rank are walked ONE AT A TIME in ascending layer order (tickets) -- two threads of a process
+        # inside two communicators at once is not something RCCL promises to survive, and with every rank following the same
+        # total order the pair of the lowest unfinished layer is always free to proceed.
+        order = sorted(list(self.mine) + list(self.helped))
+        done = {i: threading.Event() for i in order}
+
+        def ticket(i):
+            before = [j for j in order if j < i]
+            return lambda: [done[j].wait() for j in before]
 
         def own_layer(i):
             try:
@@ -857,28 +1026,41 @@ class AssistedJob:
                 tm = {}
                 out[i] = prune_layer_assisted(m["engine"], "owner", self.dist, self.groups[i], rank, s["c"], m["W2"], s["N"], s["rank"],
                                               s.get("alpha_in", self.alpha_in), X=m["X"], Y=m["Y"], rank_tol=self.rank_tol,
-                                              rng=np.random.RandomState(self.seed(s)), timings=tm)[:3]
+                                              rng=np.random.RandomState(self.seed(s)), timings=tm,
+                                              before_collectives=ticket(i))[:3]
                 self.last_timings[s.get("name", i)] = {k: round(v * 1e3, 3) for k, v in tm.items()}
             except BaseException as e:   # noqa
                 errors.append(e)
+            finally:
+                done[i].set()
 
         def help_layer(i):
             try:
                 s, m = self.specs[i], self.helped[i]
                 prune_layer_assisted(m["engine"], "helper", self.dist, self.groups[i], self.owner[i], s["c"], m["W2"], s["N"], s["rank"],
-                                     s.get("alpha_in", self.alpha_in))
+                                     s.get("alpha_in", self.alpha_in), before_collectives=ticket(i))
             except BaseException as e:   # noqa
                 errors.append(e)
+            finally:
+                done[i].set()
 
         threads = [threading.Thread(target=own_layer, args=(i,)) for i in self.mine] + \
                   [threading.Thread(target=help_layer, args=(i,)) for i in self.helped]
         for t in threads:
             t.start()
-        rest = self.rset() if self.rset is not None else []
+        rest_error = None
+        try:
+            rest = self.rset() if self.rset is not None else []
+        except BaseException as e:   # noqa   (the assisted threads still have peers waiting for them: join before raising)
+            rest, rest_error = [], e
         for t in threads:
             t.join()
+        if rest_error is not None:
+            raise rest_error
         if errors:
-            raise errors[0]
+            # this rank's own failure first; an AssistPeerError only says that the OTHER rank of a pair has one
+            own_errors = [e for e in errors if not isinstance(e, AssistPeerError)]
+            raise (own_errors or errors)[0]
         for i, r in zip(self.rset_index, rest):
             out[i] = r
         return [out[i] for i in sorted(out)]           # this rank's layers in layer order, as prune_sharded expects

@@ -95,7 +95,8 @@ __device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_l
     }
     // Not observed outside the test: the host reads info[0] != 0 as "this factorisation is not to be trusted" and the refit
     // goes on to its rank-revealing path (refit.hip: refit_solve_tail -> refit_robust), which factors again -- a slower
-    // route to the same result, never a failed layer and never a hang.
+    // route to the same result and never a hang (that path can still end in CP_ERR_NUMERIC on a matrix it cannot factor
+    // either; a time-out alone does not make a layer fail).
     atomicCAS(info, 0, 0x7fffffff);
 }
 
@@ -270,8 +271,12 @@ __device__ __forceinline__ void factor_block_inreg(v4f64s v, double *sm, int p, 
     }
     const unsigned long long any_bad = __ballot(bad);
     if (any_bad != 0 && lane == 0) {
-        const int first = __ffsll((long long)any_bad) - 1;            // lane (kq, k) -> column k = lane & 15
-        atomicCAS(info, 0, blk * NB + k0 + (first & 15) + 1);
+        // the lane that tests pivot k is (k & 3) * 16 + k: lane order is not pivot order (pivot 1 sits in lane 17, pivot 4 in
+        // lane 4), and after the first failing pivot the block is NaN-poisoned so that later pivots are flagged too.  Report
+        // the smallest column among the flagged lanes -- the first pivot that really failed
+        int first = 16;
+        for (unsigned long long m = any_bad; m; m &= m - 1) first = min(first, (__ffsll((long long)m) - 1) & 15);
+        atomicCAS(info, 0, blk * NB + k0 + first + 1);
     }
     double *Dp = sm + pk(p, p) * 256;
 #pragma unroll
@@ -342,6 +347,7 @@ __device__ __noinline__ void diag_factor_lookahead(double *sm, double piv_tol, i
                                    (unsigned long long)__double_as_longlong(Tp[(fk + 4 * r) * 16 + fi]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CP_HANDOFF_RELEASE();          // nothing unless built with -DCP_HANDOFF_FENCES=1 (cp_common.h)
             if (lane == 0) __hip_atomic_store(info + 1 + blk, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (p + 1 >= NPAN) break;
@@ -542,6 +548,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
     for (int q = 0; q < NPAN; ++q) {
         if (tid == 0) flag_wait(info + 1 + s, info, spin_limit, q + 1);  // bounded; running out is reported as a failed factorisation
         __syncthreads();
+        CP_HANDOFF_ACQUIRE();
         if (q == NPAN - 1) CP_STAMP(3);
         // (q + 1) blocks of 256 words, a word per thread and round: sc1 loads (see flag_wait), all in flight together
         constexpr int ROUNDS_MAX = (NPAN * 256 + PT - 1) / PT;

@@ -11,6 +11,27 @@
 
 #include "cpmi355.h"
 
+// The cross-workgroup hand-offs of chol_step.hip and gemm_f64.hip (relaxed agent-scope `sc1` stores, each wave's own
+// `s_waitcnt vmcnt(0)`, a relaxed flag, `sc1` loads on the consumer side, no acquire / release fence) lean on how gfx942 /
+// gfx950 treat sc1 accesses: written through to, and read from, the memory side of the XCD L2s.  That is outside what the
+// LLVM AMDGPU memory model promises in general, so the device code refuses to build for anything else;
+// -DCP_HANDOFF_FENCES=1 puts agent-scope release / acquire fences around the same hand-offs (tests/: the parity suite runs
+// against either build).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "libcpmi355 device code is written for gfx950 (MI355X); its fence-free sc1 hand-offs are not valid on other targets"
+#endif
+#ifndef CP_HANDOFF_FENCES
+#define CP_HANDOFF_FENCES 0
+#endif
+// release side: after the data stores, before the flag is raised; acquire side: after the flag was seen, before the data loads
+#if CP_HANDOFF_FENCES
+#define CP_HANDOFF_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define CP_HANDOFF_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define CP_HANDOFF_RELEASE() ((void)0)
+#define CP_HANDOFF_ACQUIRE() ((void)0)
+#endif
+
 // what a deferred refit (cp_prune_layers) leaves behind: everything its factorisation and substitution launches need,
 // so that the batch can run them as ONE launch each for all of its layers
 struct cp_refit_deferred {

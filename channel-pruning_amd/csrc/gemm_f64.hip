@@ -330,6 +330,7 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         // kernel shows `s_waitcnt vmcnt(0)` directly before the `s_barrier` below only with this statement), and without it
         // another wave's block could still be in flight when thread 0 counts the workgroup in.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CP_HANDOFF_RELEASE();              // nothing unless built with -DCP_HANDOFF_FENCES=1 (cp_common.h)
         __syncthreads();
         if (tid == 0) {
             const int prev = __hip_atomic_fetch_add(sch.cnt + t_split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -338,6 +339,7 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
         }
         __syncthreads();
         if (!s_last) return;
+        CP_HANDOFF_ACQUIRE();
         // chunk by chunk, the 16 loads of a row of MFMA tiles in flight together (element by element the nz blocks would be
         // nz dependent memory latencies per element: measured 0.4 ms for eight blocks)
         const unsigned long long *b0 = reinterpret_cast<const unsigned long long *>(sch.Pb) + size_t(t_split) * nz * (TM * TM);

@@ -154,10 +154,21 @@ int prune_layer_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int c, 
     res->uploaded = 0;
     auto upload_rest = [&]() -> int {   // X, Y on the side stream; the host thread stages the pageable arrays meanwhile
         if (ctx->pre.ready && (X == ctx->pre.X || Y == ctx->pre.Y)) cp_precompute_void(ctx);   // new contents
+        // a copy may be in flight out of the caller's pageable array when a later step fails: that return joins the side
+        // stream itself (UploadJoin only knows about copies an event was recorded behind), and `uploaded` stays 0 -- the
+        // device buffers are partially overwritten and the Python side re-arms the upload
+        struct SideJoin {
+            hipStream_t side;
+            bool armed = true;
+            ~SideJoin() {
+                if (armed) (void)hipStreamSynchronize(side);
+            }
+        } side_join{side};
         CP_HIP(ctx, hipMemcpyAsync(const_cast<void *>(X), host.X, x_bytes, hipMemcpyHostToDevice, side));
         CP_HIP(ctx, hipMemcpyAsync(const_cast<double *>(Y), host.Y, y_bytes, hipMemcpyHostToDevice, side));
         if (!ctx->ev_upload) CP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
         CP_HIP(ctx, hipEventRecord(ctx->ev_upload, side));
+        side_join.armed = false;
         upload_join.enqueued = true;
         res->uploaded = 1;            // from here on X_dev / Y_dev hold (or are about to hold) the caller's arrays
         return CP_OK;

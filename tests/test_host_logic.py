@@ -109,7 +109,7 @@ def _shard_worker(rank, world, port, q):
                                           ls="numpy")
         return out[0], out[1], out[2]
 
-    res = prune_sharded(specs, compute, dist=dist)
+    res = prune_sharded(specs, compute, dist=dist, exchange="allgather")
     import hashlib   # exact bytes: a floating-point sum would depend on the alignment of the (sliced) receive buffer
     q.put((rank, calls, [(r[0].tolist(), r[1].shape, hashlib.sha1(np.ascontiguousarray(r[1]).tobytes()).hexdigest(),
                           hashlib.sha1(np.ascontiguousarray(r[2]).tobytes()).hexdigest()) for r in res]))
@@ -133,7 +133,7 @@ def _exchange_worker(rank, world, port, q):
             idxs = rs.rand(s["c"]) < 0.6
             idxs[0] = True
             mine[i] = (idxs, rs.randn(s["n"], int(idxs.sum()), s["k"], s["k"]), rs.randn(s["n"]))
-    res = shard.exchange_results(specs, owner, mine, dist)
+    res = shard.exchange_results(specs, owner, mine, dist, mode="allgather")
     q.put((rank, [(r[0].tolist(), r[1].shape, hashlib.sha1(np.ascontiguousarray(r[1]).tobytes()).hexdigest(),
                    hashlib.sha1(np.ascontiguousarray(r[2]).tobytes()).hexdigest()) for r in res],
            dict(shard.LAST_EXCHANGE_MS)))
@@ -183,6 +183,70 @@ def _vgg16_world8_specs():
                  cost=cost[s["c"]]) for s in jobs.vgg16_4x()]
 
 
+def _exchange_modes_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import hashlib
+
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    from cpmi355 import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = [dict(layer_id=i, N=10, c=c, n=n, k=k, rank=1) for i, (c, n, k) in enumerate([(16, 3, 3), (5, 4, 1), (9, 2, 3), (16, 1, 1)])]
+    owner = [2, 0, 2, 1]
+    mine = {}
+    for i, s in enumerate(specs):
+        if owner[i] == rank:
+            rs = np.random.RandomState(50 + i)
+            idxs = rs.rand(s["c"]) < 0.6
+            idxs[0] = True
+            mine[i] = (idxs, rs.randn(s["n"], int(idxs.sum()), s["k"], s["k"]), rs.randn(s["n"]))
+    sha = lambda a: None if a is None else hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()   # noqa: E731
+    out = {}
+    for mode in ("allgather", "gather", "masks"):
+        res = shard.exchange_results(specs, owner, mine, dist, mode=mode)
+        out[mode] = ([(r[0].tolist(), sha(r[1]), sha(r[2])) for r in res], dict(shard.LAST_EXCHANGE_MS))
+    res = shard.prune_sharded(specs, compute_fn=lambda s_: mine[s_["layer_id"]], dist=dist, owner=owner)     # the default
+    out["default"] = ([(r[0].tolist(), sha(r[1]), sha(r[2])) for r in res], dict(shard.LAST_EXCHANGE_MS))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_exchange_modes_gather_to_rank0_is_the_default_world_size_3_gloo():
+    """north_star's split of the exchange: the masks' all_gather reaches every rank in every mode; the packed (W, b) go to rank 0
+    only by default ("gather": exact segment lengths, point to point), everywhere with "allgather", nowhere with "masks".
+    Rank 0's results are byte-identical in "gather" and "allgather"; the other ranks keep their own layers' weights and see
+    (mask, None, None) for foreign ones; bytes sent per rank: its own segment once (gather) against world - 1 times over its links."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33100 + (os.getpid() % 1900)
+    procs = [ctx.Process(target=_exchange_modes_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owner = [2, 0, 2, 1]
+    full = got[0]["allgather"][0]
+    assert all(w is not None and b is not None for _, w, b in full)
+    for r in range(3):
+        assert got[r]["allgather"][0] == full
+        for mode in ("gather", "masks", "default"):
+            res, info = got[r][mode]
+            assert [m for m, _, _ in res] == [m for m, _, _ in full]                     # every mask on every rank
+            for i, (m, w, b) in enumerate(res):
+                has = owner[i] == r or (mode != "masks" and r == 0)
+                assert ((w, b) == full[i][1:]) if has else (w is None and b is None)
+        assert got[r]["default"][1]["mode"] == "gather"
+        seg = got[r]["allgather"][1]["bytes_sent"]
+        assert got[r]["allgather"][1]["link_bytes_out"] == 2 * seg
+        assert got[r]["gather"][1]["bytes_sent"] == got[r]["gather"][1]["link_bytes_out"] == (0 if r == 0 else seg)
+        assert got[r]["masks"][1]["bytes_sent"] == 0
+    assert got[0]["gather"][1]["bytes_received"] == got[1]["gather"][1]["bytes_sent"] + got[2]["gather"][1]["bytes_sent"]
+    assert got[1]["gather"][1]["bytes_received"] == 0
+
+
 def _exchange8_worker(rank, world, port, q, case):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import hashlib
@@ -202,7 +266,7 @@ def _exchange8_worker(rank, world, port, q, case):
             idxs = rs.rand(s["c"]) < 0.87
             idxs[0] = True
             mine[i] = (idxs, rs.randn(s["n"], int(idxs.sum()), s["k"], s["k"]), rs.randn(s["n"]))
-    res = shard.exchange_results(specs, owner, mine, dist)
+    res = shard.exchange_results(specs, owner, mine, dist, mode="allgather")
     q.put((rank, owner, [(r[0].tolist(), tuple(r[1].shape), hashlib.sha1(np.ascontiguousarray(r[1]).tobytes()).hexdigest(),
                           hashlib.sha1(np.ascontiguousarray(r[2]).tobytes()).hexdigest()) for r in res],
            dict(shard.LAST_EXCHANGE_MS)))
@@ -282,9 +346,10 @@ def _rounds_worker(rank, world, port, q):
         return out
 
     shard.exchange_results = logged
-    res = shard.prune_sharded(specs, dist=dist, owner=owner, compute_many=shard.ThreadedLayerSet(own, compute), rounds=rounds)
+    res = shard.prune_sharded(specs, dist=dist, owner=owner, compute_many=shard.ThreadedLayerSet(own, compute), rounds=rounds,
+                              exchange="allgather")
     shard.exchange_results = real
-    plain = shard.prune_sharded(specs, dist=dist, owner=owner, compute_many=shard.ThreadedLayerSet(own, compute))
+    plain = shard.prune_sharded(specs, dist=dist, owner=owner, compute_many=shard.ThreadedLayerSet(own, compute), exchange="allgather")
     same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) for a, b in zip(res, plain))
     heavy_end = max([ended[s["layer_id"]] for s in own if s["cost"] > 0.3], default=None)
     q.put((rank, owner, rounds, same, len(exchanged), (exchanged[0] < heavy_end) if heavy_end is not None else None,
@@ -488,6 +553,105 @@ def test_layer_whose_owner_is_helped_by_a_second_rank_world_size_3_gloo():
         idxs, W, b, alpha, nxt = got[0][lid - 1]
         assert idxs == ref[0].tolist() and alpha == ref[3] and nxt == int(rng.randint(0, 2147483647))
         assert np.linalg.norm(W - ref[1]) <= 1e-9 * np.linalg.norm(ref[1]) and np.linalg.norm(b - ref[2]) <= 1e-9 * max(1.0, np.linalg.norm(ref[2]))
+
+
+class _FailingEngine(_NumpyRowEngine):
+    """_NumpyRowEngine that raises in one named stage"""
+
+    def __init__(self, stage):
+        self.stage = stage
+
+    def select(self, *a, **k):
+        if self.stage == "select":
+            raise ValueError("boom in select")
+        return super().select(*a, **k)
+
+    def gram(self, *a, **k):
+        if self.stage == "gram":
+            raise ValueError("boom in gram")
+        return super().gram(*a, **k)
+
+
+def _assist_failure_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "channel-pruning_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cp_oracle
+    from cpmi355 import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    group = dist.new_group(ranks=[0, 1])
+    N, c, n, k, r = 600, 16, 12, 3, 8
+    X, W2, Y, B2 = cp_oracle.synth_layer(1, N, c, n, k)
+    cut = N // 2
+    seen = []
+    # (stage that fails on the owner, stage that fails on the helper): the rank at fault raises its own error, the other one
+    # AssistPeerError, and nobody stays behind in a collective (the barrier after each case would time out otherwise)
+    for own_stage, help_stage in (("select", None), (None, "gram"), ("gram", None), (None, None)):
+        eng = _FailingEngine(own_stage if rank == 0 else help_stage)
+        eng.load_rows(X[:cut], Y[:cut]) if rank == 0 else eng.load_rows(X[cut:], Y[cut:])
+        try:
+            if rank == 0:
+                shard.prune_layer_assisted(eng, "owner", dist, group, 0, c, W2, N, r, 1e-3, X=X, Y=Y, rng=np.random.RandomState(1235))
+            else:
+                shard.prune_layer_assisted(eng, "helper", dist, group, 0, c, W2, N, r, 1e-3)
+            seen.append("ok")
+        except shard.AssistPeerError:
+            seen.append("peer")
+        except ValueError as e:
+            seen.append(str(e))
+        dist.barrier()
+    # prune_sharded: rank 1's layer raises -> both ranks raise (rank 0 a ShardPeerError naming rank 1) instead of rank 0
+    # waiting in the exchange for ever; a clean job right after still works (the process group is intact)
+    specs = [dict(layer_id=10 + i, N=200, c=8, n=6, k=1, rank=4) for i in range(4)]
+
+    def compute(spec, fail=False):
+        if fail and spec["layer_id"] == 11:
+            raise ValueError("boom in layer 11")
+        m = np.zeros(spec["c"], dtype=bool)
+        m[:4] = True
+        return m, np.full((spec["n"], 4, 1, 1), float(spec["layer_id"])), np.zeros(spec["n"])
+
+    owner = [0, 1, 0, 1]
+    for rounds in (None, [0, 0, 1, 1]):
+        layer_set = shard.ThreadedLayerSet([specs[i] for i in range(4) if owner[i] == rank], lambda s_: compute(s_, True))
+        try:
+            shard.prune_sharded(specs, compute_many=layer_set, dist=dist, owner=owner, rounds=rounds)
+            seen.append("ok")
+        except shard.ShardPeerError as e:
+            seen.append("peer%s" % e.ranks)
+        except ValueError as e:
+            seen.append(str(e))
+        dist.barrier()
+    res = shard.prune_sharded(specs, compute_fn=compute, dist=dist, owner=owner, exchange="allgather")
+    seen.append([float(r_[1].ravel()[0]) for r_ in res])
+    q.put((rank, seen))
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_never_leaves_its_peers_waiting_in_a_collective_gloo():
+    """advisor, round 5: no failure path across ranks.  An assisted layer whose owner fails in the alpha search, or whose
+    owner / helper fails in the Gram stage, ends with the faulty rank raising its own error and its peer AssistPeerError --
+    both having walked broadcast -> all-reduce -> all-reduce; a rank whose layer raises inside prune_sharded (single exchange
+    and exchange in rounds) tells the others through the mask all_gather (ShardPeerError on them).  The process group stays
+    usable: a clean job follows on the same group."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 38500 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_assist_failure_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][:4] == ["boom in select", "peer", "boom in gram", "ok"]
+    assert got[1][:4] == ["peer", "boom in gram", "peer", "ok"]
+    assert got[0][4:6] == ["peer[1]", "peer[1]"] and got[1][4:6] == ["boom in layer 11", "boom in layer 11"]
+    assert got[0][6] == got[1][6] == [10.0, 11.0, 12.0, 13.0]
 
 
 def test_plan_assists_uses_ranks_with_slack_only():
