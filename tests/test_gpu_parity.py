@@ -644,6 +644,117 @@ def test_dictionary_replays_on_host_when_device_search_runs_out_of_seeds(ctx, na
     _check_against_golden(g, p, _run_dropin(p, X, W2, Y, B2, "device"))
 
 
+def _fused(ctx, X, W2, Y, rank, seed, streamed, latency_mode):
+    """one dictionary() through the fused entry: cp_prune_layer on resident operands, or cp_prune_layer_h2d from host arrays"""
+    import cpmi355
+    from cpmi355.pruner import prune_layer
+    prob = cpmi355.LayerProblem(ctx, X, W2, Y, flags=0, defer_upload=streamed)
+    rng = np.random.RandomState(seed)
+    idxs, W, b, alpha = prune_layer(prob, rank, 1e-3, rank_tol=.1, rng=rng, mode="device", latency_mode=latency_mode)
+    out = (idxs.copy(), np.array(W), np.array(b), alpha, list(prob.fits), int(rng.randint(0, 2147483647)),
+           (int(prob.refit_info.p), int(prob.refit_info.rank), int(prob.refit_info.fallback)))
+    return prob, out
+
+
+@pytest.mark.parametrize("shape", [(2, 600, 64, 48, 3, 32), (32, 5000, 256, 256, 3, 128), (7, 1500, 96, 40, 1, 50)])
+@pytest.mark.parametrize("latency_mode", [True, False])
+def test_streamed_entry_equals_resident_entry_bit_for_bit(ctx, shape, latency_mode):
+    """advisor, round 4: cp_prune_layer_h2d (host arrays; the sampled rows first, X / Y streamed in behind the alpha search)
+    against cp_prune_layer (resident operands) on the SAME operands: mask, W, b, alpha, the per-fit log, the RNG stream and
+    the refit's (p, rank, route) are equal BIT FOR BIT -- both entries were pinned to the reference to 1e-12 so far, not to
+    each other.  Small, c = 256 at full size (a conv3_x layer), and a 1 x 1 layer; with and without the precompute route."""
+    import cp_oracle
+    lid, N, c, n, k, rank = shape
+    X, W2, Y, _ = cp_oracle.synth_layer(lid, N, c, n, k)
+    pr_r, res = _fused(ctx, X, W2, Y, rank, 1234 + lid, False, latency_mode)
+    pr_s, stm = _fused(ctx, X, W2, Y, rank, 1234 + lid, True, latency_mode)
+    try:
+        assert pr_s._pending is None                                   # the call streamed the arrays in
+        assert np.array_equal(res[0], stm[0]) and res[0].sum() > 0
+        assert res[1].tobytes() == stm[1].tobytes() and res[2].tobytes() == stm[2].tobytes()
+        assert res[3:] == stm[3:]
+        # ... and the buffers the streamed call filled ARE the arrays: a refit of another mask from them equals the resident one
+        other = np.zeros(c, dtype=bool)
+        other[::2] = True
+        Wr, br = pr_r.refit(other)
+        Ws, bs = pr_s.refit(other)
+        assert Wr.tobytes() == Ws.tobytes() and br.tobytes() == bs.tobytes()
+    finally:
+        pr_r.free()
+        pr_s.free()
+
+
+def test_streamed_entry_rank_not_below_c_and_error_before_the_upload(ctx):
+    """The two corners of cp_prune_layer_h2d the drop-in never reaches through dictionary(): (a) rank >= c -- nothing to
+    select, the call only uploads and refits with every channel (csrc/prune_layer.hip, the `rank >= c` branch; lib/ takes
+    the reference's `rank == c` shortcut on the host) -- against the resident entry, bit for bit; (b) an error return that
+    comes BEFORE the upload was enqueued (a sample index out of range): cp_prune_result.uploaded = 0, the host arrays stay
+    pending on the Python side, ensure_resident() uploads them, and what follows equals the resident problem bit for bit."""
+    import cp_oracle
+    import cpmi355
+    from cpmi355 import capi
+    N, c, n, k = 700, 48, 24, 3
+    X, W2, Y, _ = cp_oracle.synth_layer(5, N, c, n, k)
+    pr_r = cpmi355.LayerProblem(ctx, X, W2, Y, flags=0)
+    pr_s = cpmi355.LayerProblem(ctx, X, W2, Y, flags=0, defer_upload=True)
+    pr_e = cpmi355.LayerProblem(ctx, X, W2, Y, flags=0, defer_upload=True)
+    try:
+        samples = np.random.RandomState(3).randint(0, N, 35)
+        outs = []
+        for pr in (pr_r, pr_s):
+            rng = np.random.RandomState(77)
+            idxs, W, b, alpha = pr.prune_fused(c, 1e-3, .1, rng, samples, latency_mode=False)          # (a)
+            outs.append((idxs.copy(), np.array(W), np.array(b), int(rng.randint(0, 2147483647))))
+        assert pr_s._pending is None and outs[0][0].all() and outs[1][0].all()
+        assert outs[0][1].tobytes() == outs[1][1].tobytes() and outs[0][2].tobytes() == outs[1][2].tobytes()
+        assert outs[0][3] == outs[1][3] == int(np.random.RandomState(77).randint(0, 2147483647))       # no draw consumed
+        bad = samples.copy()                                                                             # (b)
+        bad[3] = N
+        rng = np.random.RandomState(78)
+        with pytest.raises(capi.CpError) as err:
+            pr_e.prune_fused(24, 1e-3, .1, rng, bad, latency_mode=False)
+        assert not getattr(err.value, "uploaded", True) and pr_e._pending is not None
+        assert int(rng.randint(0, 2147483647)) == int(np.random.RandomState(78).randint(0, 2147483647))  # RNG rewound
+        got = []
+        for pr in (pr_r, pr_e):
+            rng = np.random.RandomState(79)
+            pr.lasso_gram(samples)                      # ensure_resident() on pr_e: the arrays go up now
+            alpha = pr.alpha_search(24, 1e-3, .1, rng, mode="device")
+            mask = pr.mask()
+            W, b = pr.refit(mask)
+            got.append((mask, W, b, alpha, list(pr.fits)))
+        assert pr_e._pending is None
+        assert np.array_equal(got[0][0], got[1][0]) and got[0][3:] == got[1][3:]
+        assert got[0][1].tobytes() == got[1][1].tobytes() and got[0][2].tobytes() == got[1][2].tobytes()
+    finally:
+        for pr in (pr_r, pr_s, pr_e):
+            pr.free()
+
+
+@pytest.mark.parametrize("name", golden_cases("s")[:3])
+def test_streamed_entry_replay_after_an_unsettled_search_equals_resident(ctx, name, monkeypatch):
+    """cp_prune_layer_h2d whose search runs out of pre-drawn seeds (fits_used = -1): X / Y are complete on the device when the
+    call returns, the Python side replays fit by fit from them -- same mask / W / b / alpha / fits / RNG stream as the
+    resident entry taking the same detour, bit for bit, and both equal the reference golden."""
+    import cpmi355.pruner as pruner
+    monkeypatch.setattr(pruner, "MAX_FITS", 2)
+    g, p, X, W2, Y, B2 = load_case(name)
+    if len(g["fits"]) <= 2:
+        pytest.skip("search settles within two fits")
+    pr_r, res = _fused(ctx, X, W2, Y, p["rank"], 1234 + p["layer_id"], False, False)
+    pr_s, stm = _fused(ctx, X, W2, Y, p["rank"], 1234 + p["layer_id"], True, False)
+    try:
+        assert pr_s._pending is None
+        assert np.array_equal(res[0], stm[0])
+        assert res[1].tobytes() == stm[1].tobytes() and res[2].tobytes() == stm[2].tobytes() and res[3:6] == stm[3:6]
+        if not any(p.get(k) for k in ("alpha_in", "rank_tol", "fc_ridge", "nonlinear_fc", "nofc", "autodet")):
+            assert np.array_equal(res[0], g["idxs"])
+            assert [tuple(f) for f in res[4]] == [(float(a), int(z), int(it)) for a, z, it in g["fits"]]
+    finally:
+        pr_r.free()
+        pr_s.free()
+
+
 def _cd_debug(ctx):
     import ctypes
     lib = ctx.lib
@@ -1118,15 +1229,25 @@ def _nccl_worker(rank, world, port, q, backend="nccl", force_exchange=False):
     own = [s for s, o in zip(specs, owner) if o == rank]
     rset = shard.ResidentLayerSet(gpu, own, lambda s: data[s["layer_id"]], per_stream=2, flags=3, borrow_results=True)
     ok = True
-    for it in range(2):                               # twice: the lent result blocks and the staging buffers are reused
-        # the second time with the exchange in rounds: the light layers' results travel while the heavy ones are pruned
-        res = shard.prune_sharded(specs, compute_many=rset, dist=dist, owner=owner, staging="device",
-                                  force_exchange=force_exchange, rounds=shard.plan_rounds(specs, owner) if it else None)
-        ok = ok and (it == 0 or len(shard.LAST_EXCHANGE_MS.get("rounds", [])) == 2)
-        for s, (idxs, W, b) in zip(specs, res):
+    # several times: the lent result blocks and the staging buffers are reused.  Every mode of the exchange, each as ONE
+    # exchange and in rounds (the light layers' results travel while the heavy ones are pruned)
+    for it, (mode, in_rounds) in enumerate((("allgather", False), ("allgather", True), ("gather", False), ("gather", True),
+                                            ("masks", False))):
+        res = shard.prune_sharded(specs, compute_many=rset, dist=dist, owner=owner, staging="device", exchange=mode,
+                                  force_exchange=force_exchange, rounds=shard.plan_rounds(specs, owner) if in_rounds else None)
+        ok = ok and (not in_rounds or len(shard.LAST_EXCHANGE_MS.get("rounds", [])) == 2)
+        ok = ok and shard.LAST_EXCHANGE_MS.get("mode") == mode
+        for i, (s, (idxs, W, b)) in enumerate(zip(specs, res)):
             g = np.load(os.path.join(GOLDEN_DIR, s["name"] + ".npz"))
-            ok = ok and np.array_equal(idxs, g["idxs"]) and W.shape == g["newW2"].shape
+            ok = ok and np.array_equal(idxs, g["idxs"])                  # every mask on every rank, whatever the mode
+            has = owner[i] == rank or mode == "allgather" or (mode == "gather" and rank == 0)
+            if not has:
+                ok = ok and W is None and b is None
+                continue
+            ok = ok and W.shape == g["newW2"].shape
             ok = ok and relfro(W, g["newW2"]) <= REL_W and relfro(b, g["newB2"]) <= REL_W
+    res = shard.prune_sharded(specs, compute_many=rset, dist=dist, owner=owner, staging="device", exchange="allgather",
+                              force_exchange=force_exchange)
     if force_exchange:       # the other two collectives of the package through the same backend
         every = shard.gather_masks(specs, res, dist)
         ok = ok and len(every) == world and all(np.array_equal(every[0][i], res[i][0]) for i in range(len(specs)))
@@ -1134,6 +1255,19 @@ def _nccl_worker(rank, world, port, q, backend="nccl", force_exchange=False):
         shard.allreduce_sum(dist, t)
         ok = ok and bool(torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64) * world))
         ok = ok and dist.get_backend() == backend and shard.LAST_EXCHANGE_MS.get("bytes_sent", 0) > 0
+        # the device the collectives of a WORKER THREAD use is the one it is told, not the thread's current device
+        import threading
+        seen = []
+
+        def from_a_thread():
+            h = torch.arange(10, dtype=torch.float64)
+            shard.allreduce_sum(dist, h, device=torch.device("cuda", gpu)) if world > 1 else None
+            seen.append(shard._bcast_mask(dist, np.arange(7, dtype=np.uint8), 0, None, device=gpu).tolist())
+
+        th = threading.Thread(target=from_a_thread)
+        th.start()
+        th.join()
+        ok = ok and seen == [list(range(7))]
     rset.close()
     q.put((rank, bool(ok), len(own)))
     dist.barrier()
