@@ -37,6 +37,7 @@
 #include "cp_common.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 typedef double v4f64s __attribute__((ext_vector_type(4)));
@@ -83,7 +84,7 @@ __device__ __forceinline__ double read_lane(double v, int lane) {   // lane: wav
 }
 
 // spin_limit: 1 << 26 polls of ~100 ns (seconds); 0 in the test of the time-out path (cp_debug_chol_fail_flag_wait)
-__device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_limit, int want = 1) {
+__device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_limit, int want = 1, int *stop = nullptr) {
     // RELAXED agent-scope load (global_load ... sc1: never served from this XCD's non-coherent L2 lines).  An ACQUIRE here is a
     // `buffer_inv sc1` after EVERY poll -- an invalidation of the whole L2 of the XCD, issued by ~35 panel workgroups for
     // ~45 us per step, on top of the one all their waves issued after the wait: during a job's factorisation phase every
@@ -91,8 +92,10 @@ __device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_l
     // announces is read with sc1 loads as well (role_panel), so no fence is needed at all.
     for (int spin = 0; spin < spin_limit; ++spin) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return;
+        if (stop && (spin & 15) == 15 && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         __builtin_amdgcn_s_sleep(2);
     }
+    if (stop) __hip_atomic_store(stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // Not observed outside the test: the host reads info[0] != 0 as "this factorisation is not to be trusted" and the refit
     // goes on to its rank-revealing path (refit.hip: refit_solve_tail -> refit_robust), which factors again -- a slower
     // route to the same result and never a hang (that path can still end in CP_ERR_NUMERIC on a matrix it cannot factor
@@ -109,7 +112,20 @@ __device__ __forceinline__ void flag_wait(const int *flag, int *info, int spin_l
 // last); with the columns handed out as 7, 6, 5, 4 | 0, 1, 2, 3 every SIMD carries 9.
 __device__ __forceinline__ int diag_col(int wave) { return wave < 4 ? 7 - wave : wave - 4; }
 
-template <bool SAME>
+// BSC1 (the persistent form, right-hand-side tiles): the B operand -- block rows of Y that their owners finished IN PLACE, in
+// R -- is read with agent-scope (sc1) loads: those addresses were read before, as the tiles they used to be, by workgroups
+// of any XCD, and a plain load could be served from such a stale L2 line.  (U is written once, into a buffer nobody read
+// before: plain loads, shared through the L2 by the workgroups of an XCD.)
+__device__ __forceinline__ v2f64s load_v2_sc1(gcv2p ptr) {
+    typedef const CP_GLOBAL unsigned long long *gcup_;
+    const gcup_ q = (gcup_)ptr;
+    v2f64s v;
+    v[0] = __longlong_as_double((long long)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    v[1] = __longlong_as_double((long long)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return v;
+}
+
+template <bool SAME, bool BSC1 = false>
 __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld, gcdp Bb, int ldb, int kcnt, double *sm) {
     const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
     const int wave = SAME ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6)) : __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,10 +143,14 @@ __device__ __forceinline__ void tile_update(v4f64s (&acc)[NPAN], gcdp Ab, int ld
         for (int i = 0; i < PER; ++i) {
             gcdp ab = Ab + size_t(ch * KCH + (PT >> 6) * i) * ld, bb = Bb + size_t(ch * KCH + (PT >> 6) * i) * ldb;
             ar[i] = *(gcv2p)(ab + goff);
-            if constexpr (!SAME) br[i] = *(gcv2p)(bb + goffb);
+            if constexpr (!SAME) {
+                if constexpr (BSC1) br[i] = load_v2_sc1((gcv2p)(bb + goffb));
+                else br[i] = *(gcv2p)(bb + goffb);
+            }
         }
     };
-    // kcnt (1 or 2) consecutive block rows of the operands: K = 128 kcnt, the rows of a block row are contiguous in k
+    // kcnt (1, 2; up to CHAIN_L in the persistent form) consecutive block rows of the operands: K = 128 kcnt, the rows of a
+    // block row are contiguous in k
     const int nch = kcnt * (NB / KCH);
     gload(0);
     for (int ch = 0; ch < nch; ++ch) {
@@ -472,9 +492,31 @@ struct Tile {
     int kcnt;           // block rows to apply: 0 (nothing yet), 1 or 2
 };
 
+// the tile itself crosses workgroups (and XCDs) in the persistent form -- the next task on it may run anywhere -- so it is read
+// and written with agent-scope (sc1) accesses there; between launches the kernel boundary does that job
+template <bool SC1>
+__device__ __forceinline__ double tile_ld(gcdp ptr) {
+    if constexpr (SC1) {
+        typedef const CP_GLOBAL unsigned long long *gcup_;
+        return __longlong_as_double((long long)__hip_atomic_load((gcup_)ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else {
+        return *ptr;
+    }
+}
+template <bool SC1>
+__device__ __forceinline__ void tile_st(gdp ptr, double v) {
+    if constexpr (SC1) {
+        typedef CP_GLOBAL unsigned long long *gup_;
+        __hip_atomic_store((gup_)ptr, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *ptr = v;
+    }
+}
+
 // acc <- the tile, then the pending updates (see the head of the file)
-template <bool DIAG>
-__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *Ai_, int ld, double *sm) {
+template <bool DIAG, bool PERSIST = false>
+__device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile &t_, const double *Ai_, int ld, double *sm,
+                                                 bool rhs = false) {
     const gcdp T = (gcdp)t_.T, Bop = (gcdp)t_.B, Ai = (gcdp)Ai_;
     const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
     const int wave = DIAG ? diag_col(__builtin_amdgcn_readfirstlane(tid >> 6)) : __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -486,39 +528,43 @@ __device__ __forceinline__ void tile_load_update(v4f64s (&acc)[NPAN], const Tile
             continue;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = (T + size_t(16 * t + 4 * r) * t_.ldt)[toff];
+        for (int r = 0; r < 4; ++r) acc[t][r] = tile_ld<PERSIST>((T + size_t(16 * t + 4 * r) * t_.ldt) + toff);
     }
     CP_STAMP(1);
-    if (t_.kcnt > 0) tile_update<DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm);
+    if (t_.kcnt > 0) {
+        if (PERSIST && !DIAG && rhs) tile_update<DIAG, PERSIST && !DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm);
+        else tile_update<DIAG>(acc, Ai, ld, Bop, t_.ldb, t_.kcnt, sm);
+    }
     CP_STAMP(2);
 }
 
 // the three roles of a workgroup of launch s; each is a function of its own (not inlined) so that the register allocation of
 // one role does not see the live ranges of the others (inlined, the kernel spilled ~100 registers even at 256), and each ends
 // the program itself
-__device__ __noinline__ __attribute__((noreturn)) void role_bulk(Tile t_, const double *__restrict__ Ai, int ld, int s, double *sm) {
+template <bool PERSIST>
+__device__ __noinline__ void role_bulk(Tile t_, const double *__restrict__ Ai, int ld, int s, double *sm, bool rhs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
     v4f64s acc[NPAN];
     CP_STAMP(0);
-    tile_load_update<false>(acc, t_, Ai, ld, sm);
+    tile_load_update<false, PERSIST>(acc, t_, Ai, ld, sm, rhs);
     const int toff = fk * t_.ldt + 16 * wave + fi;
     const gdp T = (gdp)t_.T;
 #pragma unroll
     for (int t = 0; t < NPAN; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) (T + size_t(16 * t + 4 * r) * t_.ldt)[toff] = acc[t][r];
+        for (int r = 0; r < 4; ++r) tile_st<PERSIST>((T + size_t(16 * t + 4 * r) * t_.ldt) + toff, acc[t][r]);
     CP_STAMP(3);
-    __builtin_amdgcn_endpgm();
+    if constexpr (!PERSIST) __builtin_amdgcn_endpgm();
 }
 
-__device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const double *__restrict__ Ai, double *__restrict__ Uss,
-                                                                 int ld, int s, const double *__restrict__ dg0, double piv_tol,
-                                                                 double *__restrict__ TIb, double *__restrict__ TITb, int *info,
-                                                                 double *sm) {
+template <bool PERSIST>
+__device__ __noinline__ void role_diag(Tile t_, const double *__restrict__ Ai, double *__restrict__ Uss, int ld, int s,
+                                       const double *__restrict__ dg0, double piv_tol, double *__restrict__ TIb,
+                                       double *__restrict__ TITb, int *info, double *sm) {
     CP_STAMP(0);
     {
         v4f64s acc[NPAN];
-        tile_load_update<true>(acc, t_, Ai, ld, sm);
+        tile_load_update<true, PERSIST>(acc, t_, Ai, ld, sm);
         diag_to_lds(acc, sm, (gcdp)dg0 + size_t(s) * NB);
     }
     CP_STAMP(3);
@@ -527,18 +573,19 @@ __device__ __noinline__ __attribute__((noreturn)) void role_diag(Tile t_, const 
     CP_STAMP(5);
     diag_inverse(sm, TIb, TITb);
     CP_STAMP(6);
-    __builtin_amdgcn_endpgm();
+    if constexpr (!PERSIST) __builtin_amdgcn_endpgm();
 }
 
 // out / ldo: where U[s,j] (or Y[s,jr]) goes; Ltjs: the transposed copy of a factor tile, null for a right-hand side
-__device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const double *__restrict__ Ai, int ld, int s,
-                                                                  double *__restrict__ out, int ldo, double *__restrict__ Ltjs,
-                                                                  const double *__restrict__ Gss, int *info, int spin_limit,
-                                                                  double *sm) {
+// stop (persistent form): the factorisation's abort word -- a time-out anywhere ends every wait of the launch
+template <bool PERSIST>
+__device__ __noinline__ void role_panel(Tile t_, const double *__restrict__ Ai, int ld, int s, double *__restrict__ out, int ldo,
+                                        double *__restrict__ Ltjs, const double *__restrict__ Gss, int *info, int spin_limit,
+                                        double *sm, bool rhs, int *stop) {
     const int tid = threadIdx.x, lane = tid & 63, fk = lane >> 4, fi = lane & 15;
     v4f64s acc[NPAN];
     CP_STAMP(0);
-    tile_load_update<false>(acc, t_, Ai, ld, sm);
+    tile_load_update<false, PERSIST>(acc, t_, Ai, ld, sm, rhs);
     // Substitution BEHIND the factorisation: block column q of the operator (the blocks (k, q), k < q, and T_q) is fetched and
     // applied as soon as the diagonal workgroup has published it (the flag word counts the published columns), so that after
     // the last publication only the last of the eight steps is left -- not the operator load and all eight.
@@ -546,7 +593,7 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
     const gcup Go = (gcup)Gss;
 #pragma unroll
     for (int q = 0; q < NPAN; ++q) {
-        if (tid == 0) flag_wait(info + 1 + s, info, spin_limit, q + 1);  // bounded; running out is reported as a failed factorisation
+        if (tid == 0) flag_wait(info + 1 + s, info, spin_limit, q + 1, stop);  // bounded; running out is reported as a failed factorisation
         __syncthreads();
         CP_HANDOFF_ACQUIRE();
         if (q == NPAN - 1) CP_STAMP(3);
@@ -584,18 +631,19 @@ __device__ __noinline__ __attribute__((noreturn)) void role_panel(Tile t_, const
         for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(Tq[(4 * r + fk) * 16 + fi], acc[q][r], y, 0, 0, 0);
         acc[q] = y;
         // rows 16 q .. 16 q + 15 of the tile are final: on their way (U[s,j] or Y[s,jr] row-major and, for a factor tile, the
-        // transpose Lt[j,s]) while the next block column is waited for
+        // transpose Lt[j,s]) while the next block column is waited for.  Persistent form: U[s,j] / Y[s,jr] are read by other
+        // workgroups of this launch (sc1 stores, waited for before the tile is announced); Lt only by later kernels
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int uoff = fk * ldo + 16 * wave + fi, loff = (16 * wave + fi) * ld + fk;
         const gdp Uo = (gdp)out, Lo = (gdp)Ltjs;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            (Uo + size_t(16 * q + 4 * r) * ldo)[uoff] = y[r];
+            tile_st<PERSIST>((Uo + size_t(16 * q + 4 * r) * ldo) + uoff, y[r]);
             if (Ltjs) (Lo + (16 * q + 4 * r))[loff] = y[r];
         }
     }
     CP_STAMP(5);
-    __builtin_amdgcn_endpgm();
+    if constexpr (!PERSIST) __builtin_amdgcn_endpgm();
 }
 
 // R (p_pad x ntr 128-column tiles, leading dimension ldr; null: none): right-hand sides riding along -- block row i of the
@@ -645,15 +693,367 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
     // bulk workgroups (of this or any other layer's launch) that share their SIMDs.
     if (i == s) __builtin_amdgcn_s_setprio(3);
     if (i > s)            // below the block row of this step: the updated tile goes back
-        role_bulk(t_, Ai, ld, s, sm);
+        role_bulk<false>(t_, Ai, ld, s, sm, rhs);
     else if (!rhs && j == s)
-        role_diag(t_, Ai, U + size_t(s) * NB * ld + size_t(s) * NB, ld, s, dg0, piv_tol, TI + size_t(s) * NB * NB,
-                  TIT + size_t(s) * NB * NB, info, sm);
+        role_diag<false>(t_, Ai, U + size_t(s) * NB * ld + size_t(s) * NB, ld, s, dg0, piv_tol, TI + size_t(s) * NB * NB,
+                         TIT + size_t(s) * NB * NB, info, sm);
     else if (!rhs)
-        role_panel(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB, Gss, info,
-                   spin_limit, sm);
+        role_panel<false>(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld, Lt + size_t(j) * NB * ld + size_t(s) * NB,
+                          Gss, info, spin_limit, sm, false, nullptr);
     else
-        role_panel(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, spin_limit, sm);
+        role_panel<false>(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, spin_limit, sm, true, nullptr);
+}
+
+// =============================================================================================================================
+// The persistent form: ONE launch per factorisation.
+//
+// In a job the launch-per-step chain above costs what its launch COUNT costs: next to other layers' products a step that takes
+// 68-75 us alone took 265 us (profiles/r05_kernels_vgg16.md: 243 launches, 64.5 ms of stream time per job), because every launch
+// is a barrier for the whole factorisation and then waits for workgroup slots on a full chip.  Here the same tile tasks -- the
+// same arithmetic on every tile, in the same order: U comes out bit for bit as from k_chol_step -- are handed out INSIDE one
+// launch: a grid of W workgroups that stay resident and take the next task off ONE counter, in a fixed linear order in which
+// every task comes after everything it depends on.  A workgroup that has claimed a task waits (bounded) for that task's
+// inputs; what it waits for was claimed earlier, hence by a workgroup that is resident and running -- no deadlock whatever
+// number of the W workgroups the chip lets in, and none between the launches of different layers.
+//
+// Tiles and tasks.  Row i of the tile grid has width(i) = nblk - i + ntr tiles: the factor tiles (i, x), x = i .. nblk - 1, then
+// the right-hand-side tiles.  Tile (i, x) receives the updates of block rows 0 .. i - 2 in chunks of at most L = CHAIN_L rows
+// ([0, L), [L, 2L), ... -- the last one may be shorter) as bulk tasks, and block row i - 1 together with its final role
+// (factor / substitute) as the chain task of step i, so that the serial piece of a step stays at K = 128.  Linear order,
+// for s = 0 .. nblk - 1:
+//     pre(s)    the LAST chunk of every tile of row s (rows .. s - 2; inputs: steps <= s - 2)           [s >= 2]
+//     chain(s)  diagonal role, then the panel roles of row s (inputs: pre(s), step s - 1, the operator of s)
+//     rest(s)   the full chunk [s - 1 - L, s - 1) of every tile of the rows below s                     [s - 1 a multiple of L, s > L]
+// pre(s + 1) and chain(s + 1) do not depend on rest(s): the chain runs ahead of the chip-filling part of the previous
+// steps as far as free workgroups let it, instead of waiting at a launch boundary.  With L = 4 a tile is read and written
+// every fourth step (K = 512 per pass) instead of every second: about half the HBM traffic of the launch-per-step form.
+//
+// Hand-over between workgroups (no fences, as for the operator -- see flag_wait):
+//   * a tile in progress (G / R in place) may be continued by any workgroup on any XCD: read and written with sc1 accesses;
+//   * a finished tile of U is written ONCE into a buffer nobody has read in this launch: sc1 stores, plain loads (shared
+//     through the XCD's L2); a finished right-hand-side tile is written in place: sc1 stores and sc1 loads;
+//   * ver[i][x] (one word per tile) = block rows applied so far, i + 1 once the tile is final; a task polls the words of its
+//     tile and of the finished tiles it multiplies with.  Every wave waits for its own stores (vmcnt(0)) before the barrier
+//     after which thread 0 raises the word.
+//   * ctl[1] is the launch's stop word: a wait that runs out sets it (and info[0]), every other wait of the launch returns at
+//     once, the workgroups drain the counter without working, and the host takes its rank-revealing route as for a failed pivot.
+constexpr int CHAIN_L_MAX = 4;
+constexpr int CHAIN_NTR_MAX = 32;    // right-hand-side tile columns the control block has words for (n_pad <= 4096)
+
+struct ChainShape {
+    int nblk, ntr, L;
+    int factor = 1;            // 0: right-hand-side tiles only (the backward sweep: "row" = level above the bottom block row)
+    __host__ __device__ int width(int i) const { return (factor ? nblk - i : 0) + ntr; }
+    __host__ __device__ int pre(int s) const { return s >= 2 ? width(s) : 0; }
+    __host__ __device__ int rest(int s) const {
+        if (s <= L || (s - 1) % L != 0 || s + 1 >= nblk) return 0;
+        const int n = nblk - s - 1;                      // rows s + 1 .. nblk - 1
+        return (factor ? n * (n + 1) / 2 : 0) + n * ntr;
+    }
+    __host__ __device__ int segment(int s) const { return pre(s) + width(s) + rest(s); }
+    __host__ __device__ int total() const {
+        int t = 0;
+        for (int s = 0; s < nblk; ++s) t += segment(s);
+        return t;
+    }
+};
+
+enum { TASK_PRE = 0, TASK_CHAIN = 1, TASK_REST = 2 };
+struct ChainTask {
+    int kind, s, i, xi;        // xi: position in row i (factor tiles first)
+    int r0, kcnt;              // block rows [r0, r0 + kcnt) to apply
+};
+
+__device__ __forceinline__ ChainTask chain_decode(const ChainShape &sh, int t) {
+    ChainTask k;
+    int s = 0;
+    for (;; ++s) {
+        const int seg = sh.segment(s);
+        if (t < seg) break;
+        t -= seg;
+    }
+    k.s = s;
+    if (t < sh.pre(s)) {
+        k.kind = TASK_PRE;
+        k.i = s;
+        k.xi = t;
+        k.r0 = sh.L * ((s - 2) / sh.L);
+        k.kcnt = s - 1 - k.r0;
+        return k;
+    }
+    t -= sh.pre(s);
+    if (t < sh.width(s)) {
+        k.kind = TASK_CHAIN;
+        k.i = s;
+        k.xi = t;
+        k.r0 = s == 0 ? 0 : s - 1;
+        k.kcnt = s == 0 ? 0 : 1;
+        return k;
+    }
+    t -= sh.width(s);
+    k.kind = TASK_REST;
+    int i = s + 1;
+    while (t >= sh.width(i)) {
+        t -= sh.width(i);
+        ++i;
+    }
+    k.i = i;
+    k.xi = t;
+    k.r0 = s - 1 - sh.L;
+    k.kcnt = sh.L;
+    return k;
+}
+
+// lanes 0 .. cnt - 1 of wave 0 each poll one word until it reaches its target; -> false when the launch was stopped / timed out
+__device__ __forceinline__ bool chain_wait(const int *word, int want, bool active, int *stop, int *info, int spin_limit) {
+    for (int spin = 0;; ++spin) {
+        const bool ok = !active || __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+        if (__all(ok)) return true;
+        if ((spin & 15) == 15 && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if (spin >= spin_limit) {
+            __hip_atomic_store(stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicCAS(info, 0, 0x7fffffff);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+__global__ void __launch_bounds__(PT, 4)
+k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int L, int total,
+             const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, double *__restrict__ TIT, int *info, int *ctl,
+             double *__restrict__ R, int ldr, int ntr, int spin_limit) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int s_task, s_go;
+    const int tid = threadIdx.x;
+    const ChainShape sh{nblk, ntr, L, 1};
+    const int XW = nblk + CHAIN_NTR_MAX;
+    int *const stop = ctl + 1, *const ver = ctl + 8;
+    for (;;) {
+        if (tid == 0) s_task = atomicAdd(ctl, 1);
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(s_task);
+        if (t >= total) return;
+        const ChainTask k = chain_decode(sh, t);
+        const int i = k.i, s = k.s;
+        const bool rhs = k.xi >= nblk - i;
+        const int j = rhs ? k.xi - (nblk - i) : i + k.xi;        // right-hand-side tile column, or block column of the factor
+        const int x = rhs ? nblk + j : j;                         // column of the tile in the ver table
+        // ---- wait for the inputs: this tile at r0 rows applied; for every block row r to apply, the finished tiles (r, i), (r, x)
+        if (tid < 64) {
+            const int lane = tid;
+            const int *word = ver;
+            int want = 0;
+            const bool active = lane < 1 + 2 * k.kcnt;
+            if (lane == 0) {
+                word = ver + i * XW + x;
+                want = k.r0;
+            } else if (active) {
+                const int r = k.r0 + ((lane - 1) >> 1);
+                word = ver + r * XW + ((lane & 1) ? i : x);
+                want = r + 1;
+            }
+            const bool go = chain_wait(word, want, active, stop, info, spin_limit);
+            if (lane == 0) s_go = go ? 1 : 0;
+        }
+        __syncthreads();
+        if (!__builtin_amdgcn_readfirstlane(s_go)) continue;      // stopped: drain the counter
+        const double *Urow = U + size_t(k.r0) * NB * ld;
+        const double *Ai = Urow + size_t(i) * NB;
+        Tile t_;
+        t_.kcnt = k.kcnt;
+        if (rhs) {
+            t_.T = R + size_t(i) * NB * ldr + size_t(j) * NB;
+            t_.ldt = ldr;
+            t_.B = R + size_t(k.r0) * NB * ldr + size_t(j) * NB;
+            t_.ldb = ldr;
+        } else {
+            t_.T = G + size_t(i) * NB * ld + size_t(j) * NB;
+            t_.ldt = ld;
+            t_.B = Urow + size_t(j) * NB;
+            t_.ldb = ld;
+        }
+        int done = k.r0 + k.kcnt;                                 // what ver[i][x] becomes
+        if (k.kind != TASK_CHAIN) {
+            role_bulk<true>(t_, Ai, ld, s, sm, rhs);
+        } else {
+            const double *Gss = G + size_t(s) * NB * ld + size_t(s) * NB;   // where the diagonal role leaves the operator of block s
+            __builtin_amdgcn_s_setprio(3);
+            if (!rhs && j == s)
+                role_diag<true>(t_, Ai, U + size_t(s) * NB * ld + size_t(s) * NB, ld, s, dg0, piv_tol, TI + size_t(s) * NB * NB,
+                                TIT + size_t(s) * NB * NB, info, sm);
+            else if (!rhs)
+                role_panel<true>(t_, Ai, ld, s, U + size_t(s) * NB * ld + size_t(j) * NB, ld,
+                                 Lt + size_t(j) * NB * ld + size_t(s) * NB, Gss, info, spin_limit, sm, false, stop);
+            else
+                role_panel<true>(t_, Ai, ld, s, t_.T, ldr, nullptr, Gss, info, spin_limit, sm, true, stop);
+            __builtin_amdgcn_s_setprio(0);
+            done = s + 1;
+        }
+        // every wave's stores are acknowledged before the barrier; then the tile's word goes up
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CP_HANDOFF_RELEASE();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ver + i * XW + x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CP_HANDOFF_ACQUIRE();
+    }
+}
+
+// =============================================================================================================================
+// The backward sweep U W = Y in the same persistent form: ONE launch instead of a strip launch + a GEMM launch per band of four
+// block rows (61 + 61 launches per vgg16 job, each waiting for slots next to the other layers' factorisations).
+//
+// Tiles: the right-hand-side tiles (b, x) only, b from the bottom block row up; "level" l = nblk - 1 - b takes the place of the
+// block row of the forward form (ChainShape with factor = 0): tile (l, x) receives W[j, x] of the rows j > b -- the levels
+// below l -- through Lt (the transposed factor: Lt[j, b] = U[b, j]^T, so that the update is the same A^T B as the forward one),
+// in chunks of L levels as bulk tasks and the level just below it together with its final role as the chain task:
+//     W[b, x] = U_bb^-1 (Y[b, x] - sum_{j > b} U[b, j] W[j, x])
+// The final role also does what the strip launches' tail did (StripFinal, refit.hip): coef[j, col] = W[col, j] into the device
+// copy and the page-locked host block (transposed through LDS: rows of coef leave as 1 KB runs, posted writes over PCIe), and
+// the tile's share of sum_col xmean[col] W[col, j]; the task of the TOP block row of a column adds the shares of all block
+// rows in a fixed order (bottom up) and writes the intercept -- deterministic whatever the order of execution was.
+struct BackFinal {
+    int p, n;                      // p == 0: no lay-out (W stays in R)
+    const double *xmean, *ymean;
+    double *coef, *b;              // device outputs: coef[n, p], b[n]
+    double *coef_host, *b_host;    // page-locked host copies (may be null)
+    int *info_host;
+    double *part;                  // [nblk x ldr] shares of the intercept sums (scratch: the factorisation's G is free by now)
+};
+
+template <bool LAYOUT>
+__device__ __noinline__ void role_back_final(Tile t_, const double *__restrict__ Ai, int ld, const double *__restrict__ TITb_, int b,
+                                             int x, int nblk, int ldr, BackFinal fin, const int *info, double *sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
+    v4f64s acc[NPAN];
+    tile_load_update<false, true>(acc, t_, Ai, ld, sm, true);
+    // W = U_bb^-1 S, block row by block row from the top: row t' needs the blocks t >= t' of S, so it may overwrite acc[t']
+    const gcdp TITb = (gcdp)TITb_;
+#pragma unroll
+    for (int tp = 0; tp < NPAN; ++tp) {
+        v4f64s o = {0., 0., 0., 0.};
+#pragma unroll
+        for (int t = tp; t < NPAN; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o = __builtin_amdgcn_mfma_f64_16x16x4f64(TITb[(16 * t + 4 * r + fk) * NB + 16 * tp + fi], acc[t][r], o, 0, 0, 0);
+        acc[tp] = o;
+    }
+    // W[b, x] in place: the B operand of the tiles above (sc1, see tile_update)
+    const gdp T = (gdp)t_.T;
+    const int toff = fk * t_.ldt + 16 * wave + fi;
+#pragma unroll
+    for (int t = 0; t < NPAN; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile_st<true>((T + size_t(16 * t + 4 * r) * t_.ldt) + toff, acc[t][r]);
+    if constexpr (LAYOUT) {
+        const int j = x * NB + 16 * wave + fi;                // the right-hand side (output channel) of this lane's column
+        // share of sum_col xmean[col] W[col, j] of the block row
+        double ps = 0.0;
+#pragma unroll
+        for (int t = 0; t < NPAN; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = b * NB + 16 * t + 4 * r + fk;
+                if (col < fin.p) ps = fma(fin.xmean[col], acc[t][r], ps);
+            }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        if (fk == 0) tile_st<true>((gdp)fin.part + size_t(b) * ldr + j, ps);
+        // coef[j, b NB + row] = W[row, j]: two halves of 64 right-hand sides through LDS (row-padded), 1 KB runs out
+        constexpr int TLD = NB + 1;
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if ((wave >> 2) == h) {
+                const int jl = 16 * (wave & 3) + fi;
+#pragma unroll
+                for (int t = 0; t < NPAN; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sm[jl * TLD + 16 * t + 4 * r + fk] = acc[t][r];
+            }
+            __syncthreads();
+            for (int e = tid; e < 64 * NB; e += PT) {
+                const int jl = e >> 7, row = e & (NB - 1);
+                const int jj = x * NB + 64 * h + jl, col = b * NB + row;
+                if (jj < fin.n && col < fin.p) {
+                    const double v = sm[jl * TLD + row];
+                    fin.coef[size_t(jj) * fin.p + col] = v;
+                    if (fin.coef_host) fin.coef_host[size_t(jj) * fin.p + col] = v;
+                }
+            }
+        }
+        if (b == 0) {     // the top block row: every block row's share is in (their tiles were final before this task started)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < NB) {
+                const int jj = x * NB + tid;
+                if (jj < fin.n) {
+                    double tot = 0.0;
+                    for (int bb = nblk - 1; bb >= 0; --bb) tot += tile_ld<true>((gcdp)fin.part + size_t(bb) * ldr + jj);
+                    const double bj = fin.ymean[jj] - tot;
+                    fin.b[jj] = bj;
+                    if (fin.b_host) fin.b_host[jj] = bj;
+                }
+            }
+            if (x == 0 && tid == 0 && fin.info_host) fin.info_host[0] = info[0];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(PT, 4)
+k_chol_back(const double *__restrict__ Lt, int ld, int nblk, int L, int total, const double *__restrict__ TIT, double *__restrict__ R,
+            int ldr, int ntr, int *info, int *ctl, BackFinal fin, int spin_limit) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int s_task, s_go;
+    const int tid = threadIdx.x;
+    const ChainShape sh{nblk, ntr, L, 0};
+    const int XW = CHAIN_NTR_MAX;
+    int *const stop = ctl + 1, *const ver = ctl + 8;
+    for (;;) {
+        if (tid == 0) s_task = atomicAdd(ctl, 1);
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(s_task);
+        if (t >= total) return;
+        const ChainTask k = chain_decode(sh, t);
+        const int l = k.i, x = k.xi, b = nblk - 1 - l;
+        if (tid < 64) {      // this tile at r0 levels applied; the finished tiles of the levels to apply
+            const int lane = tid;
+            const bool active = lane < 1 + k.kcnt;
+            const int *word = ver + l * XW + x;
+            int want = k.r0;
+            if (lane > 0 && active) {
+                const int r = k.r0 + lane - 1;
+                word = ver + r * XW + x;
+                want = r + 1;
+            }
+            const bool go = chain_wait(word, want, active, stop, info, spin_limit);
+            if (lane == 0) s_go = go ? 1 : 0;
+        }
+        __syncthreads();
+        if (!__builtin_amdgcn_readfirstlane(s_go)) continue;
+        // levels [r0, r0 + kcnt) = block rows [jlo, jlo + kcnt), ascending in k
+        const int jlo = nblk - k.r0 - k.kcnt;
+        Tile t_;
+        t_.kcnt = k.kcnt;
+        t_.T = R + size_t(b) * NB * ldr + size_t(x) * NB;
+        t_.ldt = ldr;
+        t_.B = R + size_t(jlo) * NB * ldr + size_t(x) * NB;
+        t_.ldb = ldr;
+        const double *Ai = Lt + size_t(jlo) * NB * ld + size_t(b) * NB;
+        int done = k.r0 + k.kcnt;
+        if (k.kind != TASK_CHAIN) {
+            role_bulk<true>(t_, Ai, ld, l, sm, true);
+        } else {
+            if (fin.p > 0) role_back_final<true>(t_, Ai, ld, TIT + size_t(b) * NB * NB, b, x, nblk, ldr, fin, info, sm);
+            else role_back_final<false>(t_, Ai, ld, TIT + size_t(b) * NB * NB, b, x, nblk, ldr, fin, info, sm);
+            done = l + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CP_HANDOFF_RELEASE();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ver + l * XW + x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CP_HANDOFF_ACQUIRE();
+    }
 }
 
 hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explicit opt-in, once per device
@@ -664,11 +1064,84 @@ hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explici
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_step), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        int(LDS_DOUBLES * sizeof(double)));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(LDS_DOUBLES * sizeof(double)));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_back), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(LDS_DOUBLES * sizeof(double)));
+    if (e != hipSuccess) return e;
     if (device >= 0 && device < 64) done[device] = true;
     return e;
 }
 
 }  // namespace
+
+namespace {
+int chain_form() {            // CP_CHOL_FORM=steps: the launch-per-step form (A/B measurements)
+    static const int v = [] {
+        const char *e = getenv("CP_CHOL_FORM");
+        return (e && !strcmp(e, "steps")) ? 0 : 1;
+    }();
+    return v;
+}
+int chain_lazy() {
+    static const int v = [] {
+        const char *e = getenv("CP_CHOL_LAZY");
+        const int x = e ? atoi(e) : CHAIN_L_MAX;
+        return x < 1 ? 1 : (x > CHAIN_L_MAX ? CHAIN_L_MAX : x);
+    }();
+    return v;
+}
+int chain_wg_per_blk() {
+    static const int v = [] {
+        const char *e = getenv("CP_CHOL_WG_PER_BLK");
+        const int x = e ? atoi(e) : 3;
+        return x < 1 ? 1 : x;
+    }();
+    return v;
+}
+}  // namespace
+
+// The backward sweep as ONE launch (k_chol_back).  R (p_pad x n_pad) holds Y = U^-T R on entry (the forward substitution that
+// rode in the factorisation's launch) and W on return; fin.p > 0: coefficient lay-out, intercept and info[0] leave for the host
+// from inside.  scratch: nblk x n_pad doubles (the factorisation's G is free by now).  -> CP_OK, or CP_ERR_ARG when this form
+// does not apply (the caller then takes the banded launches): *taken tells.
+int cp_chol_back_persistent(cp_ctx *ctx, const double *Lt, int ld, int nblk, const double *TIT, double *R, int n_pad, int *info,
+                            const cp_back_final *fin_, double *scratch, bool *taken) {
+    *taken = false;
+    const int ntr = n_pad / NB;
+    static const int back_on = [] {
+        const char *e = getenv("CP_CHOL_BACK");      // off by default: measured slower in the job (tools/README.md, round 6 call 06)
+        return (e && atoi(e) != 0) ? 1 : 0;
+    }();
+    if (!back_on || chain_form() != 1 || n_pad % NB || ntr > CHAIN_NTR_MAX || ntr < 1) return CP_OK;
+    CP_HIP(ctx, lds_opt_in(ctx->device));
+    const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
+    const ChainShape sh{nblk, ntr, chain_lazy(), 0};
+    const int total = sh.total();
+    BackFinal fin{};
+    if (fin_ && fin_->p > 0) {
+        fin.p = fin_->p;
+        fin.n = fin_->n;
+        fin.xmean = fin_->xmean;
+        fin.ymean = fin_->ymean;
+        fin.coef = fin_->coef;
+        fin.b = fin_->b;
+        fin.coef_host = fin_->coef_host;
+        fin.b_host = fin_->b_host;
+        fin.info_host = fin_->info_host;
+        fin.part = scratch;
+    }
+    int W = chain_wg_per_blk() * nblk;
+    if (W > total) W = total;
+    if (W > 512) W = 512;
+    int spin_limit = 1 << 26;
+    k_chol_back<<<W, PT, lds, ctx->stream>>>(Lt, ld, nblk, chain_lazy(), total, TIT, R, n_pad, ntr, info,
+                                              info + cp_chol_back_ctl_offset(nblk), fin, spin_limit);
+    CP_LAUNCH_CHECK(ctx);
+    *taken = true;
+    return CP_OK;
+}
 
 // G (p_pad x p_pad, upper tiles valid, destroyed) = U^T U: U (upper, block rows), the off-diagonal blocks of Lt = U^T,
 // TI_b = U_bb^-1, TIT_b = U_bb^-T per diagonal block.  info (zeroed by the caller's k_diag_prepare): [0] 1 + the first
@@ -684,6 +1157,21 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     if (ctx->chol_test_fail_flag_waits > 0) {   // test hook: the panel workgroups of THIS factorisation give up at once
         --ctx->chol_test_fail_flag_waits;
         spin_limit = 0;
+    }
+    const int form = chain_form(), lazy = chain_lazy(), wg_per_blk = chain_wg_per_blk();
+    if (form == 1 && ntr <= CHAIN_NTR_MAX) {
+        const ChainShape sh{nblk, ntr, lazy, 1};
+        const int total = sh.total();
+        // W: what the factorisation can keep busy on average, not what its widest step could use -- resident workgroups that
+        // wait for the chain hold slots other layers' launches want (alone, a chain uses ~13 % of the matrix time of the slots
+        // of its widest step)
+        int W = wg_per_blk * nblk + ntr;
+        if (W > total) W = total;
+        if (W > 512) W = 512;
+        k_chol_chain<<<W, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, lazy, total, dg0, piv_tol, TI, TIT, info,
+                                                   info + cp_chol_ctl_offset(nblk), R, n_pad, ntr, spin_limit);
+        CP_LAUNCH_CHECK(ctx);
+        return CP_OK;
     }
     for (int s = 0; s < nblk; ++s) {
         // block row s always; at even s >= 2 every tile below it (two block rows of updates at once), at odd s block row s + 1

@@ -140,7 +140,7 @@ __device__ __forceinline__ void chan_from_bits(const ChanBits &bits, int c, int 
 
 // ---- diagonal handling -------------------------------------------------------------------
 // dg0[i] = G[i,i] (original), gmax[0] = max_i dg0[i]; pad rows get G[i,i] = 1.
-__global__ void __launch_bounds__(1024) k_diag_prepare(double *__restrict__ G, int ld, int p, int p_pad, double ridge,
+__global__ void __launch_bounds__(256) k_diag_prepare(double *__restrict__ G, int ld, int p, int p_pad, double ridge,
                                                        double *__restrict__ dg0, double *__restrict__ gmax,
                                                        int *__restrict__ info, int n_info) {
     __shared__ double red[16];
@@ -180,8 +180,8 @@ __global__ void __launch_bounds__(RT) k_add_diag_scaled(double *__restrict__ G, 
 }
 
 // ---- factorisation: chol_step.hip -------------------------------------------------------------------
-// info of a factorisation: [0] first failed pivot + 1 (also NaN), [1 + b] diagonal block b done
-constexpr int chol_info_count(int nblk) { return 8 + 2 * nblk; }
+// info of a factorisation: cp_common.h
+constexpr int chol_info_count(int nblk) { return cp_chol_info_count(nblk); }
 typedef double v4f64c __attribute__((ext_vector_type(4)));
 constexpr int CP_REFIT_MAX_BATCH = 16;
 
@@ -741,7 +741,7 @@ int refit_robust(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal_equ
     CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, X1, p_pad, X1, p_pad, 0.0, G2, p_pad, CP_TRI_LOWER_MIRROR));
     CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, X1, p_pad, rs.Yc, n_pad, 0.0, rs.R2, n_pad, CP_TRI_NONE));
     CP_HIP(ctx, hipMemcpyAsync(Gw, G2, g_c * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gw, p_pad, p, p_pad, 0.0, dg2, gmax2, dinfo2, chol_info_count(nblk));
+    k_diag_prepare<<<1, 256, 0, ctx->stream>>>(Gw, p_pad, p, p_pad, 0.0, dg2, gmax2, dinfo2, chol_info_count(nblk));
     CP_LAUNCH_CHECK(ctx);
     k_floor_ref<<<(p + RT - 1) / RT, RT, 0, ctx->stream>>>(dg2, p, gmax2, 1e-5);   // pivot <= max(1e-11 diag, 1e-16 max diag)
     CP_LAUNCH_CHECK(ctx);
@@ -867,7 +867,13 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
         if (nblk >= solve_blocked_min_blocks()) {   // large factor: banded substitution with GEMM updates; the lay-out rides along
             StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
             bool fin_done = false;
-            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3, &fin, &fin_done));
+            if (fwd && size_t(nblk) * n_pad <= size_t(p_pad) * p_pad) {
+                // the backward sweep as ONE launch of the persistent form (chol_step.hip); G, destroyed by the factorisation,
+                // lends the scratch for the intercept shares
+                const cp_back_final bf{p, n, xmean, ymean, W_out, b_out, W_host, b_host, info_host};
+                CP_TRY(cp_chol_back_persistent(ctx, Lt, p_pad, nblk, TIT, Rm, n_pad, dinfo, &bf, G, &fin_done));
+            }
+            if (!fin_done) CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3, &fin, &fin_done));
             cp_stage_mark(ctx, "refit_solve");
             if (fin_done) {
                 CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything came back with the kernels
@@ -1232,7 +1238,7 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
                 rc = CP_ERR_HIP;
                 break;
             }
-            k_diag_prepare<<<1, 1024, 0, w->stream>>>(pc.Gw, P_pad, P, P_pad, 0.0, pc.dg0, pc.gmax, pc.finfo, chol_info_count(nblkF));
+            k_diag_prepare<<<1, 256, 0, w->stream>>>(pc.Gw, P_pad, P, P_pad, 0.0, pc.dg0, pc.gmax, pc.finfo, chol_info_count(nblkF));
             Chol chF{pc.Gw, pc.U, pc.Lt, pc.TI, pc.TIT, pc.dg0, pc.gmax, pc.finfo, P, P_pad, nblkF};
             bool fwd = false;   // F = L^-1 R rides in the launches of the factorisation
             if ((rc = chol_factor(w, chF, PIV_TOL, pc.F, n_pad, &fwd)) != CP_OK) break;
@@ -1336,7 +1342,7 @@ int refit_from_full_factor(cp_ctx *ctx, cp_precompute &pc, const std::vector<int
         cp_stage_mark(ctx, "refit_constraint_forward");
         CP_TRY(cp_gemm_tn_f64(ctx, d_pad, d_pad, P_pad, 1.0, T, d_pad, T, d_pad, 0.0, S, d_pad, CP_TRI_LOWER_MIRROR));
         CP_TRY(cp_gemm_tn_f64(ctx, d_pad, n_pad, P_pad, 1.0, T, d_pad, pc.F, n_pad, 0.0, Cm, n_pad, CP_TRI_NONE));
-        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(S, d_pad, d, d_pad, 0.0, sdg0, sgmax, sinfo, chol_info_count(nblkS));
+        k_diag_prepare<<<1, 256, 0, ctx->stream>>>(S, d_pad, d, d_pad, 0.0, sdg0, sgmax, sinfo, chol_info_count(nblkS));
         CP_LAUNCH_CHECK(ctx);
         Chol chS{S, SU, SLt, STI, STIT, sdg0, sgmax, sinfo, d, d_pad, nblkS};
         CP_TRY(chol_factor(ctx, chS, PIV_TOL));
@@ -1502,7 +1508,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
             }
             CP_LAUNCH_CHECK(ctx);
             cp_stage_mark(ctx, "refit_gather_normal_eq");
-            k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
+            k_diag_prepare<<<1, 256, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
             CP_LAUNCH_CHECK(ctx);
             return CP_OK;
         }
@@ -1517,7 +1523,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
         CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
         if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
-        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
+        k_diag_prepare<<<1, 256, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;
     };
@@ -1672,7 +1678,7 @@ extern "C" int cp_nonlinear_fc(cp_ctx *ctx, const void *X, int x_dtype, int64_t 
         k_transpose_2d<<<dim3(unsigned(Nr / 32), p_pad / 32), RT, 0, ctx->stream>>>(Xs, p_pad, XsT, int(Nr));
         CP_LAUNCH_CHECK(ctx);
         CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(Nr), 1.0, Xs, p_pad, Xs, p_pad, 0.0, G, p_pad, CP_TRI_LOWER_MIRROR));
-        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(G, p_pad, p, p_pad, 0.0, dg0, gmax, dinfo, chol_info_count(nblk));
+        k_diag_prepare<<<1, 256, 0, ctx->stream>>>(G, p_pad, p, p_pad, 0.0, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
     }
     Chol ch{G, Uf, Lt, TI, TIT, dg0, gmax, dinfo, p, p_pad, nblk};
@@ -2072,7 +2078,7 @@ extern "C" int cp_refit_shard_solve(cp_ctx *ctx, int kept, int kk, int n, int64_
     auto normal_equations = [&](double *Gd, double *Rd, bool) -> int {
         CP_HIP(ctx, hipMemcpyAsync(Gd, gram, g_b, hipMemcpyDeviceToDevice, ctx->stream));
         CP_HIP(ctx, hipMemcpyAsync(Rd, gram + size_t(p_pad) * p_pad, r_b, hipMemcpyDeviceToDevice, ctx->stream));
-        k_diag_prepare<<<1, 1024, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
+        k_diag_prepare<<<1, 256, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;
     };
