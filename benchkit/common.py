@@ -169,5 +169,5 @@ JOB_TEXT = {     # (config.workload -- at most 230 characters, it travels on the
 
 # measured ms of one layer alone by channel count (profiles/r02_*): the LPT costs of the vgg16 job
 VGG16_COST_MS = {64: 1.5, 128: 3.0, 256: 6.8, 512: 15.5}
-PROFILE_TAG = "r05"      # profiles/<tag>_pmc_{fetch,write}_size_kb.md feed roofline.traffic
+PROFILE_TAG = "r06"      # profiles/<tag>_pmc_{fetch,write}_size_kb.md feed roofline.traffic
 

@@ -157,7 +157,7 @@ def bench_job(args, env, job):
     STAGE_SAMPLE = 8
     g_ms, g_fl, exch_ms = [], [], []
     cls_ms = {"alpha_search": [], "refit_gram": [], "cholesky_chain": [], "backward_substitution": []}   # per launch / bracket, in the job
-    chol_fl, chol_steps = [], []
+    chol_fl, chol_steps, chol_pn = [], [], []
     sync_all()
     env.barrier()
     t0 = time.perf_counter()
@@ -197,6 +197,7 @@ def bench_job(args, env, job):
                         pp = float(int(pr.refit_info.p))
                         chol_fl.append(pp ** 3 / 3.0 + pp * pp * float(pr.n))    # + the forward substitution riding along
                         chol_steps.append(int(np.ceil(pp / 128.0)))
+                        chol_pn.append((pp, float(pr.n)))
                         span["cholesky_chain"].append((begin, begin + ms))
                     elif name == "refit_solve":
                         cls_ms["backward_substitution"].append(ms)
@@ -373,7 +374,7 @@ def bench_job(args, env, job):
         alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
         n_sampled = (jobs + STAGE_SAMPLE - 1) // STAGE_SAMPLE       # the jobs whose stage brackets were read
         roof = roofline_object(cls_ms, g_fl, chol_fl, n_sampled, roots[0] if roots else None, PROFILE_TAG, job, windows=windows,
-                               cd_steps_ns=cd_steps_ns, chol_steps=chol_steps)
+                               cd_steps_ns=cd_steps_ns, chol_steps=chol_steps, chol_pn=chol_pn)
         if roof is not None:
             roof["jobs_with_stage_brackets"] = n_sampled
         if roof is not None and alone_g_ms:

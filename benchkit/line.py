@@ -46,8 +46,8 @@ def compact_roofline(roof):
     out = {"bound": roof.get("bound"), "kernel": _short(roof.get("kernel", ""), 60).split(" (")[0],
            "achieved": _r(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": _r(roof.get("frac")),
            "traffic": roof.get("traffic")}
-    chol, gram = _kernel_entry(roof, "k_chol_step"), _kernel_entry(roof, "k_gemm_tn_f64")
-    top = chol if (chol is not None and out["kernel"].startswith("k_chol_step")) else gram
+    chol, gram = _kernel_entry(roof, "k_chol_"), _kernel_entry(roof, "k_gemm_tn_f64")
+    top = chol if (chol is not None and out["kernel"].startswith("k_chol_")) else gram
     if top is not None:
         out["chip_level_frac"] = _r((top.get("chip_level") or {}).get("frac"))
         out["traffic_algorithmic"] = top.get("traffic_algorithmic")

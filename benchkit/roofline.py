@@ -29,7 +29,7 @@ def pmc_traffic(pattern, round_tag):
     return out["fetch"] + out["write"], "profiles/%s_pmc_{fetch,write}_size_kb.md@%s" % (round_tag, commit or "unknown")
 
 
-def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=None, cd_steps_ns=None, chol_steps=None):
+def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=None, cd_steps_ns=None, chol_steps=None, chol_pn=None):
     """`roofline` of the JSON line.  The kernel classes of the job's MFMA work, each timed live with HIP events on its launch
     stream during the timed jobs (cp_enable_stage_timing mode 2): the refit Gram GEMM (one launch per layer) and the
     factorisation chain (the Cholesky step launches of a layer, with the forward substitution riding along).  The one
@@ -48,13 +48,13 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
             "sum_ms_per_job": round(per_job["refit_gram"], 3), "pmc_pattern": "k_gemm_tn_f64<1, 2,"}
     chol = None
     if cls_ms["cholesky_chain"] and sum(cls_ms["cholesky_chain"]) > 0:
-        chol = {"kernel": "k_chol_step (blocked Cholesky, one launch per 128-column step; per layer: p/128 launches)",
-                "flops_per_launch": "per layer: p^3 / 3 + p^2 n (the forward substitution rides in the same launches)",
+        chol = {"kernel": "k_chol_chain (blocked Cholesky, ONE persistent launch per layer: tile tasks off a counter; p/128 steps)",
+                "flops_per_launch": "p^3 / 3 + p^2 n (the forward substitution rides in the same launch)",
                 "achieved": round(sum(chol_fl) / (sum(cls_ms["cholesky_chain"]) * 1e-3) / 1e12, 3),
                 "avg_launch_ms": round(sum(cls_ms["cholesky_chain"]) / len(cls_ms["cholesky_chain"]), 4),
                 "launches": len(cls_ms["cholesky_chain"]), "sum_ms_per_job": round(per_job["cholesky_chain"], 3),
-                "pmc_pattern": "k_chol_step", "avg_launch_note": "one bracket = all step launches of a layer"}
-        if chol_steps and sum(chol_steps) > 0:      # per LAUNCH: the bracket of a layer / its p / 128 step launches
+                "pmc_pattern": "k_chol_chain"}
+        if chol_steps and sum(chol_steps) > 0:      # per 128-column step: the bracket of a layer / its p / 128 steps
             chol["avg_step_us"] = round(sum(cls_ms["cholesky_chain"]) * 1e3 / sum(chol_steps), 2)
             chol["steps_per_job"] = int(round(sum(chol_steps) / max(1, jobs)))
     top = gram if chol is None or per_job["refit_gram"] >= per_job["cholesky_chain"] else chol
@@ -88,13 +88,11 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
         if gram.get("traffic"):
             gram["traffic_ratio"] = round(gram["traffic"] / gram["traffic_algorithmic"], 2)
         if chol is not None and chol_fl:
-            # per layer: G (upper half, 4 p^2 B) + R (8 p n) read, U (4 p^2) + Y (8 p n) written; per launch: / (p / 128)
-            per_launch = [(8.0 * p_ * p_ + 16.0 * p_ * 512.0) / max(1.0, np.ceil(p_ / 128.0)) for p_ in ps]
-            chol["traffic_algorithmic"] = round(float(np.sum([(8.0 * p_ * p_ + 16.0 * p_ * 512.0) for p_ in ps]) /
-                                                      max(1.0, np.sum([np.ceil(p_ / 128.0) for p_ in ps]))), 1)
+            # per launch = per layer: G (upper half, 4 p^2 B) + R (8 p n) read once, U (4 p^2) + Y (8 p n) written once
+            pn = chol_pn or [(p_, 512.0) for p_ in ps]
+            chol["traffic_algorithmic"] = round(float(np.mean([8.0 * p_ * p_ + 16.0 * p_ * n_ for p_, n_ in pn])), 1)
             if chol.get("traffic"):
                 chol["traffic_ratio"] = round(chol["traffic"] / chol["traffic_algorithmic"], 2)
-            del per_launch
     out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": top["frac"], "traffic": traffic, "traffic_source": source,
            "traffic_note": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + WRITE_SIZE "

@@ -742,13 +742,12 @@ constexpr int CHAIN_NTR_MAX = 32;    // right-hand-side tile columns the control
 
 struct ChainShape {
     int nblk, ntr, L;
-    int factor = 1;            // 0: right-hand-side tiles only (the backward sweep: "row" = level above the bottom block row)
-    __host__ __device__ int width(int i) const { return (factor ? nblk - i : 0) + ntr; }
+    __host__ __device__ int width(int i) const { return nblk - i + ntr; }
     __host__ __device__ int pre(int s) const { return s >= 2 ? width(s) : 0; }
     __host__ __device__ int rest(int s) const {
         if (s <= L || (s - 1) % L != 0 || s + 1 >= nblk) return 0;
         const int n = nblk - s - 1;                      // rows s + 1 .. nblk - 1
-        return (factor ? n * (n + 1) / 2 : 0) + n * ntr;
+        return n * (n + 1) / 2 + n * ntr;
     }
     __host__ __device__ int segment(int s) const { return pre(s) + width(s) + rest(s); }
     __host__ __device__ int total() const {
@@ -826,7 +825,7 @@ k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict_
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int s_task, s_go;
     const int tid = threadIdx.x;
-    const ChainShape sh{nblk, ntr, L, 1};
+    const ChainShape sh{nblk, ntr, L};
     const int XW = nblk + CHAIN_NTR_MAX;
     int *const stop = ctl + 1, *const ver = ctl + 8;
     for (;;) {
@@ -899,163 +898,6 @@ k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict_
     }
 }
 
-// =============================================================================================================================
-// The backward sweep U W = Y in the same persistent form: ONE launch instead of a strip launch + a GEMM launch per band of four
-// block rows (61 + 61 launches per vgg16 job, each waiting for slots next to the other layers' factorisations).
-//
-// Tiles: the right-hand-side tiles (b, x) only, b from the bottom block row up; "level" l = nblk - 1 - b takes the place of the
-// block row of the forward form (ChainShape with factor = 0): tile (l, x) receives W[j, x] of the rows j > b -- the levels
-// below l -- through Lt (the transposed factor: Lt[j, b] = U[b, j]^T, so that the update is the same A^T B as the forward one),
-// in chunks of L levels as bulk tasks and the level just below it together with its final role as the chain task:
-//     W[b, x] = U_bb^-1 (Y[b, x] - sum_{j > b} U[b, j] W[j, x])
-// The final role also does what the strip launches' tail did (StripFinal, refit.hip): coef[j, col] = W[col, j] into the device
-// copy and the page-locked host block (transposed through LDS: rows of coef leave as 1 KB runs, posted writes over PCIe), and
-// the tile's share of sum_col xmean[col] W[col, j]; the task of the TOP block row of a column adds the shares of all block
-// rows in a fixed order (bottom up) and writes the intercept -- deterministic whatever the order of execution was.
-struct BackFinal {
-    int p, n;                      // p == 0: no lay-out (W stays in R)
-    const double *xmean, *ymean;
-    double *coef, *b;              // device outputs: coef[n, p], b[n]
-    double *coef_host, *b_host;    // page-locked host copies (may be null)
-    int *info_host;
-    double *part;                  // [nblk x ldr] shares of the intercept sums (scratch: the factorisation's G is free by now)
-};
-
-template <bool LAYOUT>
-__device__ __noinline__ void role_back_final(Tile t_, const double *__restrict__ Ai, int ld, const double *__restrict__ TITb_, int b,
-                                             int x, int nblk, int ldr, BackFinal fin, const int *info, double *sm) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fk = lane >> 4, fi = lane & 15;
-    v4f64s acc[NPAN];
-    tile_load_update<false, true>(acc, t_, Ai, ld, sm, true);
-    // W = U_bb^-1 S, block row by block row from the top: row t' needs the blocks t >= t' of S, so it may overwrite acc[t']
-    const gcdp TITb = (gcdp)TITb_;
-#pragma unroll
-    for (int tp = 0; tp < NPAN; ++tp) {
-        v4f64s o = {0., 0., 0., 0.};
-#pragma unroll
-        for (int t = tp; t < NPAN; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                o = __builtin_amdgcn_mfma_f64_16x16x4f64(TITb[(16 * t + 4 * r + fk) * NB + 16 * tp + fi], acc[t][r], o, 0, 0, 0);
-        acc[tp] = o;
-    }
-    // W[b, x] in place: the B operand of the tiles above (sc1, see tile_update)
-    const gdp T = (gdp)t_.T;
-    const int toff = fk * t_.ldt + 16 * wave + fi;
-#pragma unroll
-    for (int t = 0; t < NPAN; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tile_st<true>((T + size_t(16 * t + 4 * r) * t_.ldt) + toff, acc[t][r]);
-    if constexpr (LAYOUT) {
-        const int j = x * NB + 16 * wave + fi;                // the right-hand side (output channel) of this lane's column
-        // share of sum_col xmean[col] W[col, j] of the block row
-        double ps = 0.0;
-#pragma unroll
-        for (int t = 0; t < NPAN; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = b * NB + 16 * t + 4 * r + fk;
-                if (col < fin.p) ps = fma(fin.xmean[col], acc[t][r], ps);
-            }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
-        if (fk == 0) tile_st<true>((gdp)fin.part + size_t(b) * ldr + j, ps);
-        // coef[j, b NB + row] = W[row, j]: two halves of 64 right-hand sides through LDS (row-padded), 1 KB runs out
-        constexpr int TLD = NB + 1;
-        for (int h = 0; h < 2; ++h) {
-            __syncthreads();
-            if ((wave >> 2) == h) {
-                const int jl = 16 * (wave & 3) + fi;
-#pragma unroll
-                for (int t = 0; t < NPAN; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sm[jl * TLD + 16 * t + 4 * r + fk] = acc[t][r];
-            }
-            __syncthreads();
-            for (int e = tid; e < 64 * NB; e += PT) {
-                const int jl = e >> 7, row = e & (NB - 1);
-                const int jj = x * NB + 64 * h + jl, col = b * NB + row;
-                if (jj < fin.n && col < fin.p) {
-                    const double v = sm[jl * TLD + row];
-                    fin.coef[size_t(jj) * fin.p + col] = v;
-                    if (fin.coef_host) fin.coef_host[size_t(jj) * fin.p + col] = v;
-                }
-            }
-        }
-        if (b == 0) {     // the top block row: every block row's share is in (their tiles were final before this task started)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid < NB) {
-                const int jj = x * NB + tid;
-                if (jj < fin.n) {
-                    double tot = 0.0;
-                    for (int bb = nblk - 1; bb >= 0; --bb) tot += tile_ld<true>((gcdp)fin.part + size_t(bb) * ldr + jj);
-                    const double bj = fin.ymean[jj] - tot;
-                    fin.b[jj] = bj;
-                    if (fin.b_host) fin.b_host[jj] = bj;
-                }
-            }
-            if (x == 0 && tid == 0 && fin.info_host) fin.info_host[0] = info[0];
-        }
-    }
-}
-
-__global__ void __launch_bounds__(PT, 4)
-k_chol_back(const double *__restrict__ Lt, int ld, int nblk, int L, int total, const double *__restrict__ TIT, double *__restrict__ R,
-            int ldr, int ntr, int *info, int *ctl, BackFinal fin, int spin_limit) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ int s_task, s_go;
-    const int tid = threadIdx.x;
-    const ChainShape sh{nblk, ntr, L, 0};
-    const int XW = CHAIN_NTR_MAX;
-    int *const stop = ctl + 1, *const ver = ctl + 8;
-    for (;;) {
-        if (tid == 0) s_task = atomicAdd(ctl, 1);
-        __syncthreads();
-        const int t = __builtin_amdgcn_readfirstlane(s_task);
-        if (t >= total) return;
-        const ChainTask k = chain_decode(sh, t);
-        const int l = k.i, x = k.xi, b = nblk - 1 - l;
-        if (tid < 64) {      // this tile at r0 levels applied; the finished tiles of the levels to apply
-            const int lane = tid;
-            const bool active = lane < 1 + k.kcnt;
-            const int *word = ver + l * XW + x;
-            int want = k.r0;
-            if (lane > 0 && active) {
-                const int r = k.r0 + lane - 1;
-                word = ver + r * XW + x;
-                want = r + 1;
-            }
-            const bool go = chain_wait(word, want, active, stop, info, spin_limit);
-            if (lane == 0) s_go = go ? 1 : 0;
-        }
-        __syncthreads();
-        if (!__builtin_amdgcn_readfirstlane(s_go)) continue;
-        // levels [r0, r0 + kcnt) = block rows [jlo, jlo + kcnt), ascending in k
-        const int jlo = nblk - k.r0 - k.kcnt;
-        Tile t_;
-        t_.kcnt = k.kcnt;
-        t_.T = R + size_t(b) * NB * ldr + size_t(x) * NB;
-        t_.ldt = ldr;
-        t_.B = R + size_t(jlo) * NB * ldr + size_t(x) * NB;
-        t_.ldb = ldr;
-        const double *Ai = Lt + size_t(jlo) * NB * ld + size_t(b) * NB;
-        int done = k.r0 + k.kcnt;
-        if (k.kind != TASK_CHAIN) {
-            role_bulk<true>(t_, Ai, ld, l, sm, true);
-        } else {
-            if (fin.p > 0) role_back_final<true>(t_, Ai, ld, TIT + size_t(b) * NB * NB, b, x, nblk, ldr, fin, info, sm);
-            else role_back_final<false>(t_, Ai, ld, TIT + size_t(b) * NB * NB, b, x, nblk, ldr, fin, info, sm);
-            done = l + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CP_HANDOFF_RELEASE();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(ver + l * XW + x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        CP_HANDOFF_ACQUIRE();
-    }
-}
-
 hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explicit opt-in, once per device
     static std::mutex mu;
     static bool done[64] = {};
@@ -1065,9 +907,6 @@ hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explici
                                        int(LDS_DOUBLES * sizeof(double)));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            int(LDS_DOUBLES * sizeof(double)));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_back), hipFuncAttributeMaxDynamicSharedMemorySize,
                             int(LDS_DOUBLES * sizeof(double)));
     if (e != hipSuccess) return e;
     if (device >= 0 && device < 64) done[device] = true;
@@ -1102,47 +941,6 @@ int chain_wg_per_blk() {
 }
 }  // namespace
 
-// The backward sweep as ONE launch (k_chol_back).  R (p_pad x n_pad) holds Y = U^-T R on entry (the forward substitution that
-// rode in the factorisation's launch) and W on return; fin.p > 0: coefficient lay-out, intercept and info[0] leave for the host
-// from inside.  scratch: nblk x n_pad doubles (the factorisation's G is free by now).  -> CP_OK, or CP_ERR_ARG when this form
-// does not apply (the caller then takes the banded launches): *taken tells.
-int cp_chol_back_persistent(cp_ctx *ctx, const double *Lt, int ld, int nblk, const double *TIT, double *R, int n_pad, int *info,
-                            const cp_back_final *fin_, double *scratch, bool *taken) {
-    *taken = false;
-    const int ntr = n_pad / NB;
-    static const int back_on = [] {
-        const char *e = getenv("CP_CHOL_BACK");      // off by default: measured slower in the job (tools/README.md, round 6 call 06)
-        return (e && atoi(e) != 0) ? 1 : 0;
-    }();
-    if (!back_on || chain_form() != 1 || n_pad % NB || ntr > CHAIN_NTR_MAX || ntr < 1) return CP_OK;
-    CP_HIP(ctx, lds_opt_in(ctx->device));
-    const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
-    const ChainShape sh{nblk, ntr, chain_lazy(), 0};
-    const int total = sh.total();
-    BackFinal fin{};
-    if (fin_ && fin_->p > 0) {
-        fin.p = fin_->p;
-        fin.n = fin_->n;
-        fin.xmean = fin_->xmean;
-        fin.ymean = fin_->ymean;
-        fin.coef = fin_->coef;
-        fin.b = fin_->b;
-        fin.coef_host = fin_->coef_host;
-        fin.b_host = fin_->b_host;
-        fin.info_host = fin_->info_host;
-        fin.part = scratch;
-    }
-    int W = chain_wg_per_blk() * nblk;
-    if (W > total) W = total;
-    if (W > 512) W = 512;
-    int spin_limit = 1 << 26;
-    k_chol_back<<<W, PT, lds, ctx->stream>>>(Lt, ld, nblk, chain_lazy(), total, TIT, R, n_pad, ntr, info,
-                                              info + cp_chol_back_ctl_offset(nblk), fin, spin_limit);
-    CP_LAUNCH_CHECK(ctx);
-    *taken = true;
-    return CP_OK;
-}
-
 // G (p_pad x p_pad, upper tiles valid, destroyed) = U^T U: U (upper, block rows), the off-diagonal blocks of Lt = U^T,
 // TI_b = U_bb^-1, TIT_b = U_bb^-T per diagonal block.  info (zeroed by the caller's k_diag_prepare): [0] 1 + the first
 // pivot <= piv_tol * its original diagonal dg0 (also NaN), [1 + b] block b factored.
@@ -1160,7 +958,7 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     }
     const int form = chain_form(), lazy = chain_lazy(), wg_per_blk = chain_wg_per_blk();
     if (form == 1 && ntr <= CHAIN_NTR_MAX) {
-        const ChainShape sh{nblk, ntr, lazy, 1};
+        const ChainShape sh{nblk, ntr, lazy};
         const int total = sh.total();
         // W: what the factorisation can keep busy on average, not what its widest step could use -- resident workgroups that
         // wait for the chain hold slots other layers' launches want (alone, a chain uses ~13 % of the matrix time of the slots

@@ -204,19 +204,8 @@ struct cp_search_job {
 // info of a factorisation (zeroed by the caller: k_diag_prepare / k_add_diag_scaled): [0] first failed pivot + 1 (also NaN;
 // 0x7fffffff: a bounded wait ran out), [1 + b] block columns of the operator of block b published; from cp_chol_ctl_offset on,
 // the control block of the persistent form: [0] task counter, [1] stop word, [8 + i (nblk + 32) + x] version word of tile (i, x)
-// ... and after it the control block of the persistent backward sweep: [0] task counter, [1] stop word, [8 + l 32 + x] version
-// word of the right-hand-side tile of level l (block row nblk - 1 - l), tile column x
 constexpr int cp_chol_ctl_offset(int nblk) { return 8 + 2 * nblk; }
-constexpr int cp_chol_back_ctl_offset(int nblk) { return cp_chol_ctl_offset(nblk) + 8 + nblk * (nblk + 32); }
-constexpr int cp_chol_info_count(int nblk) { return cp_chol_back_ctl_offset(nblk) + 8 + nblk * 32; }
-struct cp_back_final {             // what the backward sweep leaves for the caller of the refit (refit.hip: StripFinal)
-    int p, n;
-    const double *xmean, *ymean;
-    double *coef, *b, *coef_host, *b_host;
-    int *info_host;
-};
-int cp_chol_back_persistent(cp_ctx *ctx, const double *Lt, int ld, int nblk, const double *TIT, double *R, int n_pad, int *info,
-                            const cp_back_final *fin, double *scratch, bool *taken);
+constexpr int cp_chol_info_count(int nblk) { return cp_chol_ctl_offset(nblk) + 8 + nblk * (nblk + 32); }
 int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, int nblk, const double *dg0,
                          double piv_tol, double *TI, double *TIT, int *info, double *R = nullptr, int n_pad = 0);
 int cp_alpha_search_enqueue_batch(cp_ctx *const *ctxs, int n_jobs, const cp_search_job *jobs, bool allow_multi = true);

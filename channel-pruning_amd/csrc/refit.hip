@@ -867,13 +867,7 @@ int refit_solve_tail(cp_ctx *ctx, const RefitSolve &rs, NormalEquations &&normal
         if (nblk >= solve_blocked_min_blocks()) {   // large factor: banded substitution with GEMM updates; the lay-out rides along
             StripFinal fin{p, n, xmean, ymean, W_out, b_out, W_host, b_host, dinfo, info_host};
             bool fin_done = false;
-            if (fwd && size_t(nblk) * n_pad <= size_t(p_pad) * p_pad) {
-                // the backward sweep as ONE launch of the persistent form (chol_step.hip); G, destroyed by the factorisation,
-                // lends the scratch for the intercept shares
-                const cp_back_final bf{p, n, xmean, ymean, W_out, b_out, W_host, b_host, info_host};
-                CP_TRY(cp_chol_back_persistent(ctx, Lt, p_pad, nblk, TIT, Rm, n_pad, dinfo, &bf, G, &fin_done));
-            }
-            if (!fin_done) CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3, &fin, &fin_done));
+            CP_TRY(chol_solve_blocked(ctx, ch, Rm, n_pad, fwd ? 2 : 3, &fin, &fin_done));
             cp_stage_mark(ctx, "refit_solve");
             if (fin_done) {
                 CP_HIP(ctx, cp_stream_wait(ctx));  // the only wait of the call; everything came back with the kernels

@@ -153,70 +153,6 @@ int main(int argc, char **argv) {
         hipFree(b.G); hipFree(b.U); hipFree(b.Lt); hipFree(b.TI); hipFree(b.TIT); hipFree(b.dg0); hipFree(b.R); hipFree(b.info);
     }
     printf("\n%s\n\n", bad ? "MISMATCH" : "all identical");
-    // ---- the backward sweep (k_chol_back) behind the persistent factorisation: W solves G W = R; lay-out and intercept ----
-    printf("## backward sweep in one launch: residual of G W = R (sampled), coefficient lay-out, intercept\n\n"
-           "| blocks | rhs columns | L | W | max |G W - R| / max |R| | lay-out | intercept max err |\n|---|---|---|---|---|---|---|\n");
-    for (auto &shp : shapes) {
-        if (shp[1] == 0 || (quick && shp[0] > 14)) continue;
-        for (int L : {1, 2, 4})
-            for (int W : {1, 5, 64}) {
-                if (shp[0] > 14 && (W == 1 || L == 1)) continue;
-                Bufs b = make(shp[0], shp[1]);
-                reset(b);
-                if (run_chain(b, L, 400) < 0) { ++bad; continue; }
-                const int nblk = b.nblk, ntr = b.n_pad / NB, pfull = b.p, p = std::max(1, pfull - 37), n = std::max(1, b.n_pad - 5);
-                std::vector<double> hx(pfull), hy(b.n_pad);
-                for (int i = 0; i < pfull; ++i) hx[i] = 0.25 + 1e-3 * (i % 97);
-                for (int j = 0; j < b.n_pad; ++j) hy[j] = 3.0 - 1e-2 * (j % 31);
-                double *xmean, *ymean, *coef, *bo, *part;
-                int *info_host;
-                hipMalloc(&xmean, pfull * 8); hipMalloc(&ymean, b.n_pad * 8); hipMalloc(&coef, size_t(n) * p * 8); hipMalloc(&bo, n * 8);
-                hipMalloc(&part, size_t(nblk) * b.n_pad * 8); hipMalloc(&info_host, 64);
-                hipMemcpy(xmean, hx.data(), pfull * 8, hipMemcpyHostToDevice);
-                hipMemcpy(ymean, hy.data(), b.n_pad * 8, hipMemcpyHostToDevice);
-                hipMemset(coef, 0xff, size_t(n) * p * 8);
-                BackFinal fin{p, n, xmean, ymean, coef, bo, nullptr, nullptr, info_host, part};
-                const ChainShape sh{nblk, ntr, L, 0};
-                const int total = sh.total();
-                const size_t lds = size_t(LDS_DOUBLES) * sizeof(double);
-                k_chol_back<<<std::min(W, total), PT, lds>>>(b.Lt, b.p, nblk, L, total, b.TIT, b.R, b.n_pad, ntr, b.info,
-                                                             b.info + cp_chol_back_ctl_offset(nblk), fin, 1 << 24);
-                if (hipDeviceSynchronize() != hipSuccess) { printf("back launch failed\n"); ++bad; continue; }
-                std::vector<double> hW(size_t(pfull) * b.n_pad), hc(size_t(n) * p), hb(n);
-                hipMemcpy(hW.data(), b.R, hW.size() * 8, hipMemcpyDeviceToHost);
-                hipMemcpy(hc.data(), coef, hc.size() * 8, hipMemcpyDeviceToHost);
-                hipMemcpy(hb.data(), bo, hb.size() * 8, hipMemcpyDeviceToHost);
-                unsigned rs = 777u;
-                auto rnd = [&](int m) { rs = rs * 1664525u + 1013904223u; return int((rs >> 8) % unsigned(m)); };
-                double worst = 0, rmax = 0;
-                for (int t = 0; t < 400; ++t) {
-                    const int i = rnd(pfull), j = rnd(b.n_pad);
-                    double acc = 0;
-                    for (int k = 0; k < pfull; ++k)
-                        acc += (i == k ? 2.0 * pfull : sin(1e-3 * double(i + 1) * double(k + 1))) * hW[size_t(k) * b.n_pad + j];
-                    const size_t e = size_t(i) * b.n_pad + j;
-                    const double want = cos(7e-4 * double(e % 9973) + 1e-2 * double(e / b.n_pad));
-                    worst = std::max(worst, fabs(acc - want));
-                    rmax = std::max(rmax, fabs(want));
-                }
-                bool lay = true;
-                for (int j = 0; j < n && lay; ++j)
-                    for (int col = 0; col < p; ++col)
-                        if (hc[size_t(j) * p + col] != hW[size_t(col) * b.n_pad + j]) { lay = false; break; }
-                double berr = 0;
-                for (int j = 0; j < n; ++j) {
-                    double tot = 0;
-                    for (int col = 0; col < p; ++col) tot += hx[col] * hW[size_t(col) * b.n_pad + j];
-                    berr = std::max(berr, fabs(hb[j] - (hy[j] - tot)));
-                }
-                const bool ok = worst <= 1e-9 * rmax * pfull && lay && berr <= 1e-9;
-                bad += !ok;
-                printf("| %d | %d | %d | %d | %.2e | %s | %.2e |%s\n", shp[0], shp[1], L, W, worst / rmax, lay ? "exact" : "WRONG", berr, ok ? "" : " FAILED");
-                hipFree(xmean); hipFree(ymean); hipFree(coef); hipFree(bo); hipFree(part); hipFree(info_host);
-                hipFree(b.G); hipFree(b.U); hipFree(b.Lt); hipFree(b.TI); hipFree(b.TIT); hipFree(b.dg0); hipFree(b.R); hipFree(b.info);
-            }
-    }
-    printf("\n%s\n\n", bad ? "FAILED" : "backward sweep ok");
     if (quick) return bad != 0;
     printf("## alone on the chip, 36 blocks (P = 4608), 4 right-hand-side tile columns (n = 512): ms per factorisation (best of 3)\n\n");
     Bufs b = make(36, 512);
