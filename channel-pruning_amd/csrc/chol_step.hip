@@ -737,71 +737,7 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
 //     after which thread 0 raises the word.
 //   * ctl[1] is the launch's stop word: a wait that runs out sets it (and info[0]), every other wait of the launch returns at
 //     once, the workgroups drain the counter without working, and the host takes its rank-revealing route as for a failed pivot.
-constexpr int CHAIN_L_MAX = 4;
-constexpr int CHAIN_NTR_MAX = 32;    // right-hand-side tile columns the control block has words for (n_pad <= 4096)
-
-struct ChainShape {
-    int nblk, ntr, L;
-    __host__ __device__ int width(int i) const { return nblk - i + ntr; }
-    __host__ __device__ int pre(int s) const { return s >= 2 ? width(s) : 0; }
-    __host__ __device__ int rest(int s) const {
-        if (s <= L || (s - 1) % L != 0 || s + 1 >= nblk) return 0;
-        const int n = nblk - s - 1;                      // rows s + 1 .. nblk - 1
-        return n * (n + 1) / 2 + n * ntr;
-    }
-    __host__ __device__ int segment(int s) const { return pre(s) + width(s) + rest(s); }
-    __host__ __device__ int total() const {
-        int t = 0;
-        for (int s = 0; s < nblk; ++s) t += segment(s);
-        return t;
-    }
-};
-
-enum { TASK_PRE = 0, TASK_CHAIN = 1, TASK_REST = 2 };
-struct ChainTask {
-    int kind, s, i, xi;        // xi: position in row i (factor tiles first)
-    int r0, kcnt;              // block rows [r0, r0 + kcnt) to apply
-};
-
-__device__ __forceinline__ ChainTask chain_decode(const ChainShape &sh, int t) {
-    ChainTask k;
-    int s = 0;
-    for (;; ++s) {
-        const int seg = sh.segment(s);
-        if (t < seg) break;
-        t -= seg;
-    }
-    k.s = s;
-    if (t < sh.pre(s)) {
-        k.kind = TASK_PRE;
-        k.i = s;
-        k.xi = t;
-        k.r0 = sh.L * ((s - 2) / sh.L);
-        k.kcnt = s - 1 - k.r0;
-        return k;
-    }
-    t -= sh.pre(s);
-    if (t < sh.width(s)) {
-        k.kind = TASK_CHAIN;
-        k.i = s;
-        k.xi = t;
-        k.r0 = s == 0 ? 0 : s - 1;
-        k.kcnt = s == 0 ? 0 : 1;
-        return k;
-    }
-    t -= sh.width(s);
-    k.kind = TASK_REST;
-    int i = s + 1;
-    while (t >= sh.width(i)) {
-        t -= sh.width(i);
-        ++i;
-    }
-    k.i = i;
-    k.xi = t;
-    k.r0 = s - 1 - sh.L;
-    k.kcnt = sh.L;
-    return k;
-}
+#include "chain_order.h"
 
 // lanes 0 .. cnt - 1 of wave 0 each poll one word until it reaches its target; -> false when the launch was stopped / timed out
 __device__ __forceinline__ bool chain_wait(const int *word, int want, bool active, int *stop, int *info, int spin_limit) {

@@ -1366,6 +1366,44 @@ def test_alpha_carry_over_the_vgg16_job_matches_the_reference_chain(ctx):
     cfgs.alpha = 1e-3
 
 
+_FORM_SCRIPT = r"""
+import hashlib, json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "channel-pruning_amd")); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import cp_oracle, cpmi355
+ctx = cpmi355.Context(0)
+out = {}
+for lid, N, c, n, k, keep in ((3, 900, 40, 24, 3, 30), (4, 2500, 160, 200, 3, 150), (5, 5000, 512, 512, 3, 472), (6, 1500, 300, 130, 1, 280)):
+    X, W2, Y, _ = cp_oracle.synth_layer(lid, N, c, n, k)
+    pr = cpmi355.LayerProblem(ctx, X, W2, Y, flags=0)
+    mask = np.zeros(c, dtype=bool); mask[np.random.RandomState(lid).permutation(c)[:keep]] = True
+    W, b = pr.refit(mask)
+    out[str(lid)] = [hashlib.sha1(np.ascontiguousarray(W).tobytes()).hexdigest(), hashlib.sha1(np.ascontiguousarray(b).tobytes()).hexdigest(),
+                     int(pr.refit_info.p), int(pr.refit_info.fallback)]
+    pr.free()
+print(json.dumps(out))
+"""
+
+
+def test_persistent_cholesky_equals_the_launch_per_step_form_bit_for_bit_through_the_c_abi():
+    """cp_lstsq_refit with the factorisation as ONE persistent launch (k_chol_chain, the default) and as one launch per
+    128-column step (CP_CHOL_FORM=steps: the form of rounds 4-5, kept as the reference form): W and b of four refits -- 3, 12, 34
+    and 3 block rows; 1, 2, 4 and 2 right-hand-side tile columns -- are equal BIT FOR BIT, and so for every lazy period.  (Each
+    form in a process of its own: the library reads the switch once.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    got = {}
+    for name, env in (("steps", {"CP_CHOL_FORM": "steps"}), ("chain", {}), ("chain_L1", {"CP_CHOL_LAZY": "1"}),
+                      ("chain_L3_w1", {"CP_CHOL_LAZY": "3", "CP_CHOL_WG_PER_BLK": "1"})):
+        r = subprocess.run([sys.executable, "-c", _FORM_SCRIPT, ROOT], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert all(v[3] == 0 for v in got["steps"].values())          # the Cholesky route, no fallback
+    assert got["chain"] == got["steps"] and got["chain_L1"] == got["steps"] and got["chain_L3_w1"] == got["steps"]
+
+
 def _chol_debug(ctx):
     import ctypes
     lib = ctx.lib

@@ -142,6 +142,19 @@ def test_rand_r_sequence_matches_published_xorshift():
             assert np.array_equal(cp_oracle.coord_sequence(seed, n, 500), ref(seed, n, 500))
 
 
+def test_persistent_cholesky_task_order_is_a_topological_order_host_build():
+    """tests/host/test_chain_order.cpp walks the linear task order of the persistent blocked Cholesky (csrc/chain_order.h, the
+    header k_chol_chain itself decodes its tasks with) for 1154 shapes (1 .. 48 block rows, 0 .. 32 right-hand-side tile columns,
+    lazy periods 1 .. 4, and 144 block rows): every task finds its tile at exactly the version it expects and every finished tile
+    it multiplies with ALREADY final -- i.e. handing the tasks out off one counter cannot deadlock --, every tile receives
+    every block row once, in order, and ends final."""
+    exe = "/tmp/cp_test_chain_order"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "channel-pruning_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host", "test_chain_order.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "chain order ok" in out.stdout, out.stdout[-2000:]
+
+
 def test_xorshift_jump_ahead_host_build():
     """The device kernel's batched index stream (xorshift_jump.h) checked against the sequential
     generator by a g++-compiled host program."""
