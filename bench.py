@@ -112,7 +112,6 @@ def parse_args():
                     help="block: worker groups (3 HIP streams each) running passes over the block concurrently")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("CP_BENCH_BATCH", "8")),
                     help="block: block copies a worker group prunes per cp_prune_layers call")
-    ap.add_argument("--extras-only", action="store_true", help=argparse.SUPPRESS)   # the child process of the default run's extras
     ap.add_argument("--detail", default=os.environ.get("CP_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
                     help="where everything that is not on the line goes (JSON; '' = nowhere)")
     return ap.parse_args()
@@ -136,30 +135,16 @@ def vgg16_extras(args, env, out):
         from benchkit.gather import bench_patch_gather
         out["patch_gather"] = bench_patch_gather(env.local_rank)
     if args.workload == "vgg16" and not args.no_extras:
-        # In a process of their own (`bench.py --extras-only`): behind the legs above, in THIS process, the same three legs run
-        # 20-45 % slower than in a fresh one (resnet50 44.6 / 32.2 ms, vgg16_5x 36.9 / 24.5 ms, R3 2.92 / 2.00 s; the more legs
-        # before them, the slower -- tools/README.md, round 6 call 11; creating and closing contexts alone does not do it:
-        # tools/probes/ctx_churn.py), and what the line should carry is what these workloads do, not what this process did before
-        import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--extras-only", "--gpus", "1"]
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
-                               env=dict(os.environ, CP_BENCH_DEVICE=str(env.local_rank)))
-            got = json.loads(r.stdout.strip().splitlines()[-1])
-            out["other_workloads"], out["r3"] = got["other_workloads"], got["r3"]
-        except Exception as e:   # noqa   (the line still goes out; the detail says what happened)
-            out["extras_error"] = "%s: %s" % (type(e).__name__, e)
+        # (Behind the other legs these three used to run 20-45 % slower than in a process of their own: the process had had more
+        #  than ~16 hardware queues alive, and the runtime never gives one back.  GPU_MAX_HW_QUEUES is 16 now -- cpmi355/capi.py.)
+        from benchkit.extras import short_job
+        from benchkit.r3 import r3_short_pass
+        out["other_workloads"] = {job: short_job(env.local_rank, job) for job in ("resnet50", "vgg16_5x")}
+        out["r3"] = r3_short_pass(env.local_rank)
 
 
 def main():
     args = parse_args()
-    if args.extras_only:
-        from benchkit.extras import short_job
-        from benchkit.r3 import r3_short_pass
-        dev = int(os.environ.get("CP_BENCH_DEVICE", "0"))
-        print(json.dumps({"other_workloads": {job: short_job(dev, job) for job in ("resnet50", "vgg16_5x")},
-                          "r3": r3_short_pass(dev)}), flush=True)
-        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     env = Env()

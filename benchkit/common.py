@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # one hardware queue per stream (before any HIP initialisation)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before any HIP initialisation; why 16: cpmi355/capi.py::load
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.path.join(ROOT, "channel-pruning_amd") not in sys.path:

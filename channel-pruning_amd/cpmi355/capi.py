@@ -139,7 +139,12 @@ def load():
         # Independent layers run on their own HIP streams.  With the runtime's default of 4 hardware
         # queues several streams share one, and a multi-millisecond single-wave CD kernel then holds up
         # every kernel queued behind it; has to be in the environment before the HIP runtime starts.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+        # 16, not more: the runtime never gives a hardware queue back, and a process that has once had more than
+        # ~16 of them alive runs EVERYTHING afterwards slower -- the vgg16_5x job 24.7 ms in a fresh process,
+        # 26.4 / 27.0 ms after a leg with 24 streams alive when the limit is 24, 27.8 / 28.0 ms when it is 32,
+        # 24.7 ms when it is 16 (tools/probes/leg_residue.py).  The jobs themselves do not
+        # care: vgg16 (12 streams) 24.2-24.6 ms at 12 / 16 / 24 / 32, resnet50 (24 streams) 32.7 against 32.1 ms.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         # torch ships its own libamdhip64 / libhsa-runtime64.  Whichever HIP runtime enters the process first serves
         # both; torch cannot initialise on the system one ("No HIP GPUs are available"), this library runs equally
         # fast on either (measured).  So a process that also uses torch.cuda (cpmi355.shard's row-sharded path,
