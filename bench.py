@@ -93,6 +93,8 @@ def parse_args():
     ap.add_argument("--precompute-heaviest", type=int, default=None,
                     help="layers whose full normal equations are computed under their alpha search (default: the library's 2)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-jobs-in-flight leg (N = 1)")
+    ap.add_argument("--no-form-ab", action="store_true",
+                    help="skip the A/B of the factorisation's two forms (launch per step / persistent) on the resident job (N = 1)")
     ap.add_argument("--no-row-assist", action="store_true",
                     help="N > 1, strong: never split a layer's refit rows over its owner and a helper rank (shard.plan_assists)")
     ap.add_argument("--no-exchange-rounds", action="store_true",

@@ -311,6 +311,38 @@ def bench_job(args, env, job):
                        "note": "every GPU prunes its own instance of the whole job; the only collective is ONE uint8 all_gather of "
                                "the channel masks per job"}
 
+    # ---- N = 1: the job with the factorisation as one launch per 128-column step (the form of rounds 4-5) and as one persistent
+    # ---- launch (the default), back to back in this process: bit-identical results, what differs is the schedule
+    form_ab = None
+    if env.world == 1 and not args.profile_mode and not args.no_form_ab:
+        import ctypes
+        lib = roots[0].lib
+        lib.cp_debug_set_chol_form.argtypes = [ctypes.c_int]
+        lib.cp_debug_set_chol_form.restype = ctypes.c_int
+        form_ab = {}
+        nj = max(6, int(np.ceil(0.5 / max(job_ms * 1e-3, 1e-3))))
+        try:
+            for rep in range(2):
+                for name, form in (("launch_per_step", 0), ("persistent", 1)):
+                    lib.cp_debug_set_chol_form(form)
+                    for _ in range(3):
+                        rset()
+                    sync_all()
+                    t_f = time.perf_counter()
+                    for _ in range(nj):
+                        res_f = rset()
+                    sync_all()
+                    form_ab.setdefault(name, []).append(round((time.perf_counter() - t_f) / nj * 1e3, 3))
+                    form_ab["masks_identical"] = bool(form_ab.get("masks_identical", True) and
+                                                      all(np.array_equal(a[0], b[0]) for a, b in zip(res_f, results)))
+        finally:
+            lib.cp_debug_set_chol_form(-1)
+        form_ab = {"job_ms_launch_per_step": min(form_ab["launch_per_step"]), "job_ms_persistent": min(form_ab["persistent"]),
+                   "runs": {k: v for k, v in form_ab.items() if isinstance(v, list)}, "jobs_per_run": nj,
+                   "masks_identical": form_ab["masks_identical"],
+                   "note": "cp_debug_set_chol_form: the same resident job, the factorisation of every refit as one launch per step / "
+                           "as ONE persistent launch (the default); alternating runs, the best of two each"}
+
     # ---- N = 1: TWO instances of the job in flight (outside the timed region; `value` stays one job at a time).  A job alone
     # ---- leaves the chip idle under its widest layers' alpha searches (8 ms of one workgroup each) and is bound by the matrix
     # ---- pipe afterwards; a second, independent instance (another network, or another checkpoint of this one) fills the head
@@ -445,6 +477,8 @@ def bench_job(args, env, job):
             out["replica_throughput"] = replica
         if pipelined is not None:
             out["two_jobs_in_flight"] = pipelined
+        if form_ab is not None:
+            out["chol_form_ab"] = form_ab
         if not weak:
             # what sharding ONE job's layers can give: a job cannot be shorter than its longest layer alone (every layer's alpha
             # search is one serial chain, cd_team.hip), whatever the number of GPUs

@@ -16,7 +16,7 @@ ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 
 # dropped first .. last when a line would still be too long (never a contract key)
-SHEDDABLE = ("patch_gather", "two_jobs_in_flight_layers_per_s", "owner_rank_of_layer", "replica_throughput", "r3",
+SHEDDABLE = ("patch_gather", "chol_form_ab_job_ms", "two_jobs_in_flight_layers_per_s", "owner_rank_of_layer", "replica_throughput", "r3",
              "other_workloads", "exchange", "value_conv3_block")
 
 
@@ -132,6 +132,9 @@ def compact_line(d):
     tj = d.get("two_jobs_in_flight")
     if tj:
         out["two_jobs_in_flight_layers_per_s"] = tj.get("value")
+    ab = d.get("chol_form_ab")
+    if ab:
+        out["chol_form_ab_job_ms"] = {"launch_per_step": ab.get("job_ms_launch_per_step"), "persistent": ab.get("job_ms_persistent")}
     pg = (d.get("patch_gather") or {}).get("one_launch")
     if pg:
         out["patch_gather"] = {"GBps_algorithmic": pg.get("kernel_GBps_algorithmic", pg.get("GBps_algorithmic")),

@@ -36,6 +36,7 @@
 // (rocprof timeline of the job: the first steps of a factorisation took 1.1-1.4 ms next to other layers' Gram GEMMs).
 #include "cp_common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -852,12 +853,14 @@ hipError_t lds_opt_in(int device) {   // > 64 KB of dynamic LDS needs an explici
 }  // namespace
 
 namespace {
-int chain_form() {            // CP_CHOL_FORM=steps: the launch-per-step form (A/B measurements)
+std::atomic<int> g_chain_form_override{-1};   // cp_debug_set_chol_form: -1 = what CP_CHOL_FORM says
+int chain_form() {            // CP_CHOL_FORM=steps: the launch-per-step form (the reference form of the tests, A/B measurements)
     static const int v = [] {
         const char *e = getenv("CP_CHOL_FORM");
         return (e && !strcmp(e, "steps")) ? 0 : 1;
     }();
-    return v;
+    const int o = g_chain_form_override.load(std::memory_order_relaxed);
+    return o >= 0 ? o : v;
 }
 int chain_lazy() {
     static const int v = [] {
@@ -917,6 +920,14 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
         CP_LAUNCH_CHECK(ctx);
     }
     return CP_OK;
+}
+
+// cp_debug_set_chol_form: which form the factorisations launched from now on take, process-wide -- 1 the persistent launch
+// (k_chol_chain), 0 one launch per 128-column step (k_chol_step), -1 back to the default / CP_CHOL_FORM.  Results are bit for
+// bit the same; bench.py's A/B leg and the tests use it.  Returns the form now in force.
+extern "C" int cp_debug_set_chol_form(int form) {
+    g_chain_form_override.store(form < 0 ? -1 : (form ? 1 : 0), std::memory_order_relaxed);
+    return chain_form();
 }
 
 // Test hooks (not part of the public ABI).  cp_debug_chol_fail_flag_wait: the next `count` factorisations on this context run
