@@ -36,6 +36,7 @@
 // (rocprof timeline of the job: the first steps of a factorisation took 1.1-1.4 ms next to other layers' Gram GEMMs).
 #include "cp_common.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -706,7 +707,8 @@ k_chol_step(double *__restrict__ G, double *__restrict__ U, double *__restrict__
 }
 
 // =============================================================================================================================
-// The persistent form: ONE launch per factorisation.
+// The persistent form: the whole factorisation as ONE task list, handed out inside one to four launches (cp_chol_factor_steps
+// cuts the list at step boundaries: the trailing matrix shrinks, and each launch brings the workgroups ITS rows can use).
 //
 // In a job the launch-per-step chain above costs what its launch COUNT costs: next to other layers' products a step that takes
 // 68-75 us alone took 265 us (profiles/r05_kernels_vgg16.md: 243 launches, 64.5 ms of stream time per job), because every launch
@@ -756,7 +758,8 @@ __device__ __forceinline__ bool chain_wait(const int *word, int want, bool activ
 }
 
 __global__ void __launch_bounds__(PT, 4)
-k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int L, int total,
+k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int L, int t_begin, int total,
+             int phase,
              const double *__restrict__ dg0, double piv_tol, double *__restrict__ TI, double *__restrict__ TIT, int *info, int *ctl,
              double *__restrict__ R, int ldr, int ntr, int spin_limit) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -766,7 +769,7 @@ k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict_
     const int XW = nblk + CHAIN_NTR_MAX;
     int *const stop = ctl + 1, *const ver = ctl + 8;
     for (;;) {
-        if (tid == 0) s_task = atomicAdd(ctl, 1);
+        if (tid == 0) s_task = t_begin + atomicAdd(ctl + 2 + phase, 1);    // the tasks [t_begin, total) of this launch
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(s_task);
         if (t >= total) return;
@@ -873,7 +876,7 @@ int chain_lazy() {
 int chain_wg_per_blk() {
     static const int v = [] {
         const char *e = getenv("CP_CHOL_WG_PER_BLK");
-        const int x = e ? atoi(e) : 3;
+        const int x = e ? atoi(e) : 6;
         return x < 1 ? 1 : x;
     }();
     return v;
@@ -898,16 +901,30 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
     const int form = chain_form(), lazy = chain_lazy(), wg_per_blk = chain_wg_per_blk();
     if (form == 1 && ntr <= CHAIN_NTR_MAX) {
         const ChainShape sh{nblk, ntr, lazy};
-        const int total = sh.total();
         // W: what the factorisation can keep busy on average, not what its widest step could use -- resident workgroups that
         // wait for the chain hold slots other layers' launches want (alone, a chain uses ~13 % of the matrix time of the slots
-        // of its widest step)
-        int W = wg_per_blk * nblk + ntr;
-        if (W > total) W = total;
-        if (W > 512) W = 512;
-        k_chol_chain<<<W, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, lazy, total, dg0, piv_tol, TI, TIT, info,
-                                                   info + cp_chol_ctl_offset(nblk), R, n_pad, ntr, spin_limit);
-        CP_LAUNCH_CHECK(ctx);
+        // of its widest step).  The trailing matrix shrinks, so the task list is cut into `phases` launches at step boundaries,
+        // each with the workgroups ITS rows can keep busy: the others' half CUs go back to the dispatcher in between.
+        static const int phases_cfg = [] {
+            const char *e = getenv("CP_CHOL_PHASES");
+            const int v = e ? atoi(e) : 4;           // vgg16 job: 24.6 / 24.2 / 24.0 / 23.8 ms with 1 / 2 / 3 / 4 (and 6 / 4 / 5 / 6
+            return v < 1 ? 1 : (v > 6 ? 6 : v);      // workgroups per block row), 24.1-24.2 ms with the launch-per-step form
+        }();
+        const int phases = std::max(1, std::min(phases_cfg, nblk / 4));       // at least four block rows per launch
+        int t_begin = 0, s_begin = 0;
+        for (int ph = 0; ph < phases; ++ph) {
+            const int s_end = ph + 1 == phases ? nblk : (nblk * (ph + 1)) / phases;
+            int t_end = t_begin;
+            for (int s2 = s_begin; s2 < s_end; ++s2) t_end += sh.segment(s2);
+            int W = wg_per_blk * (nblk - s_begin) + ntr;
+            if (W > t_end - t_begin) W = t_end - t_begin;
+            if (W > 512) W = 512;
+            k_chol_chain<<<W, PT, lds, ctx->stream>>>(G, U, Lt, ld, nblk, lazy, t_begin, t_end, ph, dg0, piv_tol, TI, TIT, info,
+                                                       info + cp_chol_ctl_offset(nblk), R, n_pad, ntr, spin_limit);
+            CP_LAUNCH_CHECK(ctx);
+            t_begin = t_end;
+            s_begin = s_end;
+        }
         return CP_OK;
     }
     for (int s = 0; s < nblk; ++s) {

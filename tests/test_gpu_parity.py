@@ -1388,14 +1388,15 @@ print(json.dumps(out))
 def test_persistent_cholesky_equals_the_launch_per_step_form_bit_for_bit_through_the_c_abi():
     """cp_lstsq_refit with the factorisation as ONE persistent launch (k_chol_chain, the default) and as one launch per
     128-column step (CP_CHOL_FORM=steps: the form of rounds 4-5, kept as the reference form): W and b of four refits -- 3, 12, 34
-    and 3 block rows; 1, 2, 4 and 2 right-hand-side tile columns -- are equal BIT FOR BIT, and so for every lazy period.  (Each
-    form in a process of its own: the library reads the switch once.)"""
+    and 3 block rows; 1, 2, 4 and 2 right-hand-side tile columns -- are equal BIT FOR BIT, and so for every lazy period, number
+    of launches the task list is cut into and number of workgroups.  (Each form in a process of its own: the library reads the
+    switches once.)"""
     import subprocess
     import sys
     from conftest import ROOT
     got = {}
-    for name, env in (("steps", {"CP_CHOL_FORM": "steps"}), ("chain", {}), ("chain_L1", {"CP_CHOL_LAZY": "1"}),
-                      ("chain_L3_w1", {"CP_CHOL_LAZY": "3", "CP_CHOL_WG_PER_BLK": "1"})):
+    for name, env in (("steps", {"CP_CHOL_FORM": "steps"}), ("chain", {}), ("chain_L1", {"CP_CHOL_LAZY": "1", "CP_CHOL_PHASES": "1"}),
+                      ("chain_L3_w1", {"CP_CHOL_LAZY": "3", "CP_CHOL_WG_PER_BLK": "1", "CP_CHOL_PHASES": "6"})):
         r = subprocess.run([sys.executable, "-c", _FORM_SCRIPT, ROOT], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]

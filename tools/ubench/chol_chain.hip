@@ -94,7 +94,7 @@ static float run_chain(const Bufs &b, int L, int W, int *total_out = nullptr) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     hipEventRecord(e0);
-    k_chol_chain<<<std::min(W, total), PT, lds>>>(b.G, b.U, b.Lt, b.p, b.nblk, L, total, b.dg0, 1e-12, b.TI, b.TIT, b.info,
+    k_chol_chain<<<std::min(W, total), PT, lds>>>(b.G, b.U, b.Lt, b.p, b.nblk, L, 0, total, 0, b.dg0, 1e-12, b.TI, b.TIT, b.info,
                                                   b.info + cp_chol_ctl_offset(b.nblk), ntr ? b.R : nullptr, b.n_pad, ntr, 1 << 24);
     hipEventRecord(e1);
     if (hipEventSynchronize(e1) != hipSuccess) {
@@ -236,7 +236,7 @@ int main(int argc, char **argv) {
                 const ChainShape sh{36, ntr, L};
                 const int total = sh.total();
                 const float t = wall([&](const Bufs &b_, hipStream_t s_) {
-                    k_chol_chain<<<W, PT, lds, s_>>>(b_.G, b_.U, b_.Lt, b_.p, b_.nblk, L, total, b_.dg0, 1e-12, b_.TI, b_.TIT, b_.info,
+                    k_chol_chain<<<W, PT, lds, s_>>>(b_.G, b_.U, b_.Lt, b_.p, b_.nblk, L, 0, total, 0, b_.dg0, 1e-12, b_.TI, b_.TIT, b_.info,
                                                      b_.info + cp_chol_ctl_offset(b_.nblk), b_.R, b_.n_pad, ntr, 1 << 24);
                 });
                 printf(" %.3f |", t);
