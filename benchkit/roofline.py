@@ -6,11 +6,14 @@ import numpy as np
 
 from .common import F64_MFMA_PEAK_TFLOPS, N_SAMPLES, ROOT
 
-def pmc_traffic(pattern, round_tag):
+def pmc_traffic(pattern, round_tag, per_pattern=None):
     """-> (HBM bytes per launch of the kernel whose name contains `pattern`, "<files>@<commit of the library they profiled>")
     from the committed rocprofv3 counter passes (separate --pmc runs of `bench.py --profile-mode`; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads, WRITE_SIZE as reported).  (None, None) when absent."""
-    out, commit = {}, None
+    MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads, WRITE_SIZE as reported).  (None, None) when absent.
+    per_pattern: a kernel that is launched ONCE per layer (the refit Gram GEMM) -- the bytes are then those of all the launches
+    of `pattern` that belong to one layer (the factorisation is up to four launches per layer): per launch x the ratio of the
+    two kernels' dispatch counts in the same trace."""
+    out, commit, disp = {}, None, {}
     for key, fname, scale in (("fetch", "%s_pmc_fetch_size_kb.md" % round_tag, 2.0),
                               ("write", "%s_pmc_write_size_kb.md" % round_tag, 1.0)):
         path = os.path.join(ROOT, "profiles", fname)
@@ -19,14 +22,24 @@ def pmc_traffic(pattern, round_tag):
         for line in open(path):
             if line.startswith("commit:"):
                 commit = line.split(":", 1)[1].strip()
-            if pattern in line:
-                try:
-                    out[key] = float(line.split("|")[3]) * 1024.0 * scale
-                except (ValueError, IndexError):
-                    pass
+            for pat in (pattern, per_pattern):
+                if pat and pat in line:
+                    try:
+                        cols = line.split("|")
+                        disp[(key, pat)] = float(cols[2])
+                        if pat == pattern:
+                            out[key] = float(cols[3]) * 1024.0 * scale
+                    except (ValueError, IndexError):
+                        pass
     if len(out) != 2:
         return None, None
-    return out["fetch"] + out["write"], "profiles/%s_pmc_{fetch,write}_size_kb.md@%s" % (round_tag, commit or "unknown")
+    total = out["fetch"] + out["write"]
+    if per_pattern:
+        a, b = disp.get(("fetch", pattern)), disp.get(("fetch", per_pattern))
+        if not a or not b:
+            return None, None
+        total *= a / b
+    return total, "profiles/%s_pmc_{fetch,write}_size_kb.md@%s" % (round_tag, commit or "unknown")
 
 
 def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=None, cd_steps_ns=None, chol_steps=None, chol_pn=None):
@@ -48,8 +61,8 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
             "sum_ms_per_job": round(per_job["refit_gram"], 3), "pmc_pattern": "k_gemm_tn_f64<1, 2,"}
     chol = None
     if cls_ms["cholesky_chain"] and sum(cls_ms["cholesky_chain"]) > 0:
-        chol = {"kernel": "k_chol_chain (blocked Cholesky, ONE persistent launch per layer: tile tasks off a counter; p/128 steps)",
-                "flops_per_launch": "p^3 / 3 + p^2 n (the forward substitution rides in the same launch)",
+        chol = {"kernel": "k_chol_chain (blocked Cholesky, persistent: tile tasks off a counter, 1-4 launches per layer; p/128 steps)",
+                "flops_per_launch": "per layer (all its launches): p^3 / 3 + p^2 n (the forward substitution rides along)",
                 "achieved": round(sum(chol_fl) / (sum(cls_ms["cholesky_chain"]) * 1e-3) / 1e12, 3),
                 "avg_launch_ms": round(sum(cls_ms["cholesky_chain"]) / len(cls_ms["cholesky_chain"]), 4),
                 "launches": len(cls_ms["cholesky_chain"]), "sum_ms_per_job": round(per_job["cholesky_chain"], 3),
@@ -58,7 +71,9 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
             chol["avg_step_us"] = round(sum(cls_ms["cholesky_chain"]) * 1e3 / sum(chol_steps), 2)
             chol["steps_per_job"] = int(round(sum(chol_steps) / max(1, jobs)))
     top = gram if chol is None or per_job["refit_gram"] >= per_job["cholesky_chain"] else chol
-    traffic, source = pmc_traffic(top["pmc_pattern"], round_tag) if job == "vgg16" else (None, None)
+    if chol is not None:
+        chol["pmc_per"] = gram["pmc_pattern"]       # traffic of a factorisation = of all its launches (one Gram launch per layer)
+    traffic, source = pmc_traffic(top["pmc_pattern"], round_tag, top.get("pmc_per")) if job == "vgg16" else (None, None)
     # algorithmic HBM bytes per launch, averaged over the job's launches: Gram 8 N p + 8 p^2 (the staged rows read once, the
     # Gram written once); factorisation step: G and R read once, U and Y written once, spread over the layer's p / 128 launches
     n_gram = max(1, len(g_fl))
@@ -77,7 +92,7 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
                                "window_ms_per_job": round(sum(w) / len(w), 3),
                                "note": "flops of all the layers' brackets of this class in a job / the wall window from the first "
                                        "begin to the last end (the brackets of different layers overlap)"}
-        t_k, src_k = pmc_traffic(k["pmc_pattern"], round_tag) if job == "vgg16" else (None, None)
+        t_k, src_k = pmc_traffic(k["pmc_pattern"], round_tag, k.get("pmc_per")) if job == "vgg16" else (None, None)
         if t_k is not None:
             k["traffic"] = t_k
             k["traffic_source"] = src_k
@@ -95,8 +110,9 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
                 chol["traffic_ratio"] = round(chol["traffic"] / chol["traffic_algorithmic"], 2)
     out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": top["frac"], "traffic": traffic, "traffic_source": source,
-           "traffic_note": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-read correction) + WRITE_SIZE "
-                           "passes of `bench.py --profile-mode`, committed under profiles/ (taken at the commit named)",
+           "traffic_note": "HBM bytes per launch (factorisation: per layer = all its launches): rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
+                           "wide-read correction) + WRITE_SIZE passes of `bench.py --profile-mode`, committed under profiles/ (taken "
+                           "at the commit named)",
            "dominant_by": "sum of launch time per job among the MFMA kernels, HIP events on the launch streams during the timed jobs",
            "avg_launch_ms": top["avg_launch_ms"], "launches": top["launches"], "flops_per_launch": top["flops_per_launch"],
            "peak_nominal": F64_MFMA_PEAK_TFLOPS,
@@ -121,5 +137,6 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
                    "layers of a job exceed job_ms because the layers overlap"}
     for k in out["kernels"]:
         k.pop("pmc_pattern", None)
+        k.pop("pmc_per", None)
     return out
 

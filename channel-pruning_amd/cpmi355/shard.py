@@ -8,8 +8,10 @@ hundred bytes each, plus the reconstructed weights) over torch.distributed -- ba
 
     assign_layers(costs, world)        longest-processing-time-first assignment
     layer_cost(N, c, n, k, rank)       FLOP model of SURVEY.md section 8d (plus the serial CD term)
-    prune_sharded(specs, compute_fn)   run this rank's share, then exchange_results(): one mask all_gather + one
-                                       all_gather of the owners' packed (W, b)
+    prune_sharded(specs, compute_fn)   run this rank's share, then exchange_results(): one mask all_gather to every rank +
+                                       the owners' packed (W, b) to rank 0 (exchange="gather", the default), to every
+                                       rank ("allgather") or nowhere ("masks"); a rank that fails tells the others in the
+                                       mask all_gather (ShardPeerError) instead of leaving them waiting
     GpuLayerBatches(ctx, operands)     compute_many for it: equal-width layers through cp_prune_layers, up to 16 at a time
     ResidentLayerSet(device, specs, ..) the same with the operands resident in HBM and every width group on its own
                                        stream(s) + host thread, all in flight together (bench.py --workload vgg16)

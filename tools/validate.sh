@@ -1,11 +1,11 @@
 #!/bin/bash
-# One GPU-box call that re-validates a build: the factorisation micro-benchmark (with its U^T U check), the GPU suite, smoke(),
-# and the bench line exactly as the driver runs it.  Outputs under gpurun_out/validate/.
+# One GPU-box call that re-validates a build: the factorisation micro-benchmark (the persistent form against the launch-per-step
+# form, bit for bit), the GPU suite, smoke(), and the bench line exactly as the driver runs it.  Outputs under gpurun_out/validate/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/validate
 mkdir -p $OUT
 cd $R
-timeout -k 5 120 tools/ubench/chol_bulk > $OUT/chol_bulk.md 2>&1
+timeout -k 5 120 tools/ubench/chol_chain quick > $OUT/chol_chain_quick.md 2>&1
 timeout -k 5 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log
 timeout -k 5 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1
@@ -14,6 +14,6 @@ timeout -k 5 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.js
 python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/validate/bench.json").read().strip().splitlines()[-1])
-print({k: d[k] for k in ("value", "ms_per_step", "value_conv3_block") if k in d}, d.get("parity"))
+print({k: d[k] for k in ("value", "job_ms", "value_conv3_block", "chol_form_ab_job_ms") if k in d}, d.get("mask_parity_vs_reference_golden"), len(open("gpurun_out/validate/bench.json").read()), "bytes")
 PY
-head -12 $OUT/chol_bulk.md
+grep -E "identical|MISMATCH" $OUT/chol_chain_quick.md
