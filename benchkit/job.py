@@ -1,5 +1,6 @@
 """benchkit.job -- the whole-network jobs (vgg16 = north_star's job, resnet50, vgg16_5x): the timed region and what is
 measured around it (layers alone, PCIe-inclusive pass, two jobs in flight, replica throughput, parity against the goldens)."""
+import ctypes
 import os
 import sys
 import time
@@ -138,6 +139,14 @@ def bench_job(args, env, job):
         for cx in roots:
             cx.sync()
 
+    def xty_flops(pr):
+        """2 N p n when the layer's last refit formed X^T Y in the Gram's launch (its bracket then spans both), else 0"""
+        fn = getattr(pr.ctx.lib, "cp_debug_last_xty_fused", None)
+        if fn is None:
+            return 0.0
+        fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
+        return 2.0 * float(pr.N) * int(pr.refit_info.p) * float(pr.n) if fn(pr.ctx.h) == 1 else 0.0
+
     # ---- warm-up: 1 + W jobs, then choose jobs_per_step so that K steps take >= MIN_TIMED_SECONDS ----
     one_job()
     sync_all()
@@ -156,6 +165,7 @@ def bench_job(args, env, job):
     # hipEventElapsedTime each), which is measurement, not pruning work -- with every job instrumented it was 4 % of `value`
     STAGE_SAMPLE = 8
     g_ms, g_fl, exch_ms = [], [], []
+    g_fl_bracket, g_n = [], []         # flops the Gram bracket's launch executed (+ X^T Y when fused), n per bracket
     cls_ms = {"alpha_search": [], "refit_gram": [], "cholesky_chain": [], "backward_substitution": []}   # per launch / bracket, in the job
     chol_fl, chol_steps, chol_pn = [], [], []
     sync_all()
@@ -184,7 +194,10 @@ def bench_job(args, env, job):
                 for name, ms, begin in pr.ctx.last_stage_spans(roots[0]):
                     if name == "refit_gram_gemm":
                         g_ms.append(ms)
+                        # (the launch also forms X^T Y when the library fused the two products: cp_gemm_gram_xty)
                         g_fl.append(float(pr.N) * int(pr.refit_info.p) ** 2)
+                        g_fl_bracket.append(g_fl[-1] + xty_flops(pr))
+                        g_n.append(float(pr.n))
                         cls_ms["refit_gram"].append(ms)
                         span["refit_gram"].append((begin, begin + ms))
                     elif name == "cd_alpha_search":
@@ -254,7 +267,7 @@ def bench_job(args, env, job):
             alone_c_fl.append(pp_ ** 3 / 3.0 + pp_ * pp_ * spec["n"])
         if "refit_gram_gemm" in st:
             alone_g_ms.append(st["refit_gram_gemm"])
-            alone_g_fl.append(float(spec["N"]) * int(pr.refit_info.p) ** 2)
+            alone_g_fl.append(float(spec["N"]) * int(pr.refit_info.p) ** 2 + xty_flops(pr))
             # latency mode: the launch computed the Gram of ALL c channels during the alpha search (CP_REFIT_PRECOMPUTE)
             alone_g_ex.append(float(spec["N"]) * (spec["c"] * kk) ** 2 if ("refit_gather_normal_eq" in st or "refit_backward" in st)
                               else float(spec["N"]) * int(pr.refit_info.p) ** 2)
@@ -315,7 +328,6 @@ def bench_job(args, env, job):
     # ---- launch (the default), back to back in this process: bit-identical results, what differs is the schedule
     form_ab = None
     if env.world == 1 and not args.profile_mode and not args.no_form_ab:
-        import ctypes
         lib = roots[0].lib
         lib.cp_debug_set_chol_form.argtypes = [ctypes.c_int]
         lib.cp_debug_set_chol_form.restype = ctypes.c_int
@@ -406,7 +418,7 @@ def bench_job(args, env, job):
         alg_job, exe_job = sum(f[0] for f in fl), sum(f[1] for f in fl)
         n_sampled = (jobs + STAGE_SAMPLE - 1) // STAGE_SAMPLE       # the jobs whose stage brackets were read
         roof = roofline_object(cls_ms, g_fl, chol_fl, n_sampled, roots[0] if roots else None, PROFILE_TAG, job, windows=windows,
-                               cd_steps_ns=cd_steps_ns, chol_steps=chol_steps, chol_pn=chol_pn)
+                               cd_steps_ns=cd_steps_ns, chol_steps=chol_steps, chol_pn=chol_pn, g_fl_bracket=g_fl_bracket, g_n=g_n)
         if roof is not None:
             roof["jobs_with_stage_brackets"] = n_sampled
         if roof is not None and alone_g_ms:

@@ -14,35 +14,44 @@ def pmc_traffic(pattern, round_tag, per_pattern=None):
     of `pattern` that belong to one layer (the factorisation is up to four launches per layer): per launch x the ratio of the
     two kernels' dispatch counts in the same trace."""
     out, commit, disp = {}, None, {}
+    pats = [pattern] if isinstance(pattern, str) else list(pattern)        # alternatives of one kernel class: bytes of the first
+    pers = [per_pattern] if isinstance(per_pattern, str) else list(per_pattern or [])   # one present, dispatch counts summed
     for key, fname, scale in (("fetch", "%s_pmc_fetch_size_kb.md" % round_tag, 2.0),
                               ("write", "%s_pmc_write_size_kb.md" % round_tag, 1.0)):
         path = os.path.join(ROOT, "profiles", fname)
         if not os.path.isfile(path):
             return None, None
+        best = None
         for line in open(path):
             if line.startswith("commit:"):
                 commit = line.split(":", 1)[1].strip()
-            for pat in (pattern, per_pattern):
-                if pat and pat in line:
-                    try:
-                        cols = line.split("|")
-                        disp[(key, pat)] = float(cols[2])
-                        if pat == pattern:
-                            out[key] = float(cols[3]) * 1024.0 * scale
-                    except (ValueError, IndexError):
-                        pass
+            for group, names in (("main", pats), ("per", pers)):
+                for rank, pat in enumerate(names):
+                    if pat and pat in line:
+                        try:
+                            cols = line.split("|")
+                            disp[(key, group)] = disp.get((key, group), 0.0) + float(cols[2])
+                            if group == "main" and (best is None or rank < best):
+                                best = rank
+                                out[key] = float(cols[3]) * 1024.0 * scale
+                        except (ValueError, IndexError):
+                            pass
     if len(out) != 2:
         return None, None
     total = out["fetch"] + out["write"]
-    if per_pattern:
-        a, b = disp.get(("fetch", pattern)), disp.get(("fetch", per_pattern))
+    if pers:
+        a, b = disp.get(("fetch", "main")), disp.get(("fetch", "per"))
         if not a or not b:
             return None, None
         total *= a / b
     return total, "profiles/%s_pmc_{fetch,write}_size_kb.md@%s" % (round_tag, commit or "unknown")
 
 
-def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=None, cd_steps_ns=None, chol_steps=None, chol_pn=None):
+def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=None, cd_steps_ns=None, chol_steps=None, chol_pn=None,
+                    g_fl_bracket=None, g_n=None):
+    # g_fl: N p^2 per Gram bracket (the algorithmic Gram flops: p is derived from it); g_fl_bracket: the flops the bracket's
+    # launch executed -- N p^2 + 2 N p n where the library forms X^T Y in the Gram's launch (cp_gemm_gram_xty); g_n: n per bracket
+    g_exec = g_fl_bracket if g_fl_bracket else g_fl
     """`roofline` of the JSON line.  The kernel classes of the job's MFMA work, each timed live with HIP events on its launch
     stream during the timed jobs (cp_enable_stage_timing mode 2): the refit Gram GEMM (one launch per layer) and the
     factorisation chain (the Cholesky step launches of a layer, with the forward substitution riding along).  The one
@@ -54,11 +63,14 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
     # launch shared the chip with the tail of something else), and the ceiling is what the pipe CAN issue
     probe_tf, ghz, cyc = max((ctx0.probe_mfma_f64_clock() for _ in range(3)), key=lambda t: t[0])
     per_job = {k: sum(v) / max(1, jobs) for k, v in cls_ms.items()}
-    gram = {"kernel": "k_gemm_tn_f64<lower, refit Gram> (G = Xs^T Xs, one launch per layer)",
-            "flops_per_launch": "N p^2 (symmetric half of 2 N p^2), p = kept k k",
-            "achieved": round(sum(g_fl) / (sum(cls_ms["refit_gram"]) * 1e-3) / 1e12, 3),
+    fused = bool(g_fl_bracket) and sum(g_fl_bracket) > sum(g_fl)
+    gram = {"kernel": "k_gemm_tn_f64<Gram + X^T Y, refit> (G = Xs^T Xs and R = Xs^T Yc, one launch per layer)" if fused else
+                      "k_gemm_tn_f64<lower, refit Gram> (G = Xs^T Xs, one launch per layer)",
+            "flops_per_launch": "N p^2 (symmetric half of 2 N p^2) + 2 N p n, p = kept k k" if fused else
+                                "N p^2 (symmetric half of 2 N p^2), p = kept k k",
+            "achieved": round(sum(g_exec) / (sum(cls_ms["refit_gram"]) * 1e-3) / 1e12, 3),
             "avg_launch_ms": round(sum(cls_ms["refit_gram"]) / len(cls_ms["refit_gram"]), 4), "launches": len(cls_ms["refit_gram"]),
-            "sum_ms_per_job": round(per_job["refit_gram"], 3), "pmc_pattern": "k_gemm_tn_f64<1, 2,"}
+            "sum_ms_per_job": round(per_job["refit_gram"], 3), "pmc_pattern": ("k_gemm_tn_f64<3, 2,", "k_gemm_tn_f64<1, 2,")}
     chol = None
     if cls_ms["cholesky_chain"] and sum(cls_ms["cholesky_chain"]) > 0:
         chol = {"kernel": "k_chol_chain (blocked Cholesky, persistent: tile tasks off a counter, 1-4 launches per layer; p/128 steps)",
@@ -78,7 +90,7 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
     # Gram written once); factorisation step: G and R read once, U and Y written once, spread over the layer's p / 128 launches
     n_gram = max(1, len(g_fl))
     gram["traffic_algorithmic"] = None
-    for k, flops, cls in ((gram, g_fl, "refit_gram"), (chol, chol_fl, "cholesky_chain")):
+    for k, flops, cls in ((gram, g_exec, "refit_gram"), (chol, chol_fl, "cholesky_chain")):
         if k is None:
             continue
         k["frac"] = round(k["achieved"] / F64_MFMA_PEAK_TFLOPS, 4)
@@ -99,7 +111,8 @@ def roofline_object(cls_ms, g_fl, chol_fl, jobs, ctx0, round_tag, job, windows=N
     if job == "vgg16" and g_fl:
         # p from N p^2; 8 N p + 8 p^2 per Gram launch
         ps = [np.sqrt(f / N_SAMPLES) for f in g_fl]
-        gram["traffic_algorithmic"] = round(float(np.mean([8.0 * N_SAMPLES * p_ + 8.0 * p_ * p_ for p_ in ps])), 1)
+        ns = g_n if (fused and g_n and len(g_n) == len(ps)) else [0.0] * len(ps)      # + Yc read, R written when fused
+        gram["traffic_algorithmic"] = round(float(np.mean([8.0 * N_SAMPLES * (p_ + n_) + 8.0 * p_ * (p_ + n_) for p_, n_ in zip(ps, ns)])), 1)
         if gram.get("traffic"):
             gram["traffic_ratio"] = round(gram["traffic"] / gram["traffic_algorithmic"], 2)
         if chol is not None and chol_fl:

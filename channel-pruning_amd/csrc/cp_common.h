@@ -124,7 +124,12 @@ struct cp_ctx {
     int cd_fallbacks = 0;             // searches / fits re-run on the one-workgroup team after a hand-off time-out of the multi-CU team
     int chol_test_fail_flag_waits = 0;   // cp_debug_chol_fail_flag_wait: that many factorisations run with a spin limit of 0 (tests)
     bool cd_test_fail_multi = false;  // cp_debug_cd_fail_multi: the next multi-CU launches give up at once (tests of that fallback)
+    bool last_xty_fused = false;      // the last refit of this context formed G and X^T Y in one launch (cp_gemm_gram_xty)
 };
+
+// process-wide experiment switches (cp_debug_knob; cp_ctx.hip): plain ints, 0 by default, read when work is enqueued
+enum { CP_KNOB_SPLIT_XTY = 0, CP_KNOB_COUNT = 8 };
+int cp_knob(int id);
 
 int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
 
@@ -181,6 +186,11 @@ enum { CP_GEMM_GENERIC = 0, CP_GEMM_LASSO_GRAM = 1, CP_GEMM_REFIT_GRAM = 2, CP_G
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda,
                    const double *B, int ldb, double beta, double *C, int ldc, int tri);
 size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri);
+// G = X^T X (both triangles) and R = X^T Y in one launch (gemm_f64.hip); *fused == false: nothing was launched (plan with
+// reduction planes), run the two products separately
+int cp_gemm_gram_xty(cp_ctx *ctx, int p_pad, int n_pad, int K, const double *X, int ldx, const double *Y, int ldy, double *G,
+                     int ldg, double *R, int ldr, bool *fused);
+size_t cp_gemm_gram_xty_workspace(const cp_ctx *ctx, int p_pad, int n_pad, int K);
 // two products of the same shape (different operands / K), one launch when neither needs split-K
 int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const double *A1, const double *B1, double *C1,
                         int K2, const double *A2, const double *B2, double *C2, int lda, int ldb, int ldc, int tri);

@@ -2,6 +2,8 @@
 // micro-probes of libcpmi355.so.
 #include "cp_common.h"
 
+#include <atomic>
+
 #include <algorithm>
 #include <vector>
 
@@ -471,4 +473,15 @@ extern "C" int cp_probe_hbm_copy(cp_ctx *ctx, size_t bytes, double *gbps) {
     hipEventDestroy(e1);
     *gbps = 2.0 * double(bytes) * reps / (ms * 1e-3) / 1e9;
     return CP_OK;
+}
+
+// ---- process-wide experiment switches (A/B measurements in one process: tools/probes/job_knobs.py) --------------------------
+namespace {
+std::atomic<int> g_knobs[CP_KNOB_COUNT] = {};
+}
+int cp_knob(int id) { return id >= 0 && id < CP_KNOB_COUNT ? g_knobs[id].load(std::memory_order_relaxed) : 0; }
+// cp_debug_knob(id, value): sets switch `id` (CP_KNOB_*, cp_common.h), returns the previous value (-1: no such switch)
+extern "C" int cp_debug_knob(int id, int value) {
+    if (id < 0 || id >= CP_KNOB_COUNT) return -1;
+    return g_knobs[id].exchange(value, std::memory_order_relaxed);
 }

@@ -121,6 +121,18 @@ struct GemmSecond {
     int K;
 };
 
+// Gram and right-hand side of the normal equations in ONE launch (TRI == TRI_AUG, cp_gemm_gram_xty): the lower triangle of
+// [X | Y]^T [X | Y] without its Y^T Y corner.  Tile rows ti < tp are rows of G = X^T X (lower tile + mirror, as
+// CP_TRI_LOWER_MIRROR); tile rows ti >= tp take their A operand from Y (A2, lda2) and hold a tile of Y^T X = R^T, which is
+// written transposed into R (C2, ldc2); the tiles with tj >= tp are not wanted and their workgroups leave at once.
+struct GemmAug {
+    const double *A2;
+    int lda2, tp;
+    double *C2;
+    int ldc2;
+};
+constexpr int TRI_AUG = 3;
+
 // How the workgroups of a launch divide the tiles (the tile list is ordered as decode_tile / decode_tile_blocked say):
 //   units [0, n_full)                      tile `unit` computed whole, written straight to C
 //   units [n_full, n_full + n_split * s)   tile n_full + t, k-chunk z: partial block -> Pb[t * s + z]; the last arrival
@@ -195,7 +207,7 @@ template <int TRI, int TAG, int WT, int NTH>
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
 k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
               const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
-              double *__restrict__ P, int n_tiles, int tiles_n, GemmSched sch, GemmSecond second) {
+              double *__restrict__ P, int n_tiles, int tiles_n, GemmSched sch, GemmSecond second, GemmAug aug) {
     int kchunk = sch.kchunk;
     if (blockIdx.y == 1) {
         A = second.A;
@@ -223,9 +235,15 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
     const int tid = threadIdx.x;
     const int L = blockIdx.x;
     // ---- unit -> (tile, chunk z of nz) ----
-    const GemmUnit un = gemm_unit(TRI, L, n_tiles, M / TM, tiles_n, sch);
+    const GemmUnit un = gemm_unit(TRI == TRI_AUG ? CP_TRI_LOWER_MIRROR : TRI, L, n_tiles, M / TM, tiles_n, sch);
     if (un.idle) return;                             // the grid of a tail split is padded to the XCD with the most tiles
     const int ti = un.ti, tj = un.tj, z = un.z, nz = un.nz, t_split = un.t_split;
+    const bool rhs_tile = TRI == TRI_AUG && ti >= aug.tp;      // a tile of Y^T X (workgroup-uniform)
+    if (TRI == TRI_AUG && tj >= aug.tp) return;                // the Y^T Y corner: not wanted (its counters are never touched)
+    if (rhs_tile) {
+        A = aug.A2 - size_t(aug.tp) * TM;                      // column m0 of [X | Y] is column m0 - tp TM of Y
+        lda = aug.lda2;
+    }
     const int m0 = ti * TM, n0 = tj * TM;
     const int k0 = nz > 1 ? z * kchunk : 0;
     int k1 = nz > 1 ? k0 + kchunk : K;
@@ -369,11 +387,15 @@ k_gemm_tn_f64(int M, int N, int K, double alpha, const double *__restrict__ A, i
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm + i * 16 + fk + 4 * r, col = n0 + wn + j * 16 + fi;
                 double v = alpha * acc[i][j][r];
+                if (TRI == TRI_AUG && rhs_tile) {      // (Y^T X)[row - tp TM, col] = R[col, row - tp TM]
+                    aug.C2[size_t(col) * aug.ldc2 + (row - aug.tp * TM)] = v;
+                    continue;
+                }
                 double *c = C + size_t(row) * ldc + col;
                 if (beta != 0.0) v += beta * *c;
                 *c = v;
                 // lower-triangle product: the mirrored tile from the same registers (4 consecutive doubles per lane group)
-                if (TRI == CP_TRI_LOWER_MIRROR && ti != tj) C[size_t(col) * ldc + row] = v;
+                if ((TRI == CP_TRI_LOWER_MIRROR || TRI == TRI_AUG) && ti != tj) C[size_t(col) * ldc + row] = v;
             }
 }
 
@@ -504,11 +526,32 @@ size_t cp_gemm_tn_workspace(const cp_ctx *ctx, int M, int N, int K, int tri) {
 }
 
 static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
-                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second);
+                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second,
+                       const GemmAug *aug = nullptr);
 
 int cp_gemm_tn_f64(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
                    int ldb, double beta, double *C, int ldc, int tri) {
     return gemm_launch(ctx, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, nullptr);
+}
+
+// G = X^T X (p_pad x p_pad, both triangles) and R = X^T Y (p_pad x n_pad) in ONE launch: the lower triangle of the Gram of
+// [X | Y] without its Y^T Y corner (GemmAug) -- R's tiles ride in the Gram's launch with the Gram's tile schedule instead of
+// a second, skinny product (4 tile columns: a third of the chip, split along K and reduced) that a busy chip makes the
+// layer wait for.  false in *fused: the shape's plan needs the legacy plane reduction (few tiles): the caller runs the
+// two products one after the other as before.
+int cp_gemm_gram_xty(cp_ctx *ctx, int p_pad, int n_pad, int K, const double *X, int ldx, const double *Y, int ldy, double *G,
+                     int ldg, double *R, int ldr, bool *fused) {
+    const int Ma = p_pad + n_pad;
+    *fused = false;
+    if (p_pad % BM || n_pad % BN || K % BK) return CP_OK;
+    const GemmPlan p = make_plan(ctx, Ma, Ma, K, CP_TRI_LOWER_MIRROR);
+    if (p.planes || p.small) return CP_OK;
+    const GemmAug ag{Y, ldy, p_pad / BM, R, ldr};
+    *fused = true;
+    return gemm_launch(ctx, Ma, Ma, K, 1.0, X, ldx, X, ldx, 0.0, G, ldg, CP_TRI_LOWER_MIRROR, nullptr, &ag);
+}
+size_t cp_gemm_gram_xty_workspace(const cp_ctx *ctx, int p_pad, int n_pad, int K) {
+    return cp_gemm_tn_workspace(ctx, p_pad + n_pad, p_pad + n_pad, K, CP_TRI_LOWER_MIRROR);
 }
 
 // C1 = alpha A1^T B1 (K1) and C2 = alpha A2^T B2 (K2), same M, N, leading dimensions and tri, in one launch when
@@ -526,7 +569,7 @@ int cp_gemm_tn_f64_pair(cp_ctx *ctx, int M, int N, double alpha, int K1, const d
 }
 
 static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
-                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second) {
+                       int ldb, double beta, double *C, int ldc, int tri, const GemmSecond *second, const GemmAug *aug) {
     if (M <= 0 || N <= 0) return CP_OK;
     if (M % BM || N % BN || K % BK || (lda & 1) || (ldb & 1) || (tri != CP_TRI_NONE && M != N))
         return cp_set_error(ctx, CP_ERR_ARG, "gemm_tn: unaligned shape M=%d N=%d K=%d lda=%d ldb=%d", M, N, K, lda,
@@ -557,14 +600,15 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
     if (!p.planes && p.n_full > 0 && p.n_split > 0) units = p.n_full + 8 * ((p.n_split + 7) / 8) * p.s;   // tail: per-XCD ranges, padded
     const dim3 grid(units, second ? 2 : 1);
     const GemmSecond sec = second ? *second : GemmSecond{nullptr, nullptr, nullptr, 0};
+    const GemmAug ag = aug ? *aug : GemmAug{nullptr, 0, 0, nullptr, 0};
 #define CP_GEMM_LAUNCH(T, G)                                                                                  \
     do {                                                                                                      \
         if (p.small)                                                                                          \
             k_gemm_tn_f64<T, G, 32, 256><<<grid, 256, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
-                                                                          P, p.n_tiles, p.tiles_n, sch, sec);   \
+                                                                          P, p.n_tiles, p.tiles_n, sch, sec, ag);   \
         else                                                                                                  \
             k_gemm_tn_f64<T, G, 64, 512><<<grid, 512, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, \
-                                                                          P, p.n_tiles, p.tiles_n, sch, sec);   \
+                                                                          P, p.n_tiles, p.tiles_n, sch, sec, ag);   \
     } while (0)
     const int tag = ctx->gemm_tag;
     ctx->gemm_tag = CP_GEMM_GENERIC;
@@ -573,6 +617,9 @@ static int gemm_launch(cp_ctx *ctx, int M, int N, int K, double alpha, const dou
             CP_GEMM_LAUNCH(CP_TRI_NONE, CP_GEMM_REFIT_XTY);
         else
             CP_GEMM_LAUNCH(CP_TRI_NONE, CP_GEMM_GENERIC);
+    } else if (tri == CP_TRI_LOWER_MIRROR && aug) {
+        k_gemm_tn_f64<TRI_AUG, CP_GEMM_REFIT_GRAM, 64, 512><<<grid, 512, 0, ctx->stream>>>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, P,
+                                                                                        p.n_tiles, p.tiles_n, sch, sec, ag);
     } else if (tri == CP_TRI_LOWER_MIRROR) {
         if (tag == CP_GEMM_LASSO_GRAM)
             CP_GEMM_LAUNCH(CP_TRI_LOWER_MIRROR, CP_GEMM_LASSO_GRAM);

@@ -625,6 +625,8 @@ __global__ void __launch_bounds__(RT) k_scale_rows(double *__restrict__ M, int l
 }  // namespace
 
 extern "C" int cp_debug_itq_sweeps(cp_ctx *ctx) { return ctx ? ctx->itq_sweeps : -1; }
+// 1: the last refit of this context formed G and X^T Y in ONE launch (cp_gemm_gram_xty) -- its "refit_gram_gemm" bracket holds both
+extern "C" int cp_debug_last_xty_fused(cp_ctx *ctx) { return ctx ? int(ctx->last_xty_fused) : -1; }
 // what: 0 = Newton-Schulz steps, 1 = alternations that took the sign-function route (of the last cp_itq_iterate)
 extern "C" int cp_debug_itq_sign(cp_ctx *ctx, int what) {
     return !ctx ? -1 : (what == 0 ? ctx->itq_ns_steps : ctx->itq_sign_alternations);
@@ -1085,6 +1087,11 @@ bool prefactor_wanted() {
     static const bool on = !(getenv("CP_REFIT_PREFACTOR") && getenv("CP_REFIT_PREFACTOR")[0] == '0');
     return on;
 }
+// CP_REFIT_FUSED_XTY=0 (or cp_debug_knob(CP_KNOB_SPLIT_XTY, 1)): Gram and X^T Y as two launches, as before round 6
+bool fused_xty_wanted() {
+    static const bool on = !(getenv("CP_REFIT_FUSED_XTY") && getenv("CP_REFIT_FUSED_XTY")[0] == '0');
+    return on && cp_knob(CP_KNOB_SPLIT_XTY) == 0;
+}
 }  // namespace
 
 // Enqueue, on the device's shared side stream, the normal equations of the layer over ALL c channels:
@@ -1137,6 +1144,7 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
     const int RB = 64, rows_per_block = int((N + RB - 1) / RB);
     size_t ws = std::max(cp_gemm_tn_workspace(w, P_pad, P_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
                          cp_gemm_tn_workspace(w, P_pad, n_pad, int(N_pad), CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_gram_xty_workspace(w, P_pad, n_pad, int(N_pad)));
     // Few channels are dropped (rank hint >= 0.8 c): also factor the FULL Gram and forward-substitute the right-hand side
     // here; the refit then needs no factorisation of its own after the search (refit_from_full_factor).
     const bool want_factor = prefactor_wanted() && rank_hint >= 0.8 * double(c) && rank_hint < double(c);
@@ -1207,16 +1215,25 @@ int cp_refit_precompute_enqueue(cp_ctx *ctx, const void *X, int x_dtype, int64_t
     CP_LAUNCH_CHECK(ctx);
     cp_stage_mark(w, "refit_gather_center");
     cp_stage_mark(w, "refit_gram_begin");
-    w->gemm_tag = CP_GEMM_REFIT_GRAM;
-    w->gemm_mark = "refit_gram_gemm";
-    if (cp_gemm_tn_f64(w, P_pad, P_pad, int(N_pad), 1.0, Xs, P_pad, Xs, P_pad, 0.0, pc.G, P_pad, CP_TRI_LOWER_MIRROR) != CP_OK)
-        return cp_set_error(ctx, CP_ERR_HIP, "refit precompute: %s", w->err);
-    cp_stage_mark(w, "refit_gram_reduce");
-    w->gemm_tag = CP_GEMM_REFIT_XTY;
-    w->gemm_mark = "refit_xty_gemm";
-    if (cp_gemm_tn_f64(w, P_pad, n_pad, int(N_pad), 1.0, Xs, P_pad, Yc, n_pad, 0.0, pc.R, n_pad, CP_TRI_NONE) != CP_OK)
-        return cp_set_error(ctx, CP_ERR_HIP, "refit precompute: %s", w->err);
-    cp_stage_mark(w, "refit_xty_reduce");
+    bool fused = false;
+    if (fused_xty_wanted()) {
+        w->gemm_mark = "refit_gram_gemm";
+        if (cp_gemm_gram_xty(w, P_pad, n_pad, int(N_pad), Xs, P_pad, Yc, n_pad, pc.G, P_pad, pc.R, n_pad, &fused) != CP_OK)
+            return cp_set_error(ctx, CP_ERR_HIP, "refit precompute: %s", w->err);
+        if (!fused) w->gemm_mark = nullptr;
+    }
+    if (!fused) {
+        w->gemm_tag = CP_GEMM_REFIT_GRAM;
+        w->gemm_mark = "refit_gram_gemm";
+        if (cp_gemm_tn_f64(w, P_pad, P_pad, int(N_pad), 1.0, Xs, P_pad, Xs, P_pad, 0.0, pc.G, P_pad, CP_TRI_LOWER_MIRROR) != CP_OK)
+            return cp_set_error(ctx, CP_ERR_HIP, "refit precompute: %s", w->err);
+        cp_stage_mark(w, "refit_gram_reduce");
+        w->gemm_tag = CP_GEMM_REFIT_XTY;
+        w->gemm_mark = "refit_xty_gemm";
+        if (cp_gemm_tn_f64(w, P_pad, n_pad, int(N_pad), 1.0, Xs, P_pad, Yc, n_pad, 0.0, pc.R, n_pad, CP_TRI_NONE) != CP_OK)
+            return cp_set_error(ctx, CP_ERR_HIP, "refit precompute: %s", w->err);
+        cp_stage_mark(w, "refit_xty_reduce");
+    }
     if (want_factor) {
         // The factorisation is a chain of short dependent launches: on this context's OWN stream, so that two layers'
         // chains run side by side while their long products take turns on the shared one.
@@ -1404,6 +1421,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
                  part_b = size_t(RB) * size_t(p_pad + n_pad) * 8;
     size_t ws = std::max(cp_gemm_tn_workspace(ctx, p_pad, p_pad, int(N_pad), CP_TRI_LOWER_MIRROR),
                          cp_gemm_tn_workspace(ctx, p_pad, n_pad, int(N_pad), CP_TRI_NONE));
+    ws = std::max(ws, cp_gemm_gram_xty_workspace(ctx, p_pad, n_pad, int(N_pad)));
     ws = std::max(ws, cp_gemm_tn_workspace(ctx, p_pad, n_pad, p_pad, CP_TRI_NONE));
     ws = std::max(ws, chol_solve_blocked_workspace(ctx, p_pad, n_pad));
     const size_t need = xs_b + yc_b + 4 * g_b + 4 * r_b + 2 * ti_b + part_b + size_t(p_pad) * 8 * 3 + size_t(n_pad) * 8 +
@@ -1492,6 +1510,7 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
     // Gram and right-hand side into (Gd, Rd), diagonal prepared (ridge, unit pad diagonal, dg0, gmax, info = 0)
     auto normal_equations = [&](double *Gd, double *Rd, bool mark) -> int {
         if (from_pre && mark) {   // the kept rows / columns of the precomputed full normal equations
+            ctx->last_xty_fused = false;
             if (c <= CHAN_BITS_MAX) {
                 k_gather_normal_eq<true><<<p_pad, RT, 0, ctx->stream>>>(pc.G, pc.P_pad, pc.R, pc.xmean, nullptr, chan_bits(chan), c, kk, p,
                                                                         p_pad, n_pad, Gd, Rd, xmean);
@@ -1509,14 +1528,23 @@ int cp_lstsq_refit_impl(cp_ctx *ctx, const void *X, int x_dtype, int64_t N, int 
         CP_TRY(stage_rows());
         if (mark) cp_stage_mark(ctx, "refit_gather_center");
         if (mark) cp_stage_mark(ctx, "refit_gram_begin");   // opens the bracket of the refit Gram GEMM (timing mode 2)
-        ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
-        ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
-        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad, CP_TRI_LOWER_MIRROR));
-        if (mark) cp_stage_mark(ctx, "refit_gram_reduce");
-        ctx->gemm_tag = CP_GEMM_REFIT_XTY;
-        ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
-        CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
-        if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
+        bool fused = false;
+        if (fused_xty_wanted()) {   // Gram and X^T Y as ONE launch (cp_gemm_gram_xty); the bracket "refit_gram_gemm" then spans both
+            ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
+            CP_TRY(cp_gemm_gram_xty(ctx, p_pad, n_pad, int(N_pad), Xs, p_pad, Yc, n_pad, Gd, p_pad, Rd, n_pad, &fused));
+            if (!fused) ctx->gemm_mark = nullptr;
+        }
+        if (!fused) {
+            ctx->gemm_tag = CP_GEMM_REFIT_GRAM;
+            ctx->gemm_mark = mark ? "refit_gram_gemm" : nullptr;
+            CP_TRY(cp_gemm_tn_f64(ctx, p_pad, p_pad, int(N_pad), 1.0, Xs, p_pad, Xs, p_pad, 0.0, Gd, p_pad, CP_TRI_LOWER_MIRROR));
+            if (mark) cp_stage_mark(ctx, "refit_gram_reduce");
+            ctx->gemm_tag = CP_GEMM_REFIT_XTY;
+            ctx->gemm_mark = mark ? "refit_xty_gemm" : nullptr;
+            CP_TRY(cp_gemm_tn_f64(ctx, p_pad, n_pad, int(N_pad), 1.0, Xs, p_pad, Yc, n_pad, 0.0, Rd, n_pad, CP_TRI_NONE));
+            if (mark) cp_stage_mark(ctx, "refit_xty_reduce");
+        }
+        ctx->last_xty_fused = fused;
         k_diag_prepare<<<1, 256, 0, ctx->stream>>>(Gd, p_pad, p, p_pad, ridge, dg0, gmax, dinfo, chol_info_count(nblk));
         CP_LAUNCH_CHECK(ctx);
         return CP_OK;
