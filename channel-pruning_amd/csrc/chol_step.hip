@@ -898,7 +898,8 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
         --ctx->chol_test_fail_flag_waits;
         spin_limit = 0;
     }
-    const int form = chain_form(), lazy = chain_lazy(), wg_per_blk = chain_wg_per_blk();
+    const int form = chain_form(), lazy = chain_lazy();
+    const int wg_per_blk = cp_knob(CP_KNOB_CHOL_WG) > 0 ? cp_knob(CP_KNOB_CHOL_WG) : chain_wg_per_blk();
     if (form == 1 && ntr <= CHAIN_NTR_MAX) {
         const ChainShape sh{nblk, ntr, lazy};
         // W: what the factorisation can keep busy on average, not what its widest step could use -- resident workgroups that
@@ -910,7 +911,8 @@ int cp_chol_factor_steps(cp_ctx *ctx, double *G, double *U, double *Lt, int ld, 
             const int v = e ? atoi(e) : 4;           // vgg16 job: 24.6 / 24.2 / 24.0 / 23.8 ms with 1 / 2 / 3 / 4 (and 6 / 4 / 5 / 6
             return v < 1 ? 1 : (v > 6 ? 6 : v);      // workgroups per block row), 24.1-24.2 ms with the launch-per-step form
         }();
-        const int phases = std::max(1, std::min(phases_cfg, nblk / 4));       // at least four block rows per launch
+        const int phases_want = cp_knob(CP_KNOB_CHOL_PHASES) > 0 ? std::min(cp_knob(CP_KNOB_CHOL_PHASES), 6) : phases_cfg;
+        const int phases = std::max(1, std::min(phases_want, nblk / 4));       // at least four block rows per launch
         int t_begin = 0, s_begin = 0;
         for (int ph = 0; ph < phases; ++ph) {
             const int s_end = ph + 1 == phases ? nblk : (nblk * (ph + 1)) / phases;

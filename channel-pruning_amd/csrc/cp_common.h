@@ -128,7 +128,7 @@ struct cp_ctx {
 };
 
 // process-wide experiment switches (cp_debug_knob; cp_ctx.hip): plain ints, 0 by default, read when work is enqueued
-enum { CP_KNOB_SPLIT_XTY = 0, CP_KNOB_COUNT = 8 };
+enum { CP_KNOB_SPLIT_XTY = 0, CP_KNOB_CHOL_PHASES = 1, CP_KNOB_CHOL_WG = 2, CP_KNOB_COUNT = 8 };
 int cp_knob(int id);
 
 int cp_set_error(cp_ctx *ctx, int code, const char *fmt, ...);
