@@ -426,15 +426,19 @@ def exchange_results(specs, owner, mine, dist, device=None, staging=None, failed
             every = _all_gather_rows(dist, send if on_gpu else torch.from_numpy(send))
             parts = {r: every[r, :seg[r]] for r in range(world) if r != rank and seg[r]}
         else:
-            # a gather of uneven parts: the root posts one receive per owner, every other owner one send
+            # a gather of uneven parts: the root posts one receive per owner, every other owner one send.  Device tensors only
+            # through "nccl" (= RCCL: grouped ncclSend / ncclRecv over xGMI); any other backend gets host tensors, as in
+            # _all_gather_rows (gloo handed CUDA tensors for send / recv took 2 s per 50 MB: two ranks on one GPU, round 6)
             ops, parts = [], {}
+            p2p_dev = dev if (on_gpu and dist.get_backend() == "nccl") else torch.device("cpu")
             if rank == root:
                 for r in range(world):
                     if r != root and seg[r]:
-                        parts[r] = torch.empty(seg[r], dtype=torch.float64, device=dev)
+                        parts[r] = torch.empty(seg[r], dtype=torch.float64, device=p2p_dev)
                         ops.append(dist.P2POp(dist.irecv, parts[r], r))
             elif sends:
-                ops.append(dist.P2POp(dist.isend, send if on_gpu else torch.from_numpy(send), root))
+                out_t = send if on_gpu else torch.from_numpy(send)
+                ops.append(dist.P2POp(dist.isend, out_t if out_t.device == p2p_dev else out_t.to(p2p_dev), root))
             for req in (dist.batch_isend_irecv(ops) if ops else []):
                 req.wait()
         t_gather = time.perf_counter()
