@@ -757,6 +757,9 @@ __device__ __forceinline__ bool chain_wait(const int *word, int want, bool activ
     }
 }
 
+#ifdef CP_CHAIN_STATS   // tools/ubench/chol_chain -DCP_CHAIN_STATS: [kind] cycles waited for inputs, [4 + kind] tasks, [8 + kind] cycles working
+__device__ unsigned long long g_chain_stats[12];
+#endif
 __global__ void __launch_bounds__(PT, 4)
 k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict__ Lt, int ld, int nblk, int L, int t_begin, int total,
              int phase,
@@ -764,6 +767,9 @@ k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict_
              double *__restrict__ R, int ldr, int ntr, int spin_limit) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int s_task, s_go;
+#ifdef CP_CHAIN_STATS
+    __shared__ unsigned long long s_t0;
+#endif
     const int tid = threadIdx.x;
     const ChainShape sh{nblk, ntr, L};
     const int XW = nblk + CHAIN_NTR_MAX;
@@ -792,7 +798,17 @@ k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict_
                 word = ver + r * XW + ((lane & 1) ? i : x);
                 want = r + 1;
             }
+#ifdef CP_CHAIN_STATS
+            const unsigned long long w0 = __builtin_readcyclecounter();
+#endif
             const bool go = chain_wait(word, want, active, stop, info, spin_limit);
+#ifdef CP_CHAIN_STATS
+            if (lane == 0) {
+                atomicAdd(&g_chain_stats[k.kind], __builtin_readcyclecounter() - w0);          // cycles waited, by task kind
+                atomicAdd(&g_chain_stats[4 + k.kind], 1ull);                                    // tasks
+                s_t0 = __builtin_readcyclecounter();
+            }
+#endif
             if (lane == 0) s_go = go ? 1 : 0;
         }
         __syncthreads();
@@ -834,6 +850,9 @@ k_chol_chain(double *__restrict__ G, double *__restrict__ U, double *__restrict_
         CP_HANDOFF_RELEASE();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(ver + i * XW + x, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CP_CHAIN_STATS
+        if (tid == 0) atomicAdd(&g_chain_stats[8 + k.kind], __builtin_readcyclecounter() - s_t0);   // cycles working
+#endif
         CP_HANDOFF_ACQUIRE();
     }
 }

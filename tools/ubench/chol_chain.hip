@@ -9,6 +9,7 @@
 #include <cmath>
 
 int cp_arena_reserve(cp_ctx *, size_t) { return CP_ERR_NOMEM; }
+int cp_knob(int) { return 0; }
 int cp_set_error(cp_ctx *, int code, const char *fmt, ...) {
     fprintf(stderr, "cp_set_error %d: %s\n", code, fmt);
     return code;
@@ -129,6 +130,30 @@ static bool same(const Snap &a, const Snap &b) {
 
 int main(int argc, char **argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+#ifdef CP_CHAIN_STATS
+    if (argc > 1 && !strcmp(argv[1], "stats")) {   // where the resident workgroups' time goes: waiting for inputs / working, by task kind
+        if (lds_opt_in(0) != hipSuccess) return 1;
+        Bufs b1 = make(36, 512);
+        for (int W : {108, 216, 288}) {
+            reset(b1);
+            run_chain(b1, 4, W);
+            unsigned long long z[12] = {};
+            hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stats), z, sizeof(z));
+            reset(b1);
+            const float ms = run_chain(b1, 4, W);
+            unsigned long long st[12];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_chain_stats), sizeof(st));
+            const double tot = double(W) * ms * 1e-3 * 2.4e9;   // workgroup-cycles of the launch at 2.4 GHz (upper bound: not all resident at once)
+            printf("W = %d: %.3f ms; workgroup-cycles %.3g\n", W, ms, tot);
+            const char *nm[3] = {"pre", "chain", "rest"};
+            for (int k = 0; k < 3; ++k)
+                printf("  %-5s tasks %6llu  waited %.3g cycles (%.1f %% of the launch's workgroup-cycles, %.0f per task)  worked %.3g (%.1f %%, %.0f per task)\n",
+                       nm[k], st[4 + k], double(st[k]), 100.0 * double(st[k]) / tot, st[4 + k] ? double(st[k]) / double(st[4 + k]) : 0.0,
+                       double(st[8 + k]), 100.0 * double(st[8 + k]) / tot, st[4 + k] ? double(st[8 + k]) / double(st[4 + k]) : 0.0);
+        }
+        return 0;
+    }
+#endif
     if (lds_opt_in(0) != hipSuccess) return 1;
     int bad = 0;
     printf("## bit-for-bit against the launch-per-step form\n\n| blocks | rhs columns | L | W | tasks | identical | info[0] |\n|---|---|---|---|---|---|---|\n");
