@@ -9,6 +9,7 @@
 #include <cmath>
 
 int cp_arena_reserve(cp_ctx *, size_t) { return CP_ERR_NOMEM; }   // only cp_debug_lds_hog wants it (not used here)
+int cp_knob(int) { return 0; }
 int cp_set_error(cp_ctx *, int code, const char *fmt, ...) {
     fprintf(stderr, "cp_set_error %d: %s\n", code, fmt);
     return code;
