@@ -1405,6 +1405,45 @@ def test_persistent_cholesky_equals_the_launch_per_step_form_bit_for_bit_through
     assert got["chain"] == got["steps"] and got["chain_L1"] == got["steps"] and got["chain_L3_w1"] == got["steps"]
 
 
+def test_gram_and_xty_in_one_launch_against_the_two_launch_form():
+    """cp_lstsq_refit forms G = Xs^T Xs and R = Xs^T Yc in ONE launch (cp_gemm_gram_xty: R's tiles ride in the Gram's tile
+    triangle and are written transposed from the epilogue) where the shape's plan allows it, and as two launches otherwise
+    (few tiles: the plan with reduction planes) or when cp_debug_knob(CP_KNOB_SPLIT_XTY = 0, 1) says so.  Same operands through
+    both forms: W and b agree to rounding (the tile plans differ -- 38 against 34 tile rows, another tail split -- so G's and
+    R's sums are formed in another order: 1e-11 relative is what is asserted, 1e-15 ... 1.5e-13 what is seen, the latter at
+    512 channels), the refit takes the Cholesky route in both, and cp_debug_last_xty_fused tells which form ran -- the wide shapes
+    fused, the 300-channel 1 x 1 one not (its plan needs reduction planes), nothing fused once the knob is set."""
+    import ctypes
+    import cp_oracle
+    import cpmi355
+    ctx = cpmi355.capi.default_context()
+    lib = ctx.lib
+    lib.cp_debug_knob.argtypes, lib.cp_debug_knob.restype = [ctypes.c_int, ctypes.c_int], ctypes.c_int
+    lib.cp_debug_last_xty_fused.argtypes, lib.cp_debug_last_xty_fused.restype = [ctypes.c_void_p], ctypes.c_int
+    fused_seen = {}
+    try:
+        for lid, N, c, n, k, keep in ((3, 900, 40, 24, 3, 30), (4, 2500, 160, 200, 3, 150), (5, 5000, 512, 512, 3, 472), (6, 1500, 300, 130, 1, 280)):
+            X, W2, Y, _ = cp_oracle.synth_layer(lid, N, c, n, k)
+            pr = cpmi355.LayerProblem(ctx, X, W2, Y, flags=0)
+            mask = np.zeros(c, dtype=bool)
+            mask[np.random.RandomState(lid).permutation(c)[:keep]] = True
+            got = {}
+            for form, knob in (("one", 0), ("two", 1)):
+                lib.cp_debug_knob(0, knob)
+                W, b = pr.refit(mask)
+                got[form] = (np.array(W), np.array(b), int(pr.refit_info.fallback), int(lib.cp_debug_last_xty_fused(ctx.h)))
+            pr.free()
+            assert got["one"][2] == 0 and got["two"][2] == 0
+            assert got["two"][3] == 0
+            fused_seen[lid] = got["one"][3]
+            assert relfro(got["one"][0], got["two"][0]) <= 1e-11, (lid, relfro(got["one"][0], got["two"][0]))
+            assert relfro(got["one"][1], got["two"][1]) <= 1e-11
+    finally:
+        lib.cp_debug_knob(0, 0)
+    assert fused_seen[4] == 1 and fused_seen[5] == 1, fused_seen
+    assert fused_seen[6] == 0, fused_seen          # 5 tile rows, K = 1504: the plan with reduction planes -> two launches
+
+
 def _chol_debug(ctx):
     import ctypes
     lib = ctx.lib
