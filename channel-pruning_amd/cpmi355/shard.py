@@ -152,10 +152,22 @@ class ResidentLayerSet:
         # than the idle head can absorb only adds flops to a chip that is busy afterwards.
         if precompute_heaviest is None:
             precompute_heaviest = 2      # vgg16 job: 29.7 / 28.0 / 27.9 / 28.0 / 28.9 / 30.0 ms with 0 .. 5
+        cost_of = lambda ch: layer_cost(*[self.specs[ch["members"][0]][k] for k in ("N", "c", "n", "k", "rank")])   # noqa: E731
         single = [ch for ch in self.chunks if len(ch["members"]) == 1]
-        single.sort(key=lambda ch: -layer_cost(*[self.specs[ch["members"][0]][k] for k in ("N", "c", "n", "k", "rank")]))
+        single.sort(key=lambda ch: -cost_of(ch))
         self._latency_chunks = set(id(ch) for ch in single[:max(0, precompute_heaviest)]) if len(self.chunks) > 2 else \
             set(id(ch) for ch in single)
+        # WHICH of the equally heavy layers get it is re-decided after every run from what the run showed (finish()): the ones
+        # whose alpha searches were the longest -- their refits start last, and the precompute takes Gram and X^T Y off exactly
+        # that path.  The cost model cannot know: the number of fits of a search depends on the data (6, 7 or 8 for the five
+        # 512-channel layers of the vgg16 job).  vgg16 job 22.7-22.9 against 23.5-23.7 ms with the first two of the five
+        # (three processes each, alternating; CP_PRECOMPUTE_ADAPT=0 keeps the first choice).  Masks do not depend on the
+        # choice; a layer's coefficients move at the 1e-16 level when it changes sides (another summation order).
+        import os
+        self._adapt = len(self.chunks) > 2 and precompute_heaviest > 0 and os.environ.get("CP_PRECOMPUTE_ADAPT", "1") != "0"
+        top = cost_of(single[0]) if single else 0.0
+        self._adapt_pool = [ch for ch in single if cost_of(ch) >= 0.9 * top]       # the heaviest class (equal widths)
+        self._adapt_n = min(max(0, precompute_heaviest), len(self._adapt_pool))
         # a set of one or two layers has the chip to itself: the full treatment (pruner.precompute_flag)
         self._latency_kind = "gram" if len(self.chunks) > 2 else True
         self._stop = False
@@ -248,6 +260,14 @@ class ResidentLayerSet:
                 continue
             for i, r in zip(ch["members"], ch["out"]):
                 out[i] = r
+        if self._adapt and all(ch["error"] is None for ch in self.chunks):
+            # coordinate steps of a layer's search = sum of n_iter over its fits x channels (LayerProblem.fits); the later
+            # starter wins a tie (its search ends later)
+            order = {id(ch): k for k, ch in enumerate(self.chunks)}
+            steps = lambda ch: sum(f[2] for f in (ch["probs"][0].fits or [])) * int(self.specs[ch["members"][0]]["c"])   # noqa: E731
+            ranked = sorted(self._adapt_pool, key=lambda ch: (-steps(ch), -order[id(ch)]))
+            others = self._latency_chunks - set(id(ch) for ch in self._adapt_pool)
+            self._latency_chunks = others | set(id(ch) for ch in ranked[:self._adapt_n])
         return out
 
     def run(self):

@@ -987,6 +987,68 @@ def test_resident_layer_set_chunks_streams_and_latency_layers(monkeypatch):
         rset.close()
 
 
+def test_resident_layer_set_gives_the_precompute_to_the_longest_searches(monkeypatch):
+    """cpmi355.shard.ResidentLayerSet (device calls stubbed out): which of the equally heavy single-layer chunks run with their
+    normal equations precomputed under the search is re-decided after every run -- the `precompute_heaviest` layers whose
+    searches took the most coordinate steps (sum of n_iter over the fits x channels; the later starter wins a tie); the
+    first run takes the first ones; CP_PRECOMPUTE_ADAPT=0 keeps that choice; narrower layers never enter the pool."""
+    from cpmi355 import capi, pruner, shard
+    calls = []
+    n_iter = {0: 10, 1: 30, 2: 10, 3: 20, 4: 99}          # layer_id -> epochs of its one fit
+
+    class FakeCtx:
+        def __init__(self, device=0, name=None, priority=None):
+            pass
+
+        def sibling(self):
+            return FakeCtx()
+
+        def close(self):
+            pass
+
+    class FakeProb:
+        def __init__(self, ctx, X, W2, Y, flags=0):
+            self.ctx, self.tag, self.fits = ctx, X, []
+
+        def free(self):
+            pass
+
+    def fake_single(prob, rank, alpha_in, rank_tol=.1, rng=None, mode="device", latency_mode=True, **kw):
+        calls.append((prob.tag, latency_mode))
+        prob.fits = [(0.5, 1, n_iter[prob.tag])]
+        return np.array([True]), np.full((1, 1, 1, 1), prob.tag), np.zeros(1), 0.5
+
+    monkeypatch.setattr(capi, "Context", FakeCtx)
+    monkeypatch.setattr(pruner, "LayerProblem", FakeProb)
+    monkeypatch.setattr(pruner, "prune_layer", fake_single)
+    specs = [dict(layer_id=i, N=5000, c=c, n=c, k=3, rank=int(c / 1.15)) for i, c in enumerate([512, 512, 512, 512, 64])]
+
+    def picked():
+        return sorted(tag for tag, mode in calls if mode == "gram")
+
+    for adapt, expect in (("1", [[0, 1], [1, 3], [1, 3]]), ("0", [[0, 1], [0, 1], [0, 1]])):
+        monkeypatch.setenv("CP_PRECOMPUTE_ADAPT", adapt)
+        rset = shard.ResidentLayerSet(0, specs, lambda s: (s["layer_id"], None, None), per_stream=1, precompute_heaviest=2)
+        try:
+            for want in expect:
+                calls.clear()
+                out = rset.run()
+                assert [int(W[0, 0, 0, 0]) for _, W, _, _ in out] == list(range(5))
+                assert picked() == want, (adapt, picked(), want)          # the 64-channel layer (99 epochs) is not in the pool
+        finally:
+            rset.close()
+    n_iter.update({0: 30, 3: 30})                                         # ties: 0, 1, 3 equal -> the later starters (1 and 3)
+    monkeypatch.setenv("CP_PRECOMPUTE_ADAPT", "1")
+    rset = shard.ResidentLayerSet(0, specs, lambda s: (s["layer_id"], None, None), per_stream=1, precompute_heaviest=2)
+    try:
+        rset.run()
+        calls.clear()
+        rset.run()
+        assert picked() == [1, 3]
+    finally:
+        rset.close()
+
+
 def test_bench_vgg16_job_is_the_reference_rank_table():
     """bench.py's whole-network job: d_c = max(int(c / 1.15), rank) with the reference's rank table x 4/3 (net.py:1309-1327,
     1346-1349) for the 12 conv -> conv pairs; golden names V01..V12 exist for every layer."""

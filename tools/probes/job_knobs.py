@@ -22,13 +22,15 @@ def main():
     ap.add_argument("--job", default="vgg16")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--jobs", type=int, default=20)
+    ap.add_argument("--pre", type=int, default=None, help="ResidentLayerSet(precompute_heaviest=...)")
     ap.add_argument("settings", nargs="+")
     a = ap.parse_args()
     import ctypes
     from cpmi355 import shard
     specs = cpjobs.JOBS[a.job]()
     per_stream = 1 if a.job != "resnet50" else {"default": 2, 2048: 1}
-    rset = shard.ResidentLayerSet(0, specs, lambda sp: cpjobs.synth(sp)[:3], per_stream=per_stream, flags=CD_FLAGS, borrow_results=True)
+    rset = shard.ResidentLayerSet(0, specs, lambda sp: cpjobs.synth(sp)[:3], per_stream=per_stream, flags=CD_FLAGS, borrow_results=True,
+                                  precompute_heaviest=a.pre)
     roots = [ch["ctxs"][0] for ch in rset.chunks]
     lib = roots[0].lib
     lib.cp_debug_knob.argtypes, lib.cp_debug_knob.restype = [ctypes.c_int, ctypes.c_int], ctypes.c_int
