@@ -23,12 +23,18 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--jobs", type=int, default=20)
     ap.add_argument("--pre", type=int, default=None, help="ResidentLayerSet(precompute_heaviest=...)")
+    ap.add_argument("--per-stream", default="", help="layers per stream by width, e.g. 64:2,128:2 (default 1)")
     ap.add_argument("settings", nargs="+")
     a = ap.parse_args()
     import ctypes
     from cpmi355 import shard
     specs = cpjobs.JOBS[a.job]()
     per_stream = 1 if a.job != "resnet50" else {"default": 2, 2048: 1}
+    if a.per_stream:
+        per_stream = {"default": 1} if not isinstance(per_stream, dict) else dict(per_stream)
+        for item in a.per_stream.split(","):
+            k, v = item.split(":")
+            per_stream[int(k)] = int(v)
     rset = shard.ResidentLayerSet(0, specs, lambda sp: cpjobs.synth(sp)[:3], per_stream=per_stream, flags=CD_FLAGS, borrow_results=True,
                                   precompute_heaviest=a.pre)
     roots = [ch["ctxs"][0] for ch in rset.chunks]
